@@ -1,0 +1,337 @@
+"""TEST INFRASTRUCTURE: deterministic synthetic inputs for the oracle / golden vectors / parity tests.
+
+Inputs follow SURVEY.md section 8(d): seeded torch.Generator (CPU RNG -- deterministic for a fixed
+torch build; every golden file also stores a sha256 of its regenerated inputs so that an RNG change
+is detected instead of silently comparing different data).
+"""
+import hashlib
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle.cpu_ref import HeadConfig
+
+COCO17 = ['nose', 'leye', 'reye', 'lear', 'rear', 'lsho', 'rsho', 'lelb', 'relb', 'lwri', 'rwri',
+          'lhip', 'rhip', 'lkne', 'rkne', 'lank', 'rank']
+COCO17_EDGES = [(0, 1), (0, 2), (1, 3), (2, 4), (5, 6), (5, 7), (7, 9), (6, 8), (8, 10), (5, 11),
+                (6, 12), (11, 12), (11, 13), (13, 15), (12, 14), (14, 16)]
+
+
+def mirror_mapping(names):
+    """Left/right swap by leading 'l'/'r' (posepile JointInfo convention; see
+    oracle/ref_harness.py:_JointInfoStub)."""
+    index = {n: i for i, n in enumerate(names)}
+    out = []
+    for n in names:
+        if n.startswith('l') and ('r' + n[1:]) in index:
+            out.append(index['r' + n[1:]])
+        elif n.startswith('r') and ('l' + n[1:]) in index:
+            out.append(index['l' + n[1:]])
+        else:
+            out.append(index[n])
+    return np.array(out, dtype=np.int64)
+
+
+def sha256_of(*tensors):
+    h = hashlib.sha256()
+    for t in tensors:
+        a = t.detach().cpu().contiguous().numpy() if isinstance(t, torch.Tensor) else np.ascontiguousarray(t)
+        h.update(str(a.dtype).encode())
+        h.update(str(a.shape).encode())
+        h.update(a.tobytes())
+    return h.hexdigest()
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(int(seed))
+
+
+# ------------------------------------------------------------------------------------ heads
+
+HEAD_CASES = {
+    # name: dict(B, J, D, H, W, sigma, dtype, cfg overrides)
+    's256': dict(B=4, J=17, D=8, H=8, W=8, sigma=1.0, seed=101, cfg={}),
+    's256_legacy': dict(B=4, J=17, D=8, H=8, W=8, sigma=3.0, seed=102,
+                        cfg=dict(centered_stride=False, legacy_centered_stride_bug=True)),
+    's256_peaked': dict(B=4, J=17, D=8, H=8, W=8, sigma=10.0, seed=103, cfg={}),
+    'l384': dict(B=3, J=17, D=8, H=12, W=12, sigma=1.0, seed=104, cfg=dict(proc_side=384)),
+    'l384_j122': dict(B=1, J=122, D=8, H=12, W=12, sigma=2.0, seed=105, cfg=dict(proc_side=384)),
+    's256_d72': dict(B=2, J=17, D=72, H=8, W=8, sigma=1.0, seed=106, cfg=dict(depth=72)),
+    's256_stride16': dict(B=2, J=17, D=8, H=16, W=16, sigma=2.0, seed=107,
+                          cfg=dict(stride_test=16)),
+    'odd160': dict(B=3, J=5, D=8, H=5, W=5, sigma=2.0, seed=108, cfg=dict(proc_side=160)),
+    's256_fp16': dict(B=4, J=17, D=8, H=8, W=8, sigma=3.0, seed=109, dtype='float16', cfg={}),
+    's256_j1': dict(B=2, J=1, D=8, H=8, W=8, sigma=1.0, seed=110, cfg={}),
+    's256_spike': dict(B=2, J=17, D=8, H=8, W=8, sigma=1.0, seed=111, spike=60.0, cfg={}),
+}
+
+
+def head_case(name):
+    c = dict(HEAD_CASES[name])
+    cfg = HeadConfig(**c['cfg'])
+    g = gen(c['seed'])
+    n_out = c['J'] * (1 + c['D'])
+    logits = torch.randn(c['B'], n_out, c['H'], c['W'], generator=g) * c['sigma']
+    if c.get('spike'):
+        # one dominant voxel per joint: exercises the exp range of the softmax
+        for b in range(c['B']):
+            for j in range(c['J']):
+                d = int(torch.randint(0, c['D'], (1,), generator=g))
+                h = int(torch.randint(0, c['H'], (1,), generator=g))
+                w = int(torch.randint(0, c['W'], (1,), generator=g))
+                logits[b, c['J'] + d * c['J'] + j, h, w] += c['spike']
+                logits[b, j, h, w] += c['spike']
+    if c.get('dtype') == 'float16':
+        logits = logits.half()
+    return logits, c['J'], cfg
+
+
+HEADCONV_CASES = {
+    's256_c64': dict(B=4, C=64, J=17, D=8, H=8, W=8, gain=1.0, seed=201, cfg={}),
+    's256_c1280': dict(B=2, C=1280, J=17, D=8, H=8, W=8, gain=1.0, seed=202, cfg={}),
+    's256_c1280_peaked': dict(B=2, C=1280, J=17, D=8, H=8, W=8, gain=20.0, seed=203, cfg={}),
+    'l384_c1280': dict(B=2, C=1280, J=17, D=8, H=12, W=12, gain=4.0, seed=204,
+                       cfg=dict(proc_side=384)),
+    'r18_c512': dict(B=1, C=512, J=17, D=8, H=8, W=8, gain=4.0, seed=205, cfg={}),
+    'l384_j122_c96': dict(B=2, C=96, J=122, D=8, H=12, W=12, gain=4.0, seed=206,
+                          cfg=dict(proc_side=384)),
+}
+
+
+def default_conv_init(n_out, c_in, g):
+    """torch.nn.Conv2d default init (kaiming_uniform a=sqrt(5) -> U(-1/sqrt(fan_in), ..))."""
+    bound = 1.0 / np.sqrt(c_in)
+    w = (torch.rand(n_out, c_in, generator=g) * 2 - 1) * bound
+    b = (torch.rand(n_out, generator=g) * 2 - 1) * bound
+    return w, b
+
+
+def headconv_case(name):
+    c = dict(HEADCONV_CASES[name])
+    cfg = HeadConfig(**c['cfg'])
+    g = gen(c['seed'])
+    feat = torch.randn(c['B'], c['C'], c['H'], c['W'], generator=g)
+    w, b = default_conv_init(c['J'] * (1 + c['D']), c['C'], g)
+    return feat, w * c['gain'], b * c['gain'], c['J'], cfg
+
+
+# ------------------------------------------------------------------------------------ reconstruct
+
+RECON_CASES = {
+    'b64_j17': dict(B=64, J=17, seed=301, cfg={}),
+    'b5_j122_384': dict(B=5, J=122, seed=302, cfg=dict(proc_side=384)),
+    'b1_j17': dict(B=1, J=17, seed=303, cfg={}),
+    'b8_legacy': dict(B=8, J=17, seed=304,
+                      cfg=dict(centered_stride=False, legacy_centered_stride_bug=True)),
+    'b8_weak': dict(B=8, J=17, seed=305, cfg=dict(weak_perspective=True)),
+    'b6_nomix': dict(B=6, J=17, seed=306, cfg=dict(mix_3d_inside_fov=None)),
+    'b4_outfov': dict(B=4, J=17, seed=307, cfg={}, all_out_of_fov=True),
+}
+
+
+def recon_case(name):
+    """Synthetic *consistent* pose (SURVEY.md 8c KAT 5): pick ref point, K and rel pose, project,
+    add prediction noise; ~10 % joints pushed out of the FOV."""
+    c = dict(RECON_CASES[name])
+    cfg_kw = dict(c['cfg'])
+    mix = cfg_kw.pop('mix_3d_inside_fov', 0.5) if 'mix_3d_inside_fov' in cfg_kw else 0.5
+    cfg = HeadConfig(**cfg_kw)
+    cfg.mix_3d_inside_fov = mix
+    g = gen(c['seed'])
+    B, J, P = c['B'], c['J'], cfg.proc_side
+    f = (450 + 100 * torch.rand(B, generator=g)) * (P / 256)
+    K = torch.zeros(B, 3, 3)
+    K[:, 0, 0] = f
+    K[:, 1, 1] = f * (0.98 + 0.04 * torch.rand(B, generator=g))
+    K[:, 0, 2] = P / 2
+    K[:, 1, 2] = P / 2
+    K[:, 2, 2] = 1
+    ref = torch.stack([
+        200 * torch.randn(B, generator=g), 200 * torch.randn(B, generator=g),
+        2000 + 3000 * torch.rand(B, generator=g)], dim=1)
+    rel = torch.randn(B, J, 3, generator=g) * torch.tensor([350.0, 450.0, 250.0])
+    abs3d = rel + ref[:, None]
+    proj = abs3d[..., :2] / abs3d[..., 2:]
+    coords2d = proj * torch.stack([K[:, 0, 0], K[:, 1, 1]], dim=1)[:, None] + K[:, None, :2, 2]
+    coords2d = coords2d + 1.5 * torch.randn(B, J, 2, generator=g)
+    rel = rel + 15 * torch.randn(B, J, 3, generator=g)
+    push = torch.rand(B, J, generator=g) < 0.1
+    coords2d = torch.where(push[..., None], coords2d * 0.02 - 3.0, coords2d)
+    if c.get('all_out_of_fov'):
+        coords2d[0] = -50.0 + torch.rand(J, 2, generator=g)
+    return coords2d.contiguous(), rel.contiguous(), K, cfg
+
+
+# ------------------------------------------------------------------------------------ images / warp
+
+def synth_images(n, h, w, seed):
+    """uint8 [n,3,h,w]: even images are uniform noise (worst case for bilinear rounding), odd
+    images are smooth gradients + mild noise."""
+    g = gen(seed)
+    imgs = torch.randint(0, 256, (n, 3, h, w), dtype=torch.uint8, generator=g)
+    yy, xx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing='ij')
+    for i in range(1, n, 2):
+        base = torch.stack([
+            127 + 100 * torch.sin(xx / 17.0 + i), 127 + 100 * torch.cos(yy / 23.0 - i),
+            (xx + yy).float() % 256], dim=0)
+        noise = torch.randint(-6, 7, (3, h, w), generator=g)
+        imgs[i] = torch.clip(base + noise, 0, 255).to(torch.uint8)
+    return imgs
+
+
+def synth_boxes(n_images, h, w, max_boxes, seed, min_boxes=0):
+    """list of [n_i,5] float32 boxes (x, y, w, h, conf=1); may contain empty entries."""
+    g = gen(seed)
+    out = []
+    for _ in range(n_images):
+        n = int(torch.randint(min_boxes, max_boxes + 1, (1,), generator=g))
+        bw = (0.15 + 0.35 * torch.rand(n, generator=g)) * w
+        bh = (0.3 + 0.6 * torch.rand(n, generator=g)) * h
+        bx = torch.rand(n, generator=g) * (w - bw * 0.7) - 0.15 * bw
+        by = torch.rand(n, generator=g) * (h - bh * 0.7) - 0.15 * bh
+        out.append(torch.stack([bx, by, bw, bh, torch.ones(n)], dim=1).float())
+    return out
+
+
+DISTORTION_5 = (-0.1, 0.01, 1e-3, 1e-3, 0.0)
+DISTORTION_12 = (-0.08, 0.012, 8e-4, -6e-4, 1e-3, 0.01, -2e-3, 1e-4, 3e-4, -2e-4, 1e-4, 2e-4)
+
+
+def intrinsics_for(h, w, fov_degrees=55.0, jitter_seed=None):
+    f = max(h, w) / (np.tan(np.deg2rad(fov_degrees) / 2) * 2)
+    K = torch.tensor([[f, 0, w / 2], [0, f, h / 2], [0, 0, 1]], dtype=torch.float32)
+    if jitter_seed is not None:
+        g = gen(jitter_seed)
+        K[0, 0] *= float(0.95 + 0.1 * torch.rand(1, generator=g))
+        K[1, 1] *= float(0.95 + 0.1 * torch.rand(1, generator=g))
+        K[0, 1] = float(0.5 * torch.randn(1, generator=g))  # a little skew
+        K[0, 2] += float(3 * torch.randn(1, generator=g))
+        K[1, 2] += float(3 * torch.randn(1, generator=g))
+    return K
+
+
+# ------------------------------------------------------------------------------------ e2e tiny model
+
+class TinyBackbone(torch.nn.Module):
+    """Deterministic stand-in for the CNN backbone (out of scope): /32
+    average pool, 1x1 conv 3->C, tanh.  Cheap, and nearly order-independent in fp32 so that CPU
+    and GPU features agree to ~1e-6."""
+
+    def __init__(self, c_out, stride, seed):
+        super().__init__()
+        g = gen(seed)
+        self.stride = stride
+        self.proj = torch.nn.Conv2d(3, c_out, 1)
+        with torch.no_grad():
+            self.proj.weight.copy_(torch.randn(c_out, 3, 1, 1, generator=g) * 2.0)
+            self.proj.bias.copy_(torch.randn(c_out, generator=g) * 0.5)
+
+    def forward(self, image):
+        x = F.avg_pool2d(image.float(), self.stride)
+        return torch.tanh(self.proj(x * 2 - 1)) * 2.0
+
+
+def tiny_head_weights(c_in, n_points, depth, seed, gain=6.0):
+    g = gen(seed)
+    w, b = default_conv_init(n_points * (1 + depth), c_in, g)
+    return w * gain, b * gain
+
+
+E2E_CASES = {
+    # res 64 keeps the golden crops small; geometry/TTA/post-processing code paths are identical.
+    'aug1': dict(seed=401, n_images=2, imh=120, imw=160, res=64, num_aug=1, aa=1, dist=None,
+                 ibs=64, average_aug=True, extr=False, skeleton=False, jtm=False, known_k=False),
+    'aug5': dict(seed=402, n_images=3, imh=120, imw=160, res=64, num_aug=5, aa=1, dist=None,
+                 ibs=10, average_aug=True, extr=False, skeleton=False, jtm=False, known_k=True),
+    'aug5_dist_aa2': dict(seed=403, n_images=2, imh=150, imw=200, res=64, num_aug=5, aa=2,
+                          dist=DISTORTION_5, ibs=64, average_aug=False, extr=True, skeleton=True,
+                          jtm=True, known_k=True),
+    'aug4_dist12': dict(seed=404, n_images=2, imh=120, imw=160, res=64, num_aug=4, aa=1,
+                        dist=DISTORTION_12, ibs=3, average_aug=True, extr=True, skeleton=False,
+                        jtm=False, known_k=True),
+    'aug2_aa4_bigbox': dict(seed=405, n_images=1, imh=400, imw=600, res=32, num_aug=2, aa=4,
+                            dist=None, ibs=64, average_aug=True, extr=False, skeleton=False,
+                            jtm=False, known_k=False),
+}
+
+E2E_C = 24  # tiny backbone channels
+E2E_SKELETON = [0, 5, 6, 11, 12, 15, 16]
+
+
+def e2e_case(name):
+    c = dict(E2E_CASES[name])
+    images = synth_images(c['n_images'], c['imh'], c['imw'], c['seed'])
+    boxes = synth_boxes(c['n_images'], c['imh'], c['imw'], 3, c['seed'] + 1, min_boxes=1)
+    if name == 'aug5':
+        boxes[1] = boxes[1][:0]  # an image without detections (ragged edge case)
+    if c['known_k']:
+        K = torch.stack([intrinsics_for(c['imh'], c['imw'], 60.0, c['seed'] + 10 + i)
+                         for i in range(c['n_images'])])
+    else:
+        K = torch.tensor([[[-1.0] * 3] * 3])
+    dist = torch.tensor([list(c['dist'])], dtype=torch.float32) if c['dist'] else torch.zeros(1, 5)
+    if c['extr']:
+        g = gen(c['seed'] + 2)
+        ang = 0.3 * torch.randn(3, generator=g)
+        cx, sx, cy, sy = torch.cos(ang[0]), torch.sin(ang[0]), torch.cos(ang[1]), torch.sin(ang[1])
+        rx = torch.tensor([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+        ry = torch.tensor([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+        E = torch.eye(4)
+        E[:3, :3] = rx @ ry
+        E[:3, 3] = torch.tensor([100.0, -50.0, 800.0])
+        extr = E[None]
+        world_up = torch.tensor([0.0, 0.0, 1.0])
+    else:
+        extr = torch.eye(4)[None]
+        world_up = torch.tensor([0.0, -1.0, 0.0])
+    # stride res/8 -> an 8x8 heatmap, the EffNetV2-S/256 shape, at a tiny crop resolution
+    cfg = HeadConfig(proc_side=c['res'], stride_train=c['res'] // 8, stride_test=c['res'] // 8)
+    backbone = TinyBackbone(E2E_C, cfg.stride_test, c['seed'] + 3)
+    w, b = tiny_head_weights(E2E_C, 17, cfg.depth, c['seed'] + 4)
+    jtm = None
+    if c['jtm']:
+        g = gen(c['seed'] + 5)
+        jtm = torch.eye(17) * 0.7 + 0.3 * torch.softmax(torch.randn(17, 17, generator=g), dim=0)
+    skeleton = E2E_SKELETON if c['skeleton'] else list(range(17))
+    return dict(images=images, boxes=boxes, K=K, dist=dist, extr=extr, world_up=world_up,
+                cfg=cfg, backbone=backbone, head_w=w, head_b=b, jtm=jtm, skeleton=skeleton,
+                num_aug=c['num_aug'], aa=c['aa'], ibs=c['ibs'], average_aug=c['average_aug'],
+                res=c['res'])
+
+
+WARP_CASES = {
+    'nodist': dict(seed=501, dist=None, res=48),
+    'dist5': dict(seed=502, dist=DISTORTION_5, res=48),
+    'dist12': dict(seed=503, dist=DISTORTION_12, res=40),
+}
+
+
+def warp_case(name):
+    """Direct inputs of warping.warp_images_with_pyramid: 2 images, 6 crops spanning all three
+    pyramid levels and partially out-of-frame homographies."""
+    c = dict(WARP_CASES[name])
+    g = gen(c['seed'])
+    imh, imw, res = 120, 160, c['res']
+    images_u8 = synth_images(2, imh, imw, c['seed'])
+    images = (images_u8.float() / 255) ** 2.2
+    n = 6
+    K = torch.stack([intrinsics_for(imh, imw, 55.0, c['seed'] + i) for i in range(n)])
+    crop_scales = torch.tensor([1.6, 0.9, 0.45, 0.3, 0.2, 0.1])
+    image_ids = torch.tensor([0, 1, 0, 1, 1, 0])
+    hinvs = []
+    for i in range(n):
+        s = float(crop_scales[i])
+        newK = torch.tensor([[K[i, 0, 0] * s, K[i, 0, 1] * s, res / 2],
+                             [0, K[i, 1, 1] * s, res / 2], [0, 0, 1]])
+        ang = 0.4 * torch.randn(3, generator=g)
+        ca, sa = torch.cos(ang[2]), torch.sin(ang[2])
+        rz = torch.tensor([[ca, -sa, 0], [sa, ca, 0], [0, 0, 1]])
+        cb, sb = torch.cos(ang[0] * 0.3), torch.sin(ang[0] * 0.3)
+        ry = torch.tensor([[cb, 0, sb], [0, 1, 0], [-sb, 0, cb]])
+        hinvs.append(torch.linalg.inv(newK @ (rz @ ry)))
+    hinv = torch.stack(hinvs)
+    dist = (torch.tensor([list(c['dist'])] * n, dtype=torch.float32) if c['dist']
+            else torch.zeros(n, 5))
+    return dict(images_u8=images_u8, images=images, K=K, hinv=hinv, dist=dist,
+                crop_scales=crop_scales, image_ids=image_ids, res=res)

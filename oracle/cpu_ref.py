@@ -1,0 +1,577 @@
+"""ORACLE -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Plain-PyTorch fp32 CPU restatement of the MeTRAbs per-crop hot path of the reference
+(isarandi/metrabs, ``metrabs_pytorch/``).  Every function cites the reference file:line it
+follows.  Op order is kept wherever it decides rounding (softmax as exp(x-max)/sum, marginal sums
+then dot with linspace, batch-global RMS, weights mask+1e-4, ridge rows) so that this file is
+BIT-IDENTICAL to the reference on CPU; ``tests/test_oracle_pin.py`` proves that against the live
+reference in the build container and against the golden vectors in ``tests/golden/`` everywhere.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg may import this
+file.  The product (``metrabs_amd``) never does: it fails loudly without its HIP library.
+
+Differences from the reference that are deliberate (none changes a number):
+  * configuration is an explicit ``HeadConfig`` instead of the global hydra ``get_config()``
+    (metrabs_pytorch/util.py:41-57);
+  * ragged splits use Python ints (the reference passes Tensors to torch.split, which torch 2.10
+    rejects -- multiperson_model.py:154-155,171).
+"""
+import dataclasses
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+@dataclasses.dataclass
+class HeadConfig:
+    """Keys of metrabs_pytorch/config/config.yaml:1-22 (+ config_s_256.yaml:5-9) that the hot
+    path reads at call time."""
+    proc_side: int = 256
+    stride_train: int = 32
+    stride_test: int = 32
+    centered_stride: bool = True
+    legacy_centered_stride_bug: bool = False
+    depth: int = 8
+    box_size_mm: float = 2200.0
+    weak_perspective: bool = False
+    mix_3d_inside_fov: float = 0.5
+
+    def as_dict(self):
+        return dataclasses.asdict(self)
+
+
+# ----------------------------------------------------------------------------------------------
+# ptu.py
+# ----------------------------------------------------------------------------------------------
+
+def ref_linspace(start, stop, num, dtype=None, endpoint=True):
+    """ptu.linspace, metrabs_pytorch/ptu.py:78-92.  num==1 with endpoint=True gives the midpoint."""
+    start = torch.as_tensor(start, dtype=dtype)
+    stop = torch.as_tensor(stop, dtype=dtype)
+    if endpoint:
+        if num == 1:
+            return torch.mean(torch.stack([start, stop], dim=0), dim=0, keepdim=True)
+        return torch.linspace(start, stop, num, dtype=dtype)
+    if num > 1:
+        step = (stop - start) / num
+        return torch.linspace(start, stop - step, num, dtype=dtype)
+    return torch.linspace(start, stop, num, dtype=dtype)
+
+
+def joint_softmax(x, dims):
+    """ptu.softmax, metrabs_pytorch/ptu.py:47-51: one softmax jointly over several dims."""
+    peak = torch.amax(x, dim=dims, keepdim=True)
+    e = torch.exp(x - peak)
+    return e / torch.sum(e, dim=dims, keepdim=True)
+
+
+def expectation_decode(prob, dims):
+    """ptu.decode_heatmap, metrabs_pytorch/ptu.py:58-75.  For every heatmap axis: marginalise over
+    the other heatmap axes, then dot with linspace(0, 1, n).  Output coordinate order = ``dims``
+    order."""
+    dims = tuple(d if d >= 0 else prob.ndim + d for d in dims)
+    coords = []
+    for d in dims:
+        others = [o for o in dims if o != d]
+        marginal = torch.sum(prob, dim=others, keepdim=True)
+        grid = ref_linspace(0.0, 1.0, prob.shape[d], dtype=prob.dtype)
+        val = torch.tensordot(marginal, grid, dims=([d], [0]))
+        val = torch.unsqueeze(val, d)
+        for hd in sorted(dims, reverse=True):
+            val = val.squeeze(hd)
+        coords.append(val)
+    return torch.stack(coords, dim=-1)
+
+
+def soft_argmax(x, dims):
+    """ptu.soft_argmax, metrabs_pytorch/ptu.py:54-55."""
+    return expectation_decode(joint_softmax(x, dims), dims)
+
+
+def reduce_sum_masked(x, valid, dim, keepdim):
+    """ptu.reduce_sum_masked, metrabs_pytorch/ptu.py:37-44 (dim given)."""
+    valid = valid.reshape(tuple(valid.shape) + (1,) * (x.ndim - valid.ndim))
+    return torch.where(valid, x, torch.zeros_like(x)).sum(dim=dim, keepdim=keepdim)
+
+
+def reduce_mean_masked(x, valid, dim, keepdim):
+    """ptu.reduce_mean_masked, metrabs_pytorch/ptu.py:22-34 (mask and dim given)."""
+    valid = valid.reshape(tuple(valid.shape) + (1,) * (x.ndim - valid.ndim))
+    total = torch.where(valid, x, torch.zeros_like(x)).sum(dim=dim, keepdim=keepdim)
+    count = valid.sum(dim=dim, keepdim=keepdim, dtype=x.dtype)
+    return torch.nan_to_num(total / count)
+
+
+def mean_stdev_masked(x, valid, items_dim, dimensions_dim):
+    """ptu.mean_stdev_masked, metrabs_pytorch/ptu.py:4-19 (fixed_ref=None)."""
+    mean = reduce_mean_masked(x, valid, dim=items_dim, keepdim=True)
+    centered = x - mean
+    valid_b = valid.reshape(tuple(valid.shape) + (1,) * (x.ndim - valid.ndim))
+    n_valid = valid_b.sum(dim=items_dim, keepdim=True, dtype=x.dtype)
+    ssd = reduce_sum_masked(
+        torch.square(centered), valid_b, dim=(items_dim, dimensions_dim), keepdim=True)
+    stdev = torch.sqrt(torch.nan_to_num(ssd / n_valid) + 1e-10)
+    return mean, stdev
+
+
+# ----------------------------------------------------------------------------------------------
+# models/util.py and models/metrabs.py (MetrabsHeads)
+# ----------------------------------------------------------------------------------------------
+
+def heatmap_to_image(coords, cfg, is_training=False):
+    """models/util.py:6-20."""
+    stride = cfg.stride_train if is_training else cfg.stride_test
+    last_pixel = cfg.proc_side - 1
+    last_center = last_pixel - (last_pixel % stride)
+    out = coords * last_center
+    if cfg.centered_stride:
+        out = out + stride // 2
+    if cfg.legacy_centered_stride_bug:
+        out = out + stride // 2
+    return out
+
+
+def heatmap_to_metric(coords, cfg, is_training=False):
+    """models/util.py:29-33."""
+    xy = heatmap_to_image(coords[..., :2], cfg, is_training) * cfg.box_size_mm / cfg.proc_side
+    return torch.cat([xy, coords[..., 2:] * cfg.box_size_mm], dim=-1)
+
+
+def heads_from_logits(logits, n_points, cfg):
+    """MetrabsHeads.forward after the 1x1 conv, models/metrabs.py:78-85.
+
+    logits: [B, n_points*(1+depth), H, W]; channel n<J is the 2D heatmap of joint n, channel
+    J + d*J + j is depth slice d of joint j ('b (d j) h w -> b d j h w')."""
+    j = n_points
+    logits2d, logits3d = torch.split(logits, [j, cfg.depth * j], dim=1)
+    b, _, h, w = logits3d.shape
+    logits3d = logits3d.reshape(b, cfg.depth, j, h, w)
+    coords3d = soft_argmax(logits3d.float(), dims=(4, 3, 1))
+    coords3d_rel = heatmap_to_metric(coords3d, cfg)
+    coords2d = soft_argmax(logits2d.float(), dims=(3, 2))
+    coords2d_px = heatmap_to_image(coords2d, cfg)
+    return coords2d_px, coords3d_rel
+
+
+def heads_forward(features, weight, bias, n_points, cfg):
+    """MetrabsHeads.forward, models/metrabs.py:75-85.  weight: [J(1+D), C, 1, 1], bias [J(1+D)]
+    (torch.nn.LazyConv2d(kernel_size=1), models/metrabs.py:73)."""
+    if weight.ndim == 2:
+        weight = weight[:, :, None, None]
+    logits = F.conv2d(features, weight, bias)
+    return heads_from_logits(logits, n_points, cfg)
+
+
+# ----------------------------------------------------------------------------------------------
+# ptu3d.py
+# ----------------------------------------------------------------------------------------------
+
+def to_homogeneous(x):
+    """ptu3d.py:52-53."""
+    return torch.cat([x, torch.ones_like(x[..., :1])], dim=-1)
+
+
+def project(points):
+    """ptu3d.py:145-146."""
+    return points[..., :2] / points[..., 2:3]
+
+
+def back_project(camcoords2d, delta_z, z_offset):
+    """ptu3d.py:108-110."""
+    return to_homogeneous(camcoords2d) * torch.unsqueeze(
+        delta_z + torch.unsqueeze(z_offset, -1), -1)
+
+
+def is_within_fov(imcoords, cfg, border_factor=0.75):
+    """ptu3d.py:113-121."""
+    offset = -cfg.stride_train / 2 if not cfg.centered_stride else 0
+    lower = cfg.stride_train * border_factor + offset
+    upper = cfg.proc_side - cfg.stride_train * border_factor + offset
+    return torch.all(torch.logical_and(imcoords >= lower, imcoords <= upper), dim=-1)
+
+
+def reconstruct_ref_weakpersp(normalized_2d, coords3d_rel, validity_mask):
+    """ptu3d.py:36-49."""
+    mean3d, stdev3d = mean_stdev_masked(
+        coords3d_rel[..., :2], validity_mask, items_dim=1, dimensions_dim=2)
+    mean2d, stdev2d = mean_stdev_masked(
+        normalized_2d[..., :2], validity_mask, items_dim=1, dimensions_dim=2)
+    stdev2d = torch.maximum(stdev2d, torch.tensor(1e-5))
+    stdev3d = torch.maximum(stdev3d, torch.tensor(1e-5))
+    old_mean = reduce_mean_masked(coords3d_rel, validity_mask, dim=1, keepdim=True)
+    new_mean_z = torch.nan_to_num(stdev3d / stdev2d)
+    new_mean = to_homogeneous(mean2d) * new_mean_z
+    return torch.squeeze(new_mean - old_mean, 1)
+
+
+def _batch_rms_normalize(x):
+    """rms_normalize inside reconstruct_ref_fullpersp, ptu3d.py:71-74.  NB: the RMS is over the
+    WHOLE tensor, i.e. over every crop of the crop_model call."""
+    scale = x.square().mean().sqrt()
+    return scale, x / scale
+
+
+def reconstruct_ref_fullpersp(normalized_2d, coords3d_rel, validity_mask):
+    """ptu3d.py:56-105: weighted ridge least squares for the reference point.
+
+    Rows per joint: [1 0 -x; 0 1 -y] ref = x*z_rel - xy_rel, with x and the rhs each divided by a
+    batch-global RMS; weights mask+1e-4; three ridge rows sqrt(1e-2)*I; torch.linalg.lstsq."""
+    n_batch, n_points = normalized_2d.shape[:2]
+    dtype = normalized_2d.dtype
+    eye2 = torch.eye(2, dtype=dtype).unsqueeze(0).repeat(n_batch, n_points, 1)
+    scale2d, xy_n = _batch_rms_normalize(normalized_2d.reshape(-1, n_points * 2, 1))
+    a_data = torch.cat([eye2, -xy_n], dim=2)
+    eye3 = torch.eye(3, dtype=dtype).unsqueeze(0).repeat(n_batch, 1, 1)
+    a_full = torch.cat([a_data, eye3], dim=1)
+
+    rel_backproj = normalized_2d * coords3d_rel[:, :, 2:] - coords3d_rel[:, :, :2]
+    scale_rhs, rhs = _batch_rms_normalize(rel_backproj.reshape(-1, n_points * 2, 1))
+    rhs_full = torch.cat([rhs, torch.zeros(n_batch, 3, 1, dtype=torch.float32)], dim=1)
+
+    w = validity_mask.float() + np.float32(1e-4)
+    w = torch.repeat_interleave(w, 2, dim=1).unsqueeze(-1)  # 'b j -> b (j c) 1', c=2
+    w_ridge = torch.full((n_batch, 3, 1), np.sqrt(1e-2), dtype=torch.float32)
+    w_full = torch.cat([w, w_ridge], dim=1)
+
+    ref = torch.linalg.lstsq(a_full * w_full, rhs_full * w_full).solution
+    ref = torch.cat([ref[:, :2] * scale_rhs, ref[:, 2:] * (scale_rhs / scale2d)], dim=1)
+    return torch.squeeze(ref, dim=-1)
+
+
+def reconstruct_absolute(coords2d, coords3d_rel, intrinsics, cfg, mix_3d_inside_fov='cfg',
+                         weak_perspective=None):
+    """ptu3d.py:9-33.  ``mix_3d_inside_fov='cfg'`` takes cfg.mix_3d_inside_fov, which is what
+    Metrabs.forward passes (models/metrabs.py:57-59)."""
+    if mix_3d_inside_fov == 'cfg':
+        mix_3d_inside_fov = cfg.mix_3d_inside_fov
+    inv_k = torch.linalg.inv(intrinsics.to(coords2d.dtype))
+    normalized = (to_homogeneous(coords2d) @ inv_k.transpose(1, 2))[..., :2]
+    if weak_perspective is None:
+        weak_perspective = cfg.weak_perspective
+    in_fov = is_within_fov(coords2d, cfg)
+    if weak_perspective:
+        ref = reconstruct_ref_weakpersp(normalized, coords3d_rel, in_fov)
+    else:
+        ref = reconstruct_ref_fullpersp(normalized, coords3d_rel, in_fov)
+    abs_3d_based = coords3d_rel + ref[:, np.newaxis]
+    abs_2d_based = back_project(normalized, coords3d_rel[..., 2], ref[:, 2])
+    if mix_3d_inside_fov is not None:
+        abs_2d_based = (mix_3d_inside_fov * abs_3d_based +
+                        (1 - mix_3d_inside_fov) * abs_2d_based)
+    return torch.where(in_fov[..., np.newaxis], abs_2d_based, abs_3d_based)
+
+
+def crop_model_from_features(features, weight, bias, intrinsics, n_points, cfg):
+    """Metrabs.forward after the backbone, models/metrabs.py:50-59."""
+    coords2d, coords3d_rel = heads_forward(features, weight, bias, n_points, cfg)
+    return reconstruct_absolute(coords2d, coords3d_rel, intrinsics, cfg)
+
+
+def lookat_matrix(forward_vector, up_vector):
+    """ptu3d.py:129-142."""
+    new_z = forward_vector / torch.linalg.norm(forward_vector, dim=-1, keepdim=True)
+    new_x = torch.linalg.cross(new_z, up_vector)
+    new_x_alt = torch.stack([new_z[:, 2], torch.zeros_like(new_z[:, 2]), -new_z[:, 0]], dim=1)
+    new_x = torch.where(torch.linalg.norm(new_x, dim=-1, keepdim=True) == 0, new_x_alt, new_x)
+    new_x = new_x / torch.linalg.norm(new_x, dim=-1, keepdim=True)
+    new_y = torch.linalg.cross(new_z, new_x)
+    return torch.stack([new_x, new_y, new_z], dim=1)
+
+
+def intrinsic_matrix_from_field_of_view(fov_degrees, imshape):
+    """ptu3d.py:149-161."""
+    imshape = torch.tensor(imshape, dtype=torch.float32)
+    fov_radians = fov_degrees * torch.tensor(np.pi / 180, dtype=torch.float32)
+    larger_side = torch.max(imshape)
+    focal = larger_side / (torch.tan(fov_radians / 2) * 2)
+    zero = torch.tensor(0, dtype=torch.float32)
+    one = torch.tensor(1, dtype=torch.float32)
+    return torch.stack([
+        torch.stack([focal, zero, imshape[1] / 2], dim=-1),
+        torch.stack([zero, focal, imshape[0] / 2], dim=-1),
+        torch.stack([zero, zero, one], dim=-1)], dim=-2).unsqueeze(0)
+
+
+def rotation_mat_z(angle):
+    """ptu3d.rotation_mat(angle, rot_axis='z'), ptu3d.py:164-184."""
+    sin, cos = torch.sin(angle), torch.cos(angle)
+    zero, one = torch.zeros_like(angle), torch.ones_like(angle)
+    return torch.stack([
+        torch.stack([cos, -sin, zero], dim=-1),
+        torch.stack([sin, cos, zero], dim=-1),
+        torch.stack([zero, zero, one], dim=-1)], dim=-2)
+
+
+# ----------------------------------------------------------------------------------------------
+# multiperson/warping.py
+# ----------------------------------------------------------------------------------------------
+
+def corner_aligned_scale_mat(factor):
+    """warping.py:128-133."""
+    shift = (factor - 1) / 2
+    return torch.from_numpy(np.array(
+        [[factor, 0, shift], [0, factor, shift], [0, 0, 1]], dtype=np.float32))
+
+
+def _pad_last_to(x, size):
+    """warping.pad_axis_to_size(x, size, -1), warping.py:110-113."""
+    return F.pad(x, (0, size - x.shape[-1]))
+
+
+def distortion_formula_parts(points, coeffs):
+    """warping.py:90-107.  OpenCV order (k1,k2,p1,p2,k3,k4,k5,k6,s1,s2,s3,s4), zero padded."""
+    d = _pad_last_to(coeffs, 12)
+    shape = ([-1] if d.ndim > 1 else []) + [1] * (points.ndim - d.ndim) + [12]
+    d = torch.reshape(d, shape)
+    r2 = torch.sum(torch.square(points), dim=-1, keepdim=True)
+    a = ((((d[..., 4:5] * r2 + d[..., 1:2]) * r2 + d[..., 0:1]) * r2 + 1) /
+         (((d[..., 7:8] * r2 + d[..., 6:7]) * r2 + d[..., 5:6]) * r2 + 1))
+    p2_1 = torch.flip(d[..., 2:4], dims=[-1])
+    b = 2 * torch.sum(points * p2_1, dim=-1, keepdim=True)
+    c = (d[..., 9:12:2] * r2 + p2_1 + d[..., 8:11:2]) * r2
+    return a, b, c
+
+
+def distort_points(points, coeffs):
+    """warping.py:57-62 (all-zero coefficients short-circuit bit-exactly)."""
+    if torch.all(coeffs == 0):
+        return points
+    a, b, c = distortion_formula_parts(points, coeffs)
+    return points * (a + b) + c
+
+
+def undistort_points(points, coeffs):
+    """warping.py:65-73: five fixed-point iterations."""
+    if torch.all(coeffs == 0):
+        return points
+    und = points
+    for _ in range(5):
+        a, b, c = distortion_formula_parts(und, coeffs)
+        und = (points - c - und * b) / a
+    return und
+
+
+def warp_single_image(image, intrinsic_matrix, new_invprojmat, distortion_coeffs, output_shape):
+    """warping.py:41-54.  image [3,H,W] linear light; returns [3,oh,ow]."""
+    grid = torch.stack(torch.meshgrid(
+        torch.arange(output_shape[1]), torch.arange(output_shape[0]), indexing='xy'),
+        dim=-1).float()
+    rays = torch.einsum('hwc,Cc->hwC', to_homogeneous(grid), new_invprojmat)
+    rays = to_homogeneous(distort_points(project(rays), distortion_coeffs))
+    src = torch.einsum('hwc,Cc->hwC', rays, intrinsic_matrix)[..., :2]
+    size = torch.tensor([image.shape[2], image.shape[1]], dtype=src.dtype)
+    src_n = (src / (size - 1)) * 2 - 1
+    return F.grid_sample(
+        image.unsqueeze(0), src_n.unsqueeze(0), align_corners=True, mode='bilinear',
+        padding_mode='zeros').squeeze(0)
+
+
+def build_pyramid(images, n_levels=3):
+    """warping.py:10-13: 2x2 box filter, floor on odd sizes."""
+    levels = [images]
+    for _ in range(1, n_levels):
+        levels.append(F.avg_pool2d(levels[-1], 2, 2))
+    return levels
+
+
+def pyramid_level_index(crop_scales, n_levels=3):
+    """warping.py:20-21."""
+    return torch.clip(torch.floor(-torch.log2(crop_scales)), 0, n_levels - 1).int()
+
+
+def warp_images_with_pyramid(images, intrinsic_matrix, new_invprojmats, distortion_coeffs,
+                             crop_scales, output_shape, image_ids, n_pyramid_levels=3):
+    """warping.py:6-28."""
+    levels = build_pyramid(images, n_pyramid_levels)
+    k_levels = [corner_aligned_scale_mat(1 / 2 ** lvl) @ intrinsic_matrix
+                for lvl in range(n_pyramid_levels)]
+    lvl_idx = pyramid_level_index(crop_scales, n_pyramid_levels)
+    return torch.stack([
+        warp_single_image(
+            levels[lvl_idx[i]][image_ids[i]], k_levels[lvl_idx[i]][i], new_invprojmats[i],
+            distortion_coeffs[i], output_shape)
+        for i in range(len(image_ids))])
+
+
+# ----------------------------------------------------------------------------------------------
+# multiperson/multiperson_model.py
+# ----------------------------------------------------------------------------------------------
+
+UNKNOWN_INTRINSIC_MATRIX = ((-1, -1, -1), (-1, -1, -1), (-1, -1, -1))
+DEFAULT_EXTRINSIC_MATRIX = ((1, 0, 0, 0), (0, 1, 0, 0), (0, 0, 1, 0), (0, 0, 0, 1))
+DEFAULT_DISTORTION = (0, 0, 0, 0, 0)
+DEFAULT_WORLD_UP = (0, -1, 0)
+
+
+def tta_params(num_aug, rot_aug_degrees=25):
+    """multiperson_model.py:108-137 -> dict(gammas, angles, scales, should_flip, rotflipmat)."""
+    gammas = ref_linspace(np.float32(0.6), np.float32(1.0), num_aug)
+    angle_range = np.float32(np.deg2rad(rot_aug_degrees))
+    angles = ref_linspace(-angle_range, angle_range, num_aug)
+    scales = torch.cat([
+        ref_linspace(0.8, 1.0, num_aug // 2, endpoint=False),
+        torch.linspace(1.0, 1.1, num_aug - num_aug // 2)], dim=0)
+    should_flip = (torch.arange(0, num_aug) - num_aug // 2) % 2 != 0
+    flipmat = torch.tensor([[-1, 0, 0], [0, 1, 0], [0, 0, 1]], dtype=torch.float32)
+    maybe_flip = torch.where(should_flip[:, np.newaxis, np.newaxis], flipmat, torch.eye(3))
+    rotflipmat = maybe_flip @ rotation_mat_z(-angles)
+    return dict(gammas=gammas, angles=angles, scales=scales, should_flip=should_flip,
+                rotflipmat=rotflipmat)
+
+
+def get_new_rotation_and_scale(intrinsic_matrix, distortion_coeffs, camspace_up, boxes, res):
+    """multiperson_model.py:322-355."""
+    x, y, w, h = boxes[:, 0], boxes[:, 1], boxes[:, 2], boxes[:, 3]
+    boxpoints = to_homogeneous(torch.stack([
+        torch.stack([x + w / 2, y + h / 2], dim=1),
+        torch.stack([x + w / 2, y], dim=1),
+        torch.stack([x + w, y + h / 2], dim=1),
+        torch.stack([x + w / 2, y + h], dim=1),
+        torch.stack([x, y + h / 2], dim=1)], dim=1))
+    cam = torch.einsum('bpc,bCc->bpC', boxpoints, torch.linalg.inv(intrinsic_matrix))
+    cam = to_homogeneous(undistort_points(cam[:, :, :2], distortion_coeffs))
+    r_noaug = lookat_matrix(forward_vector=cam[:, 0], up_vector=camspace_up)
+    sides = project(torch.einsum('bpc,bCc->bpC', cam[:, 1:5], intrinsic_matrix @ r_noaug))
+    vertical = torch.linalg.norm(sides[:, 0] - sides[:, 2], dim=-1)
+    horizontal = torch.linalg.norm(sides[:, 1] - sides[:, 3], dim=-1)
+    box_size = torch.maximum(vertical, horizontal)
+    box_scales = torch.tensor(res, dtype=box_size.dtype) / box_size
+    return r_noaug, box_scales
+
+
+def get_crops(images_linear, intrinsic_matrix, distortion_coeffs, camspace_up, boxes, image_ids,
+              aug_rotflipmat, aug_scales, aug_gammas, antialias_factor, res):
+    """multiperson_model.py:264-320.  images_linear: float linear-light [N,3,H,W]."""
+    r_noaug, box_scales = get_new_rotation_and_scale(
+        intrinsic_matrix, distortion_coeffs, camspace_up, boxes, res)
+    crop_scales = aug_scales[:, np.newaxis] * box_scales[np.newaxis, :]
+    num_box, num_aug = boxes.shape[0], aug_gammas.shape[0]
+    new_k = torch.cat([
+        torch.cat([
+            intrinsic_matrix[np.newaxis, :, :2, :2] * crop_scales[:, :, np.newaxis, np.newaxis],
+            torch.full((num_aug, num_box, 2, 1), res / 2, dtype=torch.float32)], dim=3),
+        torch.cat([
+            torch.zeros((num_aug, num_box, 1, 2), dtype=torch.float32),
+            torch.ones((num_aug, num_box, 1, 1), dtype=torch.float32)], dim=3)], dim=2)
+    rot = aug_rotflipmat[:, np.newaxis] @ r_noaug
+    new_invprojmat = torch.linalg.inv(new_k @ rot)
+    if antialias_factor > 1:
+        new_invprojmat = new_invprojmat @ corner_aligned_scale_mat(1 / antialias_factor)
+    crops = warp_images_with_pyramid(
+        images_linear,
+        intrinsic_matrix=torch.tile(intrinsic_matrix, [num_aug, 1, 1]),
+        new_invprojmats=torch.reshape(new_invprojmat, [-1, 3, 3]),
+        distortion_coeffs=torch.tile(distortion_coeffs, [num_aug, 1]),
+        crop_scales=torch.reshape(crop_scales, [-1]) * antialias_factor,
+        output_shape=(res * antialias_factor, res * antialias_factor),
+        image_ids=torch.tile(image_ids, [num_aug]))
+    if antialias_factor == 2:
+        crops = F.avg_pool2d(crops, 2, 2)
+    elif antialias_factor == 4:
+        crops = F.avg_pool2d(crops, 4, 4)
+    elif antialias_factor > 4:
+        raise NotImplementedError('antialias_factor > 4 needs torchvision (not in this image)')
+    crops = torch.reshape(crops, [num_aug, num_box, 3, res, res])
+    crops **= torch.reshape(aug_gammas / 2.2, [-1, 1, 1, 1, 1])
+    return crops, new_k, rot
+
+
+def predict_single_batch(crop_model, mirror_mapping, n_joints, images_linear, intrinsic_matrix,
+                         distortion_coeffs, camspace_up, boxes, image_ids, tta, antialias_factor,
+                         res):
+    """multiperson_model.py:227-259.  crop_model((crops[n,3,res,res], K[n,3,3])) -> [n,J,3]."""
+    crops, new_k, rot = get_crops(
+        images_linear, intrinsic_matrix, distortion_coeffs, camspace_up, boxes, image_ids,
+        tta['rotflipmat'], tta['scales'], tta['gammas'], antialias_factor, res)
+    poses_flat = crop_model((torch.reshape(crops, (-1, 3, res, res)),
+                             torch.reshape(new_k, (-1, 3, 3))))
+    num_aug = tta['should_flip'].shape[0]
+    poses = torch.reshape(poses_flat, [num_aug, -1, n_joints, 3])
+    swapped = poses[..., mirror_mapping, :]
+    poses = torch.where(torch.reshape(tta['should_flip'], [-1, 1, 1, 1]), swapped, poses)
+    return (poses @ rot).transpose(0, 1)
+
+
+def predict_in_batches(crop_model, mirror_mapping, n_joints, images_u8, intrinsic_matrix,
+                       distortion_coeffs, camspace_up, boxes, internal_batch_size, tta,
+                       antialias_factor, res):
+    """multiperson_model.py:184-225."""
+    num_aug = len(tta['gammas'])
+    boxes_per_batch = internal_batch_size // num_aug
+    boxes_flat = torch.cat(boxes, dim=0)
+    image_id_per_box = torch.repeat_interleave(
+        torch.arange(len(boxes)), torch.tensor([len(b) for b in boxes]))
+    images_linear = (images_u8.float() / 255) ** 2.2
+    args = (crop_model, mirror_mapping, n_joints, images_linear)
+    if boxes_per_batch == 0:
+        return predict_single_batch(
+            *args, intrinsic_matrix, distortion_coeffs, camspace_up, boxes_flat,
+            image_id_per_box, tta, antialias_factor, res)
+    n_batches = int(np.ceil(len(boxes_flat) / boxes_per_batch))
+    out = []
+    for i in range(n_batches):
+        s = slice(i * boxes_per_batch, (i + 1) * boxes_per_batch)
+        out.append(predict_single_batch(
+            *args, intrinsic_matrix[s], distortion_coeffs[s], camspace_up[s], boxes_flat[s],
+            image_id_per_box[s], tta, antialias_factor, res))
+    return torch.cat(out, dim=0)
+
+
+def estimate_poses_batched(crop_model, mirror_mapping, n_joints, res, images, boxes,
+                           intrinsic_matrix, distortion_coeffs, extrinsic_matrix, world_up_vector,
+                           default_fov_degrees=55, internal_batch_size=64, antialias_factor=1,
+                           num_aug=5, average_aug=True, skeleton_indices=None,
+                           joint_transform_matrix=None):
+    """Pose3dEstimator._estimate_poses_batched, multiperson_model.py:76-182.
+
+    images: uint8 [N,3,H,W]; boxes: list of [n_i,5]; camera params as float32 tensors with a
+    leading dim of 1 or N.  Returns dict(boxes, poses3d, poses2d) with ragged lists."""
+    n_images = len(images)
+    if len(intrinsic_matrix) == 1:
+        if torch.all(intrinsic_matrix == -1):
+            intrinsic_matrix = intrinsic_matrix_from_field_of_view(
+                default_fov_degrees, images.shape[2:4])
+        intrinsic_matrix = torch.repeat_interleave(intrinsic_matrix, n_images, dim=0)
+    if len(distortion_coeffs) == 1:
+        distortion_coeffs = torch.repeat_interleave(distortion_coeffs, n_images, dim=0)
+    if len(extrinsic_matrix) == 1:
+        extrinsic_matrix = torch.repeat_interleave(extrinsic_matrix, n_images, dim=0)
+
+    counts = [len(b) for b in boxes]
+    n_box_per_image = torch.tensor(counts)
+    intrinsic_matrix = torch.repeat_interleave(intrinsic_matrix, n_box_per_image, dim=0)
+    distortion_coeffs = torch.repeat_interleave(distortion_coeffs, n_box_per_image, dim=0)
+    camspace_up = torch.einsum('c,bCc->bC', world_up_vector, extrinsic_matrix[..., :3, :3])
+    camspace_up = torch.repeat_interleave(camspace_up, n_box_per_image, dim=0)
+
+    tta = tta_params(num_aug)
+    poses3d_flat = predict_in_batches(
+        crop_model, mirror_mapping, n_joints, images, intrinsic_matrix, distortion_coeffs,
+        camspace_up, boxes, internal_batch_size, tta, antialias_factor, res)
+    if joint_transform_matrix is not None:
+        poses3d_flat = torch.einsum('bank,nN->baNk', poses3d_flat, joint_transform_matrix)
+
+    poses2d_norm = to_homogeneous(distort_points(project(poses3d_flat), distortion_coeffs))
+    poses2d_flat = torch.einsum('bank,bjk->banj', poses2d_norm, intrinsic_matrix[:, :2, :])
+
+    inv_ext = torch.repeat_interleave(
+        torch.linalg.inv(extrinsic_matrix), n_box_per_image, dim=0)
+    poses3d_flat = torch.einsum(
+        'bank,bjk->banj', to_homogeneous(poses3d_flat), inv_ext[:, :3, :])
+    poses3d = list(torch.split(poses3d_flat, counts))
+    poses2d = list(torch.split(poses2d_flat, counts))
+    if skeleton_indices is not None:
+        poses3d = [p[..., skeleton_indices, :] for p in poses3d]
+        poses2d = [p[..., skeleton_indices, :] for p in poses2d]
+    if average_aug:
+        poses3d = [torch.mean(p, dim=-3) for p in poses3d]
+        poses2d = [torch.mean(p, dim=-3) for p in poses2d]
+    return dict(boxes=boxes, poses3d=poses3d, poses2d=poses2d)
+
+
+def mpjpe(a, b):
+    """Mean per-joint position error (mean L2 over joints), metrabs_tf/models/eval_metrics.py:17-18
+    without root-centering (ours-vs-oracle comparison)."""
+    return float(torch.linalg.norm(a.double() - b.double(), dim=-1).mean())

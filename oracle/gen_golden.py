@@ -1,0 +1,223 @@
+"""TEST INFRASTRUCTURE: mint the golden vectors in tests/golden/ by RUNNING THE REAL REFERENCE.
+
+Run in the build container (where /root/reference is mounted):
+
+    python -m oracle.gen_golden            # writes tests/golden/*.npz
+
+The reference modules are imported unmodified through oracle/ref_harness.py; inputs come from
+oracle/cases.py (seeded).  Each file stores the reference outputs plus a sha256 of the inputs they
+were computed from.  Nothing here is used by the product.
+"""
+import os
+import platform
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from oracle import cases, ref_harness as rh  # noqa: E402
+
+OUT_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                       'tests', 'golden')
+
+
+def cpu_tag():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor()
+
+
+def meta():
+    return dict(torch_version=np.array(torch.__version__), cpu=np.array(cpu_tag()),
+                num_threads=np.array(torch.get_num_threads()))
+
+
+def save(name, **arrays):
+    os.makedirs(OUT_DIR, exist_ok=True)
+    conv = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = v
+    conv.update(meta())
+    path = os.path.join(OUT_DIR, name + '.npz')
+    np.savez_compressed(path, **conv)
+    print(f'{name}: {os.path.getsize(path) / 1024:.1f} KiB')
+
+
+def cfg_kwargs(cfg):
+    d = cfg.as_dict()
+    return d
+
+
+def gen_heads(ref):
+    for name in cases.HEAD_CASES:
+        logits, J, cfg = cases.head_case(name)
+        with rh.config(**cfg_kwargs(cfg)), torch.inference_mode():
+            heads = ref.metrabs_model.MetrabsHeads(n_points=J).eval()
+            heads.conv_final = torch.nn.Identity()  # run the reference's own forward on logits
+            c2d, c3d = heads(logits)
+        save(f'heads_{name}', coords2d=c2d, coords3d_rel=c3d,
+             input_sha256=np.array(cases.sha256_of(logits)))
+
+
+def gen_headconv(ref):
+    for name in cases.HEADCONV_CASES:
+        feat, w, b, J, cfg = cases.headconv_case(name)
+        with rh.config(**cfg_kwargs(cfg)), torch.inference_mode():
+            heads = ref.metrabs_model.MetrabsHeads(n_points=J).eval()
+            conv = torch.nn.Conv2d(w.shape[1], w.shape[0], 1)
+            conv.weight.copy_(w[:, :, None, None])
+            conv.bias.copy_(b)
+            heads.conv_final = conv
+            c2d, c3d = heads(feat)
+            logits = conv(feat)
+        # fp64 evaluation of the same conv -> the reference's own rounding floor for this case
+        logits64 = torch.nn.functional.conv2d(feat.double(), w.double()[:, :, None, None], b.double())
+        save(f'headconv_{name}', coords2d=c2d, coords3d_rel=c3d,
+             logits_absmax=np.array(float(logits.abs().max())),
+             logits_fp32_vs_fp64_maxerr=np.array(float((logits.double() - logits64).abs().max())),
+             input_sha256=np.array(cases.sha256_of(feat, w, b)))
+
+
+def gen_recon(ref):
+    for name in cases.RECON_CASES:
+        c2d, rel, K, cfg = cases.recon_case(name)
+        if cfg.weak_perspective:
+            # reconstruct_ref_weakpersp cannot run in the reference on torch 2.10
+            # (ptu.py:30 'torch.Size + list' TypeError) -> that branch is PARITY-UNPINNED; the
+            # oracle restates it from the code (and the TF twin tfu3d.py:145-162) only.
+            print(f'recon_{name}: skipped (reference branch not executable)')
+            continue
+        with rh.config(**cfg_kwargs(cfg)), torch.inference_mode():
+            out = ref.ptu3d.reconstruct_absolute(
+                c2d, rel, K, mix_3d_inside_fov=cfg.mix_3d_inside_fov)
+            # the reference point itself (pre-mix), useful for debugging the solver
+            inv_k = torch.linalg.inv(K)
+            norm2d = (ref.ptu3d.to_homogeneous(c2d) @ inv_k.transpose(1, 2))[..., :2]
+            in_fov = ref.ptu3d.is_within_fov(c2d)
+            fn = (ref.ptu3d.reconstruct_ref_weakpersp if cfg.weak_perspective
+                  else ref.ptu3d.reconstruct_ref_fullpersp)
+            refpoint = fn(norm2d, rel, in_fov)
+        save(f'recon_{name}', poses3d=out, ref_point=refpoint, in_fov=in_fov,
+             input_sha256=np.array(cases.sha256_of(c2d, rel, K)))
+
+
+def gen_warp(ref):
+    for name in cases.WARP_CASES:
+        c = cases.warp_case(name)
+        with torch.inference_mode():
+            crops = ref.warping.warp_images_with_pyramid(
+                c['images'], c['K'], c['hinv'], c['dist'], c['crop_scales'],
+                (c['res'], c['res']), c['image_ids'])
+        save(f'warp_{name}', crops=crops,
+             input_sha256=np.array(cases.sha256_of(
+                 c['images_u8'], c['K'], c['hinv'], c['dist'], c['crop_scales'], c['image_ids'])))
+
+
+def gen_tta(ref):
+    """TTA parameter tables computed by the reference's own expressions:
+    run _estimate_poses_batched with a recording stub for _predict_in_batches."""
+    out = {}
+    for num_aug in range(1, 7):
+        rec = {}
+
+        class CM(torch.nn.Module):
+            joint_names = np.array(cases.COCO17)
+            joint_edges = np.array(cases.COCO17_EDGES)
+            input_resolution = 64
+
+        est = ref.multiperson_model.Pose3dEstimator(
+            CM(), {'': dict(indices=list(range(17)), names=cases.COCO17, edges=cases.COCO17_EDGES)},
+            np.eye(17, dtype=np.float32))
+
+        def fake_predict(images, K, dist, up, boxes, ibs, should_flip, rotflip, gammas, scales, aa):
+            rec.update(should_flip=should_flip, rotflipmat=rotflip, gammas=gammas, scales=scales)
+            n = sum(len(b) for b in boxes)
+            return torch.zeros(n, len(gammas), 17, 3) + torch.tensor([0.0, 0.0, 1000.0])
+
+        est._predict_in_batches = fake_predict
+        images = torch.zeros(1, 3, 32, 32, dtype=torch.uint8)
+        boxes = [torch.tensor([[4.0, 4.0, 10.0, 20.0, 1.0]])]
+        with torch.inference_mode():
+            est._estimate_poses_batched(
+                images, boxes, torch.tensor([[[-1.0] * 3] * 3]), torch.zeros(1, 5),
+                torch.eye(4)[None], torch.tensor([0.0, -1.0, 0.0]), 55, 64, 1, num_aug, True, '',
+                False)
+        for k, v in rec.items():
+            out[f'a{num_aug}_{k}'] = v
+    save('tta_params', **out)
+
+
+def build_reference_estimator(ref, case):
+    joint_info = rh._JointInfoStub(cases.COCO17, cases.COCO17_EDGES)
+    crop_model = ref.metrabs_model.Metrabs(case['backbone'], joint_info).eval()
+    conv = torch.nn.Conv2d(cases.E2E_C, 17 * (1 + case['cfg'].depth), 1)
+    with torch.no_grad():
+        conv.weight.copy_(case['head_w'][:, :, None, None])
+        conv.bias.copy_(case['head_b'])
+    crop_model.heatmap_heads.conv_final = conv
+    skel = {'': dict(indices=case['skeleton'], names=[cases.COCO17[i] for i in case['skeleton']],
+                     edges=[[0, 1]])}
+    jtm = case['jtm'] if case['jtm'] is not None else np.eye(17, dtype=np.float32)
+    est = ref.multiperson_model.Pose3dEstimator(crop_model, skel, jtm)
+    if case['jtm'] is None:
+        est.joint_transform_matrix = None
+    return est
+
+
+def gen_e2e(ref):
+    import warnings
+    warnings.filterwarnings('ignore', message='.*CUDA is not available.*')
+    for name in cases.E2E_CASES:
+        case = cases.e2e_case(name)
+        with rh.config(**cfg_kwargs(case['cfg'])), torch.inference_mode():
+            est = build_reference_estimator(ref, case)
+            recorded = []
+            orig_get_crops = est._get_crops
+
+            def rec_get_crops(*a, **k):
+                r = orig_get_crops(*a, **k)
+                recorded.append([x.clone() for x in r])
+                return r
+
+            est._get_crops = rec_get_crops
+            res = est._estimate_poses_batched(
+                case['images'], case['boxes'], case['K'], case['dist'], case['extr'],
+                case['world_up'], 55, case['ibs'], case['aa'], case['num_aug'],
+                case['average_aug'], '', False)
+        crops0, newk0, rot0 = recorded[0]
+        flat = crops0.reshape(-1, *crops0.shape[2:])
+        arrays = dict(
+            poses3d=torch.cat(res['poses3d']), poses2d=torch.cat(res['poses2d']),
+            counts=np.array([len(p) for p in res['poses3d']]),
+            batch0_crops_head=flat[:4], batch0_new_k=newk0, batch0_rot=rot0,
+            batch0_crop_mean=flat.double().mean(dim=(1, 2, 3)),
+            batch0_crop_sqsum=flat.double().square().sum(dim=(1, 2, 3)),
+            n_internal_batches=np.array(len(recorded)),
+            input_sha256=np.array(cases.sha256_of(
+                case['images'], torch.cat(case['boxes']), case['K'], case['dist'], case['extr'],
+                case['head_w'], case['head_b'])))
+        save(f'e2e_{name}', **arrays)
+
+
+def main():
+    torch.manual_seed(0)
+    ref = rh.load()
+    gen_heads(ref)
+    gen_headconv(ref)
+    gen_recon(ref)
+    gen_warp(ref)
+    gen_tta(ref)
+    gen_e2e(ref)
+
+
+if __name__ == '__main__':
+    main()

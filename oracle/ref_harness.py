@@ -1,0 +1,158 @@
+"""TEST INFRASTRUCTURE ONLY -- loads the *real* reference (isarandi/metrabs, metrabs_pytorch) read-only.
+
+This module imports the reference's PyTorch modules unmodified from ``/root/reference`` by
+pre-registering small stub modules for dependencies that are absent in this image
+(hydra/posepile/simplepyutils/torchvision/ultralytics).  It is used for two
+things only:
+
+* ``oracle/gen_golden.py`` -- minting the golden vectors under ``tests/golden/``;
+* ``tests/test_oracle_pin.py`` -- re-checking the in-repo restatement (``oracle/cpu_ref.py``)
+  against the live reference when ``/root/reference`` is present (build container only).
+
+``/root/reference`` does not exist on the GPU box; nothing in ``-m gpu`` tests, ``smoke()`` or
+``bench.py`` may import this file.  No reference source is copied: the modules are executed where
+they lie.
+"""
+import contextlib
+import os
+import sys
+import types
+
+REFERENCE_ROOT = os.environ.get('METRABS_REFERENCE_ROOT', '/root/reference')
+
+
+def reference_available():
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, 'metrabs_pytorch'))
+
+
+class RefConfig(types.SimpleNamespace):
+    """Stand-in for the hydra config returned by metrabs_pytorch.util.get_config()
+    (metrabs_pytorch/util.py:41-57; keys from metrabs_pytorch/config/config.yaml:1-22 and
+    config_s_256.yaml:5-9)."""
+
+
+DEFAULT_CONFIG = dict(
+    proc_side=256, stride_train=32, stride_test=32, centered_stride=True,
+    legacy_centered_stride_bug=False, depth=8, box_size_mm=2200.0, weak_perspective=False,
+    mix_3d_inside_fov=0.5, affine_weights=None, transform_coords=False,
+    predict_all_and_latents=False, regularize_to_manifold=False)
+
+_config = RefConfig(**DEFAULT_CONFIG)
+_loaded = {}
+
+
+def set_config(**kwargs):
+    """Mutates the live config object that the reference reads at call time."""
+    for k, v in kwargs.items():
+        if k not in DEFAULT_CONFIG:
+            raise KeyError(k)
+        setattr(_config, k, v)
+
+
+@contextlib.contextmanager
+def config(**kwargs):
+    old = {k: getattr(_config, k) for k in kwargs}
+    set_config(**kwargs)
+    try:
+        yield _config
+    finally:
+        set_config(**old)
+
+
+class _JointInfoStub:
+    """posepile.joint_info.JointInfo as far as multiperson_model.py:25,246-251 needs it:
+    ``n_joints``, ``names``, ``stick_figure_edges`` and ``mirror_mapping`` (left/right swap found
+    by the leading 'l'/'r' of the joint name, which is posepile's documented convention)."""
+
+    def __init__(self, names, edges):
+        import numpy as np
+        self.names = [str(n) for n in names]
+        self.n_joints = len(self.names)
+        self.stick_figure_edges = [tuple(int(x) for x in e) for e in edges]
+        index = {n: i for i, n in enumerate(self.names)}
+        mapping = []
+        for n in self.names:
+            if n.startswith('l') and ('r' + n[1:]) in index:
+                mapping.append(index['r' + n[1:]])
+            elif n.startswith('r') and ('l' + n[1:]) in index:
+                mapping.append(index['l' + n[1:]])
+            else:
+                mapping.append(index[n])
+        self.mirror_mapping = np.array(mapping, dtype=np.int64)
+
+
+def _install_stubs():
+    import torch
+
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+
+    pkg = types.ModuleType('metrabs_pytorch')
+    pkg.__path__ = [os.path.join(REFERENCE_ROOT, 'metrabs_pytorch')]
+    sys.modules['metrabs_pytorch'] = pkg
+
+    util = types.ModuleType('metrabs_pytorch.util')
+    util.get_config = lambda *a, **k: _config
+    sys.modules['metrabs_pytorch.util'] = util
+    pkg.util = util
+
+    posepile = types.ModuleType('posepile')
+    posepile.__path__ = []
+    paths = types.ModuleType('posepile.paths')
+    paths.DATA_ROOT = '/nonexistent'
+    ji = types.ModuleType('posepile.joint_info')
+    ji.JointInfo = _JointInfoStub
+    posepile.paths, posepile.joint_info = paths, ji
+    sys.modules.update({'posepile': posepile, 'posepile.paths': paths,
+                        'posepile.joint_info': ji})
+
+    tv = types.ModuleType('torchvision')
+    tv.__path__ = []
+    tvt = types.ModuleType('torchvision.transforms')
+    tvt.__path__ = []
+    tvf = types.ModuleType('torchvision.transforms.functional')
+    tv.transforms, tvt.functional = tvt, tvf
+    sys.modules.update({'torchvision': tv, 'torchvision.transforms': tvt,
+                        'torchvision.transforms.functional': tvf})
+
+    ul = types.ModuleType('ultralytics')
+
+    class YOLO:  # the detector is out of scope; boxes are supplied by the caller
+        def __init__(self, *a, **k):
+            pass
+
+    ul.YOLO = YOLO
+    sys.modules['ultralytics'] = ul
+
+    # multiperson_model.py:154-155,171 pass a Tensor of sizes to torch.split, which torch 2.10
+    # rejects; accept it the way older torch did.
+    if not getattr(torch.split, '_mtr_compat', False):
+        orig_split = torch.split
+
+        def split_compat(tensor, split_size_or_sections, dim=0):
+            if isinstance(split_size_or_sections, torch.Tensor):
+                split_size_or_sections = [int(x) for x in split_size_or_sections]
+            return orig_split(tensor, split_size_or_sections, dim)
+
+        split_compat._mtr_compat = True
+        torch.split = split_compat
+
+
+def load():
+    """Returns a namespace with the reference modules (ptu, ptu3d, model_util, metrabs_model,
+    warping, multiperson_model)."""
+    if _loaded:
+        return types.SimpleNamespace(**_loaded)
+    if not reference_available():
+        raise RuntimeError(f'reference not found at {REFERENCE_ROOT}')
+    _install_stubs()
+    import importlib
+    _loaded['ptu'] = importlib.import_module('metrabs_pytorch.ptu')
+    _loaded['ptu3d'] = importlib.import_module('metrabs_pytorch.ptu3d')
+    _loaded['model_util'] = importlib.import_module('metrabs_pytorch.models.util')
+    _loaded['metrabs_model'] = importlib.import_module('metrabs_pytorch.models.metrabs')
+    _loaded['warping'] = importlib.import_module('metrabs_pytorch.multiperson.warping')
+    _loaded['multiperson_model'] = importlib.import_module(
+        'metrabs_pytorch.multiperson.multiperson_model')
+    _loaded['JointInfo'] = _JointInfoStub
+    return types.SimpleNamespace(**_loaded)
