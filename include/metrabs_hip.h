@@ -1,0 +1,176 @@
+/*
+ * metrabs_hip.h -- C-ABI of the MI355X-native MeTRAbs per-crop hot path (libmetrabs_hip.so).
+ *
+ * The reference (isarandi/metrabs) is pure Python and has no FFI boundary; the path is reached by
+ * ordinary method calls.  Each entry point below replaces the reference
+ * call(s) cited next to it; the Python drop-ins in metrabs_amd/ (same class / function names as the
+ * reference) are the only callers, via ctypes (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless it says "host";
+ *   - nothing allocates, synchronises or touches global state: every call only enqueues work on
+ *     `stream` (a hipStream_t), so all of them are hipGraph-capturable and re-entrant;
+ *   - return value: 0 = ok, <0 = argument error detected on the host before any launch
+ *     (MTR_E_*), >0 = hipError_t of a failed launch.  Nothing throws or exits across the ABI;
+ *   - tensors are dense, row-major in the index order written in the comment.
+ */
+#ifndef METRABS_HIP_H_
+#define METRABS_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTR_VERSION 100 /* 0.1.0 */
+
+typedef void* mtr_stream_t; /* hipStream_t */
+
+enum mtr_dtype { MTR_F32 = 0, MTR_F16 = 1, MTR_BF16 = 2 };
+
+enum mtr_layout {
+  MTR_NCHW = 0, /* metrabs_pytorch: [B, C, H, W]            (models/metrabs.py:79 'b (d j) h w') */
+  MTR_NHWC = 1  /* metrabs_tf / torch channels_last: [B,H,W,C] (tf models/metrabs.py:100-101)      */
+};
+
+enum mtr_error {
+  MTR_OK = 0,
+  MTR_E_NULL = -1,      /* a required pointer is NULL                      */
+  MTR_E_SHAPE = -2,     /* a dimension is <= 0 or out of the supported range */
+  MTR_E_DTYPE = -3,     /* unsupported dtype / layout combination           */
+  MTR_E_PARAM = -4,     /* inconsistent params struct                       */
+  MTR_E_WORKSPACE = -5, /* workspace too small / misaligned                 */
+  MTR_E_ALIGN = -6      /* a pointer violates the documented alignment      */
+};
+
+/* The flags the reference reads from its global config at call time
+ * (metrabs_pytorch/config/config.yaml:1-22, config_s_256.yaml:5-9; read in models/util.py:7,24,30). */
+typedef struct mtr_head_params {
+  int32_t proc_side;                  /* FLAGS.proc_side (256 / 384)                          */
+  int32_t stride_test;                /* FLAGS.stride_test: inference stride of heatmap_to_image */
+  int32_t centered_stride;            /* FLAGS.centered_stride                                 */
+  int32_t legacy_centered_stride_bug; /* FLAGS.legacy_centered_stride_bug                      */
+  float box_size_mm;                  /* FLAGS.box_size_mm (2200)                              */
+} mtr_head_params;
+
+/* Flags / constants of ptu3d.reconstruct_absolute and friends (ptu3d.py:9-33,56-121). */
+typedef struct mtr_recon_params {
+  int32_t proc_side;         /* FLAGS.proc_side                                   */
+  int32_t stride_train;      /* FLAGS.stride_train (is_within_fov, ptu3d.py:115)  */
+  int32_t centered_stride;   /* FLAGS.centered_stride (ptu3d.py:116)              */
+  int32_t weak_perspective;  /* FLAGS.weak_perspective (ptu3d.py:14-18)           */
+  int32_t mix_enabled;       /* 0 <=> mix_3d_inside_fov is None (ptu3d.py:28)     */
+  float mix_3d_inside_fov;   /* FLAGS.mix_3d_inside_fov (0.5)                     */
+  float l2_reg;              /* 1e-2   (ridge rows sqrt(1e-2), ptu3d.py:96-97)    */
+  float weight_eps;          /* 1e-4   (weights = mask + 1e-4, ptu3d.py:94)       */
+  float fov_border_factor;   /* 0.75   (is_within_fov default, ptu3d.py:113)      */
+} mtr_recon_params;
+
+int mtr_version(void);
+const char* mtr_strerror(int code);
+
+/* ------------------------------------------------------------------------------------------------
+ * K2-K4: volumetric soft-argmax decode.  Replaces, for logits already in memory,
+ *   MetrabsHeads.forward after the 1x1 conv   metrabs_pytorch/models/metrabs.py:78-85
+ *   ptu.softmax / ptu.decode_heatmap          metrabs_pytorch/ptu.py:47-75
+ *   heatmap_to_image / heatmap_to_metric      metrabs_pytorch/models/util.py:6-33
+ *
+ * logits   [B, J*(1+D), H, W] (MTR_NCHW) or [B, H, W, J*(1+D)] (MTR_NHWC), dtype f32/f16/bf16.
+ *          channel n < J: 2D heatmap of joint n; channel J + d*J + j: depth slice d of joint j.
+ * coords2d     [B, J, 2] f32, pixels (x, y) of the crop
+ * coords3d_rel [B, J, 3] f32, millimetres (x, y, z) relative to the unknown reference point
+ */
+int mtr_softargmax_decode(const void* logits, int dtype, int layout, int B, int J, int D, int H,
+                          int W, const mtr_head_params* p, float* coords2d, float* coords3d_rel,
+                          mtr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K1+K2-K4 fused: 1x1 heatmap-projection GEMM (MFMA) with the decode as its epilogue; the logits
+ * never reach HBM.  Replaces MetrabsHeads.forward as a whole (models/metrabs.py:75-85; the conv is
+ * torch.nn.LazyConv2d(kernel_size=1), models/metrabs.py:73).
+ *
+ * mtr_head_pack_weights re-orders conv_final.weight [J*(1+D), C] (+bias) ONCE into the joint-major
+ * tiled layout the kernel streams; `packed` must hold
+ * mtr_head_packed_bytes(...) bytes.  features: [B, C, H, W] (NCHW) or [B, H, W, C] (NHWC).
+ */
+size_t mtr_head_packed_bytes(int C, int J, int D, int feat_dtype);
+int mtr_head_pack_weights(const float* weight /*[J*(1+D), C] f32*/, const float* bias /*[J*(1+D)]*/,
+                          int C, int J, int D, int feat_dtype, void* packed, mtr_stream_t stream);
+int mtr_head_fused(const void* features, int feat_dtype, int layout, int B, int C, int H, int W,
+                   const void* packed, int J, int D, const mtr_head_params* p, float* coords2d,
+                   float* coords3d_rel, mtr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K5: absolute (camera-space) reconstruction.  Replaces
+ *   ptu3d.reconstruct_absolute        metrabs_pytorch/ptu3d.py:9-33
+ *   ptu3d.reconstruct_ref_fullpersp   metrabs_pytorch/ptu3d.py:56-105
+ *   ptu3d.reconstruct_ref_weakpersp   metrabs_pytorch/ptu3d.py:36-49
+ *   ptu3d.is_within_fov / back_project           ptu3d.py:108-121
+ *
+ * The two RMS scalars of reconstruct_ref_fullpersp are taken over the WHOLE call batch
+ * (ptu3d.py:71-74): B here must be the reference's internal batch for bit-comparable results.
+ * workspace: mtr_reconstruct_workspace_bytes(B, J) bytes, 16-byte aligned.
+ *
+ * The split form exposes the batch moments so that a sharded caller can all-reduce them
+ * (SURVEY.md section 8e "exact-monolithic mode"):
+ *   mtr_reconstruct_moments -> moments[0] = sum(normalized2d^2), moments[1] = sum(rel_backproj^2),
+ *                              moments[2] = number of summed elements (B*J*2), all f64;
+ *   mtr_reconstruct_solve   <- the (possibly all-reduced) moments.
+ */
+size_t mtr_reconstruct_workspace_bytes(int B, int J);
+int mtr_reconstruct_absolute(const float* coords2d /*[B,J,2]*/, const float* coords3d_rel /*[B,J,3]*/,
+                             const float* intrinsics /*[B,3,3]*/, int B, int J,
+                             const mtr_recon_params* p, float* poses3d /*[B,J,3]*/, void* workspace,
+                             size_t workspace_bytes, mtr_stream_t stream);
+int mtr_reconstruct_moments(const float* coords2d, const float* coords3d_rel,
+                            const float* intrinsics, int B, int J, double* moments /*[3]*/,
+                            void* workspace, size_t workspace_bytes, mtr_stream_t stream);
+int mtr_reconstruct_solve(const float* coords2d, const float* coords3d_rel, const float* intrinsics,
+                          int B, int J, const mtr_recon_params* p, const double* moments /*[3]*/,
+                          float* poses3d, mtr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K6: crop sampler.
+ *
+ * mtr_build_pyramid replaces the whole-image gamma decode `(u8/255)**2.2`
+ * (multiperson_model.py:196) and the box-filter pyramid (warping.py:10-13):
+ *   images_u8 [N,3,Hi,Wi] u8  ->  level0 [N,3,Hi,Wi], level1 [N,3,Hi/2,Wi/2], level2 [N,3,Hi/4,Wi/4]
+ *   (f32 linear light, floor division on odd sizes as avg_pool2d(2,2)).
+ *
+ * mtr_crop_geometry replaces Pose3dEstimator._get_new_rotation_and_scale and the matrix set-up of
+ * _get_crops (multiperson_model.py:264-305,322-355; ptu3d.lookat_matrix ptu3d.py:129-142;
+ * warping.undistort_points warping.py:65-73): one thread per (aug, box).
+ *   boxes [n_box,4(+)] (x,y,w,h; row stride box_stride floats), intrinsics [n_box,3,3],
+ *   distortion [n_box,12] (zero padded), camspace_up [n_box,3], aug_rotflipmat [n_aug,3,3],
+ *   aug_scales [n_aug]
+ *   -> new_intrinsics [n_aug,n_box,3,3], rot [n_aug,n_box,3,3], warp_params [n_aug*n_box, MTR_WARP_PARAM_FLOATS].
+ *
+ * mtr_warp_crops replaces warping.warp_images_with_pyramid / warp_single_image (warping.py:6-54:
+ * homography, lens distortion warping.py:57-107, per-level intrinsics warping.py:128-133,
+ * grid_sample bilinear/zeros/align_corners=True), the antialias avg_pool2d and the per-crop gamma
+ * `crops **= gamma/2.2` of _get_crops (multiperson_model.py:308-319).
+ *   warp_params [n_crops, MTR_WARP_PARAM_FLOATS] as laid out below; out [n_crops,3,res,res]
+ *   (NCHW) or [n_crops,res,res,3] (NHWC), dtype f32/f16/bf16.
+ */
+#define MTR_WARP_PARAM_FLOATS 36
+/* warp_params row (floats): [0..8] Hinv (new_invprojmat incl. the antialias scale), [9..17] K of
+ * the chosen pyramid level, [18..29] 12 distortion coefficients, [30] has_distortion (0/1),
+ * [31] pyramid level (0..2), [32] image id, [33] gamma exponent (gamma_aug / 2.2), [34..35] pad */
+
+int mtr_build_pyramid(const uint8_t* images_u8, int N, int Hi, int Wi, float* level0, float* level1,
+                      float* level2, mtr_stream_t stream);
+int mtr_crop_geometry(const float* boxes, int box_stride, const float* intrinsics,
+                      const float* distortion, const float* camspace_up, const int32_t* image_ids,
+                      const float* aug_rotflipmat, const float* aug_scales, const float* aug_gammas,
+                      int n_box, int n_aug, int res, int antialias, float* new_intrinsics,
+                      float* rot, float* warp_params, mtr_stream_t stream);
+int mtr_warp_crops(const float* level0, const float* level1, const float* level2, int N, int Hi,
+                   int Wi, const float* warp_params, int n_crops, int res, int antialias,
+                   int out_dtype, int out_layout, void* out, mtr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* METRABS_HIP_H_ */

@@ -1,0 +1,106 @@
+"""ctypes binding of libmetrabs_hip.so (the C-ABI declared in include/metrabs_hip.h).
+
+The product path has NO CPU fallback: if the library is missing, or a kernel entry point returns an
+error, a RuntimeError is raised.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_uint8, c_void_p
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libmetrabs_hip.so')
+
+MTR_F32, MTR_F16, MTR_BF16 = 0, 1, 2
+MTR_NCHW, MTR_NHWC = 0, 1
+MTR_WARP_PARAM_FLOATS = 36
+
+
+class HeadParams(ctypes.Structure):
+    """mtr_head_params (include/metrabs_hip.h)."""
+    _fields_ = [('proc_side', c_int32), ('stride_test', c_int32), ('centered_stride', c_int32),
+                ('legacy_centered_stride_bug', c_int32), ('box_size_mm', c_float)]
+
+
+class ReconParams(ctypes.Structure):
+    """mtr_recon_params (include/metrabs_hip.h)."""
+    _fields_ = [('proc_side', c_int32), ('stride_train', c_int32), ('centered_stride', c_int32),
+                ('weak_perspective', c_int32), ('mix_enabled', c_int32),
+                ('mix_3d_inside_fov', c_float), ('l2_reg', c_float), ('weight_eps', c_float),
+                ('fov_border_factor', c_float)]
+
+
+# name -> (restype, argtypes); must list EVERY symbol the header declares
+# (tests/test_capi_symbols.py cross-checks this table against include/metrabs_hip.h).
+SIGNATURES = {
+    'mtr_version': (c_int, []),
+    'mtr_strerror': (c_char_p, [c_int]),
+    'mtr_softargmax_decode': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                      POINTER(HeadParams), c_void_p, c_void_p, c_void_p]),
+    'mtr_head_packed_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
+    'mtr_head_pack_weights': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                      c_void_p]),
+    'mtr_head_fused': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                               c_int, POINTER(HeadParams), c_void_p, c_void_p, c_void_p]),
+    'mtr_reconstruct_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'mtr_reconstruct_absolute': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                         POINTER(ReconParams), c_void_p, c_void_p, c_size_t,
+                                         c_void_p]),
+    'mtr_reconstruct_moments': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                        c_void_p, c_size_t, c_void_p]),
+    'mtr_reconstruct_solve': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                      POINTER(ReconParams), c_void_p, c_void_p, c_void_p]),
+    'mtr_build_pyramid': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                  c_void_p]),
+    'mtr_crop_geometry': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                  c_void_p, c_void_p, c_void_p]),
+    'mtr_warp_crops': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
+                               c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def load(path=None):
+    """Loads the library and declares every prototype.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f'{path} not found: the HIP extension is not built. Run `python -m metrabs_amd.build` '
+            f'(needs hipcc). metrabs_amd has no CPU fallback.')
+    lib = ctypes.CDLL(path)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().mtr_strerror(code).decode()
+        raise RuntimeError(f'{what} failed: {msg} (code {code})')
+
+
+def dtype_code(torch_dtype):
+    import torch
+    try:
+        return {torch.float32: MTR_F32, torch.float16: MTR_F16, torch.bfloat16: MTR_BF16}[torch_dtype]
+    except KeyError:
+        raise TypeError(f'unsupported dtype {torch_dtype}') from None
+
+
+def current_stream_ptr(device=None):
+    import torch
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                'metrabs_amd kernels run on the GPU only (tensor on %s); there is no CPU fallback'
+                % t.device)

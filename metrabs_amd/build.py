@@ -1,0 +1,81 @@
+"""Builds libmetrabs_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+    python -m metrabs_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  The .so lands next to the sources
+(metrabs_amd/csrc/libmetrabs_hip.so): it is git-ignored but travels with gpurun snapshots.
+"""
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
+LIB_PATH = os.path.join(CSRC, 'libmetrabs_hip.so')
+BUILD_DIR = os.path.join(CSRC, 'build')
+ARCH = 'gfx950'
+FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function']
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
+
+
+def _hipcc():
+    exe = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(exe):
+        raise RuntimeError('hipcc not found; metrabs_amd needs ROCm to build its HIP kernels')
+    return exe
+
+
+def _digest(path):
+    h = hashlib.sha256()
+    h.update(' '.join(FLAGS).encode())
+    for dep in [path] + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith('.h')] \
+            + [os.path.join(os.path.dirname(os.path.dirname(CSRC)), 'include', 'metrabs_hip.h')]:
+        with open(dep, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _compile(src, force):
+    path = os.path.join(CSRC, src)
+    obj = os.path.join(BUILD_DIR, src + '.o')
+    stamp = obj + '.sha256'
+    digest = _digest(path)
+    if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == digest:
+        return obj, False
+    cmd = [_hipcc(), *FLAGS, '-c', path, '-o', obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'hipcc failed for {src}:\n{r.stdout}\n{r.stderr}')
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    with open(stamp, 'w') as f:
+        f.write(digest)
+    return obj, True
+
+
+def build_library(force=False, verbose=True):
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    srcs = sources()
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        results = list(ex.map(lambda s: _compile(s, force), srcs))
+    objs = [o for o, _ in results]
+    rebuilt = any(r for _, r in results)
+    if rebuilt or force or not os.path.exists(LIB_PATH):
+        cmd = [_hipcc(), '-shared', '-fPIC', f'--offload-arch={ARCH}', *objs, '-o', LIB_PATH]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
+        if verbose:
+            print(f'built {LIB_PATH} from {len(srcs)} sources')
+    elif verbose:
+        print(f'{LIB_PATH} is up to date')
+    return LIB_PATH
+
+
+if __name__ == '__main__':
+    build_library(force='--force' in sys.argv)

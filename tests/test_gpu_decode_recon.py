@@ -1,0 +1,158 @@
+"""GPU parity: HIP soft-argmax decode (K2-K4) and reconstruct_absolute (K5) vs the oracle and the
+golden vectors, called through the C-ABI (ctypes).  Tolerances are stated per assertion."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import cases, cpu_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def mcfg(cfg):
+    from metrabs_amd.config import MetrabsConfig
+    return MetrabsConfig.from_any(cfg.as_dict())
+
+
+def report(tag, ours, ref):
+    d = (ours.double() - ref.double())
+    print(f'[parity] {tag}: max-abs {float(d.abs().max()):.3e}  '
+          f'mean-L2 {float(torch.linalg.norm(d, dim=-1).mean()):.3e}')
+
+
+@pytest.mark.parametrize('name', list(cases.HEAD_CASES))
+def test_decode_vs_golden(name, hip_lib):
+    """Identical logits -> coords.  Bound: 1e-3 mm max-abs on coords3d_rel (north star), 2e-4 px on
+    coords2d.  (The reference's own fp32-vs-fp64 floor is ~3e-4 mm, SURVEY.md Appendix B.)"""
+    from metrabs_amd import kernels
+    g = load_golden(f'heads_{name}')
+    logits, J, cfg = cases.head_case(name)
+    assert cases.sha256_of(logits) == str(g['input_sha256'])
+    c2d, c3d = kernels.softargmax_decode(logits.cuda(), J, mcfg(cfg))
+    ref2d, ref3d = torch.from_numpy(g['coords2d']), torch.from_numpy(g['coords3d_rel'])
+    report(f'decode {name} coords3d_rel[mm]', c3d.cpu(), ref3d)
+    report(f'decode {name} coords2d[px]', c2d.cpu(), ref2d)
+    assert float((c3d.cpu() - ref3d).abs().max()) <= 1e-3
+    assert float((c2d.cpu() - ref2d).abs().max()) <= 2e-4
+
+
+@pytest.mark.parametrize('shape', [(5, 17, 8, 8, 8), (3, 23, 8, 12, 12), (2, 4, 3, 6, 10),
+                                   (2, 6, 8, 7, 9), (1, 1, 1, 1, 1), (3, 9, 16, 24, 24),
+                                   (2, 3, 8, 64, 64), (70, 17, 8, 8, 8)])
+def test_decode_vs_oracle_odd_shapes(shape, hip_lib):
+    """Ragged / odd shapes incl. non-square maps, H*W not a multiple of 4, D=1, 1x1 maps, and the
+    stride-4 64x64 map: vs the oracle on the same seeded logits; same bounds as above."""
+    from metrabs_amd import kernels
+    B, J, D, H, W = shape
+    cfg = cpu_ref.HeadConfig(depth=D, proc_side=max(H, W) * 8, stride_test=8, stride_train=8)
+    g = cases.gen(7000 + sum(shape))
+    logits = torch.randn(B, J * (1 + D), H, W, generator=g) * 3
+    with torch.inference_mode():
+        o2d, o3d = cpu_ref.heads_from_logits(logits, J, cfg)
+    c2d, c3d = kernels.softargmax_decode(logits.cuda(), J, mcfg(cfg))
+    report(f'decode odd {shape}', c3d.cpu(), o3d)
+    assert float((c3d.cpu() - o3d).abs().max()) <= 1e-3
+    assert float((c2d.cpu() - o2d).abs().max()) <= 2e-4
+
+
+def test_decode_kat_spike_uniform(hip_lib):
+    from metrabs_amd import kernels
+    from metrabs_amd.config import MetrabsConfig
+    J, D, H, W = 3, 8, 8, 8
+    logits = torch.zeros(1, J * (1 + D), H, W)
+    d, h, w = 5, 2, 7
+    logits[0, J + d * J + 1, h, w] = 1e4
+    logits[0, 1, h, w] = 1e4
+    c2d, c3d = kernels.softargmax_decode(logits.cuda(), J, MetrabsConfig())
+    c2d, c3d = c2d.cpu(), c3d.cpu()
+    exp_px = torch.tensor([w / 7 * 224 + 16, h / 7 * 224 + 16])
+    assert torch.allclose(c2d[0, 1], exp_px, atol=1e-4)
+    assert torch.allclose(c3d[0, 1], torch.tensor(
+        [exp_px[0] * 2200 / 256, exp_px[1] * 2200 / 256, d / 7 * 2200]), atol=1e-3)
+    assert torch.allclose(c2d[0, 0], torch.tensor([128.0, 128.0]), atol=1e-4)
+    assert torch.allclose(c3d[0, 0], torch.tensor([1100.0] * 3), atol=1e-3)
+
+
+def test_decode_large_batch_properties(hip_lib):
+    """BASELINE size (B=32768 crops, 1.28 GB of logits): size-independent properties --
+    (i) permutation equivariance over crops, (ii) shift invariance (adding a per-joint constant to
+    every logit does not move the expectation), (iii) a sampled subset equals the oracle."""
+    from metrabs_amd import kernels
+    from metrabs_amd.config import MetrabsConfig
+    cfg = MetrabsConfig()
+    B, J, D = 32768, 17, 8
+    g = torch.Generator(device='cuda').manual_seed(3)
+    logits = torch.randn(B, J * (1 + D), 8, 8, generator=g, device='cuda')
+    c2d, c3d = kernels.softargmax_decode(logits, J, cfg)
+    perm = torch.randperm(B, device='cuda', generator=g)
+    p2d, p3d = kernels.softargmax_decode(logits[perm].contiguous(), J, cfg)
+    assert torch.equal(p2d, c2d[perm]) and torch.equal(p3d, c3d[perm])
+    shifted = logits[:4096] + 3.25
+    s2d, s3d = kernels.softargmax_decode(shifted, J, cfg)
+    assert float((s3d - c3d[:4096]).abs().max()) <= 1e-3
+    idx = torch.arange(0, B, 4099, device='cuda')
+    with torch.inference_mode():
+        o2d, o3d = cpu_ref.heads_from_logits(logits[idx].cpu(), J, cpu_ref.HeadConfig())
+    assert float((c3d[idx].cpu() - o3d).abs().max()) <= 1e-3
+    assert float((c2d[idx].cpu() - o2d).abs().max()) <= 2e-4
+
+
+@pytest.mark.parametrize('name', list(cases.RECON_CASES))
+def test_reconstruct_vs_golden_and_oracle(name, hip_lib):
+    """Identical coords -> absolute poses.  The reference solves with fp32 LAPACK lstsq (its own
+    run-to-run jitter is 5e-4 mm); ours solves the fp64 normal equations.  Bound: MPJPE <= 1e-3 mm
+    and max-abs <= 4e-3 mm (1.5e-3 max / 3.6e-4 MPJPE expected)."""
+    from metrabs_amd import kernels
+    c2d, rel, K, cfg = cases.recon_case(name)
+    with torch.inference_mode():
+        oracle = cpu_ref.reconstruct_absolute(c2d, rel, K, cfg)
+    out = kernels.reconstruct_absolute(c2d.cuda(), rel.cuda(), K.cuda(), mcfg(cfg)).cpu()
+    report(f'recon {name} vs oracle [mm]', out, oracle)
+    if name != 'b8_weak':  # weak perspective has no golden: the reference branch cannot run
+        g = load_golden(f'recon_{name}')
+        golden = torch.from_numpy(g['poses3d'])
+        report(f'recon {name} vs golden [mm]', out, golden)
+        assert cpu_ref.mpjpe(out, golden) <= 1e-3
+        assert float((out - golden).abs().max()) <= 4e-3
+    assert cpu_ref.mpjpe(out, oracle) <= 1e-3
+    assert float((out - oracle).abs().max()) <= 4e-3
+
+
+def test_reconstruct_batch_coupling_and_split(hip_lib):
+    """(i) the same crop in another batch differs the way the oracle differs (batch-global RMS);
+    (ii) the split moments/solve API with summed shard moments equals the monolithic call."""
+    from metrabs_amd import kernels
+    c2d, rel, K, cfg = cases.recon_case('b64_j17')
+    m = mcfg(cfg)
+    full = kernels.reconstruct_absolute(c2d.cuda(), rel.cuda(), K.cuda(), m).cpu()
+    one = kernels.reconstruct_absolute(c2d[:1].cuda(), rel[:1].cuda(), K[:1].cuda(), m).cpu()
+    with torch.inference_mode():
+        o_full = cpu_ref.reconstruct_absolute(c2d, rel, K, cfg)
+        o_one = cpu_ref.reconstruct_absolute(c2d[:1], rel[:1], K[:1], cfg)
+    ours_delta, oracle_delta = full[:1] - one, o_full[:1] - o_one
+    assert float(oracle_delta.abs().max()) > 1e-4
+    assert float((ours_delta - oracle_delta).abs().max()) <= 4e-3
+    # sharded: two halves, moments summed (what an all-reduce would do)
+    halves = [slice(0, 40), slice(40, 64)]
+    moments = sum(kernels.reconstruct_moments(c2d[s].cuda(), rel[s].cuda(), K[s].cuda())
+                  for s in halves)
+    parts = [kernels.reconstruct_solve(c2d[s].cuda(), rel[s].cuda(), K[s].cuda(), moments, m)
+             for s in halves]
+    assert float((torch.cat(parts).cpu() - full).abs().max()) <= 1e-4
+
+
+def test_error_codes(hip_lib):
+    import ctypes
+    from metrabs_amd import _lib
+    hp = _lib.HeadParams(256, 32, 1, 0, 2200.0)
+    rc = hip_lib.mtr_softargmax_decode(None, 0, 0, 1, 17, 8, 8, 8, ctypes.byref(hp), None, None, None)
+    assert rc == -1 and b'NULL' in hip_lib.mtr_strerror(rc)
+    x = torch.zeros(4, device='cuda')
+    p = ctypes.c_void_p(x.data_ptr())
+    assert hip_lib.mtr_softargmax_decode(p, 0, 0, 1, 0, 8, 8, 8, ctypes.byref(hp), p, p, None) == -2
+    assert hip_lib.mtr_softargmax_decode(p, 7, 0, 1, 1, 1, 1, 1, ctypes.byref(hp), p, p, None) == -3
+    with pytest.raises(RuntimeError):
+        from metrabs_amd import kernels
+        from metrabs_amd.config import MetrabsConfig
+        kernels.softargmax_decode(torch.zeros(1, 9, 8, 8), 1, MetrabsConfig())  # CPU tensor
