@@ -161,6 +161,10 @@ int mtr_reconstruct_solve(const float* coords2d, const float* coords3d_rel, cons
 
 int mtr_build_pyramid(const uint8_t* images_u8, int N, int Hi, int Wi, float* level0, float* level1,
                       float* level2, mtr_stream_t stream);
+/* Same pyramid from an already linear-light f32 level 0 (the argument warping.warp_images_with_pyramid
+ * receives, warping.py:6-13): writes level1 / level2 only. */
+int mtr_pyramid_from_level0(const float* level0, int N, int Hi, int Wi, float* level1, float* level2,
+                            mtr_stream_t stream);
 int mtr_crop_geometry(const float* boxes, int box_stride, const float* intrinsics,
                       const float* distortion, const float* camspace_up, const int32_t* image_ids,
                       const float* aug_rotflipmat, const float* aug_scales, const float* aug_gammas,

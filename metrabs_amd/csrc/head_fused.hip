@@ -1,0 +1,344 @@
+// K1 + K2-K4 fused: 1x1 heatmap projection on the matrix cores with the volumetric soft-argmax
+// decode as the epilogue -- logits never reach HBM.
+//
+// Replaces MetrabsHeads.forward as a whole (metrabs_pytorch/models/metrabs.py:75-85):
+//   x = conv_final(inp)                               (LazyConv2d 1x1, models/metrabs.py:73,76)
+//   split / rearrange 'b (d j) h w -> b d j h w'      (:78-79)
+//   soft_argmax 3D + heatmap_to_metric, soft_argmax 2D + heatmap_to_image   (:80-83)
+//
+// Per crop the projection is a GEMM  logits[N_out, HW] = Wt[N_out, C] . feat[C, HW]  (N_out =
+// J*(1+D) = 153, HW = 64, C = 1280 for EffNetV2-S/256): 25 MFLOP over 328 KB of features
+// = 76 FLOP/B, above the f32-MFMA ridge (157 TF / 6.3-8 TB/s = 20-25), so in fp32 this kernel is
+// MATRIX-bound.  It uses v_mfma_f32_16x16x4_f32: exact fp32 (bitwise an fmaf chain), the same
+// precision class as the reference's fp32 CPU conv.
+//
+// Decomposition
+//   * weights are re-packed once (mtr_head_pack_weights) joint-major: joint j owns rows
+//     [2D chan j, depth 0 .. D-1] so a JOINT GROUP is a contiguous <=64-row block that can be
+//     decoded without leaving the workgroup; layout [group][c][64 rows] (k-major) so that the
+//     weight tile is staged with the same full-line 16-B loads as the feature tile;
+//   * one workgroup (4 waves) = (crop, joint group): wave w owns row tile w (16 rows) x all NT
+//     column tiles; K streams through LDS in 32-channel stages, double buffered, global loads for
+//     stage s+1 in flight under the MFMAs of stage s;
+//   * LDS rows are padded so that row stride = 16 (mod 32) words: the A/B fragment reads
+//     (lane (l&15, l>>4) -> [k0 + (l>>4)][16*tile + (l&15)]) are bank-conflict free;
+//   * epilogue: accumulators (+bias) -> LDS [64][HWpad], then each 16-lane group decodes one joint
+//     (softmax over its D slices, fp64 moment sums) exactly like decode.hip;
+//   * 1-D grid with an XCD-aware remap: the joint groups of one crop run on the same XCD so the
+//     crop's features are fetched from HBM once and re-read from that XCD's L2.
+#include "common.h"
+
+namespace mtr {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kRows = 64;       // rows (output channels) per workgroup = 4 waves x 16
+constexpr int kRowsPad = 80;    // LDS row stride of the weight tile, 80 = 16 (mod 32)
+constexpr int kKC = 32;         // channels per pipeline stage
+
+__host__ __device__ constexpr int hw_pad(int nt) { return (nt & 1) ? nt * 16 : nt * 16 + 16; }
+
+struct HeadGeom {
+  int n_groups;      // joint groups
+  int jg;            // joints per group (last group may hold fewer)
+  int c_pad;         // C rounded up to kKC
+};
+
+__host__ __device__ inline HeadGeom head_geom(int C, int J, int D) {
+  HeadGeom g;
+  const int per = 1 + D;
+  const int jg_max = kRows / per;  // >= 1 is checked by the caller
+  g.n_groups = (J + jg_max - 1) / jg_max;
+  g.jg = (J + g.n_groups - 1) / g.n_groups;  // balanced groups
+  g.c_pad = (C + kKC - 1) / kKC * kKC;
+  return g;
+}
+
+// packed = [n_groups][c_pad][64] weights, then [n_groups][64] bias (all f32)
+__global__ void head_pack_kernel(const float* __restrict__ w, const float* __restrict__ bias, int C,
+                                 int J, int D, HeadGeom g, float* __restrict__ packed) {
+  const int per = 1 + D;
+  const size_t n_w = (size_t)g.n_groups * g.c_pad * kRows;
+  const size_t total = n_w + (size_t)g.n_groups * kRows;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (size_t)gridDim.x * blockDim.x) {
+    const bool is_bias = t >= n_w;
+    const size_t u = is_bias ? t - n_w : t;
+    const int row = (int)(u % kRows);
+    const int c = is_bias ? 0 : (int)((u / kRows) % g.c_pad);
+    const int grp = is_bias ? (int)(u / kRows) : (int)(u / ((size_t)kRows * g.c_pad));
+    const int jl = row / per, k = row % per;
+    const int j = grp * g.jg + jl;
+    float v = 0.0f;
+    if (jl < g.jg && j < J && c < C) {
+      // reference channel order: n = j for the 2D map, J + d*J + j for depth slice d
+      const int n = (k == 0) ? j : J + (k - 1) * J + j;
+      v = is_bias ? bias[n] : w[(size_t)n * C + c];
+    }
+    packed[t] = v;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ float4 load4_as_f32(const T* p) {
+  float v[4];
+  load_vec<T, 4>(p, v);
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+
+template <typename FeatT, int NT>
+__global__ __launch_bounds__(256) void head_fused_kernel(
+    const FeatT* __restrict__ feat, const float* __restrict__ packed, int B, int C, int H, int W,
+    int J, int D, HeadGeom g, HeadScale hs, float* __restrict__ coords2d,
+    float* __restrict__ coords3d_rel) {
+  constexpr int HWP = hw_pad(NT);
+  constexpr int A_STAGE = kKC * kRowsPad;            // floats
+  constexpr int B_STAGE = kKC * HWP;                 // floats
+  constexpr int B_VECS = (kKC * NT * 16 / 4 + 255) / 256;  // float4 per thread per stage (upper bound)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                 // [2][kKC][kRowsPad]
+  float* Bs = smem + 2 * A_STAGE;   // [2][kKC][HWP]
+  float* Ls = smem;                 // epilogue alias: [kRows][HWP]
+
+  const int HW = H * W;
+  // ---- XCD-aware remap (block id b runs on XCD b % 8): the groups of a crop share an XCD
+  const int chunk = 8 * g.n_groups;
+  const int id = blockIdx.x;
+  const int crop = (id / chunk) * 8 + (id % 8);
+  const int grp = (id % chunk) / 8;
+  if (crop >= B) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const FeatT* fcrop = feat + (size_t)crop * C * HW;
+  const float* wgrp = packed + (size_t)grp * g.c_pad * kRows;
+  const float* bgrp = packed + (size_t)g.n_groups * g.c_pad * kRows + (size_t)grp * kRows;
+
+  const int vec_per_row = HW / 4;              // HW % 4 == 0 (checked on the host)
+  const int b_total = kKC * vec_per_row;       // feature float4s per stage
+  float4 a_reg[2], b_reg[B_VECS];
+
+  auto load_stage = [&](int c0) {
+    // weight tile: rows c0..c0+31 of [c_pad][64], fully contiguous 8 KiB
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      a_reg[i] = *reinterpret_cast<const float4*>(wgrp + (size_t)c0 * kRows + (size_t)(tid + i * 256) * 4);
+#pragma unroll
+    for (int i = 0; i < B_VECS; ++i) {
+      const int v = tid + i * 256;
+      const int r = v / vec_per_row, q = v - r * vec_per_row;
+      b_reg[i] = (v < b_total && c0 + r < C)
+                     ? load4_as_f32<FeatT>(fcrop + (size_t)(c0 + r) * HW + q * 4)
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int v = tid + i * 256;
+      const int r = v / (kRows / 4), q = v % (kRows / 4);
+      *reinterpret_cast<float4*>(As + buf * A_STAGE + r * kRowsPad + q * 4) = a_reg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_VECS; ++i) {
+      const int v = tid + i * 256;
+      const int r = v / vec_per_row, q = v - r * vec_per_row;
+      if (v < b_total) *reinterpret_cast<float4*>(Bs + buf * B_STAGE + r * HWP + q * 4) = b_reg[i];
+    }
+  };
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // columns >= HW of the feature tile are never written: zero them once in both buffers
+  if (NT * 16 > HW) {
+    for (int v = tid; v < 2 * kKC * HWP; v += 256) Bs[v] = 0.0f;
+    __syncthreads();
+  }
+
+  const int n_stages = g.c_pad / kKC;
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+  const int fr = lane & 15, fk = lane >> 4;
+  for (int s = 0; s < n_stages; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < n_stages) load_stage((s + 1) * kKC);  // in flight under the MFMAs below
+    const float* Ab = As + buf * A_STAGE + wid * 16 + fr;
+    const float* Bb = Bs + buf * B_STAGE + fr;
+#pragma unroll
+    for (int k0 = 0; k0 < kKC; k0 += 4) {
+      const float a = Ab[(k0 + fk) * kRowsPad];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const float b = Bb[(k0 + fk) * HWP + n * 16];
+        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[n], 0, 0, 0);
+      }
+    }
+    if (s + 1 < n_stages) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue 1: logits (+bias) -> LDS [64][HWP]; D-layout: col = l&15, row = (l>>4)*4 + reg
+  // (the final __syncthreads of the loop already separates the last MFMA reads from these writes)
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wid * 16 + fk * 4 + r;
+      Ls[row * HWP + n * 16 + fr] = acc[n][r] + bgrp[row];
+    }
+  __syncthreads();
+
+  // ---- epilogue 2: one 16-lane group per joint of this group
+  const int per = 1 + D;
+  const int li = lane & 15;
+  for (int jl = wid * 4 + (lane >> 4); jl < g.jg; jl += 16) {
+    const int j = grp * g.jg + jl;
+    if (j >= J) continue;
+    const float* row2d = Ls + (size_t)(jl * per) * HWP;
+    const float* row3d = row2d + HWP;
+    float m2 = -INFINITY, m3 = -INFINITY;
+    for (int p = li * 4; p < HW; p += 64) {
+      const float4 v = *reinterpret_cast<const float4*>(row2d + p);
+      m2 = fmaxf(m2, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+      for (int d = 0; d < D; ++d) {
+        const float4 u = *reinterpret_cast<const float4*>(row3d + (size_t)d * HWP + p);
+        m3 = fmaxf(m3, fmaxf(fmaxf(u.x, u.y), fmaxf(u.z, u.w)));
+      }
+    }
+    // the 16 lanes of this joint sit in one quarter of the wave: width-16 butterflies
+    m2 = group_max<16>(m2);
+    m3 = group_max<16>(m3);
+    double s2 = 0, sx2 = 0, sy2 = 0, s3 = 0, sx3 = 0, sy3 = 0, sz3 = 0;
+    for (int p = li * 4; p < HW; p += 64) {
+      const float4 v = *reinterpret_cast<const float4*>(row2d + p);
+      const float v2[4] = {v.x, v.y, v.z, v.w};
+      double col[4] = {0, 0, 0, 0};
+      for (int d = 0; d < D; ++d) {
+        const float4 u = *reinterpret_cast<const float4*>(row3d + (size_t)d * HWP + p);
+        const float u3[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double e = (double)expf(u3[q] - m3);
+          col[q] += e;
+          sz3 += e * (double)d;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int h = (p + q) / W, w = (p + q) - h * W;  // W < 4 maps wrap more than once
+        const double e2 = (double)expf(v2[q] - m2);
+        s2 += e2; sx2 += e2 * w; sy2 += e2 * h;
+        s3 += col[q]; sx3 += col[q] * w; sy3 += col[q] * h;
+      }
+    }
+    s2 = group_sum<16>(s2); sx2 = group_sum<16>(sx2); sy2 = group_sum<16>(sy2);
+    s3 = group_sum<16>(s3); sx3 = group_sum<16>(sx3); sy3 = group_sum<16>(sy3);
+    sz3 = group_sum<16>(sz3);
+    if (li == 0) {
+      const size_t o = (size_t)crop * J + j;
+      coords2d[o * 2 + 0] = heatmap_to_px(axis_coord(sx2, s2, W), hs);
+      coords2d[o * 2 + 1] = heatmap_to_px(axis_coord(sy2, s2, H), hs);
+      coords3d_rel[o * 3 + 0] = heatmap_to_mm_xy(axis_coord(sx3, s3, W), hs);
+      coords3d_rel[o * 3 + 1] = heatmap_to_mm_xy(axis_coord(sy3, s3, H), hs);
+      coords3d_rel[o * 3 + 2] = heatmap_to_mm_z(axis_coord(sz3, s3, D), hs);
+    }
+  }
+}
+
+template <int NT>
+constexpr size_t head_lds_bytes() {
+  constexpr size_t stage = (size_t)2 * kKC * (kRowsPad + hw_pad(NT));
+  constexpr size_t logits = (size_t)kRows * hw_pad(NT);
+  return (stage > logits ? stage : logits) * sizeof(float);
+}
+
+template <typename FeatT, int NT>
+static int launch_head(const void* feat, const float* packed, int B, int C, int H, int W, int J,
+                       int D, const HeadGeom& g, const HeadScale& hs, float* c2d, float* c3d,
+                       hipStream_t stream) {
+  constexpr size_t lds = head_lds_bytes<NT>();
+  auto kern = head_fused_kernel<FeatT, NT>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int chunk = 8 * g.n_groups;
+  const long long blocks = (long long)((B + 7) / 8) * chunk;
+  if (blocks > 0x7fffffffLL) return MTR_E_SHAPE;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, (const FeatT*)feat,
+                     packed, B, C, H, W, J, D, g, hs, c2d, c3d);
+  MTR_CHECK_LAUNCH();
+  return MTR_OK;
+}
+
+template <typename FeatT>
+static int dispatch_head(const void* feat, const float* packed, int B, int C, int H, int W, int J,
+                         int D, const HeadGeom& g, const HeadScale& hs, float* c2d, float* c3d,
+                         hipStream_t stream) {
+  const int HW = H * W;
+  if (HW <= 16) return launch_head<FeatT, 1>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+  if (HW <= 32) return launch_head<FeatT, 2>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+  if (HW <= 64) return launch_head<FeatT, 4>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+  if (HW <= 144) return launch_head<FeatT, 9>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+  if (HW <= 256) return launch_head<FeatT, 16>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+  return MTR_E_SHAPE;
+}
+
+static int check_head_dims(int C, int J, int D) {
+  if (C <= 0 || J <= 0 || D <= 0) return MTR_E_SHAPE;
+  if (1 + D > kRows) return MTR_E_SHAPE;  // one joint must fit a 64-row workgroup tile
+  return MTR_OK;
+}
+
+}  // namespace mtr
+
+extern "C" size_t mtr_head_packed_bytes(int C, int J, int D, int feat_dtype) {
+  (void)feat_dtype;  // weights stay f32 for every feature dtype (exact-f32 MFMA)
+  if (mtr::check_head_dims(C, J, D)) return 0;
+  const mtr::HeadGeom g = mtr::head_geom(C, J, D);
+  return ((size_t)g.n_groups * g.c_pad * mtr::kRows + (size_t)g.n_groups * mtr::kRows) * sizeof(float);
+}
+
+extern "C" int mtr_head_pack_weights(const float* weight, const float* bias, int C, int J, int D,
+                                     int feat_dtype, void* packed, mtr_stream_t stream) {
+  if (!weight || !bias || !packed) return MTR_E_NULL;
+  if (feat_dtype != MTR_F32 && feat_dtype != MTR_F16 && feat_dtype != MTR_BF16) return MTR_E_DTYPE;
+  int rc = mtr::check_head_dims(C, J, D);
+  if (rc) return rc;
+  if ((uintptr_t)packed % 16) return MTR_E_ALIGN;
+  const mtr::HeadGeom g = mtr::head_geom(C, J, D);
+  const size_t total = (size_t)g.n_groups * g.c_pad * mtr::kRows + (size_t)g.n_groups * mtr::kRows;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(mtr::head_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     weight, bias, C, J, D, g, (float*)packed);
+  MTR_CHECK_LAUNCH();
+  return MTR_OK;
+}
+
+extern "C" int mtr_head_fused(const void* features, int feat_dtype, int layout, int B, int C, int H,
+                              int W, const void* packed, int J, int D, const mtr_head_params* p,
+                              float* coords2d, float* coords3d_rel, mtr_stream_t stream) {
+  if (!features || !packed || !p || !coords2d || !coords3d_rel) return MTR_E_NULL;
+  if (B < 0 || H <= 0 || W <= 0) return MTR_E_SHAPE;
+  int rc = mtr::check_head_dims(C, J, D);
+  if (rc) return rc;
+  if (layout != MTR_NCHW) return MTR_E_DTYPE;         // channels_last features: use NCHW or decode
+  if ((H * W) % 4 != 0 || H * W > 256) return MTR_E_SHAPE;  // wider maps: GEMM + mtr_softargmax_decode
+  if (p->proc_side <= 0 || p->stride_test <= 0) return MTR_E_PARAM;
+  if (((uintptr_t)features % 16) || ((uintptr_t)packed % 16)) return MTR_E_ALIGN;
+  if (B == 0) return MTR_OK;
+  const mtr::HeadGeom g = mtr::head_geom(C, J, D);
+  const mtr::HeadScale hs = mtr::make_head_scale(*p);
+  hipStream_t s = (hipStream_t)stream;
+  const float* pk = (const float*)packed;
+  switch (feat_dtype) {
+    case MTR_F32: return mtr::dispatch_head<float>(features, pk, B, C, H, W, J, D, g, hs, coords2d, coords3d_rel, s);
+    case MTR_F16: return mtr::dispatch_head<__half>(features, pk, B, C, H, W, J, D, g, hs, coords2d, coords3d_rel, s);
+    case MTR_BF16: return mtr::dispatch_head<__hip_bfloat16>(features, pk, B, C, H, W, J, D, g, hs, coords2d, coords3d_rel, s);
+    default: return MTR_E_DTYPE;
+  }
+}

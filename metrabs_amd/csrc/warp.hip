@@ -1,0 +1,486 @@
+// K6: crop sampler -- gamma decode + box pyramid, per-box crop geometry, perspective/lens warp.
+//
+// Replaces (all in metrabs_pytorch/multiperson/):
+//   multiperson_model.py:196        images = (u8/255)**2.2           -> build_pyramid_kernel (LUT)
+//   warping.py:10-13                avg_pool2d 2x2 pyramid, 3 levels  -> build_pyramid_kernel
+//   multiperson_model.py:322-355    _get_new_rotation_and_scale       -> crop_geometry_kernel
+//   multiperson_model.py:264-305    new intrinsics, R, inv(K_new R)   -> crop_geometry_kernel
+//   warping.py:15-21,128-133        per-level intrinsics, level pick   -> crop_geometry_kernel
+//   warping.py:23-54                per-crop Python loop: meshgrid, 2 einsums, distort,
+//                                   grid_sample(bilinear, zeros, align_corners=True)
+//                                                                      -> warp_crops_kernel
+//   multiperson_model.py:308-319    avg_pool2d(aa) and crops **= gamma/2.2 -> warp_crops_kernel
+//
+// The reference spends ~10 launches per crop in a Python loop (~100 crops/s on 8 CPU cores); here
+// the whole internal batch is ONE launch.  Bound: HBM for the streaming output (3*res^2*sizeof(out)
+// per crop) plus the clipped source footprint, which normally stays in L2 / Infinity Cache.
+#include "common.h"
+
+namespace mtr {
+
+// ------------------------------------------------------------------------------------------------
+// pyramid: each thread owns a 4x4 block of level-0 pixels = 2x2 of level 1 = 1 pixel of level 2.
+// avg_pool2d accumulates row-major ((a+b)+c)+d and divides by 4 (exact in fp32).
+template <bool FROM_U8>
+__global__ __launch_bounds__(256) void build_pyramid_kernel(
+    const void* __restrict__ src_any, int planes, int Hi, int Wi, float* __restrict__ l0,
+    float* __restrict__ l1, float* __restrict__ l2) {
+  __shared__ float lut[256];
+  if (FROM_U8) {
+    // (v/255)**2.2: fp32 division like torch, pow evaluated in fp64 and rounded once
+    lut[threadIdx.x] = (float)pow((double)__fdiv_rn((float)threadIdx.x, 255.0f), (double)2.2f);
+    __syncthreads();
+  }
+  const uint8_t* __restrict__ src = (const uint8_t*)src_any;
+  const float* __restrict__ srcf = (const float*)src_any;
+
+  const int H1 = Hi / 2, W1 = Wi / 2, H2 = H1 / 2, W2 = W1 / 2;
+  const int bw = (Wi + 3) / 4, bh = (Hi + 3) / 4;
+  const long long total = (long long)planes * bh * bw;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int bx = (int)(t % bw);
+    const int by = (int)((t / bw) % bh);
+    const int pl = (int)(t / ((long long)bw * bh));
+    const int x0 = bx * 4, y0 = by * 4;
+    const uint8_t* sp = src + (size_t)pl * Hi * Wi;
+    const float* spf = srcf + (size_t)pl * Hi * Wi;
+    float* d0 = l0 + (size_t)pl * Hi * Wi;
+    float v[4][4];
+    const bool fast = (Wi % 4 == 0) && (x0 + 4 <= Wi) && (y0 + 4 <= Hi);
+    if (!FROM_U8) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int y = y0 + r, x = x0 + c;
+          v[r][c] = (y < Hi && x < Wi) ? spf[(size_t)y * Wi + x] : 0.0f;
+        }
+    } else if (fast) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t raw = *reinterpret_cast<const uint32_t*>(sp + (size_t)(y0 + r) * Wi + x0);
+        v[r][0] = lut[raw & 0xff];
+        v[r][1] = lut[(raw >> 8) & 0xff];
+        v[r][2] = lut[(raw >> 16) & 0xff];
+        v[r][3] = lut[raw >> 24];
+        *reinterpret_cast<float4*>(d0 + (size_t)(y0 + r) * Wi + x0) =
+            make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int y = y0 + r, x = x0 + c;
+          float val = 0.0f;
+          if (y < Hi && x < Wi) {
+            val = lut[sp[(size_t)y * Wi + x]];
+            d0[(size_t)y * Wi + x] = val;
+          }
+          v[r][c] = val;
+        }
+    }
+    float q[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float s = __fadd_rn(__fadd_rn(__fadd_rn(v[2 * r][2 * c], v[2 * r][2 * c + 1]),
+                                            v[2 * r + 1][2 * c]), v[2 * r + 1][2 * c + 1]);
+        q[r][c] = s * 0.25f;
+        const int y1 = by * 2 + r, x1 = bx * 2 + c;
+        if (y1 < H1 && x1 < W1) l1[((size_t)pl * H1 + y1) * W1 + x1] = q[r][c];
+      }
+    if (by < H2 && bx < W2) {
+      const float s = __fadd_rn(__fadd_rn(__fadd_rn(q[0][0], q[0][1]), q[1][0]), q[1][1]);
+      l2[((size_t)pl * H2 + by) * W2 + bx] = s * 0.25f;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// geometry: one thread per (aug, box); fp64 internally, fp32 in/out.
+
+struct D3 { double x, y, z; };
+__device__ __forceinline__ D3 cross3(D3 a, D3 b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ double norm3(D3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+
+__device__ __forceinline__ void inv3x3(const double* m, double* o) {
+  const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7],
+               i = m[8];
+  const double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+  const double inv = 1.0 / (a * A + b * B + c * C);
+  o[0] = A * inv; o[1] = -(b * i - c * h) * inv; o[2] = (b * f - c * e) * inv;
+  o[3] = B * inv; o[4] = (a * i - c * g) * inv;  o[5] = -(a * f - c * d) * inv;
+  o[6] = C * inv; o[7] = -(a * h - b * g) * inv; o[8] = (a * e - b * d) * inv;
+}
+__device__ __forceinline__ void matmul3(const double* a, const double* b, double* o) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      o[r * 3 + c] = a[r * 3] * b[c] + a[r * 3 + 1] * b[3 + c] + a[r * 3 + 2] * b[6 + c];
+}
+
+// OpenCV rational + tangential + thin-prism model, warping.py:90-107
+template <typename F>
+__device__ __forceinline__ void distortion_parts(F x, F y, const F* d, F& a, F& b, F& cx, F& cy) {
+  const F r2 = x * x + y * y;
+  a = (((d[4] * r2 + d[1]) * r2 + d[0]) * r2 + F(1)) / (((d[7] * r2 + d[6]) * r2 + d[5]) * r2 + F(1));
+  b = F(2) * (x * d[3] + y * d[2]);
+  cx = (d[9] * r2 + d[3] + d[8]) * r2;
+  cy = (d[11] * r2 + d[2] + d[10]) * r2;
+}
+
+__global__ __launch_bounds__(64) void crop_geometry_kernel(
+    const float* __restrict__ boxes, int box_stride, const float* __restrict__ intr,
+    const float* __restrict__ dist, const float* __restrict__ up, const int32_t* __restrict__ ids,
+    const float* __restrict__ rotflip, const float* __restrict__ aug_scales,
+    const float* __restrict__ aug_gammas, int n_box, int n_aug, int res, int aa,
+    float* __restrict__ new_k, float* __restrict__ rot_out, float* __restrict__ wp) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_box * n_aug) return;
+  const int a = t / n_box, i = t % n_box;  // crops are [aug, box]-major (multiperson_model.py:237-240)
+
+  double K[9], Kinv[9], dc[12];
+  bool has_dist = false;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) K[k] = intr[(size_t)i * 9 + k];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) { dc[k] = dist[(size_t)i * 12 + k]; has_dist |= (dc[k] != 0.0); }
+  inv3x3(K, Kinv);
+
+  // five box points: centre, top-, right-, bottom-, left-mid (multiperson_model.py:325-330)
+  const double bx = boxes[(size_t)i * box_stride], by = boxes[(size_t)i * box_stride + 1],
+               bw = boxes[(size_t)i * box_stride + 2], bh = boxes[(size_t)i * box_stride + 3];
+  const double px[5] = {bx + bw / 2, bx + bw / 2, bx + bw, bx + bw / 2, bx};
+  const double py[5] = {by + bh / 2, by, by + bh / 2, by + bh, by + bh / 2};
+  double cx[5], cy[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    // [x, y, 1] @ inv(K)^T, first two components (the reference slices [:, :, :2], :334)
+    const double ux = Kinv[0] * px[k] + Kinv[1] * py[k] + Kinv[2];
+    const double uy = Kinv[3] * px[k] + Kinv[4] * py[k] + Kinv[5];
+    double x = ux, y = uy;
+    if (has_dist) {  // undistort_points: 5 fixed-point iterations (warping.py:65-73)
+      for (int itn = 0; itn < 5; ++itn) {
+        double pa, pb, pcx, pcy;
+        distortion_parts<double>(x, y, dc, pa, pb, pcx, pcy);
+        const double nx = (ux - pcx - x * pb) / pa, ny = (uy - pcy - y * pb) / pa;
+        x = nx; y = ny;
+      }
+    }
+    cx[k] = x; cy[k] = y;
+  }
+  // look-at rotation (ptu3d.py:129-142)
+  D3 f{cx[0], cy[0], 1.0};
+  const double fn = norm3(f);
+  D3 z{f.x / fn, f.y / fn, f.z / fn};
+  D3 upv{up[(size_t)i * 3], up[(size_t)i * 3 + 1], up[(size_t)i * 3 + 2]};
+  D3 x = cross3(z, upv);
+  if (norm3(x) == 0.0) x = D3{z.z, 0.0, -z.x};
+  const double xn = norm3(x);
+  x = D3{x.x / xn, x.y / xn, x.z / xn};
+  D3 y = cross3(z, x);
+  double Rn[9] = {x.x, x.y, x.z, y.x, y.y, y.z, z.x, z.y, z.z};
+
+  // side mid-points through K @ R_noaug (multiperson_model.py:343-345)
+  double M[9];
+  matmul3(K, Rn, M);
+  double sx[4], sy[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double qx = M[0] * cx[k + 1] + M[1] * cy[k + 1] + M[2];
+    const double qy = M[3] * cx[k + 1] + M[4] * cy[k + 1] + M[5];
+    const double qz = M[6] * cx[k + 1] + M[7] * cy[k + 1] + M[8];
+    sx[k] = qx / qz; sy[k] = qy / qz;
+  }
+  const double vertical = hypot(sx[0] - sx[2], sy[0] - sy[2]);
+  const double horizontal = hypot(sx[1] - sx[3], sy[1] - sy[3]);
+  const double box_scale = (double)res / fmax(vertical, horizontal);
+  const float crop_scale_f = (float)((double)aug_scales[a] * (double)(float)box_scale);
+  const double s = crop_scale_f;
+
+  // new intrinsics: top-left 2x2 of K scaled, principal point res/2 (:277-286)
+  double NK[9] = {K[0] * s, K[1] * s, res / 2.0, K[3] * s, K[4] * s, res / 2.0, 0.0, 0.0, 1.0};
+  double RF[9], R[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) RF[k] = rotflip[(size_t)a * 9 + k];
+  matmul3(RF, Rn, R);  // R = rotflip_aug @ R_noaug (:287)
+  double P[9], Hinv[9];
+  matmul3(NK, R, P);
+  inv3x3(P, Hinv);  // new_invprojmat = inv(K_new @ R) (:288)
+  if (aa > 1) {     // @ corner_aligned_scale_mat(1/aa) (:292-295, warping.py:128-133)
+    const double fct = 1.0 / aa, sh = (fct - 1.0) / 2.0;
+    double S[9] = {fct, 0, sh, 0, fct, sh, 0, 0, 1}, T[9];
+    matmul3(Hinv, S, T);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Hinv[k] = T[k];
+  }
+  // pyramid level = clip(floor(-log2(crop_scale * aa)), 0, 2) (warping.py:20-21, :303)
+  const float lv = floorf(-log2f(__fmul_rn(crop_scale_f, (float)aa)));
+  const int level = (int)fminf(fmaxf(lv, 0.0f), 2.0f);
+  const double fl = 1.0 / (double)(1 << level), shl = (fl - 1.0) / 2.0;
+  double SL[9] = {fl, 0, shl, 0, fl, shl, 0, 0, 1}, KL[9];
+  matmul3(SL, K, KL);  // corner_aligned_scale_mat(2^-l) @ K (warping.py:15-17)
+
+  const size_t o = (size_t)a * n_box + i;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    new_k[o * 9 + k] = (float)NK[k];
+    rot_out[o * 9 + k] = (float)R[k];
+    wp[o * MTR_WARP_PARAM_FLOATS + k] = (float)Hinv[k];
+    wp[o * MTR_WARP_PARAM_FLOATS + 9 + k] = (float)KL[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 12; ++k) wp[o * MTR_WARP_PARAM_FLOATS + 18 + k] = (float)dc[k];
+  wp[o * MTR_WARP_PARAM_FLOATS + 30] = has_dist ? 1.0f : 0.0f;
+  wp[o * MTR_WARP_PARAM_FLOATS + 31] = (float)level;
+  wp[o * MTR_WARP_PARAM_FLOATS + 32] = (float)ids[i];
+  wp[o * MTR_WARP_PARAM_FLOATS + 33] = __fdiv_rn(aug_gammas[a], 2.2f);  // gamma / 2.2 (:319)
+  wp[o * MTR_WARP_PARAM_FLOATS + 34] = crop_scale_f;
+  wp[o * MTR_WARP_PARAM_FLOATS + 35] = 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// warp: thread = PX consecutive output pixels of one row, all 3 channels.
+
+struct LevelDims { int H[3], W[3]; };
+
+__device__ __forceinline__ float tap(const float* __restrict__ plane, int x, int y, int W, int H) {
+  // grid_sample(padding_mode='zeros'): a tap outside [0,W-1]x[0,H-1] contributes 0
+  return (x >= 0 && x < W && y >= 0 && y < H) ? plane[(size_t)y * W + x] : 0.0f;
+}
+
+template <typename OutT> __device__ __forceinline__ OutT from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ __half from_f32<__half>(float v) { return __float2half(v); }
+template <> __device__ __forceinline__ __hip_bfloat16 from_f32<__hip_bfloat16>(float v) {
+  return __float2bfloat16(v);
+}
+
+template <typename OutT, int AA, int PX>
+__global__ __launch_bounds__(256) void warp_crops_kernel(
+    const float* __restrict__ l0, const float* __restrict__ l1, const float* __restrict__ l2,
+    LevelDims dims, const float* __restrict__ wp_all, int res, int nhwc, OutT* __restrict__ out) {
+  const int crop = blockIdx.z;
+  const float* __restrict__ wp = wp_all + (size_t)crop * MTR_WARP_PARAM_FLOATS;
+  // per-crop constants are wave-uniform -> scalar loads
+  const float h0 = wp[0], h1 = wp[1], h2 = wp[2], h3 = wp[3], h4 = wp[4], h5 = wp[5], h6 = wp[6],
+              h7 = wp[7], h8 = wp[8];
+  const float k0 = wp[9], k1 = wp[10], k2 = wp[11], k3 = wp[12], k4 = wp[13], k5 = wp[14];
+  const bool has_dist = wp[30] != 0.0f;
+  const int level = (int)wp[31];
+  const int img = (int)wp[32];
+  const float gexp = wp[33];
+  const int W = dims.W[level], H = dims.H[level];
+  const float* __restrict__ lvl = level == 0 ? l0 : (level == 1 ? l1 : l2);
+  const float* __restrict__ planes = lvl + (size_t)img * 3 * H * W;
+  const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+
+  const int u0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * PX;
+  const int v = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (v >= res || u0 >= res) return;
+
+  float acc[PX][3];
+#pragma unroll
+  for (int p = 0; p < PX; ++p) acc[p][0] = acc[p][1] = acc[p][2] = 0.0f;
+
+#pragma unroll
+  for (int p = 0; p < PX; ++p) {
+#pragma unroll
+    for (int sj = 0; sj < AA; ++sj) {
+#pragma unroll
+      for (int si = 0; si < AA; ++si) {
+        const float U = (float)((u0 + p) * AA + si), V = (float)(v * AA + sj);
+        // old = Hinv @ [U, V, 1] (warping.py:45-46)
+        const float ox = fmaf(h0, U, fmaf(h1, V, h2));
+        const float oy = fmaf(h3, U, fmaf(h4, V, h5));
+        const float oz = fmaf(h6, U, fmaf(h7, V, h8));
+        float nx = __fdiv_rn(ox, oz), ny = __fdiv_rn(oy, oz);
+        if (has_dist) {  // distort_points (warping.py:57-62)
+          float pa, pb, pcx, pcy;
+          distortion_parts<float>(nx, ny, wp + 18, pa, pb, pcx, pcy);
+          const float sc = pa + pb;
+          nx = fmaf(nx, sc, pcx);
+          ny = fmaf(ny, sc, pcy);
+        }
+        // pixel coordinates in the chosen level: (K_lvl @ [nx, ny, 1])[:2] (warping.py:49)
+        const float qx = fmaf(k0, nx, fmaf(k1, ny, k2));
+        const float qy = fmaf(k3, nx, fmaf(k4, ny, k5));
+        // the reference normalises to [-1,1] (warping.py:50-51) and grid_sample un-normalises
+        // (align_corners=True: ((g+1)/2)*(size-1)); replay the same fp32 round trip
+        const float gx = __fsub_rn(__fmul_rn(__fdiv_rn(qx, wm1), 2.0f), 1.0f);
+        const float gy = __fsub_rn(__fmul_rn(__fdiv_rn(qy, hm1), 2.0f), 1.0f);
+        const float ix = __fmul_rn(__fdiv_rn(__fadd_rn(gx, 1.0f), 2.0f), wm1);
+        const float iy = __fmul_rn(__fdiv_rn(__fadd_rn(gy, 1.0f), 2.0f), hm1);
+        const float fx0 = floorf(ix), fy0 = floorf(iy);
+        // keep far-away / non-finite coordinates out of the int conversion
+        const bool sane = (ix > -2.0f) && (iy > -2.0f) && (ix < (float)W + 1.0f) &&
+                          (iy < (float)H + 1.0f);
+        if (!sane) continue;
+        const int x0 = (int)fx0, y0 = (int)fy0;
+        const float tx1 = __fsub_rn(ix, fx0), tx0 = __fsub_rn(__fadd_rn(fx0, 1.0f), ix);
+        const float ty1 = __fsub_rn(iy, fy0), ty0 = __fsub_rn(__fadd_rn(fy0, 1.0f), iy);
+        const float wnw = tx0 * ty0, wne = tx1 * ty0, wsw = tx0 * ty1, wse = tx1 * ty1;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float* __restrict__ pl = planes + (size_t)c * H * W;
+          const float nw = tap(pl, x0, y0, W, H), ne = tap(pl, x0 + 1, y0, W, H);
+          const float sw = tap(pl, x0, y0 + 1, W, H), se = tap(pl, x0 + 1, y0 + 1, W, H);
+          const float val = fmaf(se, wse, fmaf(sw, wsw, fmaf(ne, wne, nw * wnw)));
+          acc[p][c] += val;  // avg_pool2d(aa): row-major sum, then / aa^2
+        }
+      }
+    }
+  }
+
+  // antialias average and the per-crop gamma (multiperson_model.py:308-319)
+  float res_v[PX][3];
+#pragma unroll
+  for (int p = 0; p < PX; ++p)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float val = acc[p][c];
+      if (AA > 1) val = val * (1.0f / (AA * AA));
+      res_v[p][c] = (gexp == 1.0f) ? val : powf(val, gexp);
+    }
+
+  const bool full = (u0 + PX <= res) && (res % PX == 0);
+  if (!nhwc) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      OutT* dst = out + (((size_t)crop * 3 + c) * res + v) * res + u0;
+      if (full && PX == 4 && sizeof(OutT) == 4) {
+        *reinterpret_cast<float4*>(dst) =
+            make_float4(res_v[0][c], res_v[1][c], res_v[2][c], res_v[3][c]);
+      } else if (full && PX == 4 && sizeof(OutT) == 2) {
+        OutT tmp[4] = {from_f32<OutT>(res_v[0][c]), from_f32<OutT>(res_v[1][c]),
+                       from_f32<OutT>(res_v[2][c]), from_f32<OutT>(res_v[3][c])};
+        *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<uint2*>(tmp);
+      } else {
+#pragma unroll
+        for (int p = 0; p < PX; ++p)
+          if (u0 + p < res) dst[p] = from_f32<OutT>(res_v[p][c]);
+      }
+    }
+  } else {
+    OutT* dst = out + (((size_t)crop * res + v) * res + u0) * 3;
+#pragma unroll
+    for (int p = 0; p < PX; ++p)
+      if (u0 + p < res) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dst[p * 3 + c] = from_f32<OutT>(res_v[p][c]);
+      }
+  }
+}
+
+template <typename OutT, int AA>
+static int launch_warp(const float* l0, const float* l1, const float* l2, const LevelDims& dims,
+                       const float* wp, int n_crops, int res, int nhwc, void* out,
+                       hipStream_t stream) {
+  constexpr int PX = 4;
+  dim3 grid((res + 64 * PX - 1) / (64 * PX), (res + 3) / 4, n_crops);
+  hipLaunchKernelGGL((warp_crops_kernel<OutT, AA, PX>), grid, dim3(256), 0, stream, l0, l1, l2, dims,
+                     wp, res, nhwc, (OutT*)out);
+  MTR_CHECK_LAUNCH();
+  return MTR_OK;
+}
+
+template <typename OutT>
+static int dispatch_warp_aa(const float* l0, const float* l1, const float* l2,
+                            const LevelDims& dims, const float* wp, int n_crops, int res, int aa,
+                            int nhwc, void* out, hipStream_t stream) {
+  switch (aa) {
+    case 1: return launch_warp<OutT, 1>(l0, l1, l2, dims, wp, n_crops, res, nhwc, out, stream);
+    case 2: return launch_warp<OutT, 2>(l0, l1, l2, dims, wp, n_crops, res, nhwc, out, stream);
+    case 4: return launch_warp<OutT, 4>(l0, l1, l2, dims, wp, n_crops, res, nhwc, out, stream);
+    default: return MTR_E_SHAPE;  // the reference needs torchvision for aa > 4 (:312-315)
+  }
+}
+
+}  // namespace mtr
+
+extern "C" int mtr_build_pyramid(const uint8_t* images_u8, int N, int Hi, int Wi, float* level0,
+                                 float* level1, float* level2, mtr_stream_t stream) {
+  if (!images_u8 || !level0 || !level1 || !level2) return MTR_E_NULL;
+  if (N < 0 || Hi <= 0 || Wi <= 0) return MTR_E_SHAPE;
+  if (N == 0) return MTR_OK;
+  if (((uintptr_t)level0 % 16) || ((uintptr_t)images_u8 % 4)) return MTR_E_ALIGN;
+  const long long blocks4 = (long long)N * 3 * ((Hi + 3) / 4) * ((Wi + 3) / 4);
+  long long grid = (blocks4 + 255) / 256;
+  if (grid > 8192) grid = 8192;  // grid-stride the rest
+  hipLaunchKernelGGL(mtr::build_pyramid_kernel<true>, dim3((unsigned)grid), dim3(256), 0,
+                     (hipStream_t)stream, (const void*)images_u8, N * 3, Hi, Wi, level0, level1,
+                     level2);
+  MTR_CHECK_LAUNCH();
+  return MTR_OK;
+}
+
+extern "C" int mtr_pyramid_from_level0(const float* level0, int N, int Hi, int Wi, float* level1,
+                                       float* level2, mtr_stream_t stream) {
+  if (!level0 || !level1 || !level2) return MTR_E_NULL;
+  if (N < 0 || Hi <= 0 || Wi <= 0) return MTR_E_SHAPE;
+  if (N == 0) return MTR_OK;
+  const long long blocks4 = (long long)N * 3 * ((Hi + 3) / 4) * ((Wi + 3) / 4);
+  long long grid = (blocks4 + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(mtr::build_pyramid_kernel<false>, dim3((unsigned)grid), dim3(256), 0,
+                     (hipStream_t)stream, (const void*)level0, N * 3, Hi, Wi, (float*)nullptr,
+                     level1, level2);
+  MTR_CHECK_LAUNCH();
+  return MTR_OK;
+}
+
+extern "C" int mtr_crop_geometry(const float* boxes, int box_stride, const float* intrinsics,
+                                 const float* distortion, const float* camspace_up,
+                                 const int32_t* image_ids, const float* aug_rotflipmat,
+                                 const float* aug_scales, const float* aug_gammas, int n_box,
+                                 int n_aug, int res, int antialias, float* new_intrinsics,
+                                 float* rot, float* warp_params, mtr_stream_t stream) {
+  if (!boxes || !intrinsics || !distortion || !camspace_up || !image_ids || !aug_rotflipmat ||
+      !aug_scales || !aug_gammas || !new_intrinsics || !rot || !warp_params)
+    return MTR_E_NULL;
+  if (n_box < 0 || n_aug <= 0 || res <= 0 || antialias <= 0 || box_stride < 4) return MTR_E_SHAPE;
+  if (n_box == 0) return MTR_OK;
+  const int total = n_box * n_aug;
+  hipLaunchKernelGGL(mtr::crop_geometry_kernel, dim3((total + 63) / 64), dim3(64), 0,
+                     (hipStream_t)stream, boxes, box_stride, intrinsics, distortion, camspace_up,
+                     image_ids, aug_rotflipmat, aug_scales, aug_gammas, n_box, n_aug, res,
+                     antialias, new_intrinsics, rot, warp_params);
+  MTR_CHECK_LAUNCH();
+  return MTR_OK;
+}
+
+extern "C" int mtr_warp_crops(const float* level0, const float* level1, const float* level2, int N,
+                              int Hi, int Wi, const float* warp_params, int n_crops, int res,
+                              int antialias, int out_dtype, int out_layout, void* out,
+                              mtr_stream_t stream) {
+  if (!level0 || !level1 || !level2 || !warp_params || !out) return MTR_E_NULL;
+  if (N <= 0 || Hi <= 0 || Wi <= 0 || n_crops < 0 || res <= 0) return MTR_E_SHAPE;
+  if (out_layout != MTR_NCHW && out_layout != MTR_NHWC) return MTR_E_DTYPE;
+  if (n_crops == 0) return MTR_OK;
+  if (n_crops > 65535) return MTR_E_SHAPE;  // gridDim.z
+  if ((uintptr_t)out % 16) return MTR_E_ALIGN;
+  mtr::LevelDims dims;
+  dims.H[0] = Hi; dims.W[0] = Wi;
+  dims.H[1] = Hi / 2; dims.W[1] = Wi / 2;
+  dims.H[2] = dims.H[1] / 2; dims.W[2] = dims.W[1] / 2;
+  hipStream_t s = (hipStream_t)stream;
+  const int nhwc = out_layout == MTR_NHWC;
+  switch (out_dtype) {
+    case MTR_F32:
+      return mtr::dispatch_warp_aa<float>(level0, level1, level2, dims, warp_params, n_crops, res,
+                                          antialias, nhwc, out, s);
+    case MTR_F16:
+      return mtr::dispatch_warp_aa<__half>(level0, level1, level2, dims, warp_params, n_crops, res,
+                                           antialias, nhwc, out, s);
+    case MTR_BF16:
+      return mtr::dispatch_warp_aa<__hip_bfloat16>(level0, level1, level2, dims, warp_params,
+                                                   n_crops, res, antialias, nhwc, out, s);
+    default: return MTR_E_DTYPE;
+  }
+}

@@ -92,3 +92,137 @@ def reconstruct_solve(coords2d, coords3d_rel, intrinsics, moments, cfg, mix_3d_i
         _ptr(coords2d), _ptr(coords3d_rel), _ptr(intrinsics), B, J, ctypes.byref(rp),
         _ptr(moments), _ptr(out), current_stream_ptr(coords2d.device)), 'mtr_reconstruct_solve')
     return out
+
+
+class Pyramid:
+    """Linear-light f32 image pyramid [level0, level1, level2], each [N,3,H_l,W_l]
+    (multiperson_model.py:196 + warping.py:10-13)."""
+
+    def __init__(self, levels):
+        self.levels = levels
+        self.n, _, self.h, self.w = levels[0].shape
+
+
+def _alloc_levels(n, h, w, device, with_level0=True):
+    h1, w1 = h // 2, w // 2
+    l0 = torch.empty(n, 3, h, w, device=device, dtype=torch.float32) if with_level0 else None
+    l1 = torch.empty(n, 3, h1, w1, device=device, dtype=torch.float32)
+    l2 = torch.empty(n, 3, h1 // 2, w1 // 2, device=device, dtype=torch.float32)
+    return l0, l1, l2
+
+
+def build_pyramid(images_u8):
+    """uint8 [N,3,H,W] -> Pyramid: fused gamma decode (u8/255)**2.2 + two 2x2 box levels."""
+    require_cuda(images_u8)
+    if images_u8.dtype != torch.uint8 or images_u8.ndim != 4 or images_u8.shape[1] != 3:
+        raise ValueError('images must be uint8 [N,3,H,W]')
+    images_u8 = images_u8.contiguous()
+    n, _, h, w = images_u8.shape
+    l0, l1, l2 = _alloc_levels(n, h, w, images_u8.device)
+    check(_lib.load().mtr_build_pyramid(_ptr(images_u8), n, h, w, _ptr(l0), _ptr(l1), _ptr(l2),
+                                        current_stream_ptr(images_u8.device)), 'mtr_build_pyramid')
+    return Pyramid([l0, l1, l2])
+
+
+def pyramid_from_level0(images_linear):
+    """f32 linear-light [N,3,H,W] -> Pyramid (levels 1, 2 by 2x2 box filter)."""
+    require_cuda(images_linear)
+    l0 = images_linear.contiguous().float()
+    n, _, h, w = l0.shape
+    _, l1, l2 = _alloc_levels(n, h, w, l0.device, with_level0=False)
+    check(_lib.load().mtr_pyramid_from_level0(_ptr(l0), n, h, w, _ptr(l1), _ptr(l2),
+                                              current_stream_ptr(l0.device)),
+          'mtr_pyramid_from_level0')
+    return Pyramid([l0, l1, l2])
+
+
+def crop_geometry(boxes, intrinsics, distortion12, camspace_up, image_ids, aug_rotflipmat,
+                  aug_scales, aug_gammas, res, antialias):
+    """Per (aug, box): new intrinsics [A,n,3,3], R [A,n,3,3] and the warp parameter rows
+    [A*n, 36] (multiperson_model.py:264-305,322-355)."""
+    require_cuda(boxes, intrinsics, distortion12, camspace_up, image_ids)
+    boxes = boxes.contiguous().float()
+    n_box, n_aug = boxes.shape[0], aug_gammas.shape[0]
+    dev = boxes.device
+    new_k = torch.empty(n_aug, n_box, 3, 3, device=dev, dtype=torch.float32)
+    rot = torch.empty(n_aug, n_box, 3, 3, device=dev, dtype=torch.float32)
+    wp = torch.empty(n_aug * n_box, _lib.MTR_WARP_PARAM_FLOATS, device=dev, dtype=torch.float32)
+    args = [intrinsics.contiguous().float(), distortion12.contiguous().float(),
+            camspace_up.contiguous().float(), image_ids.contiguous().to(torch.int32),
+            aug_rotflipmat.contiguous().float(), aug_scales.contiguous().float(),
+            aug_gammas.contiguous().float()]
+    if args[1].shape != (n_box, 12):
+        raise ValueError('distortion coefficients must be zero-padded to [n_box, 12]')
+    check(_lib.load().mtr_crop_geometry(
+        _ptr(boxes), boxes.stride(0), *[_ptr(a) for a in args], n_box, n_aug, int(res),
+        int(antialias), _ptr(new_k), _ptr(rot), _ptr(wp), current_stream_ptr(dev)),
+        'mtr_crop_geometry')
+    return new_k, rot, wp
+
+
+def warp_crops(pyramid, warp_params, res, antialias=1, out_dtype=torch.float32,
+               channels_last=False, out=None):
+    """Pyramid + [n,36] warp rows -> crops [n,3,res,res] (NCHW) or NHWC memory when
+    channels_last (returned as a logically-NCHW channels_last tensor)."""
+    require_cuda(warp_params)
+    n = warp_params.shape[0]
+    dev = warp_params.device
+    if out is None:
+        if channels_last:
+            out = torch.empty(n, res, res, 3, device=dev, dtype=out_dtype).permute(0, 3, 1, 2)
+        else:
+            out = torch.empty(n, 3, res, res, device=dev, dtype=out_dtype)
+    l0, l1, l2 = pyramid.levels
+    check(_lib.load().mtr_warp_crops(
+        _ptr(l0), _ptr(l1), _ptr(l2), pyramid.n, pyramid.h, pyramid.w, _ptr(warp_params), n,
+        int(res), int(antialias), dtype_code(out.dtype),
+        _lib.MTR_NHWC if channels_last else _lib.MTR_NCHW, _ptr(out), current_stream_ptr(dev)),
+        'mtr_warp_crops')
+    return out
+
+
+def head_fused_supported(C, J, D, H, W, channels_last=False):
+    """Shapes the fused projection+decode kernel covers; everything else goes through a library
+    GEMM for the 1x1 conv followed by the HIP decode kernel (same results, logits via HBM)."""
+    return (not channels_last) and (H * W) % 4 == 0 and H * W <= 256 and (1 + D) <= 64
+
+
+def head_pack_weights(weight2d, bias, n_points, depth, feat_dtype=torch.float32):
+    """conv_final.weight [J*(1+D), C] + bias -> packed joint-major tiles for mtr_head_fused."""
+    require_cuda(weight2d, bias)
+    lib = _lib.load()
+    weight2d = weight2d.contiguous().float()
+    bias = bias.contiguous().float()
+    n_out, C = weight2d.shape
+    if n_out != n_points * (1 + depth):
+        raise ValueError('weight rows != J*(1+depth)')
+    nbytes = lib.mtr_head_packed_bytes(C, n_points, depth, dtype_code(feat_dtype))
+    if nbytes == 0:
+        raise ValueError(f'fused head does not support C={C}, J={n_points}, D={depth}')
+    packed = torch.empty(nbytes // 4, device=weight2d.device, dtype=torch.float32)
+    check(lib.mtr_head_pack_weights(_ptr(weight2d), _ptr(bias), C, n_points, depth,
+                                    dtype_code(feat_dtype), _ptr(packed),
+                                    current_stream_ptr(weight2d.device)), 'mtr_head_pack_weights')
+    return packed
+
+
+def head_fused(features, packed, C, n_points, cfg, out=None):
+    """features [B,C,H,W] (f32/f16/bf16, NCHW contiguous) -> (coords2d, coords3d_rel)."""
+    require_cuda(features, packed)
+    lib = _lib.load()
+    features = features.contiguous()
+    B, Cf, H, W = features.shape
+    if Cf != C:
+        raise ValueError(f'features have {Cf} channels, weights were packed for {C}')
+    J, D = int(n_points), cfg.depth
+    if out is None:
+        c2d = torch.empty(B, J, 2, device=features.device, dtype=torch.float32)
+        c3d = torch.empty(B, J, 3, device=features.device, dtype=torch.float32)
+    else:
+        c2d, c3d = out
+    hp = cfg.head_params()
+    check(lib.mtr_head_fused(
+        _ptr(features), dtype_code(features.dtype), _lib.MTR_NCHW, B, C, H, W, _ptr(packed), J, D,
+        ctypes.byref(hp), _ptr(c2d), _ptr(c3d), current_stream_ptr(features.device)),
+        'mtr_head_fused')
+    return c2d, c3d

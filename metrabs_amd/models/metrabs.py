@@ -1,0 +1,75 @@
+"""Drop-in for metrabs_pytorch/models/metrabs.py: Metrabs (crop model) and MetrabsHeads.
+
+Same constructor roles and forward signatures as the reference; the head runs in hand-written HIP:
+the fused 1x1-projection GEMM + soft-argmax decode (csrc/head_fused.hip) or, with
+``fused=False``, a library GEMM for the 1x1 conv followed by the HIP decode kernel
+(csrc/decode.hip).  There is no CPU path."""
+import numpy as np
+import torch
+
+from metrabs_amd import kernels
+from metrabs_amd.config import MetrabsConfig
+
+
+class MetrabsHeads(torch.nn.Module):
+    """models/metrabs.py:67-85.  ``conv_final`` keeps the reference's parameter names and layout
+    (weight [J*(1+D), C, 1, 1], bias [J*(1+D)]; state_dict key heatmap_heads.conv_final.*,
+    convert_model_from_tf.py:175-177,194) so reference checkpoints load unchanged."""
+
+    def __init__(self, n_points, config=None, in_channels=None, fused=True):
+        super().__init__()
+        self.config = MetrabsConfig.from_any(config) if config is not None else MetrabsConfig()
+        self.n_points = n_points
+        self.n_outs = [n_points, self.config.depth * n_points]
+        if in_channels is None:
+            self.conv_final = torch.nn.LazyConv2d(out_channels=sum(self.n_outs), kernel_size=1)
+        else:
+            self.conv_final = torch.nn.Conv2d(in_channels, sum(self.n_outs), kernel_size=1)
+        self.fused = fused
+        self._packed = None
+        self._packed_key = None
+
+    def _packed_weights(self, feat_dtype):
+        w, b = self.conv_final.weight, self.conv_final.bias
+        key = (w.data_ptr(), w._version, b.data_ptr(), b._version, feat_dtype, w.device)
+        if self._packed_key != key:
+            self._packed = kernels.head_pack_weights(
+                w.detach().reshape(w.shape[0], -1), b.detach(), self.n_points, self.config.depth,
+                feat_dtype)
+            self._packed_key = key
+        return self._packed
+
+    def forward(self, inp):
+        if isinstance(self.conv_final, torch.nn.modules.lazy.LazyModuleMixin) and \
+                self.conv_final.has_uninitialized_params():
+            self.conv_final(inp[:1])  # materialise the lazy conv exactly like the reference would
+        _, c_in, h, w = inp.shape
+        if self.fused and kernels.head_fused_supported(c_in, self.n_points, self.config.depth, h, w):
+            return kernels.head_fused(inp, self._packed_weights(inp.dtype), c_in, self.n_points,
+                                      self.config)
+        logits = self.conv_final(inp)  # 1x1 conv as a library GEMM (rocBLAS / MIOpen)
+        return kernels.softargmax_decode(logits, self.n_points, self.config)
+
+
+class Metrabs(torch.nn.Module):
+    """models/metrabs.py:15-64 without the affine-latent options (transform_coords /
+    predict_all_and_latents call an undefined latent_points_to_joints in the reference,
+    models/metrabs.py:61-62, and are not part of the default configs)."""
+
+    def __init__(self, backbone, joint_info, config=None, in_channels=None, fused_head=True):
+        super().__init__()
+        self.config = MetrabsConfig.from_any(config) if config is not None else MetrabsConfig()
+        self.backbone = backbone
+        self.joint_names = np.array(joint_info.names)
+        self.joint_edges = np.array([[i, j] for i, j in joint_info.stick_figure_edges])
+        self.input_resolution = np.int32(self.config.proc_side)
+        self.joint_info = joint_info
+        self.heatmap_heads = MetrabsHeads(
+            n_points=joint_info.n_joints, config=self.config, in_channels=in_channels,
+            fused=fused_head)
+
+    def forward(self, inp):
+        image, intrinsics = inp
+        features = self.backbone(image)
+        coords2d, coords3d = self.heatmap_heads(features)
+        return kernels.reconstruct_absolute(coords2d, coords3d, intrinsics, self.config)

@@ -1,0 +1,282 @@
+"""Drop-in for metrabs_pytorch/multiperson/multiperson_model.py (Pose3dEstimator).
+
+Public surface, argument names/defaults, result keys and sentinels follow the reference
+(multiperson_model.py:10-13,39-74,384-429; docs/API.md).  The per-crop hot path -- gamma decode +
+pyramid, crop geometry, crop sampler, head, reconstruction -- runs in HIP kernels through
+metrabs_amd.kernels; everything here is host orchestration with no device synchronisation.
+
+Differences to the reference, all documented in DESIGN.md:
+  * the person detector is any callable ``images -> list of [n_i, 5] boxes`` (the reference hard-wires
+    an ultralytics YOLOv8, person_detector.py, which is out of scope);
+  * ``estimate_poses_batched`` accepts a list of per-image box tensors (the reference's own wrapper
+    is broken on current torch, multiperson_model.py:68);
+  * images with zero boxes are handled (TF's _predict_empty, metrabs_tf multiperson_model.py:417-439).
+"""
+import numpy as np
+import torch
+
+from metrabs_amd import kernels, ptu, ptu3d
+from metrabs_amd.joint_info import JointInfo
+from metrabs_amd.multiperson import warping
+
+# Dummy value which means that the intrinsic_matrix is unknown (multiperson_model.py:10)
+UNKNOWN_INTRINSIC_MATRIX = ((-1, -1, -1), (-1, -1, -1), (-1, -1, -1))
+DEFAULT_EXTRINSIC_MATRIX = ((1, 0, 0, 0), (0, 1, 0, 0), (0, 0, 1, 0), (0, 0, 0, 1))
+DEFAULT_DISTORTION = (0, 0, 0, 0, 0)
+DEFAULT_WORLD_UP = (0, -1, 0)
+
+
+def tta_parameters(num_aug, rot_aug_degrees=25):
+    """Test-time-augmentation table (multiperson_model.py:108-137)."""
+    gammas = ptu.linspace(np.float32(0.6), np.float32(1.0), num_aug)
+    angle_range = np.float32(np.deg2rad(rot_aug_degrees))
+    angles = ptu.linspace(-angle_range, angle_range, num_aug)
+    scales = torch.cat([
+        ptu.linspace(0.8, 1.0, num_aug // 2, endpoint=False),
+        torch.linspace(1.0, 1.1, num_aug - num_aug // 2)], dim=0)
+    should_flip = (torch.arange(0, num_aug) - num_aug // 2) % 2 != 0
+    flipmat = torch.tensor([[-1, 0, 0], [0, 1, 0], [0, 0, 1]], dtype=torch.float32)
+    maybe_flipmat = torch.where(should_flip[:, np.newaxis, np.newaxis], flipmat, torch.eye(3))
+    rotflipmat = maybe_flipmat @ ptu3d.rotation_mat(-angles, rot_axis='z')
+    return dict(gammas=gammas, angles=angles, scales=scales, should_flip=should_flip,
+                rotflipmat=rotflipmat)
+
+
+def distort_points(points, coeffs12):
+    """warping.distort_points (warping.py:57-62,90-107) as torch ops for the O(n*J) 2D projection of
+    the final poses; coeffs12 [n,12], points [n,...,2].  All-zero rows are returned unchanged."""
+    d = coeffs12.reshape(coeffs12.shape[0], *([1] * (points.ndim - 2)), 12)
+    r2 = torch.sum(torch.square(points), dim=-1, keepdim=True)
+    a = ((((d[..., 4:5] * r2 + d[..., 1:2]) * r2 + d[..., 0:1]) * r2 + 1) /
+         (((d[..., 7:8] * r2 + d[..., 6:7]) * r2 + d[..., 5:6]) * r2 + 1))
+    p2_1 = torch.flip(d[..., 2:4], dims=[-1])
+    b = 2 * torch.sum(points * p2_1, dim=-1, keepdim=True)
+    c = (d[..., 9:12:2] * r2 + p2_1 + d[..., 8:11:2]) * r2
+    distorted = points * (a + b) + c
+    has = (d != 0).any(dim=-1, keepdim=True)
+    return torch.where(has, distorted, points)
+
+
+class Pose3dEstimator(torch.nn.Module):
+    def __init__(self, crop_model, skeleton_infos, joint_transform_matrix, detector=None):
+        super().__init__()
+        self.crop_model = crop_model
+        self.joint_names = self.crop_model.joint_names
+        self.joint_edges = self.crop_model.joint_edges
+        self.joint_info = JointInfo(self.joint_names, self.joint_edges)
+        self.detector = detector
+        self.joint_transform_matrix = (
+            None if joint_transform_matrix is None
+            else torch.as_tensor(joint_transform_matrix, dtype=torch.float32))
+        self.per_skeleton_indices = {
+            k: torch.tensor(v['indices'], dtype=torch.int32) for k, v in skeleton_infos.items()}
+        self.per_skeleton_joint_names = {k: v['names'] for k, v in skeleton_infos.items()}
+        self.per_skeleton_joint_edges = {
+            k: torch.tensor(v['edges'], dtype=torch.int32) for k, v in skeleton_infos.items()}
+        self.skeleton_joint_indices_table = {k: v['indices'] for k, v in skeleton_infos.items()}
+        self._tta_cache = {}
+        self.crop_dtype = torch.float32
+        self.crop_channels_last = False
+
+    # ------------------------------------------------------------------ public API (reference names)
+
+    def detect_poses_batched(
+            self, images, intrinsic_matrix=np.array([UNKNOWN_INTRINSIC_MATRIX]),
+            distortion_coeffs=np.array([DEFAULT_DISTORTION]),
+            extrinsic_matrix=np.array([DEFAULT_EXTRINSIC_MATRIX]),
+            world_up_vector=DEFAULT_WORLD_UP, default_fov_degrees=55, internal_batch_size=64,
+            antialias_factor=1, num_aug=5, average_aug=True, skeleton='', detector_threshold=0.3,
+            detector_nms_iou_threshold=0.7, max_detections=None, detector_flip_aug=False,
+            suppress_implausible_poses=True):
+        if self.detector is None:
+            raise RuntimeError('no person detector attached: pass detector=callable to '
+                               'Pose3dEstimator or use estimate_poses*(images, boxes)')
+        boxes = self.detector(
+            images=images, threshold=detector_threshold,
+            nms_iou_threshold=detector_nms_iou_threshold, max_detections=max_detections)
+        return self._estimate_poses_batched(
+            images, boxes, intrinsic_matrix, distortion_coeffs, extrinsic_matrix, world_up_vector,
+            default_fov_degrees, internal_batch_size, antialias_factor, num_aug, average_aug,
+            skeleton, suppress_implausible_poses)
+
+    def estimate_poses_batched(
+            self, images, boxes, intrinsic_matrix=(UNKNOWN_INTRINSIC_MATRIX,),
+            distortion_coeffs=(DEFAULT_DISTORTION,),
+            extrinsic_matrix=(DEFAULT_EXTRINSIC_MATRIX,), world_up_vector=DEFAULT_WORLD_UP,
+            default_fov_degrees=55, internal_batch_size=64, antialias_factor=1, num_aug=5,
+            average_aug=True, skeleton=''):
+        boxes = [torch.cat([b[..., :4], torch.ones_like(b[..., :1])], dim=-1) for b in boxes]
+        pred = self._estimate_poses_batched(
+            images, boxes, intrinsic_matrix, distortion_coeffs, extrinsic_matrix, world_up_vector,
+            default_fov_degrees, internal_batch_size, antialias_factor, num_aug, average_aug,
+            skeleton, suppress_implausible_poses=False)
+        del pred['boxes']
+        return pred
+
+    def detect_poses(
+            self, image, intrinsic_matrix=UNKNOWN_INTRINSIC_MATRIX,
+            distortion_coeffs=DEFAULT_DISTORTION, extrinsic_matrix=DEFAULT_EXTRINSIC_MATRIX,
+            world_up_vector=DEFAULT_WORLD_UP, default_fov_degrees=55, internal_batch_size=64,
+            antialias_factor=1, num_aug=5, average_aug=True, skeleton='', detector_threshold=0.3,
+            detector_nms_iou_threshold=0.7, max_detections=-1, detector_flip_aug=False,
+            suppress_implausible_poses=True):
+        result = self.detect_poses_batched(
+            image[np.newaxis], _one(intrinsic_matrix), _one(distortion_coeffs),
+            _one(extrinsic_matrix), world_up_vector, default_fov_degrees, internal_batch_size,
+            antialias_factor, num_aug, average_aug, skeleton, detector_threshold,
+            detector_nms_iou_threshold, max_detections, detector_flip_aug,
+            suppress_implausible_poses)
+        return {k: v[0] for k, v in result.items()}
+
+    def estimate_poses(
+            self, image, boxes, intrinsic_matrix=UNKNOWN_INTRINSIC_MATRIX,
+            distortion_coeffs=DEFAULT_DISTORTION, extrinsic_matrix=DEFAULT_EXTRINSIC_MATRIX,
+            world_up_vector=DEFAULT_WORLD_UP, default_fov_degrees=55, internal_batch_size=64,
+            antialias_factor=1, num_aug=5, average_aug=True, skeleton=''):
+        result = self.estimate_poses_batched(
+            image[np.newaxis], [torch.as_tensor(boxes, dtype=torch.float32)],
+            _one(intrinsic_matrix), _one(distortion_coeffs), _one(extrinsic_matrix),
+            world_up_vector, default_fov_degrees, internal_batch_size, antialias_factor, num_aug,
+            average_aug, skeleton)
+        return {k: v[0] for k, v in result.items()}
+
+    # ------------------------------------------------------------------ implementation
+
+    def _device(self):
+        try:
+            return next(self.crop_model.parameters()).device
+        except StopIteration:
+            return torch.device('cuda')
+
+    def _tta(self, num_aug, dev):
+        key = (num_aug, str(dev))
+        if key not in self._tta_cache:
+            t = tta_parameters(num_aug)
+            self._tta_cache[key] = {k: v.to(dev) for k, v in t.items()}
+            self._tta_cache[key]['should_flip_host'] = t['should_flip']
+        return self._tta_cache[key]
+
+    def _estimate_poses_batched(
+            self, images, boxes, intrinsic_matrix, distortion_coeffs, extrinsic_matrix,
+            world_up_vector, default_fov_degrees, internal_batch_size, antialias_factor, num_aug,
+            average_aug, skeleton, suppress_implausible_poses):
+        """multiperson_model.py:76-182."""
+        dev = self._device()
+        if dev.type != 'cuda':
+            raise RuntimeError('metrabs_amd.Pose3dEstimator needs the crop model on a GPU')
+        images = torch.as_tensor(images).to(dev)
+        n_images = len(images)
+        intrinsic_matrix = torch.as_tensor(np.asarray(intrinsic_matrix) if not torch.is_tensor(
+            intrinsic_matrix) else intrinsic_matrix, dtype=torch.float32)
+        distortion_coeffs = _as_f32(distortion_coeffs)
+        extrinsic_matrix = _as_f32(extrinsic_matrix)
+        world_up_vector = _as_f32(world_up_vector)
+
+        # camera set-up on the host (tiny), then one transfer (multiperson_model.py:79-105)
+        if len(intrinsic_matrix) == 1:
+            if torch.all(intrinsic_matrix == -1):
+                intrinsic_matrix = ptu3d.intrinsic_matrix_from_field_of_view(
+                    default_fov_degrees, images.shape[2:4])
+            intrinsic_matrix = torch.repeat_interleave(intrinsic_matrix, n_images, dim=0)
+        if len(distortion_coeffs) == 1:
+            distortion_coeffs = torch.repeat_interleave(distortion_coeffs, n_images, dim=0)
+        if len(extrinsic_matrix) == 1:
+            extrinsic_matrix = torch.repeat_interleave(extrinsic_matrix, n_images, dim=0)
+        counts = [len(b) for b in boxes]
+        n_box_per_image = torch.tensor(counts)
+        camspace_up = torch.einsum('c,bCc->bC', world_up_vector, extrinsic_matrix[..., :3, :3])
+        inv_extrinsics = torch.linalg.inv(extrinsic_matrix)
+        per_box = lambda x: torch.repeat_interleave(x, n_box_per_image, dim=0).to(dev)
+        intrinsic_matrix_b = per_box(intrinsic_matrix)
+        distortion_b = per_box(warping.pad_axis_to_size(distortion_coeffs, 12))
+        camspace_up_b = per_box(camspace_up)
+        inv_extrinsics_b = per_box(inv_extrinsics)
+        image_id_per_box = per_box(torch.arange(n_images))
+        boxes_out = boxes
+        boxes_flat = torch.cat([torch.as_tensor(b, dtype=torch.float32).reshape(-1, b.shape[-1])
+                                for b in boxes], dim=0).to(dev) if sum(counts) else \
+            torch.zeros(0, 5, device=dev)
+
+        tta = self._tta(num_aug, dev)
+        n_joints = self.joint_info.n_joints
+        if sum(counts) == 0:
+            poses3d_flat = torch.zeros(0, num_aug, n_joints, 3, device=dev)
+        else:
+            poses3d_flat = self._predict_in_batches(
+                images, intrinsic_matrix_b, distortion_b, camspace_up_b, boxes_flat,
+                image_id_per_box, internal_batch_size, tta, antialias_factor)
+
+        # post-processing (multiperson_model.py:143-178)
+        if self.joint_transform_matrix is not None:
+            poses3d_flat = torch.einsum(
+                'bank,nN->baNk', poses3d_flat, self.joint_transform_matrix.to(dev))
+        poses2d_flat_normalized = ptu3d.to_homogeneous(
+            distort_points(ptu3d.project(poses3d_flat), distortion_b))
+        poses2d_flat = torch.einsum(
+            'bank,bjk->banj', poses2d_flat_normalized, intrinsic_matrix_b[:, :2, :])
+        poses3d_flat = torch.einsum(
+            'bank,bjk->banj', ptu3d.to_homogeneous(poses3d_flat), inv_extrinsics_b[:, :3, :])
+        idx = self.skeleton_joint_indices_table[skeleton]
+        poses3d_flat = poses3d_flat[..., idx, :]
+        poses2d_flat = poses2d_flat[..., idx, :]
+        if average_aug:
+            poses3d_flat = torch.mean(poses3d_flat, dim=-3)
+            poses2d_flat = torch.mean(poses2d_flat, dim=-3)
+        poses3d = list(torch.split(poses3d_flat, counts))
+        poses2d = list(torch.split(poses2d_flat, counts))
+        return dict(boxes=boxes_out, poses3d=poses3d, poses2d=poses2d)
+
+    def _predict_in_batches(self, images, intrinsic_matrix, distortion12, camspace_up, boxes_flat,
+                            image_id_per_box, internal_batch_size, tta, antialias_factor):
+        """multiperson_model.py:184-225.  The whole-image gamma decode (:196) is fused with the
+        pyramid build: one launch for all images of the call."""
+        num_aug = len(tta['gammas'])
+        boxes_per_batch = internal_batch_size // num_aug
+        pyramid = kernels.build_pyramid(images)
+        n_total = len(boxes_flat)
+        if boxes_per_batch == 0:
+            boxes_per_batch = n_total
+        out = []
+        for start in range(0, n_total, boxes_per_batch):
+            s = slice(start, start + boxes_per_batch)
+            out.append(self._predict_single_batch(
+                pyramid, intrinsic_matrix[s], distortion12[s], camspace_up[s], boxes_flat[s],
+                image_id_per_box[s], tta, antialias_factor))
+        return torch.cat(out, dim=0)
+
+    def _get_crops(self, pyramid, intrinsic_matrix, distortion12, camspace_up, boxes, image_ids, tta,
+                   antialias_factor):
+        """multiperson_model.py:264-320: two launches (geometry, sampler) for the internal batch."""
+        res = int(self.crop_model.input_resolution)
+        new_k, rot, wp = kernels.crop_geometry(
+            boxes, intrinsic_matrix, distortion12, camspace_up, image_ids, tta['rotflipmat'],
+            tta['scales'], tta['gammas'], res, antialias_factor)
+        crops = kernels.warp_crops(pyramid, wp, res, antialias_factor, out_dtype=self.crop_dtype,
+                                   channels_last=self.crop_channels_last)
+        return crops, new_k, rot
+
+    def _predict_single_batch(self, pyramid, intrinsic_matrix, distortion12, camspace_up, boxes,
+                              image_ids, tta, antialias_factor):
+        """multiperson_model.py:227-259."""
+        crops_flat, new_k, rot = self._get_crops(
+            pyramid, intrinsic_matrix, distortion12, camspace_up, boxes, image_ids, tta,
+            antialias_factor)
+        poses_flat = self.crop_model((crops_flat, new_k.reshape(-1, 3, 3)))
+        num_aug = new_k.shape[0]
+        poses = poses_flat.reshape(num_aug, -1, self.joint_info.n_joints, 3)
+        if bool(tta['should_flip_host'].any()):
+            mirror = torch.as_tensor(self.joint_info.mirror_mapping, device=poses.device)
+            swapped = poses[..., mirror, :]
+            poses = torch.where(tta['should_flip'].reshape(-1, 1, 1, 1), swapped, poses)
+        # row vectors: multiplying by R undoes the crop rotation (multiperson_model.py:253-256)
+        return (poses @ rot).transpose(0, 1)
+
+
+def _as_f32(x):
+    if torch.is_tensor(x):
+        return x.detach().to('cpu', torch.float32)
+    return torch.as_tensor(np.asarray(x), dtype=torch.float32)
+
+
+def _one(x):
+    return _as_f32(x)[np.newaxis]

@@ -1,0 +1,129 @@
+"""GPU parity of the fused head (K1+K2-K4, MFMA projection + decode epilogue) through the C-ABI.
+
+Identical features + weights -> coords.  The reference's CPU conv (oneDNN) and our exact-fp32 MFMA
+accumulate the K=C products in different orders; the golden files carry the reference's own
+fp32-vs-fp64 logit error for each case.  Bounds: MPJPE-style mean error <= 1e-3 mm on coords3d_rel
+for default-init heads; peaked heads (logit magnitude 20-50x) are bounded by 2x the reference's own
+distance to the fp64 truth, which the test computes."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+from oracle import cases, cpu_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def mcfg(cfg):
+    from metrabs_amd.config import MetrabsConfig
+    return MetrabsConfig.from_any(cfg.as_dict())
+
+
+def run_fused(feat, w, b, J, cfg):
+    from metrabs_amd import kernels
+    packed = kernels.head_pack_weights(w.cuda(), b.cuda(), J, cfg.depth, feat.dtype)
+    c2d, c3d = kernels.head_fused(feat.cuda(), packed, w.shape[1], J, mcfg(cfg))
+    return c2d.cpu(), c3d.cpu()
+
+
+def truth64(feat, w, b, J, cfg):
+    """fp64 evaluation of the same head (the yardstick for 'whose rounding is it')."""
+    logits = F.conv2d(feat.double(), w.double()[:, :, None, None], b.double())
+    with torch.inference_mode():
+        return cpu_ref.heads_from_logits(logits, J, cfg)
+
+
+@pytest.mark.parametrize('name', list(cases.HEADCONV_CASES))
+def test_fused_head_vs_golden(name, hip_lib):
+    g = load_golden(f'headconv_{name}')
+    feat, w, b, J, cfg = cases.headconv_case(name)
+    assert cases.sha256_of(feat, w, b) == str(g['input_sha256'])
+    c2d, c3d = run_fused(feat, w, b, J, cfg)
+    g2d, g3d = torch.from_numpy(g['coords2d']), torch.from_numpy(g['coords3d_rel'])
+    t2d, t3d = truth64(feat, w, b, J, cfg)
+    ours_vs_ref = (c3d - g3d).abs()
+    ours_vs_truth = (c3d.double() - t3d).abs()
+    ref_vs_truth = (g3d.double() - t3d).abs()
+    print(f'[parity] fused head {name}: |ours-ref| max {float(ours_vs_ref.max()):.2e} '
+          f'mean {float(ours_vs_ref.mean()):.2e} mm; |ours-fp64| max {float(ours_vs_truth.max()):.2e}; '
+          f'|ref-fp64| max {float(ref_vs_truth.max()):.2e} (logits absmax {float(g["logits_absmax"]):.1f})')
+    assert cpu_ref.mpjpe(c3d, g3d) <= 1e-3 or cpu_ref.mpjpe(c3d, g3d) <= 2 * cpu_ref.mpjpe(g3d, t3d.float())
+    assert float(ours_vs_ref.max()) <= max(1e-3, 2 * float(ref_vs_truth.max()) + float(ours_vs_truth.max()))
+    assert float(ours_vs_truth.max()) <= max(1e-3, 2 * float(ref_vs_truth.max()))
+    assert float((c2d - g2d).abs().max()) <= max(2e-4, 2 * float((g2d.double() - t2d).abs().max()))
+
+
+@pytest.mark.parametrize('shape', [(3, 40, 17, 8, 8, 8), (2, 24, 5, 8, 4, 4), (2, 33, 17, 8, 12, 12),
+                                   (1, 64, 3, 8, 16, 16), (2, 96, 30, 4, 10, 10), (9, 32, 1, 8, 8, 8),
+                                   (2, 100, 7, 8, 2, 8)])
+def test_fused_head_odd_shapes_vs_oracle(shape, hip_lib):
+    """C not a multiple of the 32-channel stage, J not filling the joint groups, NT in {1,2,4,9,16},
+    non-square maps, D != 8: vs the oracle's conv+decode on the same seeded inputs."""
+    B, C, J, D, H, W = shape
+    cfg = cpu_ref.HeadConfig(depth=D, proc_side=max(H, W) * 8, stride_test=8, stride_train=8)
+    g = cases.gen(8000 + sum(shape))
+    feat = torch.randn(B, C, H, W, generator=g)
+    w, b = cases.default_conv_init(J * (1 + D), C, g)
+    w, b = w * 3, b * 3
+    with torch.inference_mode():
+        o2d, o3d = cpu_ref.heads_forward(feat, w, b, J, cfg)
+    c2d, c3d = run_fused(feat, w, b, J, cfg)
+    print(f'[parity] fused head odd {shape}: max {float((c3d - o3d).abs().max()):.2e} mm')
+    assert float((c3d - o3d).abs().max()) <= 2e-3 and cpu_ref.mpjpe(c3d, o3d) <= 1e-3
+    assert float((c2d - o2d).abs().max()) <= 4e-4
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_fused_head_16bit_features(dtype, hip_lib):
+    """f16 / bf16 features (the autocast backbone output) are widened to f32 in LDS staging; weights
+    and logits stay f32.  Equals the oracle evaluated on the rounded features."""
+    feat, w, b, J, cfg = cases.headconv_case('s256_c1280')
+    feat16 = feat.to(dtype)
+    with torch.inference_mode():
+        o2d, o3d = cpu_ref.heads_forward(feat16.float(), w, b, J, cfg)
+    c2d, c3d = run_fused(feat16, w, b, J, cfg)
+    print(f'[parity] fused head {dtype}: max {float((c3d - o3d).abs().max()):.2e} mm')
+    assert float((c3d - o3d).abs().max()) <= 2e-3 and cpu_ref.mpjpe(c3d, o3d) <= 1e-3
+
+
+def test_fused_equals_unfused_and_module(hip_lib):
+    """MetrabsHeads drop-in: fused path == (library GEMM + HIP decode) path to rounding, LazyConv2d
+    materialisation, weight re-packing when the parameters change."""
+    from metrabs_amd.config import MetrabsConfig
+    from metrabs_amd.models.metrabs import MetrabsHeads
+    torch.manual_seed(0)
+    heads = MetrabsHeads(17, MetrabsConfig(), fused=True).cuda()
+    feat = torch.randn(6, 128, 8, 8, device='cuda')
+    with torch.inference_mode():
+        f2d, f3d = heads(feat)
+        heads.fused = False
+        u2d, u3d = heads(feat)
+        assert float((f3d - u3d).abs().max()) <= 2e-3 and float((f2d - u2d).abs().max()) <= 4e-4
+        heads.fused = True
+        heads.conv_final.weight.mul_(2.0)
+        g2d, g3d = heads(feat)
+        assert float((g3d - f3d).abs().max()) > 1.0  # the packed copy followed the parameter update
+    sd = heads.state_dict()
+    assert set(sd) == {'conv_final.weight', 'conv_final.bias'} and sd['conv_final.weight'].shape == (153, 128, 1, 1)
+
+
+def test_fused_head_full_size_properties(hip_lib):
+    """BASELINE config 2 (B=64, C=1280, 8x8, J=17): permutation equivariance over crops (each crop
+    is computed independently and deterministically) + sampled crops equal the oracle."""
+    from metrabs_amd import kernels
+    from metrabs_amd.config import MetrabsConfig
+    cfg = MetrabsConfig()
+    g = torch.Generator(device='cuda').manual_seed(5)
+    feat = torch.randn(64, 1280, 8, 8, device='cuda', generator=g)
+    w, b = cases.default_conv_init(153, 1280, cases.gen(6))
+    packed = kernels.head_pack_weights(w.cuda(), b.cuda(), 17, 8)
+    c2d, c3d = kernels.head_fused(feat, packed, 1280, 17, cfg)
+    perm = torch.randperm(64, device='cuda', generator=g)
+    p2d, p3d = kernels.head_fused(feat[perm].contiguous(), packed, 1280, 17, cfg)
+    assert torch.equal(p3d, c3d[perm]) and torch.equal(p2d, c2d[perm])
+    idx = [0, 31, 63]
+    with torch.inference_mode():
+        o2d, o3d = cpu_ref.heads_forward(feat[idx].cpu(), w, b, 17, cpu_ref.HeadConfig())
+    assert cpu_ref.mpjpe(c3d[idx].cpu(), o3d) <= 1e-3
