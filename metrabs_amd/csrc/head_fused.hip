@@ -9,8 +9,16 @@
 // Per crop the projection is a GEMM  logits[N_out, HW] = Wt[N_out, C] . feat[C, HW]  (N_out =
 // J*(1+D) = 153, HW = 64, C = 1280 for EffNetV2-S/256): 25 MFLOP over 328 KB of features
 // = 76 FLOP/B, above the f32-MFMA ridge (157 TF / 6.3-8 TB/s = 20-25), so in fp32 this kernel is
-// MATRIX-bound.  It uses v_mfma_f32_16x16x4_f32: exact fp32 (bitwise an fmaf chain), the same
-// precision class as the reference's fp32 CPU conv.
+// MATRIX-bound.  Precision class follows the feature dtype:
+//   * f32 features (the reference's CPU path): v_mfma_f64_16x16x4_f64 on operands widened to f64
+//     in registers -- products exact, accumulation in f64.  A sequential f32 fmaf chain over
+//     K = 1280 was measured ~4x noisier than oneDNN's blocked accumulation (1.6e-3 mm vs 3.7e-4 mm
+//     from the fp64 truth on the golden cases), which breaks the 1e-3 mm parity gate; f64
+//     accumulation puts the logits at the centre of the reference's own noise band.  Peak for this
+//     mode is the f64 matrix rate (78.6 TF);
+//   * f16 / bf16 features (the autocast GPU path, where the reference itself rounds the logits to
+//     f16): v_mfma_f32_16x16x4_f32, exact f32 fmaf chain at the 157 TF f32 matrix rate; weights and
+//     logits stay f32, i.e. strictly more accurate than the reference's f16 logits.
 //
 // Decomposition
 //   * weights are re-packed once (mtr_head_pack_weights) joint-major: joint j owns rows
@@ -26,11 +34,14 @@
 //     (softmax over its D slices, fp64 moment sums) exactly like decode.hip;
 //   * 1-D grid with an XCD-aware remap: the joint groups of one crop run on the same XCD so the
 //     crop's features are fetched from HBM once and re-read from that XCD's L2.
+#include <type_traits>
+
 #include "common.h"
 
 namespace mtr {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f64x4 = __attribute__((ext_vector_type(4))) double;
 
 constexpr int kRows = 64;       // rows (output channels) per workgroup = 4 waves x 16
 constexpr int kRowsPad = 80;    // LDS row stride of the weight tile, 80 = 16 (mod 32)
@@ -86,7 +97,7 @@ __device__ __forceinline__ float4 load4_as_f32(const T* p) {
   return make_float4(v[0], v[1], v[2], v[3]);
 }
 
-template <typename FeatT, int NT>
+template <typename FeatT, int NT, bool ACC64>
 __global__ __launch_bounds__(256) void head_fused_kernel(
     const FeatT* __restrict__ feat, const float* __restrict__ packed, int B, int C, int H, int W,
     int J, int D, HeadGeom g, HeadScale hs, float* __restrict__ coords2d,
@@ -146,9 +157,10 @@ __global__ __launch_bounds__(256) void head_fused_kernel(
     }
   };
 
-  f32x4 acc[NT];
+  using AccT = typename std::conditional<ACC64, f64x4, f32x4>::type;
+  AccT acc[NT];
 #pragma unroll
-  for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int n = 0; n < NT; ++n) acc[n] = AccT{0, 0, 0, 0};
 
   // columns >= HW of the feature tile are never written: zero them once in both buffers
   if (NT * 16 > HW) {
@@ -172,21 +184,27 @@ __global__ __launch_bounds__(256) void head_fused_kernel(
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const float b = Bb[(k0 + fk) * HWP + n * 16];
-        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[n], 0, 0, 0);
+        if constexpr (ACC64) {
+          acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a, (double)b, acc[n], 0, 0, 0);
+        } else {
+          acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[n], 0, 0, 0);
+        }
       }
     }
     if (s + 1 < n_stages) store_stage(buf ^ 1);
     __syncthreads();
   }
 
-  // ---- epilogue 1: logits (+bias) -> LDS [64][HWP]; D-layout: col = l&15, row = (l>>4)*4 + reg
+  // ---- epilogue 1: logits (+bias) -> LDS [64][HWP].  C/D layout: col = l&15 and
+  //   f32 16x16x4: row = (l>>4)*4 + reg;   f64 16x16x4: row = (l>>4) + 4*reg
   // (the final __syncthreads of the loop already separates the last MFMA reads from these writes)
 #pragma unroll
   for (int n = 0; n < NT; ++n)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = wid * 16 + fk * 4 + r;
-      Ls[row * HWP + n * 16 + fr] = acc[n][r] + bgrp[row];
+      const int row = wid * 16 + (ACC64 ? fk + 4 * r : fk * 4 + r);
+      // bias joins in the accumulator's precision; one rounding to f32
+      Ls[row * HWP + n * 16 + fr] = (float)(acc[n][r] + (decltype(acc[n][r] + 0))bgrp[row]);
     }
   __syncthreads();
 
@@ -259,7 +277,8 @@ static int launch_head(const void* feat, const float* packed, int B, int C, int 
                        int D, const HeadGeom& g, const HeadScale& hs, float* c2d, float* c3d,
                        hipStream_t stream) {
   constexpr size_t lds = head_lds_bytes<NT>();
-  auto kern = head_fused_kernel<FeatT, NT>;
+  // f32 features -> f64 accumulate (parity with the fp32 CPU reference); 16-bit -> f32 MFMA
+  auto kern = head_fused_kernel<FeatT, NT, std::is_same<FeatT, float>::value>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);

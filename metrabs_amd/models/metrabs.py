@@ -31,8 +31,12 @@ class MetrabsHeads(torch.nn.Module):
 
     def _packed_weights(self, feat_dtype):
         w, b = self.conv_final.weight, self.conv_final.bias
+        # in-place parameter updates are seen through the version counters; inference tensors
+        # (parameters created under torch.inference_mode) have none, so they are re-packed per
+        # call (one tiny launch)
+        trackable = not (w.is_inference() or b.is_inference())
         key = (w.data_ptr(), w._version, b.data_ptr(), b._version, feat_dtype, w.device)
-        if self._packed_key != key:
+        if not trackable or self._packed_key != key:
             self._packed = kernels.head_pack_weights(
                 w.detach().reshape(w.shape[0], -1), b.detach(), self.n_points, self.config.depth,
                 feat_dtype)
