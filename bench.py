@@ -1,0 +1,403 @@
+#!/usr/bin/env python
+"""Benchmark of the MI355X-native MeTRAbs per-crop hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the hot path over one internal batch of synthetic input that is already
+resident in HBM: BASELINE.json configs[1] = EfficientNetV2-S, 256 px crops, 64 crops per GPU,
+num_aug=1:
+
+    uint8 1080p frames --(gamma decode + pyramid)--> (crop geometry) --> (perspective crop sampler)
+      --> EfficientNetV2-S backbone [PyTorch-ROCm / MIOpen, random weights]
+      --> (fused 1x1-projection MFMA + volumetric soft-argmax decode) --> (absolute reconstruction)
+      --> mirror un-swap + back-rotation --> poses3d [64, 17, 3]          (+ one all-gather if N > 1)
+
+Parenthesised stages are the hand-written HIP kernels of libmetrabs_hip.so.  Metric: crops/sec,
+whole job (all ranks).  Weak scaling: every rank processes its own 64 crops per step.
+
+Prints ONE JSON line on rank 0 (see the contract in the task description) with two extra objects:
+``roofline`` for the dominant hand-written kernel of the step and ``cpu_baseline`` for the CPU
+restatement of the reference path (oracle/cpu_ref.py) timed on this box's host cores.
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s spec (MI355X_MICROARCH.md); 6.29e12 measured float4 copy
+HBM_COPY_MEASURED = 6.29e12
+MFMA_F32_PEAK = 157.3e12   # FLOP/s, f32-in MFMA
+MFMA_F64_PEAK = 78.6e12    # FLOP/s, f64 MFMA / vector
+
+JOINT_NAMES = ['nose', 'leye', 'reye', 'lear', 'rear', 'lsho', 'rsho', 'lelb', 'relb', 'lwri', 'rwri',
+               'lhip', 'rhip', 'lkne', 'rkne', 'lank', 'rank']
+JOINT_EDGES = [(0, 1), (0, 2), (1, 3), (2, 4), (5, 6), (5, 7), (7, 9), (6, 8), (8, 10), (5, 11),
+               (6, 12), (11, 12), (11, 13), (13, 15), (12, 14), (14, 16)]
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--backbone', default='effnetv2-s')
+    ap.add_argument('--res', type=int, default=256)
+    ap.add_argument('--batch', type=int, default=64, help='crops per GPU per step')
+    ap.add_argument('--num-aug', type=int, default=1)
+    ap.add_argument('--frames', type=int, default=8, help='1080p frames per step per GPU')
+    ap.add_argument('--joints', type=int, default=17)
+    ap.add_argument('--precision', default='f32', choices=['f32', 'f16', 'bf16'],
+                    help='backbone arithmetic: f32 = the reference CPU path; f16 = its autocast GPU path')
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-decode-roofline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    return ap.parse_args()
+
+
+def synth_inputs(pipe, frames, im_h, im_w, n_box, seed):
+    """Seeded synthetic inputs written straight into the pipeline's static device buffers."""
+    g = torch.Generator().manual_seed(seed)
+    pipe.images.copy_(torch.randint(0, 256, (frames, 3, im_h, im_w), dtype=torch.uint8, generator=g))
+    bw = 60 + 340 * torch.rand(n_box, generator=g)
+    bh = 150 + 750 * torch.rand(n_box, generator=g)
+    bx = torch.rand(n_box, generator=g) * (im_w - bw)
+    by = torch.rand(n_box, generator=g) * (im_h - bh).clamp_min(1.0)
+    pipe.boxes.copy_(torch.stack([bx, by, bw, bh], dim=1))
+    f = max(im_h, im_w) / (np.tan(np.deg2rad(55.0) / 2) * 2)
+    K = torch.tensor([[f, 0, im_w / 2], [0, f, im_h / 2], [0, 0, 1]], dtype=torch.float32)
+    pipe.intrinsics.copy_(K.repeat(n_box, 1, 1))
+    pipe.image_ids.copy_((torch.arange(n_box) % frames).int())
+
+
+def build_model(args, dev):
+    from metrabs_amd.backbones import build_backbone
+    from metrabs_amd.config import MetrabsConfig
+    from metrabs_amd.joint_info import JointInfo
+    from metrabs_amd.models.metrabs import Metrabs
+    from metrabs_amd.multiperson.multiperson_model import Pose3dEstimator
+    torch.manual_seed(1234)
+    cfg = MetrabsConfig(proc_side=args.res)
+    names = JOINT_NAMES if args.joints == 17 else [f'j{i}' for i in range(args.joints)]
+    edges = JOINT_EDGES if args.joints == 17 else [(i, i + 1) for i in range(args.joints - 1)]
+    ji = JointInfo(names, edges)
+    backbone = build_backbone(args.backbone)
+    autocast = {'f32': None, 'f16': torch.float16, 'bf16': torch.bfloat16}[args.precision]
+    model = Metrabs(backbone, ji, cfg, in_channels=backbone.out_channels, fused_head=True,
+                    autocast_dtype=autocast)
+    model = model.to(dev).eval()
+    if autocast is not None:
+        model = model.to(memory_format=torch.channels_last)
+    skel = {'': dict(indices=list(range(args.joints)), names=names, edges=edges)}
+    est = Pose3dEstimator(model, skel, None)
+    if autocast is not None:
+        est.crop_dtype = autocast
+        est.crop_channels_last = True
+    return est, cfg
+
+
+def time_stage(fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    start.record()
+    for _ in range(iters):
+        fn()
+    stop.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(stop) * 1e-3 / iters
+
+
+def stage_breakdown(pipe, est, args, iters):
+    """Average duration of every stage of the step, measured with HIP events on the stream the
+    kernels are launched on (torch's current stream)."""
+    from metrabs_amd import kernels
+    res, aa = args.res, 1
+    tta = pipe.tta
+    model = est.crop_model
+    st = {}
+    with torch.inference_mode():
+        st['pyramid'] = time_stage(lambda: kernels.build_pyramid(pipe.images), iters)
+        pyr = kernels.build_pyramid(pipe.images)
+        geo = lambda: kernels.crop_geometry(
+            pipe.boxes, pipe.intrinsics, pipe.distortion12, pipe.camspace_up, pipe.image_ids,
+            tta['rotflipmat'], tta['scales'], tta['gammas'], res, aa)
+        st['geometry'] = time_stage(geo, iters)
+        new_k, rot, wp = geo()
+        warp = lambda: kernels.warp_crops(pyr, wp, res, aa, out_dtype=est.crop_dtype,
+                                          channels_last=est.crop_channels_last)
+        st['warp'] = time_stage(warp, iters)
+        crops = warp()
+
+        def backbone():
+            if model.autocast_dtype is not None:
+                with torch.autocast('cuda', dtype=model.autocast_dtype):
+                    return model.backbone(crops)
+            return model.backbone(crops)
+        st['backbone'] = time_stage(backbone, max(3, iters // 3))
+        feats = backbone()
+        heads = model.heatmap_heads
+        st['head_fused'] = time_stage(lambda: heads(feats), iters)
+        c2d, c3d = heads(feats)
+        kflat = new_k.reshape(-1, 3, 3)
+        ws = kernels.reconstruct_workspace(c2d.shape[0], c2d.shape[1], c2d.device)
+        st['reconstruct'] = time_stage(
+            lambda: kernels.reconstruct_absolute(c2d, c3d, kflat, model.config, workspace=ws), iters)
+    return st, dict(wp=wp, feats=feats, c2d=c2d, c3d=c3d, kflat=kflat)
+
+
+def source_footprint_bytes(wp, res, im_h, im_w):
+    """Clipped axis-aligned bounding box (in texels of the chosen pyramid level) of each warped crop
+    quad -- SURVEY.md 8(d) S_src -- times 3 planes x 4 B."""
+    wp = wp.detach().cpu().double()
+    total = 0.0
+    corners = torch.tensor([[0.0, 0.0, 1.0], [res - 1.0, 0.0, 1.0], [0.0, res - 1.0, 1.0],
+                            [res - 1.0, res - 1.0, 1.0]], dtype=torch.float64)
+    for row in wp:
+        hinv, kl, lvl = row[0:9].reshape(3, 3), row[9:18].reshape(3, 3), int(row[31])
+        rays = corners @ hinv.T
+        n = rays[:, :2] / rays[:, 2:]
+        q = torch.cat([n, torch.ones(4, 1, dtype=torch.float64)], dim=1) @ kl.T
+        w, h = (im_w >> lvl), (im_h >> lvl)
+        x0, x1 = q[:, 0].min().clamp(0, w - 1), q[:, 0].max().clamp(0, w - 1)
+        y0, y1 = q[:, 1].min().clamp(0, h - 1), q[:, 1].max().clamp(0, h - 1)
+        total += float((x1 - x0 + 1) * (y1 - y0 + 1)) * 3 * 4
+    return total
+
+
+def decode_roofline(iters=20):
+    """K2-K4 standalone on a batch beyond the 256 MiB Infinity Cache: J=17, 8x8, D=8, B=32768
+    (1.28 GB of fp32 logits)."""
+    from metrabs_amd import kernels
+    from metrabs_amd.config import MetrabsConfig
+    B, J, D = 32768, 17, 8
+    g = torch.Generator(device='cuda').manual_seed(3)
+    logits = torch.randn(B, J * (1 + D), 8, 8, device='cuda', generator=g)
+    cfg = MetrabsConfig()
+    out = (torch.empty(B, J, 2, device='cuda'), torch.empty(B, J, 3, device='cuda'))
+    t = time_stage(lambda: kernels.softargmax_decode(logits, J, cfg, out=out), iters)
+    bytes_per_crop = J * (1 + D) * 64 * 4 + 20 * J
+    achieved = B * bytes_per_crop / t
+    del logits
+    torch.cuda.empty_cache()
+    return dict(kernel='decode_nchw_kernel<float,4,16>', bound='hbm', achieved=achieved / 1e9,
+                peak=HBM_PEAK / 1e9, unit='GB/s', frac=achieved / HBM_PEAK,
+                frac_of_measured_copy=achieved / HBM_COPY_MEASURED, avg_launch_us=t * 1e6,
+                crops=B, bytes_per_crop=bytes_per_crop, traffic=None)
+
+
+def cpu_baseline(est, pipe, args, cfg, seconds):
+    """The CPU restatement of the reference path (oracle/cpu_ref.py, pinned bit-for-bit to the
+    reference on the golden vectors) on this box's host cores, same synthetic workload, bounded
+    sample."""
+    from oracle import cpu_ref
+    ocfg = cpu_ref.HeadConfig(proc_side=cfg.proc_side)
+    model = est.crop_model
+    backbone = copy.deepcopy(model.backbone).to('cpu', torch.float32).eval()
+    w = model.heatmap_heads.conv_final.weight.detach().cpu().float()
+    b = model.heatmap_heads.conv_final.bias.detach().cpu().float()
+    J = model.joint_info.n_joints
+    mirror = model.joint_info.mirror_mapping
+
+    def crop_model(inp):
+        crops, K = inp
+        return cpu_ref.crop_model_from_features(backbone(crops), w, b, K, J, ocfg)
+
+    images = pipe.images.cpu()
+    boxes_all = torch.cat([pipe.boxes.cpu(), torch.ones(len(pipe.boxes), 1)], dim=1)
+    ids = pipe.image_ids.cpu().long()
+    K = pipe.intrinsics[:1].cpu()
+
+    def run(n_box):
+        per_image = [boxes_all[:n_box][ids[:n_box] == i] for i in range(len(images))]
+        with torch.inference_mode():
+            return cpu_ref.estimate_poses_batched(
+                crop_model, mirror, J, args.res, images, per_image, K, torch.zeros(1, 5),
+                torch.eye(4)[None], torch.tensor([0.0, -1.0, 0.0]), 55, args.batch * args.num_aug,
+                1, args.num_aug, True)
+
+    run(min(8, args.batch))  # warm-up (thread pools, oneDNN primitive cache)
+    t0 = time.time()
+    reps = 0
+    while True:
+        run(args.batch)
+        reps += 1
+        if time.time() - t0 >= seconds * 0.5 or reps >= 3:
+            break
+    dt = (time.time() - t0) / reps
+    crops = args.batch * args.num_aug
+    return dict(value=crops / dt, unit='crops/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'{reps} x {crops} crops ({args.frames} 1080p frames), same step as the GPU '
+                       f'(gamma decode + pyramid + sampler + {args.backbone} fp32 + head + '
+                       f'reconstruction), oracle/cpu_ref.py on torch CPU',
+                seconds_per_batch=dt)
+
+
+def parity_probe(est, extras, cfg):
+    """MPJPE (mm) of the HIP head + reconstruction vs the oracle on IDENTICAL backbone features
+    (the north-star parity definition), for the batch the bench just ran."""
+    from oracle import cpu_ref
+    model = est.crop_model
+    ocfg = cpu_ref.HeadConfig(proc_side=cfg.proc_side)
+    feats = extras['feats'].float().cpu()
+    w = model.heatmap_heads.conv_final.weight.detach().cpu().float()
+    b = model.heatmap_heads.conv_final.bias.detach().cpu().float()
+    J = model.joint_info.n_joints
+    with torch.inference_mode():
+        ref = cpu_ref.crop_model_from_features(feats, w, b, extras['kflat'].cpu(), J, ocfg)
+        from metrabs_amd import kernels
+        ours = kernels.reconstruct_absolute(extras['c2d'], extras['c3d'], extras['kflat'],
+                                            model.config).cpu()
+    return dict(mpjpe_mm=cpu_ref.mpjpe(ours, ref), max_abs_mm=float((ours - ref).abs().max()),
+                note='HIP fused head + reconstruct vs oracle on identical features of this batch')
+
+
+def main():
+    args = parse_args()
+    from metrabs_amd import distributed
+    rank, world, local_rank = distributed.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the hot path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    from metrabs_amd import _lib
+    from metrabs_amd.pipeline import GraphedCropPipeline
+    _lib.load()
+
+    est, cfg = build_model(args, dev)
+    n_box = args.batch // args.num_aug
+    im_h, im_w = 1080, 1920
+    pipe = GraphedCropPipeline(est, args.frames, im_h, im_w, n_box, num_aug=args.num_aug,
+                               use_graph=not args.no_graph)
+    synth_inputs(pipe, args.frames, im_h, im_w, n_box, seed=100 + rank)
+    pipe.capture()
+
+    J = est.joint_info.n_joints
+    gathered = torch.empty(world * n_box, args.num_aug, J, 3, device=dev) if world > 1 else None
+
+    def step():
+        poses = pipe.run()
+        if world > 1:
+            # the single collective of the path: KB-sized all-gather of the poses over RCCL/xGMI
+            torch.distributed.all_gather_into_tensor(gathered, poses.contiguous())
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        if world > 1:
+            torch.distributed.barrier()
+        return
+
+    crops_per_step = world * n_box * args.num_aug
+    value = crops_per_step * args.steps / elapsed
+    assert torch.isfinite(pipe.poses).all(), 'non-finite poses in the benchmark step'
+
+    # ---- per-stage timing + roofline of the dominant hand-written kernel
+    stages, extras = stage_breakdown(pipe, est, args, iters=max(10, args.steps))
+    C = est.crop_model.backbone.out_channels
+    hw = (args.res // 32) ** 2
+    D = cfg.depth
+    feat_bytes = 2 if args.precision != 'f32' else 4
+    out_bytes = 2 if args.precision != 'f32' else 4
+    n_crops = n_box * args.num_aug
+    pyr_bytes = args.frames * 3 * (im_h * im_w * (1 + 4) + (im_h // 2) * (im_w // 2) * 4 +
+                                   (im_h // 4) * (im_w // 4) * 4)
+    src_bytes = source_footprint_bytes(extras['wp'], args.res, im_h, im_w)
+    head_flops = 2.0 * C * J * (1 + D) * hw * n_crops
+    mfma_peak = MFMA_F64_PEAK if args.precision == 'f32' else MFMA_F32_PEAK
+    alg = {
+        'pyramid': dict(kernel='build_pyramid_kernel<true>', bound='hbm', bytes=pyr_bytes),
+        'warp': dict(kernel='warp_crops_kernel', bound='hbm',
+                     bytes=n_crops * 3 * args.res ** 2 * out_bytes + src_bytes),
+        'head_fused': dict(kernel='head_fused_kernel', bound='mfma', flops=head_flops,
+                           bytes=n_crops * (C * hw * feat_bytes + 20 * J)),
+    }
+    ours = {k: stages[k] for k in ('pyramid', 'geometry', 'warp', 'head_fused', 'reconstruct')}
+    dominant = max(alg, key=lambda k: stages[k])
+    a = alg[dominant]
+    if a['bound'] == 'hbm':
+        achieved, peak, unit = a['bytes'] / stages[dominant], HBM_PEAK, 'GB/s'
+    else:
+        achieved, peak, unit = a['flops'] / stages[dominant], mfma_peak, 'TFLOP/s'
+    scale = 1e9 if unit == 'GB/s' else 1e12
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(a['kernel'])
+        except (OSError, ValueError):
+            traffic = None
+    roofline = dict(kernel=a['kernel'], bound=a['bound'], achieved=achieved / scale,
+                    peak=peak / scale, unit=unit, frac=achieved / peak, traffic=traffic,
+                    avg_launch_us=stages[dominant] * 1e6,
+                    algorithmic_bytes_per_launch=a.get('bytes'),
+                    note='dominant hand-written kernel of the step by average launch duration '
+                         '(HIP events on the launch stream)')
+    kernels_us = {k: round(v * 1e6, 2) for k, v in stages.items()}
+    per_kernel = {}
+    for k, a2 in alg.items():
+        t = stages[k]
+        per_kernel[k] = dict(us=round(t * 1e6, 2), GBps=round(a2['bytes'] / t / 1e9, 1))
+        if 'flops' in a2:
+            per_kernel[k]['TFLOPs'] = round(a2['flops'] / t / 1e12, 2)
+            per_kernel[k]['frac_mfma'] = round(a2['flops'] / t / mfma_peak, 4)
+        per_kernel[k]['frac_hbm'] = round(a2['bytes'] / t / HBM_PEAK, 4)
+
+    out = {
+        'metric': 'crops/sec (256px) at N MI355X; MPJPE vs ref',
+        'value': value, 'unit': 'crops/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': args.precision, 'data': 'synthetic',
+        'config': {'workload': f'configs[1]: {args.backbone} {args.res}px, batch {n_crops} crops/GPU, '
+                               f'num_aug={args.num_aug}, {args.frames} 1080p uint8 frames/step, '
+                               f'J={J}, D={D}, random weights',
+                   'global_batch': crops_per_step, 'parallelism': f'dp{world} (crops sharded, one '
+                   f'all-gather of poses)' if world > 1 else 'single GPU',
+                   'hip_graph': not args.no_graph},
+        'roofline': roofline,
+        'stage_us': kernels_us,
+        'hand_written_kernels': per_kernel,
+        'hip_share_of_step': sum(ours.values()) / sum(stages.values()),
+    }
+    if not args.no_decode_roofline:
+        out['decode_roofline'] = decode_roofline()
+    out['parity'] = parity_probe(est, extras, cfg)
+    if world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(est, pipe, args, cfg, args.cpu_seconds)
+    else:
+        out['cpu_baseline'] = None
+    print(json.dumps(out))
+    sys.stdout.flush()
+    if world > 1:
+        torch.distributed.barrier()
+
+
+if __name__ == '__main__':
+    main()

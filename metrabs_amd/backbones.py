@@ -1,0 +1,167 @@
+"""Plain-torch.nn restatements of the reference's backbones, random-initialised, for the synthetic
+benchmark workloads of BASELINE.json (torchvision is not in this image and there is no network for
+checkpoints).  The backbone is NOT part of the hand-written hot path: it stays on PyTorch-ROCm
+(MIOpen / rocBLAS), as the north star prescribes.  Only output shape matters to the path:
+[B, C, P/32, P/32] with C = 1280 (EffNetV2-S/L, MobileNetV3-L) or 512 (ResNet-18).
+
+Architecture tables follow metrabs_pytorch/backbones/efficientnet.py:379-435 (EfficientNetV2 S/L:
+FusedMBConv/MBConv stages, SE ratio 0.25, BN eps 1e-3, PreprocLayer x*2-1 :1181-1186),
+metrabs_tf/backbones/resnet.py:746-754 (ResNet-18) and metrabs_tf/backbones/mobilenet_v3.py:387-432
+(MobileNetV3-Large, last_point_ch 1280).  Padding is symmetric k//2 (the reference uses TF-'SAME'
+fixed padding, efficientnet.py:1127-1161; irrelevant for throughput).
+"""
+import torch
+from torch import nn
+
+
+class ConvBNAct(nn.Sequential):
+    def __init__(self, cin, cout, k=3, s=1, groups=1, act=nn.SiLU, eps=1e-3):
+        layers = [nn.Conv2d(cin, cout, k, s, k // 2, groups=groups, bias=False),
+                  nn.BatchNorm2d(cout, eps=eps)]
+        if act is not None:
+            layers.append(act())
+        super().__init__(*layers)
+
+
+class SqueezeExcite(nn.Module):
+    def __init__(self, channels, squeeze, gate=nn.Sigmoid, act=nn.SiLU):
+        super().__init__()
+        self.fc1 = nn.Conv2d(channels, squeeze, 1)
+        self.fc2 = nn.Conv2d(squeeze, channels, 1)
+        self.act, self.gate = act(), gate()
+
+    def forward(self, x):
+        s = x.mean((2, 3), keepdim=True)
+        return x * self.gate(self.fc2(self.act(self.fc1(s))))
+
+
+class FusedMBConv(nn.Module):
+    def __init__(self, cin, cout, expand, stride):
+        super().__init__()
+        self.residual = stride == 1 and cin == cout
+        mid = cin * expand
+        if expand == 1:
+            self.block = ConvBNAct(cin, cout, 3, stride)
+        else:
+            self.block = nn.Sequential(ConvBNAct(cin, mid, 3, stride),
+                                       ConvBNAct(mid, cout, 1, 1, act=None))
+
+    def forward(self, x):
+        y = self.block(x)
+        return x + y if self.residual else y
+
+
+class MBConv(nn.Module):
+    def __init__(self, cin, cout, expand, stride, k=3):
+        super().__init__()
+        self.residual = stride == 1 and cin == cout
+        mid = cin * expand
+        self.block = nn.Sequential(
+            ConvBNAct(cin, mid, 1, 1), ConvBNAct(mid, mid, k, stride, groups=mid),
+            SqueezeExcite(mid, max(1, cin // 4)), ConvBNAct(mid, cout, 1, 1, act=None))
+
+    def forward(self, x):
+        y = self.block(x)
+        return x + y if self.residual else y
+
+
+class Preproc(nn.Module):
+    """PreprocLayer (efficientnet.py:1181-1186): [0,1] -> [-1,1]."""
+
+    def forward(self, x):
+        return x * 2 - 1
+
+
+EFFNETV2 = {
+    # (block, expand, stride, cin, cout, n_layers)
+    's': dict(stem=24, stages=[('f', 1, 1, 24, 24, 2), ('f', 4, 2, 24, 48, 4), ('f', 4, 2, 48, 64, 4),
+                               ('m', 4, 2, 64, 128, 6), ('m', 6, 1, 128, 160, 9),
+                               ('m', 6, 2, 160, 256, 15)], head=1280),
+    'l': dict(stem=32, stages=[('f', 1, 1, 32, 32, 4), ('f', 4, 2, 32, 64, 7), ('f', 4, 2, 64, 96, 7),
+                               ('m', 4, 2, 96, 192, 10), ('m', 6, 1, 192, 224, 19),
+                               ('m', 6, 2, 224, 384, 25), ('m', 6, 1, 384, 640, 7)], head=1280),
+}
+
+
+def efficientnetv2(size='s'):
+    cfg = EFFNETV2[size]
+    layers = [Preproc(), ConvBNAct(3, cfg['stem'], 3, 2)]
+    for kind, expand, stride, cin, cout, n in cfg['stages']:
+        for i in range(n):
+            blk = FusedMBConv if kind == 'f' else MBConv
+            layers.append(blk(cin if i == 0 else cout, cout, expand, stride if i == 0 else 1))
+    layers.append(ConvBNAct(cfg['stages'][-1][4], cfg['head'], 1, 1))
+    net = nn.Sequential(*layers)
+    net.out_channels = cfg['head']
+    return net
+
+
+class BasicBlock(nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.a = ConvBNAct(cin, cout, 3, stride, act=nn.ReLU, eps=1e-5)
+        self.b = ConvBNAct(cout, cout, 3, 1, act=None, eps=1e-5)
+        self.down = None if stride == 1 and cin == cout else ConvBNAct(cin, cout, 1, stride, act=None, eps=1e-5)
+
+    def forward(self, x):
+        idt = x if self.down is None else self.down(x)
+        return torch.relu(self.b(self.a(x)) + idt)
+
+
+def resnet18():
+    layers = [ConvBNAct(3, 64, 7, 2, act=nn.ReLU, eps=1e-5), nn.MaxPool2d(3, 2, 1)]
+    cin = 64
+    for cout, stride in [(64, 1), (128, 2), (256, 2), (512, 2)]:
+        layers += [BasicBlock(cin, cout, stride), BasicBlock(cout, cout, 1)]
+        cin = cout
+    net = nn.Sequential(*layers)
+    net.out_channels = 512
+    return net
+
+
+class MBv3Block(nn.Module):
+    def __init__(self, cin, k, exp, cout, se, hs, stride):
+        super().__init__()
+        act = nn.Hardswish if hs else nn.ReLU
+        self.residual = stride == 1 and cin == cout
+        layers = []
+        if exp != cin:
+            layers.append(ConvBNAct(cin, exp, 1, 1, act=act))
+        layers.append(ConvBNAct(exp, exp, k, stride, groups=exp, act=act))
+        if se:
+            layers.append(SqueezeExcite(exp, max(8, exp // 4), gate=nn.Hardsigmoid, act=nn.ReLU))
+        layers.append(ConvBNAct(exp, cout, 1, 1, act=None))
+        self.block = nn.Sequential(*layers)
+
+    def forward(self, x):
+        y = self.block(x)
+        return x + y if self.residual else y
+
+
+def mobilenet_v3_large():
+    table = [(3, 16, 16, 0, 0, 1), (3, 64, 24, 0, 0, 2), (3, 72, 24, 0, 0, 1), (5, 72, 40, 1, 0, 2),
+             (5, 120, 40, 1, 0, 1), (5, 120, 40, 1, 0, 1), (3, 240, 80, 0, 1, 2), (3, 200, 80, 0, 1, 1),
+             (3, 184, 80, 0, 1, 1), (3, 184, 80, 0, 1, 1), (3, 480, 112, 1, 1, 1), (3, 672, 112, 1, 1, 1),
+             (5, 672, 160, 1, 1, 2), (5, 960, 160, 1, 1, 1), (5, 960, 160, 1, 1, 1)]
+    layers = [Preproc(), ConvBNAct(3, 16, 3, 2, act=nn.Hardswish)]
+    cin = 16
+    for k, exp, cout, se, hs, s in table:
+        layers.append(MBv3Block(cin, k, exp, cout, bool(se), bool(hs), s))
+        cin = cout
+    layers += [ConvBNAct(cin, 960, 1, 1, act=nn.Hardswish), ConvBNAct(960, 1280, 1, 1, act=nn.Hardswish)]
+    net = nn.Sequential(*layers)
+    net.out_channels = 1280
+    return net
+
+
+def build_backbone(name):
+    name = name.lower()
+    if name in ('efficientnetv2-s', 'effnetv2-s', 'effv2s'):
+        return efficientnetv2('s')
+    if name in ('efficientnetv2-l', 'effnetv2-l', 'effv2l'):
+        return efficientnetv2('l')
+    if name in ('resnet18', 'resnet-18'):
+        return resnet18()
+    if name in ('mobilenetv3', 'mobilenetv3-large', 'mobilenet-v3'):
+        return mobilenet_v3_large()
+    raise ValueError(f'unknown backbone {name}')

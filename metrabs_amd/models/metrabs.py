@@ -60,8 +60,12 @@ class Metrabs(torch.nn.Module):
     predict_all_and_latents call an undefined latent_points_to_joints in the reference,
     models/metrabs.py:61-62, and are not part of the default configs)."""
 
-    def __init__(self, backbone, joint_info, config=None, in_channels=None, fused_head=True):
+    def __init__(self, backbone, joint_info, config=None, in_channels=None, fused_head=True,
+                 autocast_dtype=None):
         super().__init__()
+        # The reference runs the crop model under torch.autocast(float16) on the GPU
+        # (multiperson_model.py:241); None keeps the fp32 arithmetic of its CPU path.
+        self.autocast_dtype = autocast_dtype
         self.config = MetrabsConfig.from_any(config) if config is not None else MetrabsConfig()
         self.backbone = backbone
         self.joint_names = np.array(joint_info.names)
@@ -74,6 +78,10 @@ class Metrabs(torch.nn.Module):
 
     def forward(self, inp):
         image, intrinsics = inp
-        features = self.backbone(image)
+        if self.autocast_dtype is not None:
+            with torch.autocast('cuda', dtype=self.autocast_dtype):
+                features = self.backbone(image)
+        else:
+            features = self.backbone(image)
         coords2d, coords3d = self.heatmap_heads(features)
         return kernels.reconstruct_absolute(coords2d, coords3d, intrinsics, self.config)

@@ -15,7 +15,7 @@ Differences to the reference, all documented in DESIGN.md:
 import numpy as np
 import torch
 
-from metrabs_amd import kernels, ptu, ptu3d
+from metrabs_amd import distributed, kernels, pipeline, ptu, ptu3d
 from metrabs_amd.joint_info import JointInfo
 from metrabs_amd.multiperson import warping
 
@@ -77,6 +77,7 @@ class Pose3dEstimator(torch.nn.Module):
         self._tta_cache = {}
         self.crop_dtype = torch.float32
         self.crop_channels_last = False
+        self.shard_across_ranks = False
 
     # ------------------------------------------------------------------ public API (reference names)
 
@@ -229,20 +230,29 @@ class Pose3dEstimator(torch.nn.Module):
     def _predict_in_batches(self, images, intrinsic_matrix, distortion12, camspace_up, boxes_flat,
                             image_id_per_box, internal_batch_size, tta, antialias_factor):
         """multiperson_model.py:184-225.  The whole-image gamma decode (:196) is fused with the
-        pyramid build: one launch for all images of the call."""
+        pyramid build: one launch for all images of the call.  With ``shard_across_ranks`` the
+        internal batches are dealt round-robin to the ranks of the default process group and the
+        poses are all-gathered once at the end (metrabs_amd/distributed.py)."""
         num_aug = len(tta['gammas'])
         boxes_per_batch = internal_batch_size // num_aug
-        pyramid = kernels.build_pyramid(images)
         n_total = len(boxes_flat)
         if boxes_per_batch == 0:
             boxes_per_batch = n_total
+        rank, world = 0, 1
+        if self.shard_across_ranks and torch.distributed.is_initialized():
+            rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+        ranges = distributed.shard_internal_batches(n_total, boxes_per_batch, rank, world)
+        pyramid = kernels.build_pyramid(images)
         out = []
-        for start in range(0, n_total, boxes_per_batch):
-            s = slice(start, start + boxes_per_batch)
+        for start, stop in ranges:
+            s = slice(start, stop)
             out.append(self._predict_single_batch(
                 pyramid, intrinsic_matrix[s], distortion12[s], camspace_up[s], boxes_flat[s],
                 image_id_per_box[s], tta, antialias_factor))
-        return torch.cat(out, dim=0)
+        n_joints = self.joint_info.n_joints
+        local = torch.cat(out, dim=0) if out else \
+            torch.zeros(0, num_aug, n_joints, 3, device=boxes_flat.device)
+        return distributed.gather_poses(local, ranges, n_total, boxes_per_batch, world)
 
     def _get_crops(self, pyramid, intrinsic_matrix, distortion12, camspace_up, boxes, image_ids, tta,
                    antialias_factor):
@@ -258,18 +268,12 @@ class Pose3dEstimator(torch.nn.Module):
     def _predict_single_batch(self, pyramid, intrinsic_matrix, distortion12, camspace_up, boxes,
                               image_ids, tta, antialias_factor):
         """multiperson_model.py:227-259."""
-        crops_flat, new_k, rot = self._get_crops(
-            pyramid, intrinsic_matrix, distortion12, camspace_up, boxes, image_ids, tta,
-            antialias_factor)
-        poses_flat = self.crop_model((crops_flat, new_k.reshape(-1, 3, 3)))
-        num_aug = new_k.shape[0]
-        poses = poses_flat.reshape(num_aug, -1, self.joint_info.n_joints, 3)
-        if bool(tta['should_flip_host'].any()):
-            mirror = torch.as_tensor(self.joint_info.mirror_mapping, device=poses.device)
-            swapped = poses[..., mirror, :]
-            poses = torch.where(tta['should_flip'].reshape(-1, 1, 1, 1), swapped, poses)
-        # row vectors: multiplying by R undoes the crop rotation (multiperson_model.py:253-256)
-        return (poses @ rot).transpose(0, 1)
+        mirror = torch.as_tensor(self.joint_info.mirror_mapping, device=boxes.device)
+        return pipeline.predict_single_batch(
+            self.crop_model, mirror, tta['should_flip'], bool(tta['should_flip_host'].any()),
+            pyramid, intrinsic_matrix, distortion12, camspace_up, boxes, image_ids,
+            tta['rotflipmat'], tta['scales'], tta['gammas'], antialias_factor, self.crop_dtype,
+            self.crop_channels_last)
 
 
 def _as_f32(x):
