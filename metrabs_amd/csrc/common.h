@@ -11,6 +11,9 @@ namespace mtr {
 
 constexpr int kWave = 64;
 
+// hipGetLastError() is sticky per host thread: an unrelated earlier runtime call of the process
+// (e.g. a device probe) may have left an error behind.  Clear it before a launch, check after.
+#define MTR_CLEAR_STALE() (void)hipGetLastError()
 #define MTR_CHECK_LAUNCH()                       \
   do {                                           \
     hipError_t e_ = hipGetLastError();           \

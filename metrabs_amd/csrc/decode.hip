@@ -170,6 +170,7 @@ static int launch_decode(const void* logits, int B, int J, int D, int H, int W, 
   const int waves_per_block = 4;
   const long long blocks = (waves + waves_per_block - 1) / waves_per_block;
   if (blocks > 0x7fffffffLL) return MTR_E_SHAPE;
+  MTR_CLEAR_STALE();
   hipLaunchKernelGGL((decode_nchw_kernel<T, VEC, LPJ>), dim3((unsigned)blocks), dim3(256), 0, stream,
                      (const T*)logits, B, J, D, H, W, hs, c2d, c3d);
   MTR_CHECK_LAUNCH();

@@ -287,6 +287,7 @@ static int launch_head(const void* feat, const float* packed, int B, int C, int 
   const int chunk = 8 * g.n_groups;
   const long long blocks = (long long)((B + 7) / 8) * chunk;
   if (blocks > 0x7fffffffLL) return MTR_E_SHAPE;
+  MTR_CLEAR_STALE();
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, (const FeatT*)feat,
                      packed, B, C, H, W, J, D, g, hs, c2d, c3d);
   MTR_CHECK_LAUNCH();
@@ -332,6 +333,7 @@ extern "C" int mtr_head_pack_weights(const float* weight, const float* bias, int
   const size_t total = (size_t)g.n_groups * g.c_pad * mtr::kRows + (size_t)g.n_groups * mtr::kRows;
   size_t blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
+  MTR_CLEAR_STALE();
   hipLaunchKernelGGL(mtr::head_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                      weight, bias, C, J, D, g, (float*)packed);
   MTR_CHECK_LAUNCH();

@@ -279,9 +279,11 @@ extern "C" int mtr_reconstruct_moments(const float* coords2d, const float* coord
   hipStream_t s = (hipStream_t)stream;
   double* partials = (double*)workspace + 4;
   const int blocks = mtr::moment_blocks(B);
+  MTR_CLEAR_STALE();
   hipLaunchKernelGGL(mtr::recon_moments_kernel, dim3(blocks), dim3(256), 0, s, coords2d,
                      coords3d_rel, intrinsics, B, J, partials);
   MTR_CHECK_LAUNCH();
+  MTR_CLEAR_STALE();
   hipLaunchKernelGGL(mtr::recon_finalize_kernel, dim3(1), dim3(64), 0, s, partials, blocks,
                      (double)B * (double)J * 2.0, moments);
   MTR_CHECK_LAUNCH();
@@ -298,6 +300,7 @@ extern "C" int mtr_reconstruct_solve(const float* coords2d, const float* coords3
   if (!p->weak_perspective && !moments) return MTR_E_NULL;
   if (p->proc_side <= 0 || p->stride_train <= 0) return MTR_E_PARAM;
   if (B == 0) return MTR_OK;
+  MTR_CLEAR_STALE();
   hipLaunchKernelGGL(mtr::recon_solve_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                      coords2d, coords3d_rel, intrinsics, B, J, mtr::make_args(*p), moments,
                      poses3d);

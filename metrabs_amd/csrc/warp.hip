@@ -384,6 +384,7 @@ static int launch_warp(const float* l0, const float* l1, const float* l2, const 
                        hipStream_t stream) {
   constexpr int PX = 4;
   dim3 grid((res + 64 * PX - 1) / (64 * PX), (res + 3) / 4, n_crops);
+  MTR_CLEAR_STALE();
   hipLaunchKernelGGL((warp_crops_kernel<OutT, AA, PX>), grid, dim3(256), 0, stream, l0, l1, l2, dims,
                      wp, res, nhwc, (OutT*)out);
   MTR_CHECK_LAUNCH();
@@ -413,6 +414,7 @@ extern "C" int mtr_build_pyramid(const uint8_t* images_u8, int N, int Hi, int Wi
   const long long blocks4 = (long long)N * 3 * ((Hi + 3) / 4) * ((Wi + 3) / 4);
   long long grid = (blocks4 + 255) / 256;
   if (grid > 8192) grid = 8192;  // grid-stride the rest
+  MTR_CLEAR_STALE();
   hipLaunchKernelGGL(mtr::build_pyramid_kernel<true>, dim3((unsigned)grid), dim3(256), 0,
                      (hipStream_t)stream, (const void*)images_u8, N * 3, Hi, Wi, level0, level1,
                      level2);
@@ -428,6 +430,7 @@ extern "C" int mtr_pyramid_from_level0(const float* level0, int N, int Hi, int W
   const long long blocks4 = (long long)N * 3 * ((Hi + 3) / 4) * ((Wi + 3) / 4);
   long long grid = (blocks4 + 255) / 256;
   if (grid > 8192) grid = 8192;
+  MTR_CLEAR_STALE();
   hipLaunchKernelGGL(mtr::build_pyramid_kernel<false>, dim3((unsigned)grid), dim3(256), 0,
                      (hipStream_t)stream, (const void*)level0, N * 3, Hi, Wi, (float*)nullptr,
                      level1, level2);
@@ -447,6 +450,7 @@ extern "C" int mtr_crop_geometry(const float* boxes, int box_stride, const float
   if (n_box < 0 || n_aug <= 0 || res <= 0 || antialias <= 0 || box_stride < 4) return MTR_E_SHAPE;
   if (n_box == 0) return MTR_OK;
   const int total = n_box * n_aug;
+  MTR_CLEAR_STALE();
   hipLaunchKernelGGL(mtr::crop_geometry_kernel, dim3((total + 63) / 64), dim3(64), 0,
                      (hipStream_t)stream, boxes, box_stride, intrinsics, distortion, camspace_up,
                      image_ids, aug_rotflipmat, aug_scales, aug_gammas, n_box, n_aug, res,
