@@ -273,11 +273,20 @@ def parity_probe(est, extras, cfg):
     J = model.joint_info.n_joints
     with torch.inference_mode():
         ref = cpu_ref.crop_model_from_features(feats, w, b, extras['kflat'].cpu(), J, ocfg)
+        truth = cpu_ref.crop_model_from_features_fp64(feats, w, b, extras['kflat'].cpu(), J, ocfg)
         from metrabs_amd import kernels
         ours = kernels.reconstruct_absolute(extras['c2d'], extras['c3d'], extras['kflat'],
                                             model.config).cpu()
+        logits_absmax = float(torch.nn.functional.conv2d(feats, w[:, :, None, None], b).abs().max())
     return dict(mpjpe_mm=cpu_ref.mpjpe(ours, ref), max_abs_mm=float((ours - ref).abs().max()),
-                note='HIP fused head + reconstruct vs oracle on identical features of this batch')
+                ours_vs_fp64_mpjpe_mm=cpu_ref.mpjpe(ours, truth),
+                ref_vs_fp64_mpjpe_mm=cpu_ref.mpjpe(ref, truth),
+                ours_vs_fp64_max_mm=float((ours.double() - truth).abs().max()),
+                ref_vs_fp64_max_mm=float((ref.double() - truth).abs().max()),
+                logits_absmax=logits_absmax,
+                note='HIP fused head + reconstruct vs the oracle (fp32 CPU restatement of the '
+                     'reference) on IDENTICAL backbone features of this batch; *_vs_fp64 = distance '
+                     'of each side to a float64 evaluation of the same formulas')
 
 
 def main():

@@ -67,6 +67,11 @@ def load(path=None):
     if _lib is not None and path is None:
         return _lib
     path = path or LIB_PATH
+    # torch bundles its own libamdhip64.so.7; importing it FIRST makes the loader resolve our
+    # NEEDED libamdhip64.so.7 to that already-loaded runtime, so kernels launched here and torch's
+    # streams/allocations live in ONE HIP runtime.  Loading this library first would pull in
+    # /opt/rocm's copy instead and launches would fail with hipErrorNoDevice.
+    import torch  # noqa: F401
     if not os.path.exists(path):
         raise RuntimeError(
             f'{path} not found: the HIP extension is not built. Run `python -m metrabs_amd.build` '

@@ -139,18 +139,20 @@ def heatmap_to_metric(coords, cfg, is_training=False):
     return torch.cat([xy, coords[..., 2:] * cfg.box_size_mm], dim=-1)
 
 
-def heads_from_logits(logits, n_points, cfg):
+def heads_from_logits(logits, n_points, cfg, eval_dtype=torch.float32):
     """MetrabsHeads.forward after the 1x1 conv, models/metrabs.py:78-85.
 
     logits: [B, n_points*(1+depth), H, W]; channel n<J is the 2D heatmap of joint n, channel
-    J + d*J + j is depth slice d of joint j ('b (d j) h w -> b d j h w')."""
+    J + d*J + j is depth slice d of joint j ('b (d j) h w -> b d j h w').
+    eval_dtype=float64 evaluates the same formulas in double: the yardstick that tells the
+    reference's own fp32 rounding from ours (never the parity target)."""
     j = n_points
     logits2d, logits3d = torch.split(logits, [j, cfg.depth * j], dim=1)
     b, _, h, w = logits3d.shape
     logits3d = logits3d.reshape(b, cfg.depth, j, h, w)
-    coords3d = soft_argmax(logits3d.float(), dims=(4, 3, 1))
+    coords3d = soft_argmax(logits3d.to(eval_dtype), dims=(4, 3, 1))
     coords3d_rel = heatmap_to_metric(coords3d, cfg)
-    coords2d = soft_argmax(logits2d.float(), dims=(3, 2))
+    coords2d = soft_argmax(logits2d.to(eval_dtype), dims=(3, 2))
     coords2d_px = heatmap_to_image(coords2d, cfg)
     return coords2d_px, coords3d_rel
 
@@ -575,3 +577,12 @@ def mpjpe(a, b):
     """Mean per-joint position error (mean L2 over joints), metrabs_tf/models/eval_metrics.py:17-18
     without root-centering (ours-vs-oracle comparison)."""
     return float(torch.linalg.norm(a.double() - b.double(), dim=-1).mean())
+
+
+def crop_model_from_features_fp64(features, weight, bias, intrinsics, n_points, cfg):
+    """The same head + reconstruction evaluated in float64 end to end (yardstick only)."""
+    if weight.ndim == 2:
+        weight = weight[:, :, None, None]
+    logits = F.conv2d(features.double(), weight.double(), bias.double())
+    c2d, c3d = heads_from_logits(logits, n_points, cfg, eval_dtype=torch.float64)
+    return reconstruct_absolute(c2d, c3d, intrinsics.double(), cfg)

@@ -1,0 +1,76 @@
+"""CPU: the C-ABI shared library loads and exports EVERY symbol include/metrabs_hip.h declares; the
+ctypes table in metrabs_amd/_lib.py covers exactly that set; struct layouts match; argument checks
+that need no GPU return the documented error codes (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, 'include', 'metrabs_hip.h')
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    names = re.findall(r'^\s*(?:int|size_t|const char\*)\s+(mtr_\w+)\s*\(', text, flags=re.M)
+    return sorted(set(names))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from metrabs_amd import build, _lib
+    build.build_library(verbose=False)  # hipcc cross-compiles gfx950 without a GPU
+    return _lib.load()
+
+
+def test_header_declares_expected_surface():
+    names = declared_functions()
+    assert len(names) >= 14 and 'mtr_softargmax_decode' in names and 'mtr_warp_crops' in names
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from metrabs_amd import _lib
+    for name in declared_functions():
+        assert hasattr(lib, name), f'{name} is declared in the header but not exported'
+    assert sorted(_lib.SIGNATURES) == declared_functions(), 'ctypes table out of sync with the header'
+
+
+def test_struct_layouts_match_header():
+    from metrabs_amd import _lib
+    assert ctypes.sizeof(_lib.HeadParams) == 20 and ctypes.sizeof(_lib.ReconParams) == 36
+    assert _lib.HeadParams.box_size_mm.offset == 16 and _lib.ReconParams.mix_3d_inside_fov.offset == 20
+    text = open(HEADER).read()
+    assert int(re.search(r'#define MTR_WARP_PARAM_FLOATS (\d+)', text).group(1)) == _lib.MTR_WARP_PARAM_FLOATS
+
+
+def test_version_strerror_and_host_side_argument_checks(lib):
+    from metrabs_amd import _lib
+    assert lib.mtr_version() == 100
+    assert lib.mtr_strerror(0) == b'ok' and b'workspace' in lib.mtr_strerror(-5)
+    hp = _lib.HeadParams(256, 32, 1, 0, 2200.0)
+    # NULL pointers / bad shapes are rejected on the host before any launch
+    assert lib.mtr_softargmax_decode(None, 0, 0, 1, 17, 8, 8, 8, ctypes.byref(hp), None, None, None) == -1
+    assert lib.mtr_reconstruct_absolute(None, None, None, 1, 17, None, None, None, 0, None) == -1
+    assert lib.mtr_warp_crops(None, None, None, 1, 8, 8, None, 1, 8, 1, 0, 0, None, None) == -1
+    assert lib.mtr_head_packed_bytes(1280, 17, 8, 0) == (3 * 1280 * 64 + 3 * 64) * 4
+    assert lib.mtr_head_packed_bytes(1280, 17, 72, 0) == 0  # one joint must fit a 64-row tile
+    assert lib.mtr_reconstruct_workspace_bytes(64, 17) == (4 + 2 * 16) * 8
+
+
+def test_product_never_imports_the_oracle():
+    """The product path must not route through oracle/ (checked statically)."""
+    pkg = os.path.join(ROOT, 'metrabs_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from metrabs_amd import _lib
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        _lib.load(str(tmp_path / 'nope.so'))

@@ -1,0 +1,68 @@
+"""CPU, world_size 2 over gloo: the N>1 path -- whole internal batches dealt round-robin to ranks,
+no data-path collective, one all-gather of the poses at the end, optional all-reduce of the three
+reconstruction moments (exact-monolithic mode)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_boxes, per_batch, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from metrabs_amd import distributed
+    r, w, _ = distributed.init_from_env(backend='gloo')
+    assert (r, w) == (rank, world)
+    ranges = distributed.shard_internal_batches(n_boxes, per_batch, rank, world)
+    # a stand-in "crop model": pose of box i = i + small function of its internal batch
+    local = torch.cat([torch.arange(a, b, dtype=torch.float32).reshape(-1, 1, 1, 1).repeat(1, 2, 17, 3)
+                       + 0.001 * (a // per_batch) for a, b in ranges]) if ranges else \
+        torch.zeros(0, 2, 17, 3)
+    full = distributed.gather_poses(local, ranges, n_boxes, per_batch, world)
+    moments = torch.tensor([1.0 + rank, 10.0 * (rank + 1), float(len(local))], dtype=torch.float64)
+    moments = distributed.allreduce_moments(moments)
+    q.put((rank, full, moments))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_boxes,per_batch', [(23, 4), (8, 4), (3, 12), (5, 1)])
+def test_round_robin_shards_and_single_gather(n_boxes, per_batch):
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_boxes, per_batch, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expected = torch.arange(n_boxes, dtype=torch.float32).reshape(-1, 1, 1, 1).repeat(1, 2, 17, 3) \
+        + 0.001 * (torch.arange(n_boxes) // per_batch).float().reshape(-1, 1, 1, 1)
+    for rank, full, moments in results:
+        assert full.shape == (n_boxes, 2, 17, 3)
+        assert torch.equal(full, expected), f'rank {rank} gathered a wrong / mis-ordered result'
+        assert moments[:2].tolist() == [3.0, 30.0] and moments[2] == n_boxes
+
+
+def test_shard_partition_properties():
+    from metrabs_amd.distributed import shard_internal_batches
+    for n in (0, 1, 7, 64, 65):
+        for per in (1, 5, 12, 64):
+            for world in (1, 2, 8):
+                seen = []
+                for r in range(world):
+                    seen += [i for a, b in shard_internal_batches(n, per, r, world) for i in range(a, b)]
+                assert sorted(seen) == list(range(n))  # every box exactly once

@@ -1,0 +1,101 @@
+"""CPU: host-side mirror of the reference interface (no GPU, no compute kernels)."""
+import inspect
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import cases, cpu_ref
+
+
+def test_tta_parameters_match_reference_golden():
+    from metrabs_amd.multiperson.multiperson_model import tta_parameters
+    g = load_golden('tta_params')
+    for num_aug in range(1, 7):
+        t = tta_parameters(num_aug)
+        for k in ('gammas', 'scales', 'should_flip', 'rotflipmat'):
+            assert np.array_equal(t[k].numpy(), g[f'a{num_aug}_{k}']), (num_aug, k)
+
+
+def test_linspace_semantics():
+    from metrabs_amd import ptu
+    assert ptu.linspace(0.6, 1.0, 1).tolist() == pytest.approx([0.8])       # midpoint
+    assert ptu.linspace(0.8, 1.0, 2, endpoint=False).tolist() == pytest.approx([0.8, 0.9])
+    for n in (1, 2, 5):
+        for ep in (True, False):
+            assert torch.equal(ptu.linspace(0.8, 1.0, n, endpoint=ep),
+                               cpu_ref.ref_linspace(0.8, 1.0, n, endpoint=ep))
+
+
+def test_joint_info_mirror_mapping():
+    from metrabs_amd.joint_info import JointInfo
+    ji = JointInfo(cases.COCO17, cases.COCO17_EDGES)
+    assert ji.n_joints == 17
+    assert np.array_equal(ji.mirror_mapping, cases.mirror_mapping(cases.COCO17))
+    assert ji.mirror_mapping[cases.COCO17.index('lwri')] == cases.COCO17.index('rwri')
+    assert ji.mirror_mapping[0] == 0
+
+
+def test_config_structs_and_shipped_configs():
+    from metrabs_amd.config import CONFIG_L_384, CONFIG_S_256, MetrabsConfig
+    hp = CONFIG_S_256.head_params()
+    assert (hp.proc_side, hp.stride_test, hp.centered_stride, hp.legacy_centered_stride_bug) == (256, 32, 0, 1)
+    rp = CONFIG_L_384.recon_params()
+    assert rp.proc_side == 384 and rp.mix_enabled == 1 and abs(rp.mix_3d_inside_fov - 0.5) < 1e-7
+    assert abs(rp.l2_reg - 1e-2) < 1e-9 and abs(rp.weight_eps - 1e-4) < 1e-10
+    assert MetrabsConfig().recon_params(mix_3d_inside_fov=None).mix_enabled == 0
+    c = MetrabsConfig.from_any(cpu_ref.HeadConfig(proc_side=384, depth=4).as_dict())
+    assert c.proc_side == 384 and c.depth == 4
+
+
+def test_public_api_signature_matches_reference_defaults():
+    """Argument names and defaults of the four public methods (multiperson_model.py:39-74,384-429)."""
+    from metrabs_amd.multiperson.multiperson_model import Pose3dEstimator
+    sig = inspect.signature(Pose3dEstimator.detect_poses)
+    expected = dict(default_fov_degrees=55, internal_batch_size=64, antialias_factor=1, num_aug=5,
+                    average_aug=True, skeleton='', detector_threshold=0.3,
+                    detector_nms_iou_threshold=0.7, max_detections=-1, detector_flip_aug=False,
+                    suppress_implausible_poses=True)
+    for k, v in expected.items():
+        assert sig.parameters[k].default == v, k
+    names = list(inspect.signature(Pose3dEstimator.estimate_poses_batched).parameters)
+    assert names == ['self', 'images', 'boxes', 'intrinsic_matrix', 'distortion_coeffs',
+                     'extrinsic_matrix', 'world_up_vector', 'default_fov_degrees',
+                     'internal_batch_size', 'antialias_factor', 'num_aug', 'average_aug', 'skeleton']
+    from metrabs_amd.multiperson import multiperson_model as mm
+    assert mm.UNKNOWN_INTRINSIC_MATRIX == ((-1, -1, -1),) * 3 and mm.DEFAULT_WORLD_UP == (0, -1, 0)
+
+
+def test_warp_param_packing_and_host_distortion():
+    from metrabs_amd.multiperson import warping
+    from metrabs_amd.multiperson.multiperson_model import distort_points
+    c = cases.warp_case('dist5')
+    wp = warping.make_warp_params(c['K'], c['hinv'], c['dist'], c['crop_scales'], c['image_ids'])
+    assert wp.shape == (6, 36)
+    assert wp[:, 31].tolist() == cpu_ref.pyramid_level_index(c['crop_scales']).float().tolist()
+    k1 = cpu_ref.corner_aligned_scale_mat(0.5) @ c['K'][2]
+    assert torch.allclose(wp[2, 9:18].reshape(3, 3), k1)
+    assert wp[:, 30].tolist() == [1.0] * 6 and wp[:, 33].tolist() == [1.0] * 6
+    pts = torch.randn(6, 3, 17, 2, generator=cases.gen(3)) * 0.3
+    d12 = warping.pad_axis_to_size(c['dist'], 12)
+    assert torch.allclose(distort_points(pts, d12), cpu_ref.distort_points(pts, c['dist'][0]), atol=1e-7)
+    assert torch.equal(distort_points(pts, torch.zeros(6, 12)), pts)
+
+
+def test_cpu_tensors_are_rejected_without_fallback():
+    from metrabs_amd import kernels
+    from metrabs_amd.config import MetrabsConfig
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        kernels.softargmax_decode(torch.zeros(1, 9, 8, 8), 1, MetrabsConfig())
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        kernels.build_pyramid(torch.zeros(1, 3, 8, 8, dtype=torch.uint8))
+
+
+def test_backbone_shapes():
+    from metrabs_amd.backbones import build_backbone
+    for name, res, c in [('resnet18', 128, 512), ('mobilenetv3', 128, 1280)]:
+        net = build_backbone(name).eval()
+        with torch.inference_mode():
+            y = net(torch.rand(1, 3, res, res))
+        assert y.shape == (1, c, res // 32, res // 32) and net.out_channels == c
