@@ -277,7 +277,8 @@ def parity_probe(est, extras, cfg):
         from metrabs_amd import kernels
         ours = kernels.reconstruct_absolute(extras['c2d'], extras['c3d'], extras['kflat'],
                                             model.config).cpu()
-        logits_absmax = float(torch.nn.functional.conv2d(feats, w[:, :, None, None], b).abs().max())
+        logits_absmax = float(torch.nn.functional.conv2d(
+            feats, w.reshape(w.shape[0], -1, 1, 1), b).abs().max())
     return dict(mpjpe_mm=cpu_ref.mpjpe(ours, ref), max_abs_mm=float((ours - ref).abs().max()),
                 ours_vs_fp64_mpjpe_mm=cpu_ref.mpjpe(ours, truth),
                 ref_vs_fp64_mpjpe_mm=cpu_ref.mpjpe(ref, truth),
