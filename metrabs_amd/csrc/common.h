@@ -42,18 +42,62 @@ __device__ __forceinline__ void load_vec(const T* __restrict__ p, float (&out)[V
   }
 }
 
-// xor-butterfly reductions inside an aligned group of WIDTH lanes (WIDTH a power of two <= 64).
+// ---- cross-lane butterflies.  Inside a 16-lane DPP row the partner exchange is a VALU-rate DPP
+// move (quad_perm xor-1, xor-2, then row_ror 4 and 8), not an LDS-crossbar ds_bpermute; only the
+// two row-crossing steps of a 64-lane reduction go through __shfl_xor.
+constexpr int kDppXor1 = 0xB1;    // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;    // quad_perm [2,3,0,1]
+constexpr int kDppRor4 = 0x124;   // row_ror:4
+constexpr int kDppRor8 = 0x128;   // row_ror:8
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// every lane of an aligned group of WIDTH lanes (16 or 64) receives the group's sum / max
 template <int WIDTH, typename T>
 __device__ __forceinline__ T group_sum(T v) {
-#pragma unroll
-  for (int m = WIDTH / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+  static_assert(WIDTH == 16 || WIDTH == 64, "groups are DPP rows or whole waves");
+  v += dpp_move<kDppXor1>(v);
+  v += dpp_move<kDppXor2>(v);
+  v += dpp_move<kDppRor4>(v);
+  v += dpp_move<kDppRor8>(v);
+  if (WIDTH == 64) {
+    v += __shfl_xor(v, 16, kWave);
+    v += __shfl_xor(v, 32, kWave);
+  }
   return v;
 }
 template <int WIDTH>
 __device__ __forceinline__ float group_max(float v) {
-#pragma unroll
-  for (int m = WIDTH / 2; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, kWave));
+  static_assert(WIDTH == 16 || WIDTH == 64, "groups are DPP rows or whole waves");
+  v = fmaxf(v, dpp_move<kDppXor1>(v));
+  v = fmaxf(v, dpp_move<kDppXor2>(v));
+  v = fmaxf(v, dpp_move<kDppRor4>(v));
+  v = fmaxf(v, dpp_move<kDppRor8>(v));
+  if (WIDTH == 64) {
+    v = fmaxf(v, __shfl_xor(v, 16, kWave));
+    v = fmaxf(v, __shfl_xor(v, 32, kWave));
+  }
   return v;
+}
+
+// exp(x - m) for x <= m as ONE fma + ONE v_exp_f32: exp2(x*log2e - m*log2e); pass
+// neg_m_l2e = -m*log2e.  The argument's rounding error is |x-m|*2^-24 relative, i.e. largest on
+// the terms whose softmax weight exp(x-m) is negligible: weighted by the probabilities the error
+// of a soft-argmax sum stays at the 1-2 ulp of v_exp_f32 itself.
+constexpr float kLog2e = 1.44269504088896340736f;
+__device__ __forceinline__ float exp_shifted(float x, float neg_m_l2e) {
+  return __builtin_amdgcn_exp2f(fmaf(x, kLog2e, neg_m_l2e));
 }
 
 // heatmap coordinate in [0,1] -> crop pixels / millimetres with the reference's fp32 op sequence
@@ -90,11 +134,74 @@ __device__ __forceinline__ float heatmap_to_mm_z(float c, const HeadScale& s) {
   return __fmul_rn(c, s.box_size_mm);
 }
 
+// ---- buffer loads: one wave-uniform descriptor, per-lane byte offset in a VGPR, wave-uniform
+// byte offset in an SGPR -> no per-load 64-bit VALU address arithmetic.
+using buffer_rsrc_t = decltype(__builtin_amdgcn_make_buffer_rsrc((void*)nullptr, (short)0, 0, 0));
+__device__ __forceinline__ buffer_rsrc_t make_rsrc(const void* wave_uniform_base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wave_uniform_base), (short)0,
+                                           (int)bytes, 0x00020000);
+}
+template <typename T>
+__device__ __forceinline__ const T* uniform_ptr(const T* p) {  // provably wave-uniform for hipcc
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const T*)(((unsigned long long)hi << 32) | lo);
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void buffer_load_vec(buffer_rsrc_t rsrc, int voff_bytes, int soff_bytes,
+                                                float (&out)[VEC]) {
+  if constexpr (VEC == 4 && sizeof(T) == 4) {
+    // (bind the builtin's own 16-byte vector type with auto: converting it to a differently
+    // declared vector type silently splats element 0)
+    const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_bytes, soff_bytes, 0);
+    static_assert(sizeof(raw) == 16, "b128 load");
+    const float4 f = __builtin_bit_cast(float4, raw);
+    out[0] = f.x; out[1] = f.y; out[2] = f.z; out[3] = f.w;
+  } else if constexpr (VEC == 4 && sizeof(T) == 2) {
+    const auto raw = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff_bytes, soff_bytes, 0);
+    static_assert(sizeof(raw) == 8, "b64 load");
+    struct Pack { T h[4]; };
+    const Pack pk = __builtin_bit_cast(Pack, raw);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = to_f32(pk.h[i]);
+  } else if constexpr (VEC == 1 && sizeof(T) == 4) {
+    out[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_bytes, soff_bytes, 0));
+  } else {
+    static_assert(VEC == 1 && sizeof(T) == 2, "unsupported buffer load shape");
+    const unsigned short raw = __builtin_amdgcn_raw_buffer_load_b16(rsrc, voff_bytes, soff_bytes, 0);
+    out[0] = to_f32(__builtin_bit_cast(T, raw));
+  }
+}
+
+// 1/x in fp64 from v_rcp_f64 + two Newton steps (full double accuracy for normal x > 0): the
+// decode epilogue needs two reciprocals per joint instead of ten IEEE divisions.
+__device__ __forceinline__ double fast_rcp64(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
 // Expectation of an axis index -> [0,1]: ptu.decode_heatmap dots with linspace(0,1,n)
 // (ptu.py:68-70); ptu.linspace(num==1) is the midpoint 0.5 (ptu.py:83-84).
 __device__ __forceinline__ float axis_coord(double weighted_index_sum, double total, int n) {
   if (n <= 1) return 0.5f;
   return (float)(weighted_index_sum / total / (double)(n - 1));
+}
+// same with precomputed reciprocals: inv_nm1 = 1/(n-1) from the host (AxisInv), or < 0 for n == 1
+struct AxisInv { double w, h, d; };
+inline AxisInv make_axis_inv(int W, int H, int D) {
+  AxisInv a;
+  a.w = W > 1 ? 1.0 / (W - 1) : -1.0;
+  a.h = H > 1 ? 1.0 / (H - 1) : -1.0;
+  a.d = D > 1 ? 1.0 / (D - 1) : -1.0;
+  return a;
+}
+__device__ __forceinline__ float axis_coord_rcp(double weighted_index_sum, double inv_total,
+                                                double inv_nm1) {
+  if (inv_nm1 < 0.0) return 0.5f;
+  return (float)(weighted_index_sum * inv_total * inv_nm1);
 }
 
 }  // namespace mtr

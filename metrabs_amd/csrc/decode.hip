@@ -9,23 +9,16 @@
 //   * a group of LPJ lanes owns one (crop, joint); a wave owns 64/LPJ CONSECUTIVE joints, because
 //     channels j, j+1, .. of one depth slice are adjacent in memory ('(d j)' ordering): at 8x8
 //     (HW=64, LPJ=16, float4 per lane) every wave-wide load is one contiguous, 256-B aligned 1 KiB;
-//   * per lane an ONLINE softmax (running max m, rescale on growth) so any D (8 .. 72 ..) and any
+//   * an ONLINE softmax (group-wide running max m, rescale on growth) so any D (8 .. 72 ..) and any
 //     H*W stream through a fixed register budget; D slices are fetched 8 at a time so 8-9
 //     independent 16-B loads per lane are in flight;
-//   * exp in fp32 (accurate expf), the four moment sums (total, x, y, z) in fp64, merged across the
-//     group with xor-butterflies after rescaling each lane to the group max.
+//   * VALU budget (the first version was VALU-bound at 2.3k instructions per wave): exp(x-m) is one
+//     fma + one v_exp_f32; the depth sums of a column run in fp32 (<= 8 terms) and are promoted to
+//     fp64 once per column; the four moment sums (total, x, y, z) are fp64 and are merged across
+//     the group with DPP butterflies.
 #include "common.h"
 
 namespace mtr {
-
-struct Moments3 {
-  float m;
-  double s, sx, sy, sz;
-};
-struct Moments2 {
-  float m;
-  double s, sx, sy;
-};
 
 template <int VEC>
 __device__ __forceinline__ float vec_max(const float (&v)[VEC]) {
@@ -37,128 +30,132 @@ __device__ __forceinline__ float vec_max(const float (&v)[VEC]) {
 
 template <typename T, int VEC, int LPJ>
 __global__ __launch_bounds__(256) void decode_nchw_kernel(
-    const T* __restrict__ logits, int B, int J, int D, int H, int W, HeadScale hs,
+    const T* __restrict__ logits, int B, int J, int D, int H, int W, HeadScale hs, AxisInv ai,
     float* __restrict__ coords2d, float* __restrict__ coords3d_rel) {
   constexpr int JPW = kWave / LPJ;  // joints per wave
   constexpr int CH = 8;             // depth slices fetched per round
   const int HW = H * W;
   const int lane = threadIdx.x & (kWave - 1);
-  const int wave = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+  const int wave = __builtin_amdgcn_readfirstlane(
+      (int)(blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave)));
   const int groups_per_crop = (J + JPW - 1) / JPW;
   const int b = wave / groups_per_crop;
   if (b >= B) return;  // wave-uniform
-  const int j = (wave % groups_per_crop) * JPW + lane / LPJ;
+  const int j_raw = (wave % groups_per_crop) * JPW + lane / LPJ;
+  const bool joint_ok = j_raw < J;
+  // lanes past the last joint recompute joint J-1 (valid addresses, no exec masking) and skip
+  // the final store
+  const int j = joint_ok ? j_raw : J - 1;
   const int li = lane % LPJ;
-  const bool joint_ok = j < J;
 
-  const size_t chan = (size_t)HW;
-  const T* crop = logits + (size_t)b * (size_t)(J * (1 + D)) * chan;
-  const T* base2d = crop + (size_t)j * chan;
-  const T* base3d = crop + (size_t)(J + j) * chan;  // slice d is d*J channels further
-  const size_t dstride = (size_t)J * chan;
+  // one descriptor per wave over this crop's channels; per-lane part of the address in voff,
+  // the depth-slice part is a scalar offset
+  const int crop_elems = J * (1 + D) * HW;
+  const buffer_rsrc_t rsrc =
+      make_rsrc(uniform_ptr(logits + (size_t)b * crop_elems), (unsigned)crop_elems * sizeof(T));
+  const int slice_bytes = J * HW * (int)sizeof(T);  // depth slice d sits d*J channels further
 
-  Moments3 a3{-INFINITY, 0.0, 0.0, 0.0, 0.0};
-  Moments2 a2{-INFINITY, 0.0, 0.0, 0.0};
+  // Running maxima are GROUP-wide (shared by the LPJ lanes of the joint), so every lane rescales
+  // by the same factor and the final merge is a plain sum.
+  float m3 = -INFINITY, m2 = -INFINITY;
+  double s3 = 0.0, sx3 = 0.0, sy3 = 0.0, sz3 = 0.0;  // sum e, sum e*x, sum e*y, sum e*z
+  double s2 = 0.0, sx2 = 0.0, sy2 = 0.0;
 
   const int n_iter = (HW + VEC * LPJ - 1) / (VEC * LPJ);
   for (int it = 0; it < n_iter; ++it) {
-    const int p0 = (it * LPJ + li) * VEC;
-    const bool active = joint_ok && p0 < HW;
-    // (h, w) of the VEC elements; VEC <= W always holds for the VEC=4 instantiations (W % 4 == 0)
+    const int p_raw = (it * LPJ + li) * VEC;
+    const bool pos_ok = p_raw < HW;     // lanes past the map re-read position 0 with weight 0
+    const int p0 = pos_ok ? p_raw : 0;
+    // (h, w) of the VEC elements; the VEC=4 instantiations require W % 4 == 0, so no wrap there
     const int h0 = p0 / W, w0 = p0 - h0 * W;
-    float fx[VEC], fy[VEC];
+    double fx[VEC], fy[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       int w = w0 + v, h = h0;
       if (w >= W) { w -= W; ++h; }
-      fx[v] = (float)w;
-      fy[v] = (float)h;
+      fx[v] = (double)w;
+      fy[v] = (double)h;
     }
+    const int voff = (j * HW + p0) * (int)sizeof(T);
 
-    // ---- 2D heatmap of this joint (softmax over H*W only)
+    // ---- the 2D heatmap load is issued together with the first round of depth slices
     float v2[VEC];
-    if (active) load_vec<T, VEC>(base2d + p0, v2);
-    // ---- first round of depth slices is issued before any arithmetic
+    buffer_load_vec<T, VEC>(rsrc, voff, 0, v2);
+
     for (int d0 = 0; d0 < D; d0 += CH) {
       float v3[CH][VEC];
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
-        if (active && d0 + k < D) {
-          load_vec<T, VEC>(base3d + (size_t)(d0 + k) * dstride + p0, v3[k]);
-        } else {
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) v3[k][v] = -INFINITY;
-        }
+        const int d = (d0 + k < D) ? d0 + k : D - 1;  // tail rounds re-read slice D-1, weight 0
+        buffer_load_vec<T, VEC>(rsrc, voff, (J * HW) * (int)sizeof(T) + d * slice_bytes, v3[k]);
       }
-      if (d0 == 0 && active) {
-        const float cm = vec_max<VEC>(v2);
-        if (cm > a2.m) {
-          const double r = (double)expf(a2.m - cm);
-          a2.s *= r; a2.sx *= r; a2.sy *= r;
-          a2.m = cm;
+      if (d0 == 0) {
+        const float cm = group_max<LPJ>(pos_ok ? vec_max<VEC>(v2) : -INFINITY);
+        if (cm > m2) {  // group-uniform
+          const double r = (double)exp_shifted(m2, -cm * kLog2e);
+          s2 *= r; sx2 *= r; sy2 *= r;
+          m2 = cm;
         }
+        const float nm = pos_ok ? -m2 * kLog2e : -INFINITY;  // exp2(-inf) = 0: masked lanes
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-          const double e = (double)expf(v2[v] - a2.m);
-          a2.s += e;
-          a2.sx += e * (double)fx[v];
-          a2.sy += e * (double)fy[v];
+          const double e = (double)exp_shifted(v2[v], nm);
+          s2 += e;
+          sx2 += e * fx[v];
+          sy2 += e * fy[v];
         }
       }
-      if (active) {
+      {
         float cm = vec_max<VEC>(v3[0]);
 #pragma unroll
         for (int k = 1; k < CH; ++k) cm = fmaxf(cm, vec_max<VEC>(v3[k]));
-        if (cm > a3.m) {
-          const double r = (double)expf(a3.m - cm);
-          a3.s *= r; a3.sx *= r; a3.sy *= r; a3.sz *= r;
-          a3.m = cm;
+        cm = group_max<LPJ>(pos_ok ? cm : -INFINITY);
+        if (cm > m3) {
+          const double r = (double)exp_shifted(m3, -cm * kLog2e);
+          s3 *= r; sx3 *= r; sy3 *= r; sz3 *= r;
+          m3 = cm;
         }
-        // separable accumulation: per (h,w) column the sum over depth, then weight by x / y once
-        double col[VEC];
+        const float nm = pos_ok ? -m3 * kLog2e : -INFINITY;
+        // per (h,w) column: fp32 sums over the <= 8 depth terms of this round (2 VALU per
+        // element), promoted to fp64 once per column; x / y weights applied once per column
+        float col[VEC], colz[VEC];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) col[v] = 0.0;
+        for (int v = 0; v < VEC; ++v) col[v] = colz[v] = 0.0f;
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
-          const double fz = (double)(d0 + k);
+          const float fz = (float)(d0 + k);
+          const float nmk = (d0 + k < D) ? nm : -INFINITY;  // wave-uniform select
 #pragma unroll
           for (int v = 0; v < VEC; ++v) {
-            const double e = (double)expf(v3[k][v] - a3.m);  // exp(-inf) = 0 for padded slices
+            const float e = exp_shifted(v3[k][v], nmk);
             col[v] += e;
-            a3.sz += e * fz;
+            colz[v] = fmaf(e, fz, colz[v]);
           }
         }
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-          a3.s += col[v];
-          a3.sx += col[v] * (double)fx[v];
-          a3.sy += col[v] * (double)fy[v];
+          const double c = (double)col[v];
+          s3 += c;
+          sx3 += c * fx[v];
+          sy3 += c * fy[v];
+          sz3 += (double)colz[v];
         }
       }
     }
   }
 
-  // ---- merge the LPJ lanes of the group: rescale to the group max, then sum
-  {
-    const float gm = group_max<LPJ>(a3.m);
-    const double r = (a3.m == -INFINITY) ? 0.0 : (double)expf(a3.m - gm);
-    a3.s = group_sum<LPJ>(a3.s * r);
-    a3.sx = group_sum<LPJ>(a3.sx * r);
-    a3.sy = group_sum<LPJ>(a3.sy * r);
-    a3.sz = group_sum<LPJ>(a3.sz * r);
-    const float gm2 = group_max<LPJ>(a2.m);
-    const double r2 = (a2.m == -INFINITY) ? 0.0 : (double)expf(a2.m - gm2);
-    a2.s = group_sum<LPJ>(a2.s * r2);
-    a2.sx = group_sum<LPJ>(a2.sx * r2);
-    a2.sy = group_sum<LPJ>(a2.sy * r2);
-  }
+  // ---- merge the LPJ lanes of the group (same running max everywhere: plain sums)
+  s3 = group_sum<LPJ>(s3); sx3 = group_sum<LPJ>(sx3); sy3 = group_sum<LPJ>(sy3);
+  sz3 = group_sum<LPJ>(sz3);
+  s2 = group_sum<LPJ>(s2); sx2 = group_sum<LPJ>(sx2); sy2 = group_sum<LPJ>(sy2);
   if (joint_ok && li == 0) {
+    const double i2 = fast_rcp64(s2), i3 = fast_rcp64(s3);
     const size_t o = (size_t)b * J + j;
-    coords2d[o * 2 + 0] = heatmap_to_px(axis_coord(a2.sx, a2.s, W), hs);
-    coords2d[o * 2 + 1] = heatmap_to_px(axis_coord(a2.sy, a2.s, H), hs);
-    coords3d_rel[o * 3 + 0] = heatmap_to_mm_xy(axis_coord(a3.sx, a3.s, W), hs);
-    coords3d_rel[o * 3 + 1] = heatmap_to_mm_xy(axis_coord(a3.sy, a3.s, H), hs);
-    coords3d_rel[o * 3 + 2] = heatmap_to_mm_z(axis_coord(a3.sz, a3.s, D), hs);
+    coords2d[o * 2 + 0] = heatmap_to_px(axis_coord_rcp(sx2, i2, ai.w), hs);
+    coords2d[o * 2 + 1] = heatmap_to_px(axis_coord_rcp(sy2, i2, ai.h), hs);
+    coords3d_rel[o * 3 + 0] = heatmap_to_mm_xy(axis_coord_rcp(sx3, i3, ai.w), hs);
+    coords3d_rel[o * 3 + 1] = heatmap_to_mm_xy(axis_coord_rcp(sy3, i3, ai.h), hs);
+    coords3d_rel[o * 3 + 2] = heatmap_to_mm_z(axis_coord_rcp(sz3, i3, ai.d), hs);
   }
 }
 
@@ -172,7 +169,7 @@ static int launch_decode(const void* logits, int B, int J, int D, int H, int W, 
   if (blocks > 0x7fffffffLL) return MTR_E_SHAPE;
   MTR_CLEAR_STALE();
   hipLaunchKernelGGL((decode_nchw_kernel<T, VEC, LPJ>), dim3((unsigned)blocks), dim3(256), 0, stream,
-                     (const T*)logits, B, J, D, H, W, hs, c2d, c3d);
+                     (const T*)logits, B, J, D, H, W, hs, make_axis_inv(W, H, D), c2d, c3d);
   MTR_CHECK_LAUNCH();
   return MTR_OK;
 }

@@ -1,0 +1,137 @@
+#!/usr/bin/env python
+"""Per-kernel micro-benchmarks of libmetrabs_hip.so against their rooflines (HIP events on the launch
+stream, random non-zero data, >= 50 iterations after warm-up).
+
+    python tools/microbench.py [decode] [head] [warp] [pyramid] [recon]
+"""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from metrabs_amd import kernels  # noqa: E402
+from metrabs_amd.config import MetrabsConfig  # noqa: E402
+
+HBM = 8.0e12
+
+
+def timeit(fn, iters=50, warm=10):
+    for _ in range(warm):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e-3 / iters
+
+
+def bench_decode():
+    out = []
+    g = torch.Generator(device='cuda').manual_seed(0)
+    for name, B, J, D, H, W, dt in [('s256 fp32 (roofline shape)', 32768, 17, 8, 8, 8, torch.float32),
+                                    ('l384 J=122 fp32', 2048, 122, 8, 12, 12, torch.float32),
+                                    ('D=72 stress', 4096, 17, 72, 8, 8, torch.float32),
+                                    ('s256 fp16', 65536, 17, 8, 8, 8, torch.float16),
+                                    ('s256 B=64', 64, 17, 8, 8, 8, torch.float32)]:
+        cfg = MetrabsConfig(depth=D, proc_side=H * 32)
+        x = torch.randn(B, J * (1 + D), H, W, device='cuda', generator=g).to(dt)
+        o = (torch.empty(B, J, 2, device='cuda'), torch.empty(B, J, 3, device='cuda'))
+        t = timeit(lambda: kernels.softargmax_decode(x, J, cfg, out=o))
+        nbytes = x.numel() * x.element_size() + B * J * 20
+        out.append(dict(kernel='decode', case=name, us=round(t * 1e6, 1), GBps=round(nbytes / t / 1e9, 1),
+                        frac_hbm=round(nbytes / t / HBM, 3)))
+        del x
+    return out
+
+
+def bench_head():
+    out = []
+    g = torch.Generator(device='cuda').manual_seed(0)
+    for name, B, C, J, H, dt in [('cfg2 B=64 f32', 64, 1280, 17, 8, torch.float32),
+                                 ('B=1024 f32', 1024, 1280, 17, 8, torch.float32),
+                                 ('B=1024 f16 feats', 1024, 1280, 17, 8, torch.float16),
+                                 ('cfg3 B=32 384px f32', 32, 1280, 17, 12, torch.float32),
+                                 ('cfg5 B=32 J=122 f16', 32, 1280, 122, 12, torch.float16),
+                                 ('cfg5 B=256 J=122 f16', 256, 1280, 122, 12, torch.float16)]:
+        cfg = MetrabsConfig(proc_side=H * 32)
+        feat = torch.randn(B, C, H, H, device='cuda', generator=g).to(dt)
+        w = torch.randn(J * 9, C, device='cuda', generator=g) * 0.03
+        b = torch.zeros(J * 9, device='cuda')
+        packed = kernels.head_pack_weights(w, b, J, 8, dt)
+        o = (torch.empty(B, J, 2, device='cuda'), torch.empty(B, J, 3, device='cuda'))
+        t = timeit(lambda: kernels.head_fused(feat, packed, C, J, cfg, out=o))
+        flops = 2.0 * C * J * 9 * H * H * B
+        peak = 78.6e12 if dt == torch.float32 else 157.3e12
+        nbytes = feat.numel() * feat.element_size()
+        out.append(dict(kernel='head_fused', case=name, us=round(t * 1e6, 1),
+                        TFLOPs=round(flops / t / 1e12, 2), frac_mfma=round(flops / t / peak, 3),
+                        GBps=round(nbytes / t / 1e9, 1)))
+    return out
+
+
+def bench_warp_pyramid():
+    from metrabs_amd.multiperson.multiperson_model import tta_parameters
+    out = []
+    g = torch.Generator().manual_seed(0)
+    frames = torch.randint(0, 256, (8, 3, 1080, 1920), dtype=torch.uint8, generator=g).cuda()
+    t = timeit(lambda: kernels.build_pyramid(frames))
+    nbytes = 8 * 3 * (1080 * 1920 * 5 + 540 * 960 * 4 + 270 * 480 * 4)
+    out.append(dict(kernel='pyramid', case='8 x 1080p', us=round(t * 1e6, 1),
+                    GBps=round(nbytes / t / 1e9, 1), frac_hbm=round(nbytes / t / HBM, 3)))
+    pyr = kernels.build_pyramid(frames)
+    for name, n, num_aug, aa, dt in [('64 crops 256px f32', 64, 1, 1, torch.float32),
+                                     ('64 crops 256px f16', 64, 1, 1, torch.float16),
+                                     ('320 crops (64x5 aug) f16', 64, 5, 1, torch.float16),
+                                     ('64 crops aa=2 f32', 64, 1, 2, torch.float32)]:
+        tta = {k: v.cuda() for k, v in tta_parameters(num_aug).items()}
+        bw = 60 + 340 * torch.rand(n, generator=g)
+        bh = 150 + 750 * torch.rand(n, generator=g)
+        boxes = torch.stack([torch.rand(n, generator=g) * (1920 - bw),
+                             torch.rand(n, generator=g) * (1080 - bh).clamp_min(1), bw, bh], 1).cuda()
+        K = torch.tensor([[1844.0, 0, 960], [0, 1844.0, 540], [0, 0, 1]]).repeat(n, 1, 1).cuda()
+        up = torch.tensor([0.0, -1, 0]).repeat(n, 1).cuda()
+        ids = (torch.arange(n) % 8).int().cuda()
+        geo = lambda: kernels.crop_geometry(boxes, K, torch.zeros(n, 12).cuda(), up, ids,
+                                            tta['rotflipmat'], tta['scales'], tta['gammas'], 256, aa)
+        tg = timeit(geo)
+        _, _, wp = geo()
+        o = torch.empty(n * num_aug, 3, 256, 256, device='cuda', dtype=dt)
+        t = timeit(lambda: kernels.warp_crops(pyr, wp, 256, aa, out=o))
+        nbytes = o.numel() * o.element_size()
+        out.append(dict(kernel='warp', case=name, us=round(t * 1e6, 1), geometry_us=round(tg * 1e6, 1),
+                        out_GBps=round(nbytes / t / 1e9, 1), crops_per_s=round(n * num_aug / t)))
+    return out
+
+
+def bench_recon():
+    out = []
+    g = torch.Generator(device='cuda').manual_seed(0)
+    for B, J in [(64, 17), (32, 122), (4096, 17)]:
+        c2d = torch.rand(B, J, 2, device='cuda', generator=g) * 200 + 28
+        rel = torch.randn(B, J, 3, device='cuda', generator=g) * 300
+        K = torch.tensor([[500.0, 0, 128], [0, 500.0, 128], [0, 0, 1]], device='cuda').repeat(B, 1, 1)
+        ws = kernels.reconstruct_workspace(B, J, 'cuda')
+        o = torch.empty(B, J, 3, device='cuda')
+        t = timeit(lambda: kernels.reconstruct_absolute(c2d, rel, K, MetrabsConfig(), workspace=ws, out=o))
+        out.append(dict(kernel='reconstruct', case=f'B={B} J={J}', us=round(t * 1e6, 1)))
+    return out
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['decode', 'head', 'warp', 'recon']
+    res = []
+    if 'decode' in which:
+        res += bench_decode()
+    if 'head' in which:
+        res += bench_head()
+    if 'warp' in which or 'pyramid' in which:
+        res += bench_warp_pyramid()
+    if 'recon' in which:
+        res += bench_recon()
+    for r in res:
+        print(json.dumps(r))
