@@ -66,28 +66,24 @@ __device__ __forceinline__ double dpp_move(double v) {
 // every lane of an aligned group of WIDTH lanes (16 or 64) receives the group's sum / max
 template <int WIDTH, typename T>
 __device__ __forceinline__ T group_sum(T v) {
-  static_assert(WIDTH == 16 || WIDTH == 64, "groups are DPP rows or whole waves");
+  static_assert(WIDTH == 16 || WIDTH == 32 || WIDTH == 64, "groups are DPP rows / half / whole waves");
   v += dpp_move<kDppXor1>(v);
   v += dpp_move<kDppXor2>(v);
   v += dpp_move<kDppRor4>(v);
   v += dpp_move<kDppRor8>(v);
-  if (WIDTH == 64) {
-    v += __shfl_xor(v, 16, kWave);
-    v += __shfl_xor(v, 32, kWave);
-  }
+  if (WIDTH >= 32) v += __shfl_xor(v, 16, kWave);
+  if (WIDTH == 64) v += __shfl_xor(v, 32, kWave);
   return v;
 }
 template <int WIDTH>
 __device__ __forceinline__ float group_max(float v) {
-  static_assert(WIDTH == 16 || WIDTH == 64, "groups are DPP rows or whole waves");
+  static_assert(WIDTH == 16 || WIDTH == 32 || WIDTH == 64, "groups are DPP rows / half / whole waves");
   v = fmaxf(v, dpp_move<kDppXor1>(v));
   v = fmaxf(v, dpp_move<kDppXor2>(v));
   v = fmaxf(v, dpp_move<kDppRor4>(v));
   v = fmaxf(v, dpp_move<kDppRor8>(v));
-  if (WIDTH == 64) {
-    v = fmaxf(v, __shfl_xor(v, 16, kWave));
-    v = fmaxf(v, __shfl_xor(v, 32, kWave));
-  }
+  if (WIDTH >= 32) v = fmaxf(v, __shfl_xor(v, 16, kWave));
+  if (WIDTH == 64) v = fmaxf(v, __shfl_xor(v, 32, kWave));
   return v;
 }
 

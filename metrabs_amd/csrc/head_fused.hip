@@ -30,11 +30,12 @@
 //     stage s+1 in flight under the MFMAs of stage s;
 //   * LDS rows are padded so that row stride = 16 (mod 32) words: the A/B fragment reads
 //     (lane (l&15, l>>4) -> [k0 + (l>>4)][16*tile + (l&15)]) are bank-conflict free;
-//   * epilogue: accumulators (+bias) -> LDS [64][HWpad], then each 16-lane group decodes one joint
-//     (softmax over its D slices, fp64 moment sums) exactly like decode.hip;
+//   * epilogue: accumulators (+bias) -> LDS [64][HWpad], then each half-wave decodes one joint
+//     (softmax over its D slices, fp64 moment sums; exp in the accumulator's precision class);
 //   * 1-D grid with an XCD-aware remap: the joint groups of one crop run on the same XCD so the
 //     crop's features are fetched from HBM once and re-read from that XCD's L2.
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -90,15 +91,77 @@ __global__ void head_pack_kernel(const float* __restrict__ w, const float* __res
   }
 }
 
+// ---- global -> registers -> LDS staging of one 32-channel stage (weights tile + feature tile).
+// Plain structs + forceinline functions (a lambda capturing the register arrays by reference kept
+// them in scratch memory).
+// ---- global -> registers -> LDS staging of one 32-channel stage (weights tile + feature tile).
+// Native ext_vector loads/stores only: copying HIP's float4 *struct* between address spaces lowers
+// to llvm.memcpy (global -> private -> LDS), which SROA does not split, so the staged tile went
+// through scratch memory with a dependent scratch_load -> ds_write -> barrier chain every stage.
+using v4f = __attribute__((ext_vector_type(4))) float;
+
 template <typename T>
-__device__ __forceinline__ float4 load4_as_f32(const T* p) {
+__device__ __forceinline__ v4f load4_native(const T* p) {
   float v[4];
   load_vec<T, 4>(p, v);
-  return make_float4(v[0], v[1], v[2], v[3]);
+  return v4f{v[0], v[1], v[2], v[3]};
+}
+template <>
+__device__ __forceinline__ v4f load4_native<float>(const float* p) {
+  return *reinterpret_cast<const v4f*>(p);
 }
 
+template <int B_VECS>
+struct StageRegs {
+  v4f a[2];
+  v4f b[B_VECS];
+};
+template <typename FeatT>
+struct StageSrc {
+  const float* wgrp;    // [c_pad][64] packed weights of this joint group
+  const FeatT* fcrop;   // [C][HW] features of this crop
+  int C, HW, vec_per_row, b_total, tid;
+};
+
+template <typename FeatT, int B_VECS>
+__device__ __forceinline__ void load_stage(const StageSrc<FeatT>& s, int c0, StageRegs<B_VECS>& r) {
+  // weight tile: rows c0..c0+31 of [c_pad][64], fully contiguous 8 KiB
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    r.a[i] = *reinterpret_cast<const v4f*>(s.wgrp + (size_t)c0 * kRows + (size_t)(s.tid + i * 256) * 4);
+#pragma unroll
+  for (int i = 0; i < B_VECS; ++i) {
+    const int v = s.tid + i * 256;
+    const int row = v / s.vec_per_row, q = v - row * s.vec_per_row;
+    const bool ok = v < s.b_total && c0 + row < s.C;
+    // clamp instead of branching: every lane loads a valid address, invalid lanes get zeros
+    const FeatT* ptr = s.fcrop + (ok ? (size_t)(c0 + row) * s.HW + q * 4 : 0);
+    const v4f val = load4_native<FeatT>(ptr);
+    r.b[i] = ok ? val : v4f{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+template <int B_VECS, int HWP, typename FeatT>
+__device__ __forceinline__ void store_stage(const StageSrc<FeatT>& s, float* As_buf, float* Bs_buf,
+                                            const StageRegs<B_VECS>& r) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int v = s.tid + i * 256;
+    const int row = v / (kRows / 4), q = v % (kRows / 4);
+    *reinterpret_cast<v4f*>(As_buf + row * kRowsPad + q * 4) = r.a[i];
+  }
+#pragma unroll
+  for (int i = 0; i < B_VECS; ++i) {
+    const int v = s.tid + i * 256;
+    const int row = v / s.vec_per_row, q = v - row * s.vec_per_row;
+    if (v < s.b_total) *reinterpret_cast<v4f*>(Bs_buf + row * HWP + q * 4) = r.b[i];
+  }
+}
+
+// LDS (40-90 KiB per workgroup) already caps residency at <= 4 waves per SIMD; asking for 2 lets the
+// register allocator keep the prefetched stage and the fragment batch in VGPRs instead of scratch.
 template <typename FeatT, int NT, bool ACC64>
-__global__ __launch_bounds__(256) void head_fused_kernel(
+__global__ __launch_bounds__(256, 2) void head_fused_kernel(
     const FeatT* __restrict__ feat, const float* __restrict__ packed, int B, int C, int H, int W,
     int J, int D, HeadGeom g, HeadScale hs, float* __restrict__ coords2d,
     float* __restrict__ coords3d_rel) {
@@ -126,36 +189,7 @@ __global__ __launch_bounds__(256) void head_fused_kernel(
 
   const int vec_per_row = HW / 4;              // HW % 4 == 0 (checked on the host)
   const int b_total = kKC * vec_per_row;       // feature float4s per stage
-  float4 a_reg[2], b_reg[B_VECS];
-
-  auto load_stage = [&](int c0) {
-    // weight tile: rows c0..c0+31 of [c_pad][64], fully contiguous 8 KiB
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      a_reg[i] = *reinterpret_cast<const float4*>(wgrp + (size_t)c0 * kRows + (size_t)(tid + i * 256) * 4);
-#pragma unroll
-    for (int i = 0; i < B_VECS; ++i) {
-      const int v = tid + i * 256;
-      const int r = v / vec_per_row, q = v - r * vec_per_row;
-      b_reg[i] = (v < b_total && c0 + r < C)
-                     ? load4_as_f32<FeatT>(fcrop + (size_t)(c0 + r) * HW + q * 4)
-                     : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  auto store_stage = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int v = tid + i * 256;
-      const int r = v / (kRows / 4), q = v % (kRows / 4);
-      *reinterpret_cast<float4*>(As + buf * A_STAGE + r * kRowsPad + q * 4) = a_reg[i];
-    }
-#pragma unroll
-    for (int i = 0; i < B_VECS; ++i) {
-      const int v = tid + i * 256;
-      const int r = v / vec_per_row, q = v - r * vec_per_row;
-      if (v < b_total) *reinterpret_cast<float4*>(Bs + buf * B_STAGE + r * HWP + q * 4) = b_reg[i];
-    }
-  };
+  const StageSrc<FeatT> src{wgrp, fcrop, C, HW, vec_per_row, b_total, tid};
 
   using AccT = typename std::conditional<ACC64, f64x4, f32x4>::type;
   AccT acc[NT];
@@ -169,31 +203,65 @@ __global__ __launch_bounds__(256) void head_fused_kernel(
   }
 
   const int n_stages = g.c_pad / kKC;
-  load_stage(0);
-  store_stage(0);
-  __syncthreads();
   const int fr = lane & 15, fk = lane >> 4;
-  for (int s = 0; s < n_stages; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < n_stages) load_stage((s + 1) * kKC);  // in flight under the MFMAs below
-    const float* Ab = As + buf * A_STAGE + wid * 16 + fr;
-    const float* Bb = Bs + buf * B_STAGE + fr;
-#pragma unroll
-    for (int k0 = 0; k0 < kKC; k0 += 4) {
-      const float a = Ab[(k0 + fk) * kRowsPad];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const float b = Bb[(k0 + fk) * HWP + n * 16];
-        if constexpr (ACC64) {
-          acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a, (double)b, acc[n], 0, 0, 0);
-        } else {
-          acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[n], 0, 0, 0);
-        }
-      }
-    }
-    if (s + 1 < n_stages) store_stage(buf ^ 1);
-    __syncthreads();
+
+  // One pipeline iteration: MFMAs of stage s out of LDS buffer s&1, while the global loads of
+  // stage s+2 are issued into register set LD and the (already landed) stage s+1 held in register
+  // set ST is written to the other LDS buffer.  Two register sets alternate (HEAD_ITER is expanded
+  // twice per loop trip so that both are statically indexed): two stages = 32 KiB per workgroup
+  // are in flight, which is what it takes to cover the ~2 us load latency seen by PMC
+  // (SQ_WAIT_ANY) when fewer than one workgroup per CU is resident (B = 64).
+#define HEAD_ITER(S, LD, ST)                                                                      \
+  {                                                                                               \
+    const int s_ = (S);                                                                           \
+    const int buf = s_ & 1;                                                                       \
+    if (s_ + kAhead < n_stages) load_stage<FeatT, B_VECS>(src, (s_ + kAhead) * kKC, LD);          \
+    const float* Ab = As + buf * A_STAGE + wid * 16 + fr;                                         \
+    const float* Bb = Bs + buf * B_STAGE + fr;                                                    \
+    _Pragma("unroll") for (int kb = 0; kb < kKC / 4; kb += KS) {                                  \
+      float af[KS], bf[KS][NT];                                                                   \
+      _Pragma("unroll") for (int k = 0; k < KS; ++k) {                                            \
+        af[k] = Ab[((kb + k) * 4 + fk) * kRowsPad];                                               \
+        _Pragma("unroll") for (int n = 0; n < NT; ++n)                                            \
+            bf[k][n] = Bb[((kb + k) * 4 + fk) * HWP + n * 16];                                    \
+      }                                                                                           \
+      __builtin_amdgcn_sched_barrier(0); /* keep the reads batched ahead of the MFMAs */          \
+      _Pragma("unroll") for (int k = 0; k < KS; ++k) {                                            \
+        _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                          \
+          if constexpr (ACC64) {                                                                  \
+            acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)af[k], (double)bf[k][n],        \
+                                                          acc[n], 0, 0, 0);                       \
+          } else {                                                                                \
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k], bf[k][n], acc[n], 0, 0, 0);      \
+          }                                                                                       \
+        }                                                                                         \
+      }                                                                                           \
+    }                                                                                             \
+    if (s_ + 1 < n_stages)                                                                        \
+      store_stage<B_VECS, HWP>(src, As + (buf ^ 1) * A_STAGE, Bs + (buf ^ 1) * B_STAGE, ST);      \
+    __syncthreads();                                                                              \
   }
+
+  // k-steps per fragment batch and prefetch depth are register-budget choices: f64 accumulators
+  // take 8 VGPRs per tile (128 at NT = 16, where only one stage can be prefetched)
+  constexpr int KS = NT <= 4 ? (ACC64 ? 4 : 8) : (NT <= 9 ? 4 : 2);
+  constexpr int kAhead = (NT >= 16 && ACC64) ? 1 : 2;
+  StageRegs<B_VECS> regs0;
+  load_stage<FeatT, B_VECS>(src, 0, regs0);
+  store_stage<B_VECS, HWP>(src, As, Bs, regs0);
+  if constexpr (kAhead == 2) {
+    StageRegs<B_VECS> regs1;
+    if (n_stages > 1) load_stage<FeatT, B_VECS>(src, kKC, regs1);
+    __syncthreads();
+    for (int s = 0; s < n_stages; s += 2) {
+      HEAD_ITER(s, regs0, regs1)
+      if (s + 1 < n_stages) HEAD_ITER(s + 1, regs1, regs0)
+    }
+  } else {
+    __syncthreads();
+    for (int s = 0; s < n_stages; ++s) HEAD_ITER(s, regs0, regs0)
+  }
+#undef HEAD_ITER
 
   // ---- epilogue 1: logits (+bias) -> LDS [64][HWP].  C/D layout: col = l&15 and
   //   f32 16x16x4: row = (l>>4)*4 + reg;   f64 16x16x4: row = (l>>4) + 4*reg
@@ -208,16 +276,19 @@ __global__ __launch_bounds__(256) void head_fused_kernel(
     }
   __syncthreads();
 
-  // ---- epilogue 2: one 16-lane group per joint of this group
+  // ---- epilogue 2: a half-wave (32 lanes) per joint of this group (<= 8 joints in flight).
+  // The logits are on chip and the epilogue is a few % of the GEMM, so the f64-accumulate mode
+  // also takes exp in f64: the decode error then is the f32 rounding of the outputs only, which
+  // matters because reconstruct_absolute amplifies coords3d_rel errors ~7x.
   const int per = 1 + D;
-  const int li = lane & 15;
-  for (int jl = wid * 4 + (lane >> 4); jl < g.jg; jl += 16) {
+  const int li = lane & 31;
+  for (int jl = wid * 2 + (lane >> 5); jl < g.jg; jl += 8) {
     const int j = grp * g.jg + jl;
     if (j >= J) continue;
     const float* row2d = Ls + (size_t)(jl * per) * HWP;
     const float* row3d = row2d + HWP;
     float m2 = -INFINITY, m3 = -INFINITY;
-    for (int p = li * 4; p < HW; p += 64) {
+    for (int p = li * 4; p < HW; p += 128) {
       const float4 v = *reinterpret_cast<const float4*>(row2d + p);
       m2 = fmaxf(m2, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
       for (int d = 0; d < D; ++d) {
@@ -225,11 +296,10 @@ __global__ __launch_bounds__(256) void head_fused_kernel(
         m3 = fmaxf(m3, fmaxf(fmaxf(u.x, u.y), fmaxf(u.z, u.w)));
       }
     }
-    // the 16 lanes of this joint sit in one quarter of the wave: width-16 butterflies
-    m2 = group_max<16>(m2);
-    m3 = group_max<16>(m3);
+    m2 = group_max<32>(m2);
+    m3 = group_max<32>(m3);
     double s2 = 0, sx2 = 0, sy2 = 0, s3 = 0, sx3 = 0, sy3 = 0, sz3 = 0;
-    for (int p = li * 4; p < HW; p += 64) {
+    for (int p = li * 4; p < HW; p += 128) {
       const float4 v = *reinterpret_cast<const float4*>(row2d + p);
       const float v2[4] = {v.x, v.y, v.z, v.w};
       double col[4] = {0, 0, 0, 0};
@@ -238,7 +308,7 @@ __global__ __launch_bounds__(256) void head_fused_kernel(
         const float u3[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const double e = (double)expf(u3[q] - m3);
+          const double e = ACC64 ? exp((double)u3[q] - (double)m3) : (double)expf(u3[q] - m3);
           col[q] += e;
           sz3 += e * (double)d;
         }
@@ -246,14 +316,14 @@ __global__ __launch_bounds__(256) void head_fused_kernel(
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int h = (p + q) / W, w = (p + q) - h * W;  // W < 4 maps wrap more than once
-        const double e2 = (double)expf(v2[q] - m2);
+        const double e2 = ACC64 ? exp((double)v2[q] - (double)m2) : (double)expf(v2[q] - m2);
         s2 += e2; sx2 += e2 * w; sy2 += e2 * h;
         s3 += col[q]; sx3 += col[q] * w; sy3 += col[q] * h;
       }
     }
-    s2 = group_sum<16>(s2); sx2 = group_sum<16>(sx2); sy2 = group_sum<16>(sy2);
-    s3 = group_sum<16>(s3); sx3 = group_sum<16>(sx3); sy3 = group_sum<16>(sy3);
-    sz3 = group_sum<16>(sz3);
+    s2 = group_sum<32>(s2); sx2 = group_sum<32>(sx2); sy2 = group_sum<32>(sy2);
+    s3 = group_sum<32>(s3); sx3 = group_sum<32>(sx3); sy3 = group_sum<32>(sy3);
+    sz3 = group_sum<32>(sz3);
     if (li == 0) {
       const size_t o = (size_t)crop * J + j;
       coords2d[o * 2 + 0] = heatmap_to_px(axis_coord(sx2, s2, W), hs);
