@@ -247,6 +247,20 @@ __global__ __launch_bounds__(64) void crop_geometry_kernel(
 
 // ------------------------------------------------------------------------------------------------
 // warp: thread = PX consecutive output pixels of one row, all 3 channels.
+//
+// v1 replayed every fp32 operation of the reference (IEEE divisions, the [-1,1] normalise /
+// un-normalise round trip of grid_sample, libm powf) and cost ~900 VALU instructions per pixel: the
+// kernel was ALU-bound at 25 % of its HBM roofline.  v2 keeps the reference's geometry
+// (homography, distortion polynomial, K_level, bilinear taps with zero padding, align_corners=True
+// pixel coordinates) but
+//   * evaluates the sample position directly (the round trip only adds rounding noise the
+//     reference itself is subject to: its own fp32-vs-fp64 floor is 1e-5 in linear light);
+//   * one IEEE reciprocal per pixel for the perspective divide;
+//   * x**g as exp2(g*log2(x)) on v_log_f32 / v_exp_f32 (<= 4 ulp for dark pixels, 1 ulp above
+//     0.25; 0 -> 0 exactly);
+//   * taps as two 8-byte buffer loads per channel (columns xs, xs+1 of rows ys, ys+1 with
+//     xs = clamp(x0, 0, W-2)), zero padding folded into four per-pixel weights; the buffer
+//     descriptor (one per crop, wave-uniform) range-checks the address, so no per-tap branches.
 
 struct LevelDims { int H[3], W[3]; };
 
@@ -262,11 +276,38 @@ template <> __device__ __forceinline__ __hip_bfloat16 from_f32<__hip_bfloat16>(f
   return __float2bfloat16(v);
 }
 
+__device__ __forceinline__ float fast_pow_unit(float x, float g) {
+  // x in [0, 1]: log2(0) = -inf -> exp2(-inf) = 0
+  return __builtin_amdgcn_exp2f(g * __builtin_amdgcn_logf(x));
+}
+
+// weights of the loaded pair (columns s, s+1) for the wanted taps (i, i+1) with fractions
+// (t0 for i, t1 for i+1); n = extent.  Taps outside [0, n-1] contribute zero.
+__device__ __forceinline__ void pair_weights(int i, int s, int n, float t0, float t1, float& w_first,
+                                             float& w_second) {
+  w_first = 0.0f;
+  w_second = 0.0f;
+  if (i == s) { w_first = t0; w_second = t1; }       // both taps inside
+  else if (i == -1) { w_first = t1; }                // only tap i+1 = 0 is inside
+  else if (i == n - 1) { w_second = t0; }            // only tap i = n-1 is inside (s = n-2)
+}
+
 template <typename OutT, int AA, int PX>
 __global__ __launch_bounds__(256) void warp_crops_kernel(
     const float* __restrict__ l0, const float* __restrict__ l1, const float* __restrict__ l2,
-    LevelDims dims, const float* __restrict__ wp_all, int res, int nhwc, OutT* __restrict__ out) {
-  const int crop = blockIdx.z;
+    LevelDims dims, const float* __restrict__ wp_all, int n_crops, int res, int nhwc,
+    OutT* __restrict__ out) {
+  // ---- XCD-aware map (block id b runs on XCD b % 8): all row tiles of a crop share one XCD, so
+  // the crop's source footprint is fetched into ONE L2 instead of eight.
+  const int row_tiles = (res + 3) / 4;
+  const int x_tiles = (res + 64 * PX - 1) / (64 * PX);
+  const int per_crop = row_tiles * x_tiles;
+  const int id = blockIdx.x;
+  const int crop = (id / (8 * per_crop)) * 8 + (id % 8);
+  if (crop >= n_crops) return;
+  const int tile = (id / 8) % per_crop;
+  const int ty = tile / x_tiles, tx = tile - ty * x_tiles;
+
   const float* __restrict__ wp = wp_all + (size_t)crop * MTR_WARP_PARAM_FLOATS;
   // per-crop constants are wave-uniform -> scalar loads
   const float h0 = wp[0], h1 = wp[1], h2 = wp[2], h3 = wp[3], h4 = wp[4], h5 = wp[5], h6 = wp[6],
@@ -279,10 +320,12 @@ __global__ __launch_bounds__(256) void warp_crops_kernel(
   const int W = dims.W[level], H = dims.H[level];
   const float* __restrict__ lvl = level == 0 ? l0 : (level == 1 ? l1 : l2);
   const float* __restrict__ planes = lvl + (size_t)img * 3 * H * W;
-  const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+  const int plane_elems = H * W;
+  const buffer_rsrc_t rsrc = make_rsrc(uniform_ptr(planes), (unsigned)(3 * plane_elems) * 4u);
+  const bool tiny = W < 2 || H < 2;  // degenerate pyramid levels: per-tap path
 
-  const int u0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * PX;
-  const int v = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int u0 = (tx * 64 + (threadIdx.x & 63)) * PX;
+  const int v = ty * 4 + (threadIdx.x >> 6);
   if (v >= res || u0 >= res) return;
 
   float acc[PX][3];
@@ -296,11 +339,12 @@ __global__ __launch_bounds__(256) void warp_crops_kernel(
 #pragma unroll
       for (int si = 0; si < AA; ++si) {
         const float U = (float)((u0 + p) * AA + si), V = (float)(v * AA + sj);
-        // old = Hinv @ [U, V, 1] (warping.py:45-46)
+        // old = Hinv @ [U, V, 1] (warping.py:45-46); project (ptu3d.py:145-146)
         const float ox = fmaf(h0, U, fmaf(h1, V, h2));
         const float oy = fmaf(h3, U, fmaf(h4, V, h5));
         const float oz = fmaf(h6, U, fmaf(h7, V, h8));
-        float nx = __fdiv_rn(ox, oz), ny = __fdiv_rn(oy, oz);
+        const float inv = __fdiv_rn(1.0f, oz);
+        float nx = ox * inv, ny = oy * inv;
         if (has_dist) {  // distort_points (warping.py:57-62)
           float pa, pb, pcx, pcy;
           distortion_parts<float>(nx, ny, wp + 18, pa, pb, pcx, pcy);
@@ -308,31 +352,41 @@ __global__ __launch_bounds__(256) void warp_crops_kernel(
           nx = fmaf(nx, sc, pcx);
           ny = fmaf(ny, sc, pcy);
         }
-        // pixel coordinates in the chosen level: (K_lvl @ [nx, ny, 1])[:2] (warping.py:49)
-        const float qx = fmaf(k0, nx, fmaf(k1, ny, k2));
-        const float qy = fmaf(k3, nx, fmaf(k4, ny, k5));
-        // the reference normalises to [-1,1] (warping.py:50-51) and grid_sample un-normalises
-        // (align_corners=True: ((g+1)/2)*(size-1)); replay the same fp32 round trip
-        const float gx = __fsub_rn(__fmul_rn(__fdiv_rn(qx, wm1), 2.0f), 1.0f);
-        const float gy = __fsub_rn(__fmul_rn(__fdiv_rn(qy, hm1), 2.0f), 1.0f);
-        const float ix = __fmul_rn(__fdiv_rn(__fadd_rn(gx, 1.0f), 2.0f), wm1);
-        const float iy = __fmul_rn(__fdiv_rn(__fadd_rn(gy, 1.0f), 2.0f), hm1);
-        const float fx0 = floorf(ix), fy0 = floorf(iy);
-        // keep far-away / non-finite coordinates out of the int conversion
-        const bool sane = (ix > -2.0f) && (iy > -2.0f) && (ix < (float)W + 1.0f) &&
-                          (iy < (float)H + 1.0f);
+        // pixel coordinates in the chosen level: (K_lvl @ [nx, ny, 1])[:2] (warping.py:49);
+        // align_corners=True => these ARE the sample coordinates
+        const float ix = fmaf(k0, nx, fmaf(k1, ny, k2));
+        const float iy = fmaf(k3, nx, fmaf(k4, ny, k5));
+        // taps entirely outside the frame (or non-finite coordinates) contribute nothing
+        const bool sane = (ix > -1.0f) && (iy > -1.0f) && (ix < (float)W) && (iy < (float)H);
         if (!sane) continue;
+        const float fx0 = floorf(ix), fy0 = floorf(iy);
         const int x0 = (int)fx0, y0 = (int)fy0;
-        const float tx1 = __fsub_rn(ix, fx0), tx0 = __fsub_rn(__fadd_rn(fx0, 1.0f), ix);
-        const float ty1 = __fsub_rn(iy, fy0), ty0 = __fsub_rn(__fadd_rn(fy0, 1.0f), iy);
-        const float wnw = tx0 * ty0, wne = tx1 * ty0, wsw = tx0 * ty1, wse = tx1 * ty1;
+        const float tx1 = ix - fx0, tx0 = 1.0f - tx1;
+        const float ty1 = iy - fy0, ty0 = 1.0f - ty1;
+        if (!tiny) {
+          const int xs = min(max(x0, 0), W - 2), ys = min(max(y0, 0), H - 2);
+          float wl, wr, wt, wb;
+          pair_weights(x0, xs, W, tx0, tx1, wl, wr);
+          pair_weights(y0, ys, H, ty0, ty1, wt, wb);
+          const float w00 = wl * wt, w01 = wr * wt, w10 = wl * wb, w11 = wr * wb;
+          const int off = (ys * W + xs) * 4;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float* __restrict__ pl = planes + (size_t)c * H * W;
-          const float nw = tap(pl, x0, y0, W, H), ne = tap(pl, x0 + 1, y0, W, H);
-          const float sw = tap(pl, x0, y0 + 1, W, H), se = tap(pl, x0 + 1, y0 + 1, W, H);
-          const float val = fmaf(se, wse, fmaf(sw, wsw, fmaf(ne, wne, nw * wnw)));
-          acc[p][c] += val;  // avg_pool2d(aa): row-major sum, then / aa^2
+          for (int c = 0; c < 3; ++c) {
+            const auto top = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, c * plane_elems * 4, 0);
+            const auto bot = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + W * 4, c * plane_elems * 4, 0);
+            struct F2 { float a, b; };
+            const F2 t = __builtin_bit_cast(F2, top), b2 = __builtin_bit_cast(F2, bot);
+            acc[p][c] += fmaf(b2.b, w11, fmaf(b2.a, w10, fmaf(t.b, w01, t.a * w00)));
+          }
+        } else {
+          const float wnw = tx0 * ty0, wne = tx1 * ty0, wsw = tx0 * ty1, wse = tx1 * ty1;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float* __restrict__ pl = planes + (size_t)c * plane_elems;
+            const float nw = tap(pl, x0, y0, W, H), ne = tap(pl, x0 + 1, y0, W, H);
+            const float sw = tap(pl, x0, y0 + 1, W, H), se = tap(pl, x0 + 1, y0 + 1, W, H);
+            acc[p][c] += fmaf(se, wse, fmaf(sw, wsw, fmaf(ne, wne, nw * wnw)));
+          }
         }
       }
     }
@@ -346,7 +400,7 @@ __global__ __launch_bounds__(256) void warp_crops_kernel(
     for (int c = 0; c < 3; ++c) {
       float val = acc[p][c];
       if (AA > 1) val = val * (1.0f / (AA * AA));
-      res_v[p][c] = (gexp == 1.0f) ? val : powf(val, gexp);
+      res_v[p][c] = (gexp == 1.0f) ? val : fast_pow_unit(val, gexp);
     }
 
   const bool full = (u0 + PX <= res) && (res % PX == 0);
@@ -383,10 +437,12 @@ static int launch_warp(const float* l0, const float* l1, const float* l2, const 
                        const float* wp, int n_crops, int res, int nhwc, void* out,
                        hipStream_t stream) {
   constexpr int PX = 4;
-  dim3 grid((res + 64 * PX - 1) / (64 * PX), (res + 3) / 4, n_crops);
+  const long long per_crop = (long long)((res + 64 * PX - 1) / (64 * PX)) * ((res + 3) / 4);
+  const long long blocks = (long long)((n_crops + 7) / 8) * 8 * per_crop;
+  if (blocks > 0x7fffffffLL) return MTR_E_SHAPE;
   MTR_CLEAR_STALE();
-  hipLaunchKernelGGL((warp_crops_kernel<OutT, AA, PX>), grid, dim3(256), 0, stream, l0, l1, l2, dims,
-                     wp, res, nhwc, (OutT*)out);
+  hipLaunchKernelGGL((warp_crops_kernel<OutT, AA, PX>), dim3((unsigned)blocks), dim3(256), 0, stream,
+                     l0, l1, l2, dims, wp, n_crops, res, nhwc, (OutT*)out);
   MTR_CHECK_LAUNCH();
   return MTR_OK;
 }
@@ -467,7 +523,6 @@ extern "C" int mtr_warp_crops(const float* level0, const float* level1, const fl
   if (N <= 0 || Hi <= 0 || Wi <= 0 || n_crops < 0 || res <= 0) return MTR_E_SHAPE;
   if (out_layout != MTR_NCHW && out_layout != MTR_NHWC) return MTR_E_DTYPE;
   if (n_crops == 0) return MTR_OK;
-  if (n_crops > 65535) return MTR_E_SHAPE;  // gridDim.z
   if ((uintptr_t)out % 16) return MTR_E_ALIGN;
   mtr::LevelDims dims;
   dims.H[0] = Hi; dims.W[0] = Wi;
