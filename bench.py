@@ -293,11 +293,19 @@ def parity_probe(est, extras, cfg):
 def main():
     args = parse_args()
     from metrabs_amd import distributed
-    rank, world, local_rank = distributed.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the hot path has no CPU fallback)')
+    # one process per GPU; the device is bound BEFORE the process group exists so that RCCL's
+    # communicator and barriers land on it.  MTR_BENCH_SHARED_DEVICE=1 (+ MTR_BENCH_BACKEND=gloo)
+    # lets several ranks share cuda:0 -- only to exercise the N>1 code path on a 1-GPU box.
+    local_rank = int(os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0')))
+    if os.environ.get('MTR_BENCH_SHARED_DEVICE') == '1':
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    rank, world, _ = distributed.init_from_env(backend=os.environ.get('MTR_BENCH_BACKEND'))
+    if world != args.gpus and rank == 0:
+        print(f'note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE', file=sys.stderr)
     from metrabs_amd import _lib
     from metrabs_amd.pipeline import GraphedCropPipeline
     _lib.load()
@@ -313,11 +321,16 @@ def main():
     J = est.joint_info.n_joints
     gathered = torch.empty(world * n_box, args.num_aug, J, 3, device=dev) if world > 1 else None
 
+    use_base_gather = world > 1 and torch.distributed.get_backend() == 'nccl'
+
     def step():
         poses = pipe.run()
         if world > 1:
             # the single collective of the path: KB-sized all-gather of the poses over RCCL/xGMI
-            torch.distributed.all_gather_into_tensor(gathered, poses.contiguous())
+            if use_base_gather:
+                torch.distributed.all_gather_into_tensor(gathered, poses.contiguous())
+            else:  # gloo (test harness only)
+                torch.distributed.all_gather(list(gathered.chunk(world)), poses.contiguous())
 
     for _ in range(args.warmup):
         step()
@@ -379,7 +392,8 @@ def main():
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(a['kernel'])
+            entry = json.load(open(tpath)).get(a['kernel'])
+            traffic = entry.get('bytes') if isinstance(entry, dict) else entry
         except (OSError, ValueError):
             traffic = None
     roofline = dict(kernel=a['kernel'], bound=a['bound'], achieved=achieved / scale,
@@ -417,6 +431,11 @@ def main():
     }
     if not args.no_decode_roofline:
         out['decode_roofline'] = decode_roofline()
+        try:
+            out['decode_roofline']['traffic'] = json.load(open(tpath)).get(
+                'decode_nchw_kernel<float,4,16>', {}).get('bytes')
+        except (OSError, ValueError):
+            pass
     out['parity'] = parity_probe(est, extras, cfg)
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(est, pipe, args, cfg, args.cpu_seconds)
