@@ -10,7 +10,8 @@ num_aug=1:
     uint8 1080p frames --(gamma decode + pyramid)--> (crop geometry) --> (perspective crop sampler)
       --> EfficientNetV2-S backbone [PyTorch-ROCm / MIOpen, random weights]
       --> (fused 1x1-projection MFMA + volumetric soft-argmax decode) --> (absolute reconstruction)
-      --> mirror un-swap + back-rotation --> poses3d [64, 17, 3]          (+ one all-gather if N > 1)
+      --> (post-processing K7: mirror un-swap, back-rotation, 2D projection, TTA mean)
+      --> poses3d [64, 17, 3], poses2d [64, 17, 2]                      (+ one all-gather if N > 1)
 
 Parenthesised stages are the hand-written HIP kernels of libmetrabs_hip.so.  Metric: crops/sec,
 whole job (all ranks).  Weak scaling: every rank processes its own 64 crops per step.
@@ -171,6 +172,10 @@ def stage_breakdown(pipe, est, args, iters):
         ws = kernels.reconstruct_workspace(c2d.shape[0], c2d.shape[1], c2d.device)
         st['reconstruct'] = time_stage(
             lambda: kernels.reconstruct_absolute(c2d, c3d, kflat, model.config, workspace=ws), iters)
+        poses_flat = kernels.reconstruct_absolute(c2d, c3d, kflat, model.config, workspace=ws)
+        st['postprocess'] = time_stage(lambda: kernels.postprocess_poses(
+            poses_flat, rot, tta['should_flip'], pipe.mirror, pipe.intrinsics, pipe.distortion12,
+            pipe.inv_extrinsics, None, None, True), iters)
     return st, dict(wp=wp, feats=feats, c2d=c2d, c3d=c3d, kflat=kflat)
 
 
@@ -319,7 +324,7 @@ def main():
     pipe.capture()
 
     J = est.joint_info.n_joints
-    gathered = torch.empty(world * n_box, args.num_aug, J, 3, device=dev) if world > 1 else None
+    gathered = torch.empty(world * n_box, J, 3, device=dev) if world > 1 else None
 
     use_base_gather = world > 1 and torch.distributed.get_backend() == 'nccl'
 
@@ -380,7 +385,8 @@ def main():
         'head_fused': dict(kernel='head_fused_kernel', bound='mfma', flops=head_flops,
                            bytes=n_crops * (C * hw * feat_bytes + 20 * J)),
     }
-    ours = {k: stages[k] for k in ('pyramid', 'geometry', 'warp', 'head_fused', 'reconstruct')}
+    ours = {k: stages[k] for k in ('pyramid', 'geometry', 'warp', 'head_fused', 'reconstruct',
+                                   'postprocess')}
     dominant = max(alg, key=lambda k: stages[k])
     a = alg[dominant]
     if a['bound'] == 'hbm':

@@ -174,6 +174,25 @@ int mtr_warp_crops(const float* level0, const float* level1, const float* level2
                    int Wi, const float* warp_params, int n_crops, int res, int antialias,
                    int out_dtype, int out_layout, void* out, mtr_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * K7 (first "next" row): post-processing of the crop-model output in one launch.
+ * Replaces Pose3dEstimator._predict_single_batch post-ops (multiperson_model.py:244-259: mirror
+ * un-swap through joint_info.mirror_mapping for flipped augs, poses @ R, transpose) and the
+ * post-ops of _estimate_poses_batched (multiperson_model.py:143-178: joint_transform_matrix,
+ * 2D projection with lens distortion, world transform by inv(extrinsics), skeleton selection,
+ * mean over the TTA axis).
+ *   poses_crop [A, n, J, 3] crop-model output (aug-major), rot [A, n, 3, 3], should_flip [A] (u8),
+ *   mirror_mapping [J] (i32), joint_transform [J, Jt] or NULL, skeleton [S] (i32) or NULL,
+ *   intrinsics [n,3,3], distortion [n,12], inv_extrinsics [n,4,4] (already inverted)
+ *   -> poses3d [n, (A,) S', 3], poses2d [n, (A,) S', 2]; the A axis is dropped when average_aug;
+ *   S' = S if skeleton else (Jt if joint_transform else J).
+ */
+int mtr_postprocess_poses(const float* poses_crop, const float* rot, const uint8_t* should_flip,
+                          const int32_t* mirror_mapping, const float* joint_transform, int Jt,
+                          const int32_t* skeleton, int S, const float* intrinsics,
+                          const float* distortion, const float* inv_extrinsics, int A, int n, int J,
+                          int average_aug, float* poses3d, float* poses2d, mtr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,9 @@ SIGNATURES = {
     'mtr_crop_geometry': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                   c_void_p, c_void_p, c_void_p]),
+    'mtr_postprocess_poses': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                      c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                      c_void_p, c_void_p, c_void_p]),
     'mtr_warp_crops': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
                                c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
 }

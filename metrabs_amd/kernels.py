@@ -226,3 +226,30 @@ def head_fused(features, packed, C, n_points, cfg, out=None):
         ctypes.byref(hp), _ptr(c2d), _ptr(c3d), current_stream_ptr(features.device)),
         'mtr_head_fused')
     return c2d, c3d
+
+
+def postprocess_poses(poses_crop, rot, should_flip, mirror_mapping, intrinsics, distortion12,
+                      inv_extrinsics, joint_transform=None, skeleton=None, average_aug=True):
+    """K7: crop-model output [A*n, J, 3] (or [A,n,J,3]) + R [A,n,3,3] -> (poses3d, poses2d) in the
+    original camera / world frame: [n, S, 3|2] if average_aug else [n, A, S, 3|2]
+    (multiperson_model.py:143-178,244-259)."""
+    require_cuda(poses_crop, rot, intrinsics)
+    dev = poses_crop.device
+    A, n = rot.shape[0], rot.shape[1]
+    poses_crop = poses_crop.contiguous().float().reshape(A, n, -1, 3)
+    J = poses_crop.shape[2]
+    flip = should_flip.to(dev, torch.uint8).contiguous()
+    mirror = mirror_mapping.to(dev, torch.int32).contiguous()
+    jtm = joint_transform.to(dev, torch.float32).contiguous() if joint_transform is not None else None
+    skel = skeleton.to(dev, torch.int32).contiguous() if skeleton is not None else None
+    Jt = jtm.shape[1] if jtm is not None else J
+    S = skel.numel() if skel is not None else Jt
+    shape = (n, S) if average_aug else (n, A, S)
+    p3 = torch.empty(*shape, 3, device=dev, dtype=torch.float32)
+    p2 = torch.empty(*shape, 2, device=dev, dtype=torch.float32)
+    check(_lib.load().mtr_postprocess_poses(
+        _ptr(poses_crop), _ptr(rot.contiguous().float()), _ptr(flip), _ptr(mirror), _ptr(jtm), Jt,
+        _ptr(skel), S, _ptr(intrinsics.contiguous().float()), _ptr(distortion12.contiguous().float()),
+        _ptr(inv_extrinsics.contiguous().float()), A, n, J, int(bool(average_aug)), _ptr(p3),
+        _ptr(p2), current_stream_ptr(dev)), 'mtr_postprocess_poses')
+    return p3, p2

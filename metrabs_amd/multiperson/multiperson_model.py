@@ -78,6 +78,8 @@ class Pose3dEstimator(torch.nn.Module):
         self.crop_dtype = torch.float32
         self.crop_channels_last = False
         self.shard_across_ranks = False
+        # K7: one HIP launch for everything after the crop model (False = the torch-op sequence)
+        self.fused_postprocess = True
 
     # ------------------------------------------------------------------ public API (reference names)
 
@@ -200,39 +202,56 @@ class Pose3dEstimator(torch.nn.Module):
 
         tta = self._tta(num_aug, dev)
         n_joints = self.joint_info.n_joints
-        if sum(counts) == 0:
-            poses3d_flat = torch.zeros(0, num_aug, n_joints, 3, device=dev)
-        else:
-            poses3d_flat = self._predict_in_batches(
-                images, intrinsic_matrix_b, distortion_b, camspace_up_b, boxes_flat,
-                image_id_per_box, internal_batch_size, tta, antialias_factor)
-
-        # post-processing (multiperson_model.py:143-178)
-        if self.joint_transform_matrix is not None:
-            poses3d_flat = torch.einsum(
-                'bank,nN->baNk', poses3d_flat, self.joint_transform_matrix.to(dev))
-        poses2d_flat_normalized = ptu3d.to_homogeneous(
-            distort_points(ptu3d.project(poses3d_flat), distortion_b))
-        poses2d_flat = torch.einsum(
-            'bank,bjk->banj', poses2d_flat_normalized, intrinsic_matrix_b[:, :2, :])
-        poses3d_flat = torch.einsum(
-            'bank,bjk->banj', ptu3d.to_homogeneous(poses3d_flat), inv_extrinsics_b[:, :3, :])
         idx = self.skeleton_joint_indices_table[skeleton]
-        poses3d_flat = poses3d_flat[..., idx, :]
-        poses2d_flat = poses2d_flat[..., idx, :]
-        if average_aug:
-            poses3d_flat = torch.mean(poses3d_flat, dim=-3)
-            poses2d_flat = torch.mean(poses2d_flat, dim=-3)
+        if self.fused_postprocess:
+            n_out = len(idx)
+            if sum(counts) == 0:
+                shape = (0, n_out) if average_aug else (0, num_aug, n_out)
+                poses3d_flat = torch.zeros(*shape, 3, device=dev)
+                poses2d_flat = torch.zeros(*shape, 2, device=dev)
+            else:
+                post = dict(inv_extrinsics=inv_extrinsics_b, average_aug=average_aug,
+                            skeleton=torch.as_tensor(idx, dtype=torch.int32, device=dev),
+                            joint_transform=self.joint_transform_matrix)
+                packed = self._predict_in_batches(
+                    images, intrinsic_matrix_b, distortion_b, camspace_up_b, boxes_flat,
+                    image_id_per_box, internal_batch_size, tta, antialias_factor, post=post)
+                poses3d_flat, poses2d_flat = packed[..., :3], packed[..., 3:]
+        else:
+            if sum(counts) == 0:
+                poses3d_flat = torch.zeros(0, num_aug, n_joints, 3, device=dev)
+            else:
+                poses3d_flat = self._predict_in_batches(
+                    images, intrinsic_matrix_b, distortion_b, camspace_up_b, boxes_flat,
+                    image_id_per_box, internal_batch_size, tta, antialias_factor)
+            # post-processing as torch ops (multiperson_model.py:143-178)
+            if self.joint_transform_matrix is not None:
+                poses3d_flat = torch.einsum(
+                    'bank,nN->baNk', poses3d_flat, self.joint_transform_matrix.to(dev))
+            poses2d_flat_normalized = ptu3d.to_homogeneous(
+                distort_points(ptu3d.project(poses3d_flat), distortion_b))
+            poses2d_flat = torch.einsum(
+                'bank,bjk->banj', poses2d_flat_normalized, intrinsic_matrix_b[:, :2, :])
+            poses3d_flat = torch.einsum(
+                'bank,bjk->banj', ptu3d.to_homogeneous(poses3d_flat), inv_extrinsics_b[:, :3, :])
+            poses3d_flat = poses3d_flat[..., idx, :]
+            poses2d_flat = poses2d_flat[..., idx, :]
+            if average_aug:
+                poses3d_flat = torch.mean(poses3d_flat, dim=-3)
+                poses2d_flat = torch.mean(poses2d_flat, dim=-3)
         poses3d = list(torch.split(poses3d_flat, counts))
         poses2d = list(torch.split(poses2d_flat, counts))
         return dict(boxes=boxes_out, poses3d=poses3d, poses2d=poses2d)
 
     def _predict_in_batches(self, images, intrinsic_matrix, distortion12, camspace_up, boxes_flat,
-                            image_id_per_box, internal_batch_size, tta, antialias_factor):
+                            image_id_per_box, internal_batch_size, tta, antialias_factor, post=None):
         """multiperson_model.py:184-225.  The whole-image gamma decode (:196) is fused with the
         pyramid build: one launch for all images of the call.  With ``shard_across_ranks`` the
         internal batches are dealt round-robin to the ranks of the default process group and the
-        poses are all-gathered once at the end (metrabs_amd/distributed.py)."""
+        results are all-gathered once at the end (metrabs_amd/distributed.py).
+
+        post=None  -> poses [n, A, J, 3] in the original camera frame (torch-op post-processing);
+        post=dict  -> K7 runs per internal batch; returns [n, (A,) S, 5] = poses3d | poses2d."""
         num_aug = len(tta['gammas'])
         boxes_per_batch = internal_batch_size // num_aug
         n_total = len(boxes_flat)
@@ -246,12 +265,26 @@ class Pose3dEstimator(torch.nn.Module):
         out = []
         for start, stop in ranges:
             s = slice(start, stop)
-            out.append(self._predict_single_batch(
+            res = self._predict_single_batch(
                 pyramid, intrinsic_matrix[s], distortion12[s], camspace_up[s], boxes_flat[s],
-                image_id_per_box[s], tta, antialias_factor))
-        n_joints = self.joint_info.n_joints
-        local = torch.cat(out, dim=0) if out else \
-            torch.zeros(0, num_aug, n_joints, 3, device=boxes_flat.device)
+                image_id_per_box[s], tta, antialias_factor, raw=post is not None)
+            if post is not None:
+                poses_flat, rot = res
+                p3, p2 = kernels.postprocess_poses(
+                    poses_flat, rot, tta['should_flip'],
+                    torch.as_tensor(self.joint_info.mirror_mapping), intrinsic_matrix[s],
+                    distortion12[s], post['inv_extrinsics'][s], post['joint_transform'],
+                    post['skeleton'], post['average_aug'])
+                res = torch.cat([p3, p2], dim=-1)
+            out.append(res)
+        if out:
+            local = torch.cat(out, dim=0)
+        elif post is not None:
+            n_out = post['skeleton'].numel()
+            shape = (0, n_out, 5) if post['average_aug'] else (0, num_aug, n_out, 5)
+            local = torch.zeros(*shape, device=boxes_flat.device)
+        else:
+            local = torch.zeros(0, num_aug, self.joint_info.n_joints, 3, device=boxes_flat.device)
         return distributed.gather_poses(local, ranges, n_total, boxes_per_batch, world)
 
     def _get_crops(self, pyramid, intrinsic_matrix, distortion12, camspace_up, boxes, image_ids, tta,
@@ -266,14 +299,14 @@ class Pose3dEstimator(torch.nn.Module):
         return crops, new_k, rot
 
     def _predict_single_batch(self, pyramid, intrinsic_matrix, distortion12, camspace_up, boxes,
-                              image_ids, tta, antialias_factor):
-        """multiperson_model.py:227-259."""
+                              image_ids, tta, antialias_factor, raw=False):
+        """multiperson_model.py:227-259 (raw=True stops after the crop model: K7 does the rest)."""
         mirror = torch.as_tensor(self.joint_info.mirror_mapping, device=boxes.device)
         return pipeline.predict_single_batch(
             self.crop_model, mirror, tta['should_flip'], bool(tta['should_flip_host'].any()),
             pyramid, intrinsic_matrix, distortion12, camspace_up, boxes, image_ids,
             tta['rotflipmat'], tta['scales'], tta['gammas'], antialias_factor, self.crop_dtype,
-            self.crop_channels_last)
+            self.crop_channels_last, raw=raw)
 
 
 def _as_f32(x):

@@ -11,7 +11,7 @@ from metrabs_amd import kernels
 def predict_single_batch(crop_model, mirror_mapping, should_flip, any_flip, pyramid, intrinsic_matrix,
                          distortion12, camspace_up, boxes, image_ids, rotflipmat, aug_scales,
                          aug_gammas, antialias_factor, crop_dtype=torch.float32,
-                         channels_last=False):
+                         channels_last=False, raw=False):
     """-> poses [n_box, num_aug, J, 3] in the ORIGINAL camera frame.
 
     All tensor arguments live on the GPU; ``any_flip`` is a host bool (known from num_aug alone)."""
@@ -22,6 +22,8 @@ def predict_single_batch(crop_model, mirror_mapping, should_flip, any_flip, pyra
     crops = kernels.warp_crops(pyramid, wp, res, antialias_factor, out_dtype=crop_dtype,
                                channels_last=channels_last)
     poses_flat = crop_model((crops, new_k.reshape(-1, 3, 3)))
+    if raw:
+        return poses_flat, rot  # [A*n, J, 3] in crop camera frames + R [A,n,3,3]: K7's inputs
     num_aug = new_k.shape[0]
     poses = poses_flat.reshape(num_aug, -1, poses_flat.shape[-2], 3)
     if any_flip:
@@ -34,8 +36,9 @@ def predict_single_batch(crop_model, mirror_mapping, should_flip, any_flip, pyra
 class GraphedCropPipeline:
     """One fixed-shape internal batch (n_images frames, n_box boxes, num_aug) captured in a HIP
     graph.  ``run`` copies nothing: callers write into the static input tensors
-    (``images``, ``boxes``, ``intrinsics``, ``distortion12``, ``camspace_up``, ``image_ids``) and read
-    ``poses`` [n_box, num_aug, J, 3]."""
+    (``images``, ``boxes``, ``intrinsics``, ``distortion12``, ``camspace_up``, ``image_ids``,
+    ``inv_extrinsics``) and read ``poses3d`` [n_box, J, 3] / ``poses2d`` [n_box, J, 2] (TTA-averaged;
+    ``poses`` aliases ``poses3d``)."""
 
     def __init__(self, estimator, n_images, im_h, im_w, n_box, num_aug=1, antialias_factor=1,
                  use_graph=True, include_pyramid=True):
@@ -48,24 +51,32 @@ class GraphedCropPipeline:
         self.distortion12 = torch.zeros(n_box, 12, device=dev)
         self.camspace_up = torch.tensor([0.0, -1.0, 0.0], device=dev).repeat(n_box, 1)
         self.image_ids = torch.zeros(n_box, dtype=torch.int32, device=dev)
+        self.inv_extrinsics = torch.eye(4, device=dev).repeat(n_box, 1, 1)
+        self.average_aug = True
         self.tta = estimator._tta(num_aug, dev)
         self.mirror = torch.as_tensor(estimator.joint_info.mirror_mapping, device=dev)
         self.any_flip = bool(self.tta['should_flip_host'].any())
         self.aa = antialias_factor
         self.include_pyramid = include_pyramid
         self.pyramid = None
-        self.poses = None
+        self.poses = self.poses3d = self.poses2d = None
         self.graph = None
         self.use_graph = use_graph
 
     def _body(self):
         if self.include_pyramid or self.pyramid is None:
             self.pyramid = kernels.build_pyramid(self.images)
-        return predict_single_batch(
+        poses_flat, rot = predict_single_batch(
             self.est.crop_model, self.mirror, self.tta['should_flip'], self.any_flip, self.pyramid,
             self.intrinsics, self.distortion12, self.camspace_up, self.boxes, self.image_ids,
             self.tta['rotflipmat'], self.tta['scales'], self.tta['gammas'], self.aa,
-            self.est.crop_dtype, self.est.crop_channels_last)
+            self.est.crop_dtype, self.est.crop_channels_last, raw=True)
+        # K7: mirror un-swap, back rotation, 2D projection, world transform, TTA mean in one launch
+        self.poses3d, self.poses2d = kernels.postprocess_poses(
+            poses_flat, rot, self.tta['should_flip'], self.mirror, self.intrinsics,
+            self.distortion12, self.inv_extrinsics, self.est.joint_transform_matrix, None,
+            self.average_aug)
+        return self.poses3d
 
     def capture(self, warmup=3):
         with torch.inference_mode():

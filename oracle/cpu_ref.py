@@ -586,3 +586,28 @@ def crop_model_from_features_fp64(features, weight, bias, intrinsics, n_points, 
     logits = F.conv2d(features.double(), weight.double(), bias.double())
     c2d, c3d = heads_from_logits(logits, n_points, cfg, eval_dtype=torch.float64)
     return reconstruct_absolute(c2d, c3d, intrinsics.double(), cfg)
+
+
+def postprocess_from_crop_outputs(poses_flat, rot, should_flip, mirror_mapping, intrinsic_matrix,
+                                  distortion_coeffs, extrinsic_matrix, joint_transform_matrix=None,
+                                  skeleton_indices=None, average_aug=True):
+    """Everything the reference does after crop_model for ONE internal batch:
+    multiperson_model.py:244-259 (mirror un-swap, @R, transpose) then :143-178 (joint transform,
+    2D projection, world transform, skeleton select, TTA mean).  poses_flat [A*n, J, 3];
+    rot [A,n,3,3]; camera tensors per box ([n,...]).  Checker for the K7 kernel."""
+    num_aug = rot.shape[0]
+    poses = torch.reshape(poses_flat, [num_aug, -1, poses_flat.shape[-2], 3])
+    swapped = poses[..., mirror_mapping, :]
+    poses = torch.where(torch.reshape(should_flip, [-1, 1, 1, 1]), swapped, poses)
+    p3 = (poses @ rot).transpose(0, 1)
+    if joint_transform_matrix is not None:
+        p3 = torch.einsum('bank,nN->baNk', p3, joint_transform_matrix)
+    p2n = to_homogeneous(distort_points(project(p3), distortion_coeffs))
+    p2 = torch.einsum('bank,bjk->banj', p2n, intrinsic_matrix[:, :2, :])
+    p3 = torch.einsum('bank,bjk->banj', to_homogeneous(p3),
+                      torch.linalg.inv(extrinsic_matrix)[:, :3, :])
+    if skeleton_indices is not None:
+        p3, p2 = p3[..., skeleton_indices, :], p2[..., skeleton_indices, :]
+    if average_aug:
+        p3, p2 = torch.mean(p3, dim=-3), torch.mean(p2, dim=-3)
+    return p3, p2

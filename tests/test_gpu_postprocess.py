@@ -1,0 +1,80 @@
+"""GPU parity of K7 (fused post-processing) through the C-ABI vs the oracle's
+restatement of multiperson_model.py:143-178,244-259, on identical crop-model outputs.
+Bounds: poses3d 1.5e-3 mm max (3 ulp at 3-5 m), poses2d 2e-3 px max (poses kept in front of the
+camera so the projection is well conditioned)."""
+import pytest
+import torch
+
+from oracle import cases, cpu_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def make_inputs(n, A, J, seed, dist, jt, skeleton):
+    g = cases.gen(seed)
+    poses = torch.randn(A * n, J, 3, generator=g) * torch.tensor([300.0, 400.0, 250.0]) \
+        + torch.tensor([0.0, 0.0, 3500.0])
+    tta = cpu_ref.tta_params(A)
+    ang = 0.2 * torch.randn(A, n, 3, generator=g)
+    rot = torch.linalg.matrix_exp(torch.stack([
+        torch.stack([torch.zeros_like(ang[..., 0]), -ang[..., 2], ang[..., 1]], -1),
+        torch.stack([ang[..., 2], torch.zeros_like(ang[..., 0]), -ang[..., 0]], -1),
+        torch.stack([-ang[..., 1], ang[..., 0], torch.zeros_like(ang[..., 0])], -1)], -2))
+    rot = tta['rotflipmat'][:, None] @ rot
+    K = torch.stack([cases.intrinsics_for(1080, 1920, 55.0, seed + i) for i in range(n)])
+    d = (torch.tensor([list(dist)] * n, dtype=torch.float32) if dist else torch.zeros(n, 5))
+    E = torch.eye(4).repeat(n, 1, 1)
+    E[:, :3, :3] = torch.linalg.matrix_exp(torch.tensor(
+        [[0.0, -0.1, 0.05], [0.1, 0.0, -0.2], [-0.05, 0.2, 0.0]]))
+    E[:, :3, 3] = torch.tensor([100.0, -50.0, 400.0])
+    jtm = None
+    if jt:
+        jtm = 0.6 * torch.eye(J, jt)[:J] + 0.4 * torch.softmax(torch.randn(J, jt, generator=g), dim=0)
+    skel = torch.tensor(skeleton) if skeleton else None
+    mirror = torch.as_tensor(cases.mirror_mapping(cases.COCO17 if J == 17 else [f'j{i}' for i in range(J)]))
+    return poses, rot, tta['should_flip'], mirror, K, d, E, jtm, skel
+
+
+@pytest.mark.parametrize('cfg', [
+    dict(n=7, A=1, J=17, dist=None, jt=0, skeleton=None, avg=True),
+    dict(n=5, A=5, J=17, dist=cases.DISTORTION_5, jt=0, skeleton=[0, 5, 6, 11, 12], avg=True),
+    dict(n=3, A=4, J=17, dist=cases.DISTORTION_12, jt=24, skeleton=[1, 3, 23, 7], avg=False),
+    dict(n=2, A=5, J=122, dist=None, jt=40, skeleton=None, avg=True),
+    dict(n=64, A=2, J=17, dist=None, jt=0, skeleton=None, avg=False),
+])
+def test_postprocess_vs_oracle(cfg, hip_lib):
+    from metrabs_amd import kernels
+    from metrabs_amd.multiperson import warping
+    poses, rot, flip, mirror, K, d, E, jtm, skel = make_inputs(
+        cfg['n'], cfg['A'], cfg['J'], 4242 + cfg['n'], cfg['dist'], cfg['jt'], cfg['skeleton'])
+    with torch.inference_mode():
+        o3, o2 = cpu_ref.postprocess_from_crop_outputs(
+            poses, rot, flip, mirror, K, d, E, jtm, skel, cfg['avg'])
+    c = lambda t: None if t is None else t.cuda()
+    p3, p2 = kernels.postprocess_poses(
+        poses.cuda(), rot.cuda(), flip, mirror, K.cuda(), warping.pad_axis_to_size(d, 12).cuda(),
+        torch.linalg.inv(E).cuda(), c(jtm), c(skel), cfg['avg'])
+    assert p3.shape == o3.shape and p2.shape == o2.shape
+    e3, e2 = float((p3.cpu() - o3).abs().max()), float((p2.cpu() - o2).abs().max())
+    print(f'[parity] postprocess {cfg}: poses3d max {e3:.2e} mm, poses2d max {e2:.2e} px')
+    assert e3 <= 1.5e-3 and e2 <= 2e-3
+
+
+def test_fused_equals_torch_path_in_estimator(hip_lib):
+    """Pose3dEstimator with K7 == the torch-op post-processing, incl. ragged images and sharding-free
+    internal batching."""
+    from test_gpu_e2e import build_estimator
+    case = cases.e2e_case('aug5_dist_aa2')
+    est = build_estimator(case, True)
+    outs = []
+    for fused in (True, False):
+        est.fused_postprocess = fused
+        with torch.inference_mode():
+            outs.append(est._estimate_poses_batched(
+                case['images'], case['boxes'], case['K'], case['dist'], case['extr'],
+                case['world_up'], 55, 4, case['aa'], case['num_aug'], False, '', False))
+    for k in ('poses3d', 'poses2d'):
+        a, b = torch.cat(outs[0][k]).cpu(), torch.cat(outs[1][k]).cpu()
+        assert a.shape == b.shape
+        d = (a - b).abs().flatten()
+        assert float(d.median()) <= 1e-3 and float(torch.quantile(d, 0.95)) <= 2e-2
