@@ -174,7 +174,7 @@ def stage_breakdown(pipe, est, args, iters):
             lambda: kernels.reconstruct_absolute(c2d, c3d, kflat, model.config, workspace=ws), iters)
         poses_flat = kernels.reconstruct_absolute(c2d, c3d, kflat, model.config, workspace=ws)
         st['postprocess'] = time_stage(lambda: kernels.postprocess_poses(
-            poses_flat, rot, tta['should_flip'], pipe.mirror, pipe.intrinsics, pipe.distortion12,
+            poses_flat, rot, tta['should_flip_u8'], tta['mirror_i32'], pipe.intrinsics, pipe.distortion12,
             pipe.inv_extrinsics, None, None, True), iters)
     return st, dict(wp=wp, feats=feats, c2d=c2d, c3d=c3d, kflat=kflat)
 

@@ -238,6 +238,8 @@ def postprocess_poses(poses_crop, rot, should_flip, mirror_mapping, intrinsics, 
     A, n = rot.shape[0], rot.shape[1]
     poses_crop = poses_crop.contiguous().float().reshape(A, n, -1, 3)
     J = poses_crop.shape[2]
+    # (.to is a no-op for tensors that already have the kernel's dtype on the device; callers on a
+    # hot path pass cached uint8 / int32 device tensors)
     flip = should_flip.to(dev, torch.uint8).contiguous()
     mirror = mirror_mapping.to(dev, torch.int32).contiguous()
     jtm = joint_transform.to(dev, torch.float32).contiguous() if joint_transform is not None else None

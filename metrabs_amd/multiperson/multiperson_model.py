@@ -151,12 +151,32 @@ class Pose3dEstimator(torch.nn.Module):
         except StopIteration:
             return torch.device('cuda')
 
+    def _skeleton_tensor(self, skeleton, dev):
+        key = ('skel', skeleton, str(dev))
+        if key not in self._tta_cache:
+            self._tta_cache[key] = torch.as_tensor(
+                self.skeleton_joint_indices_table[skeleton], dtype=torch.int32, device=dev)
+        return self._tta_cache[key]
+
+    def _joint_transform_on(self, dev):
+        if self.joint_transform_matrix is None:
+            return None
+        key = ('jtm', str(dev))
+        if key not in self._tta_cache:
+            self._tta_cache[key] = self.joint_transform_matrix.to(dev, torch.float32).contiguous()
+        return self._tta_cache[key]
+
     def _tta(self, num_aug, dev):
         key = (num_aug, str(dev))
         if key not in self._tta_cache:
             t = tta_parameters(num_aug)
             self._tta_cache[key] = {k: v.to(dev) for k, v in t.items()}
             self._tta_cache[key]['should_flip_host'] = t['should_flip']
+            # kernel-ready copies (no per-call casts / host->device copies)
+            self._tta_cache[key]['should_flip_u8'] = t['should_flip'].to(dev, torch.uint8)
+            self._tta_cache[key]['mirror_i32'] = torch.as_tensor(
+                self.joint_info.mirror_mapping, dtype=torch.int32, device=dev)
+            self._tta_cache[key]['mirror_i64'] = self._tta_cache[key]['mirror_i32'].long()
         return self._tta_cache[key]
 
     def _estimate_poses_batched(
@@ -211,8 +231,8 @@ class Pose3dEstimator(torch.nn.Module):
                 poses2d_flat = torch.zeros(*shape, 2, device=dev)
             else:
                 post = dict(inv_extrinsics=inv_extrinsics_b, average_aug=average_aug,
-                            skeleton=torch.as_tensor(idx, dtype=torch.int32, device=dev),
-                            joint_transform=self.joint_transform_matrix)
+                            skeleton=self._skeleton_tensor(skeleton, dev),
+                            joint_transform=self._joint_transform_on(dev))
                 packed = self._predict_in_batches(
                     images, intrinsic_matrix_b, distortion_b, camspace_up_b, boxes_flat,
                     image_id_per_box, internal_batch_size, tta, antialias_factor, post=post)
@@ -271,8 +291,7 @@ class Pose3dEstimator(torch.nn.Module):
             if post is not None:
                 poses_flat, rot = res
                 p3, p2 = kernels.postprocess_poses(
-                    poses_flat, rot, tta['should_flip'],
-                    torch.as_tensor(self.joint_info.mirror_mapping), intrinsic_matrix[s],
+                    poses_flat, rot, tta['should_flip_u8'], tta['mirror_i32'], intrinsic_matrix[s],
                     distortion12[s], post['inv_extrinsics'][s], post['joint_transform'],
                     post['skeleton'], post['average_aug'])
                 res = torch.cat([p3, p2], dim=-1)
@@ -301,9 +320,8 @@ class Pose3dEstimator(torch.nn.Module):
     def _predict_single_batch(self, pyramid, intrinsic_matrix, distortion12, camspace_up, boxes,
                               image_ids, tta, antialias_factor, raw=False):
         """multiperson_model.py:227-259 (raw=True stops after the crop model: K7 does the rest)."""
-        mirror = torch.as_tensor(self.joint_info.mirror_mapping, device=boxes.device)
         return pipeline.predict_single_batch(
-            self.crop_model, mirror, tta['should_flip'], bool(tta['should_flip_host'].any()),
+            self.crop_model, tta['mirror_i64'], tta['should_flip'], bool(tta['should_flip_host'].any()),
             pyramid, intrinsic_matrix, distortion12, camspace_up, boxes, image_ids,
             tta['rotflipmat'], tta['scales'], tta['gammas'], antialias_factor, self.crop_dtype,
             self.crop_channels_last, raw=raw)

@@ -54,7 +54,7 @@ class GraphedCropPipeline:
         self.inv_extrinsics = torch.eye(4, device=dev).repeat(n_box, 1, 1)
         self.average_aug = True
         self.tta = estimator._tta(num_aug, dev)
-        self.mirror = torch.as_tensor(estimator.joint_info.mirror_mapping, device=dev)
+        self.mirror = self.tta['mirror_i64']
         self.any_flip = bool(self.tta['should_flip_host'].any())
         self.aa = antialias_factor
         self.include_pyramid = include_pyramid
@@ -73,9 +73,9 @@ class GraphedCropPipeline:
             self.est.crop_dtype, self.est.crop_channels_last, raw=True)
         # K7: mirror un-swap, back rotation, 2D projection, world transform, TTA mean in one launch
         self.poses3d, self.poses2d = kernels.postprocess_poses(
-            poses_flat, rot, self.tta['should_flip'], self.mirror, self.intrinsics,
-            self.distortion12, self.inv_extrinsics, self.est.joint_transform_matrix, None,
-            self.average_aug)
+            poses_flat, rot, self.tta['should_flip_u8'], self.tta['mirror_i32'], self.intrinsics,
+            self.distortion12, self.inv_extrinsics, self.est._joint_transform_on(self.images.device),
+            None, self.average_aug)
         return self.poses3d
 
     def capture(self, warmup=3):
