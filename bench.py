@@ -79,25 +79,8 @@ def synth_inputs(pipe, frames, im_h, im_w, n_box, seed):
     pipe.image_ids.copy_((torch.arange(n_box) % frames).int())
 
 
-def calibrate_batchnorm(backbone, res, dev):
-    """Random-weight networks with untouched BatchNorm statistics (mean 0 / var 1) let activations
-    grow layer by layer until they overflow.  Two forward passes in training mode on synthetic crops
-    set the running statistics (cumulative average), which keeps every layer at unit scale -- the
-    regime a trained checkpoint is in.  Weights stay random; the FLOPs are unchanged."""
-    bns = [m for m in backbone.modules() if isinstance(m, torch.nn.BatchNorm2d)]
-    for m in bns:
-        m.momentum = None
-        m.reset_running_stats()
-    backbone.train()
-    g = torch.Generator(device=dev).manual_seed(7)
-    with torch.no_grad():
-        for _ in range(2):
-            backbone(torch.rand(16, 3, res, res, device=dev, generator=g))
-    backbone.eval()
-
-
 def build_model(args, dev):
-    from metrabs_amd.backbones import build_backbone
+    from metrabs_amd.backbones import build_backbone, calibrate_batchnorm
     from metrabs_amd.config import MetrabsConfig
     from metrabs_amd.joint_info import JointInfo
     from metrabs_amd.models.metrabs import Metrabs

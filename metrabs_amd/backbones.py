@@ -165,3 +165,21 @@ def build_backbone(name):
     if name in ('mobilenetv3', 'mobilenetv3-large', 'mobilenet-v3'):
         return mobilenet_v3_large()
     raise ValueError(f'unknown backbone {name}')
+
+
+def calibrate_batchnorm(backbone, res, dev, batches=2, batch_size=16, seed=7):
+    """Random-weight networks with untouched BatchNorm statistics (mean 0 / var 1) let activations
+    grow layer by layer until they overflow.  A few forward passes in training mode on synthetic
+    crops set the running statistics (cumulative average), which keeps every layer at unit scale --
+    the regime a trained checkpoint is in.  Weights stay random; the FLOPs are unchanged."""
+    bns = [m for m in backbone.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    for m in bns:
+        m.momentum = None
+        m.reset_running_stats()
+    backbone.train()
+    g = torch.Generator(device=dev).manual_seed(seed)
+    with torch.no_grad():
+        for _ in range(batches):
+            backbone(torch.rand(batch_size, 3, res, res, device=dev, generator=g))
+    backbone.eval()
+    return backbone
