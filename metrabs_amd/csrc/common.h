@@ -144,28 +144,29 @@ __device__ __forceinline__ const T* uniform_ptr(const T* p) {  // provably wave-
   const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
   return (const T*)(((unsigned long long)hi << 32) | lo);
 }
-template <typename T, int VEC>
+// AUX = cache-policy bits of the buffer instruction (0 = default, 2 = nt: streamed once, do not keep)
+template <typename T, int VEC, int AUX = 0>
 __device__ __forceinline__ void buffer_load_vec(buffer_rsrc_t rsrc, int voff_bytes, int soff_bytes,
                                                 float (&out)[VEC]) {
   if constexpr (VEC == 4 && sizeof(T) == 4) {
     // (bind the builtin's own 16-byte vector type with auto: converting it to a differently
     // declared vector type silently splats element 0)
-    const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_bytes, soff_bytes, 0);
+    const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_bytes, soff_bytes, AUX);
     static_assert(sizeof(raw) == 16, "b128 load");
     const float4 f = __builtin_bit_cast(float4, raw);
     out[0] = f.x; out[1] = f.y; out[2] = f.z; out[3] = f.w;
   } else if constexpr (VEC == 4 && sizeof(T) == 2) {
-    const auto raw = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff_bytes, soff_bytes, 0);
+    const auto raw = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff_bytes, soff_bytes, AUX);
     static_assert(sizeof(raw) == 8, "b64 load");
     struct Pack { T h[4]; };
     const Pack pk = __builtin_bit_cast(Pack, raw);
 #pragma unroll
     for (int i = 0; i < 4; ++i) out[i] = to_f32(pk.h[i]);
   } else if constexpr (VEC == 1 && sizeof(T) == 4) {
-    out[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_bytes, soff_bytes, 0));
+    out[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_bytes, soff_bytes, AUX));
   } else {
     static_assert(VEC == 1 && sizeof(T) == 2, "unsupported buffer load shape");
-    const unsigned short raw = __builtin_amdgcn_raw_buffer_load_b16(rsrc, voff_bytes, soff_bytes, 0);
+    const unsigned short raw = __builtin_amdgcn_raw_buffer_load_b16(rsrc, voff_bytes, soff_bytes, AUX);
     out[0] = to_f32(__builtin_bit_cast(T, raw));
   }
 }

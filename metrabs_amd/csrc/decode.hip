@@ -28,12 +28,13 @@ __device__ __forceinline__ float vec_max(const float (&v)[VEC]) {
   return r;
 }
 
-template <typename T, int VEC, int LPJ>
+template <typename T, int VEC, int LPJ, int AUX>
 __global__ __launch_bounds__(256) void decode_nchw_kernel(
     const T* __restrict__ logits, int B, int J, int D, int H, int W, HeadScale hs, AxisInv ai,
     float* __restrict__ coords2d, float* __restrict__ coords3d_rel) {
   constexpr int JPW = kWave / LPJ;  // joints per wave
   constexpr int CH = 8;             // depth slices fetched per round
+  constexpr int kLoadAux = AUX;  // 2 = non-temporal: the logits are read exactly once
   const int HW = H * W;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(
@@ -80,14 +81,14 @@ __global__ __launch_bounds__(256) void decode_nchw_kernel(
 
     // ---- the 2D heatmap load is issued together with the first round of depth slices
     float v2[VEC];
-    buffer_load_vec<T, VEC>(rsrc, voff, 0, v2);
+    buffer_load_vec<T, VEC, kLoadAux>(rsrc, voff, 0, v2);
 
     for (int d0 = 0; d0 < D; d0 += CH) {
       float v3[CH][VEC];
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
         const int d = (d0 + k < D) ? d0 + k : D - 1;  // tail rounds re-read slice D-1, weight 0
-        buffer_load_vec<T, VEC>(rsrc, voff, (J * HW) * (int)sizeof(T) + d * slice_bytes, v3[k]);
+        buffer_load_vec<T, VEC, kLoadAux>(rsrc, voff, (J * HW) * (int)sizeof(T) + d * slice_bytes, v3[k]);
       }
       if (d0 == 0) {
         const float cm = group_max<LPJ>(pos_ok ? vec_max<VEC>(v2) : -INFINITY);
@@ -159,19 +160,30 @@ __global__ __launch_bounds__(256) void decode_nchw_kernel(
   }
 }
 
-template <typename T, int VEC, int LPJ>
-static int launch_decode(const void* logits, int B, int J, int D, int H, int W, const HeadScale& hs,
-                         float* c2d, float* c3d, hipStream_t stream) {
+template <typename T, int VEC, int LPJ, int AUX>
+static int launch_decode_aux(const void* logits, int B, int J, int D, int H, int W,
+                             const HeadScale& hs, float* c2d, float* c3d, hipStream_t stream) {
   constexpr int JPW = kWave / LPJ;
   const long long waves = (long long)B * ((J + JPW - 1) / JPW);
   const int waves_per_block = 4;
   const long long blocks = (waves + waves_per_block - 1) / waves_per_block;
   if (blocks > 0x7fffffffLL) return MTR_E_SHAPE;
   MTR_CLEAR_STALE();
-  hipLaunchKernelGGL((decode_nchw_kernel<T, VEC, LPJ>), dim3((unsigned)blocks), dim3(256), 0, stream,
-                     (const T*)logits, B, J, D, H, W, hs, make_axis_inv(W, H, D), c2d, c3d);
+  hipLaunchKernelGGL((decode_nchw_kernel<T, VEC, LPJ, AUX>), dim3((unsigned)blocks), dim3(256), 0,
+                     stream, (const T*)logits, B, J, D, H, W, hs, make_axis_inv(W, H, D), c2d, c3d);
   MTR_CHECK_LAUNCH();
   return MTR_OK;
+}
+
+template <typename T, int VEC, int LPJ>
+static int launch_decode(const void* logits, int B, int J, int D, int H, int W, const HeadScale& hs,
+                         float* c2d, float* c3d, hipStream_t stream) {
+  // Non-temporal loads pay when every wave-wide load covers whole 128-B lines (8x8 f32 rows are
+  // 256 B: +3 % at D=8, 73 -> 83 % of HBM at D=72); when map rows straddle lines (12x12: 576 B)
+  // the neighbouring load re-fetches the evicted line (69 -> 58 %), so those keep the default policy.
+  const bool whole_lines = ((size_t)H * W * sizeof(T)) % 128 == 0 && VEC == 4;
+  if (whole_lines) return launch_decode_aux<T, VEC, LPJ, 2>(logits, B, J, D, H, W, hs, c2d, c3d, stream);
+  return launch_decode_aux<T, VEC, LPJ, 0>(logits, B, J, D, H, W, hs, c2d, c3d, stream);
 }
 
 template <typename T>
