@@ -93,7 +93,10 @@ int mtr_softargmax_decode(const void* logits, int dtype, int layout, int B, int 
  *
  * mtr_head_pack_weights re-orders conv_final.weight [J*(1+D), C] (+bias) ONCE into the joint-major
  * tiled layout the kernel streams; `packed` must hold
- * mtr_head_packed_bytes(...) bytes.  features: [B, C, H, W] (NCHW) or [B, H, W, C] (NHWC).
+ * mtr_head_packed_bytes(...) bytes.  features: [B, C, H, W] (MTR_NCHW) or [B, H, W, C] (MTR_NHWC,
+ * C % 4 == 0); H*W must be a multiple of 4 and <= 256, 1+D <= 64 (else: 1x1-conv GEMM +
+ * mtr_softargmax_decode).  f32 features accumulate in f64 (v_mfma_f64_16x16x4_f64), f16/bf16 features
+ * in f32 (v_mfma_f32_16x16x4_f32); weights are always f32.
  */
 size_t mtr_head_packed_bytes(int C, int J, int D, int feat_dtype);
 int mtr_head_pack_weights(const float* weight /*[J*(1+D), C] f32*/, const float* bias /*[J*(1+D)]*/,

@@ -123,7 +123,13 @@ struct StageSrc {
   int C, HW, vec_per_row, b_total, tid;
 };
 
-template <typename FeatT, int B_VECS>
+constexpr int kKP = 34;  // NHWC feature tile [position][34]: row stride = 2 (mod 32) words
+
+// NCHW: the stage is kKC rows (channels) of HW contiguous values -> LDS [k][HWP].
+// NHWC (torch channels_last / the TF twin, tf models/metrabs.py:100-101): per position kKC
+// contiguous channels (128 B) -> LDS [position][kKP]; fragment reads (lane (j, g) -> [n*16+j][k0+g])
+// hit banks 2j+g: conflict-free.
+template <typename FeatT, int B_VECS, bool NHWC>
 __device__ __forceinline__ void load_stage(const StageSrc<FeatT>& s, int c0, StageRegs<B_VECS>& r) {
   // weight tile: rows c0..c0+31 of [c_pad][64], fully contiguous 8 KiB
 #pragma unroll
@@ -132,16 +138,24 @@ __device__ __forceinline__ void load_stage(const StageSrc<FeatT>& s, int c0, Sta
 #pragma unroll
   for (int i = 0; i < B_VECS; ++i) {
     const int v = s.tid + i * 256;
-    const int row = v / s.vec_per_row, q = v - row * s.vec_per_row;
-    const bool ok = v < s.b_total && c0 + row < s.C;
+    bool ok;
+    size_t off;
+    if constexpr (NHWC) {
+      const int pos = v / (kKC / 4), c4 = v % (kKC / 4);
+      ok = pos < s.HW && c0 + c4 * 4 < s.C;
+      off = (size_t)pos * s.C + c0 + c4 * 4;
+    } else {
+      const int row = v / s.vec_per_row, q = v - row * s.vec_per_row;
+      ok = v < s.b_total && c0 + row < s.C;
+      off = (size_t)(c0 + row) * s.HW + q * 4;
+    }
     // clamp instead of branching: every lane loads a valid address, invalid lanes get zeros
-    const FeatT* ptr = s.fcrop + (ok ? (size_t)(c0 + row) * s.HW + q * 4 : 0);
-    const v4f val = load4_native<FeatT>(ptr);
+    const v4f val = load4_native<FeatT>(s.fcrop + (ok ? off : 0));
     r.b[i] = ok ? val : v4f{0.f, 0.f, 0.f, 0.f};
   }
 }
 
-template <int B_VECS, int HWP, typename FeatT>
+template <int B_VECS, int HWP, bool NHWC, typename FeatT>
 __device__ __forceinline__ void store_stage(const StageSrc<FeatT>& s, float* As_buf, float* Bs_buf,
                                             const StageRegs<B_VECS>& r) {
 #pragma unroll
@@ -153,21 +167,31 @@ __device__ __forceinline__ void store_stage(const StageSrc<FeatT>& s, float* As_
 #pragma unroll
   for (int i = 0; i < B_VECS; ++i) {
     const int v = s.tid + i * 256;
-    const int row = v / s.vec_per_row, q = v - row * s.vec_per_row;
-    if (v < s.b_total) *reinterpret_cast<v4f*>(Bs_buf + row * HWP + q * 4) = r.b[i];
+    if constexpr (NHWC) {
+      using v2f = __attribute__((ext_vector_type(2))) float;
+      const int pos = v / (kKC / 4), c4 = v % (kKC / 4);
+      if (pos < s.HW) {  // rows of 136 B: 8-byte aligned -> two 8-byte writes
+        float* dst = Bs_buf + pos * kKP + c4 * 4;
+        *reinterpret_cast<v2f*>(dst) = v2f{r.b[i][0], r.b[i][1]};
+        *reinterpret_cast<v2f*>(dst + 2) = v2f{r.b[i][2], r.b[i][3]};
+      }
+    } else {
+      const int row = v / s.vec_per_row, q = v - row * s.vec_per_row;
+      if (v < s.b_total) *reinterpret_cast<v4f*>(Bs_buf + row * HWP + q * 4) = r.b[i];
+    }
   }
 }
 
 // LDS (40-90 KiB per workgroup) already caps residency at <= 4 waves per SIMD; asking for 2 lets the
 // register allocator keep the prefetched stage and the fragment batch in VGPRs instead of scratch.
-template <typename FeatT, int NT, bool ACC64>
+template <typename FeatT, int NT, bool ACC64, bool NHWC>
 __global__ __launch_bounds__(256, 2) void head_fused_kernel(
     const FeatT* __restrict__ feat, const float* __restrict__ packed, int B, int C, int H, int W,
     int J, int D, HeadGeom g, HeadScale hs, float* __restrict__ coords2d,
     float* __restrict__ coords3d_rel) {
   constexpr int HWP = hw_pad(NT);
   constexpr int A_STAGE = kKC * kRowsPad;            // floats
-  constexpr int B_STAGE = kKC * HWP;                 // floats
+  constexpr int B_STAGE = NHWC ? NT * 16 * kKP : kKC * HWP;  // floats
   constexpr int B_VECS = (kKC * NT * 16 / 4 + 255) / 256;  // float4 per thread per stage (upper bound)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                 // [2][kKC][kRowsPad]
@@ -197,8 +221,8 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(
   for (int n = 0; n < NT; ++n) acc[n] = AccT{0, 0, 0, 0};
 
   // columns >= HW of the feature tile are never written: zero them once in both buffers
-  if (NT * 16 > HW) {
-    for (int v = tid; v < 2 * kKC * HWP; v += 256) Bs[v] = 0.0f;
+  if (NT * 16 > HW || NHWC) {  // (NHWC: also the 2 pad words of every row)
+    for (int v = tid; v < 2 * B_STAGE; v += 256) Bs[v] = 0.0f;
     __syncthreads();
   }
 
@@ -215,15 +239,16 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(
   {                                                                                               \
     const int s_ = (S);                                                                           \
     const int buf = s_ & 1;                                                                       \
-    if (s_ + kAhead < n_stages) load_stage<FeatT, B_VECS>(src, (s_ + kAhead) * kKC, LD);          \
+    if (s_ + kAhead < n_stages) load_stage<FeatT, B_VECS, NHWC>(src, (s_ + kAhead) * kKC, LD);          \
     const float* Ab = As + buf * A_STAGE + wid * 16 + fr;                                         \
-    const float* Bb = Bs + buf * B_STAGE + fr;                                                    \
+    const float* Bb = Bs + buf * B_STAGE + (NHWC ? fr * kKP : fr);                                \
     _Pragma("unroll") for (int kb = 0; kb < kKC / 4; kb += KS) {                                  \
       float af[KS], bf[KS][NT];                                                                   \
       _Pragma("unroll") for (int k = 0; k < KS; ++k) {                                            \
         af[k] = Ab[((kb + k) * 4 + fk) * kRowsPad];                                               \
         _Pragma("unroll") for (int n = 0; n < NT; ++n)                                            \
-            bf[k][n] = Bb[((kb + k) * 4 + fk) * HWP + n * 16];                                    \
+            bf[k][n] = NHWC ? Bb[n * 16 * kKP + (kb + k) * 4 + fk]                                \
+                            : Bb[((kb + k) * 4 + fk) * HWP + n * 16];                             \
       }                                                                                           \
       __builtin_amdgcn_sched_barrier(0); /* keep the reads batched ahead of the MFMAs */          \
       _Pragma("unroll") for (int k = 0; k < KS; ++k) {                                            \
@@ -238,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(
       }                                                                                           \
     }                                                                                             \
     if (s_ + 1 < n_stages)                                                                        \
-      store_stage<B_VECS, HWP>(src, As + (buf ^ 1) * A_STAGE, Bs + (buf ^ 1) * B_STAGE, ST);      \
+      store_stage<B_VECS, HWP, NHWC>(src, As + (buf ^ 1) * A_STAGE, Bs + (buf ^ 1) * B_STAGE, ST);      \
     __syncthreads();                                                                              \
   }
 
@@ -247,11 +272,11 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(
   constexpr int KS = NT <= 4 ? (ACC64 ? 4 : 8) : (NT <= 9 ? 4 : 2);
   constexpr int kAhead = (NT >= 16 && ACC64) ? 1 : 2;
   StageRegs<B_VECS> regs0;
-  load_stage<FeatT, B_VECS>(src, 0, regs0);
-  store_stage<B_VECS, HWP>(src, As, Bs, regs0);
+  load_stage<FeatT, B_VECS, NHWC>(src, 0, regs0);
+  store_stage<B_VECS, HWP, NHWC>(src, As, Bs, regs0);
   if constexpr (kAhead == 2) {
     StageRegs<B_VECS> regs1;
-    if (n_stages > 1) load_stage<FeatT, B_VECS>(src, kKC, regs1);
+    if (n_stages > 1) load_stage<FeatT, B_VECS, NHWC>(src, kKC, regs1);
     __syncthreads();
     for (int s = 0; s < n_stages; s += 2) {
       HEAD_ITER(s, regs0, regs1)
@@ -335,20 +360,21 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(
   }
 }
 
-template <int NT>
+template <int NT, bool NHWC>
 constexpr size_t head_lds_bytes() {
-  constexpr size_t stage = (size_t)2 * kKC * (kRowsPad + hw_pad(NT));
+  constexpr size_t b_stage = NHWC ? (size_t)NT * 16 * kKP : (size_t)kKC * hw_pad(NT);
+  constexpr size_t stage = 2 * ((size_t)kKC * kRowsPad + b_stage);
   constexpr size_t logits = (size_t)kRows * hw_pad(NT);
   return (stage > logits ? stage : logits) * sizeof(float);
 }
 
-template <typename FeatT, int NT>
+template <typename FeatT, int NT, bool NHWC>
 static int launch_head(const void* feat, const float* packed, int B, int C, int H, int W, int J,
                        int D, const HeadGeom& g, const HeadScale& hs, float* c2d, float* c3d,
                        hipStream_t stream) {
-  constexpr size_t lds = head_lds_bytes<NT>();
+  constexpr size_t lds = head_lds_bytes<NT, NHWC>();
   // f32 features -> f64 accumulate (parity with the fp32 CPU reference); 16-bit -> f32 MFMA
-  auto kern = head_fused_kernel<FeatT, NT, std::is_same<FeatT, float>::value>;
+  auto kern = head_fused_kernel<FeatT, NT, std::is_same<FeatT, float>::value, NHWC>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
@@ -364,17 +390,26 @@ static int launch_head(const void* feat, const float* packed, int B, int C, int 
   return MTR_OK;
 }
 
-template <typename FeatT>
+template <typename FeatT, bool NHWC>
 static int dispatch_head(const void* feat, const float* packed, int B, int C, int H, int W, int J,
                          int D, const HeadGeom& g, const HeadScale& hs, float* c2d, float* c3d,
                          hipStream_t stream) {
   const int HW = H * W;
-  if (HW <= 16) return launch_head<FeatT, 1>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
-  if (HW <= 32) return launch_head<FeatT, 2>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
-  if (HW <= 64) return launch_head<FeatT, 4>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
-  if (HW <= 144) return launch_head<FeatT, 9>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
-  if (HW <= 256) return launch_head<FeatT, 16>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+  if (HW <= 16) return launch_head<FeatT, 1, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+  if (HW <= 32) return launch_head<FeatT, 2, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+  if (HW <= 64) return launch_head<FeatT, 4, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+  if (HW <= 144) return launch_head<FeatT, 9, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+  if (HW <= 256) return launch_head<FeatT, 16, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
   return MTR_E_SHAPE;
+}
+
+template <typename FeatT>
+static int dispatch_head_layout(int layout, const void* feat, const float* packed, int B, int C,
+                                int H, int W, int J, int D, const HeadGeom& g, const HeadScale& hs,
+                                float* c2d, float* c3d, hipStream_t stream) {
+  if (layout == MTR_NHWC)
+    return dispatch_head<FeatT, true>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+  return dispatch_head<FeatT, false>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
 }
 
 static int check_head_dims(int C, int J, int D) {
@@ -417,8 +452,9 @@ extern "C" int mtr_head_fused(const void* features, int feat_dtype, int layout, 
   if (B < 0 || H <= 0 || W <= 0) return MTR_E_SHAPE;
   int rc = mtr::check_head_dims(C, J, D);
   if (rc) return rc;
-  if (layout != MTR_NCHW) return MTR_E_DTYPE;         // channels_last features: use NCHW or decode
+  if (layout != MTR_NCHW && layout != MTR_NHWC) return MTR_E_DTYPE;
   if ((H * W) % 4 != 0 || H * W > 256) return MTR_E_SHAPE;  // wider maps: GEMM + mtr_softargmax_decode
+  if (layout == MTR_NHWC && C % 4 != 0) return MTR_E_SHAPE;  // 16-byte channel vectors
   if (p->proc_side <= 0 || p->stride_test <= 0) return MTR_E_PARAM;
   if (((uintptr_t)features % 16) || ((uintptr_t)packed % 16)) return MTR_E_ALIGN;
   if (B == 0) return MTR_OK;
@@ -427,9 +463,9 @@ extern "C" int mtr_head_fused(const void* features, int feat_dtype, int layout, 
   hipStream_t s = (hipStream_t)stream;
   const float* pk = (const float*)packed;
   switch (feat_dtype) {
-    case MTR_F32: return mtr::dispatch_head<float>(features, pk, B, C, H, W, J, D, g, hs, coords2d, coords3d_rel, s);
-    case MTR_F16: return mtr::dispatch_head<__half>(features, pk, B, C, H, W, J, D, g, hs, coords2d, coords3d_rel, s);
-    case MTR_BF16: return mtr::dispatch_head<__hip_bfloat16>(features, pk, B, C, H, W, J, D, g, hs, coords2d, coords3d_rel, s);
+    case MTR_F32: return mtr::dispatch_head_layout<float>(layout, features, pk, B, C, H, W, J, D, g, hs, coords2d, coords3d_rel, s);
+    case MTR_F16: return mtr::dispatch_head_layout<__half>(layout, features, pk, B, C, H, W, J, D, g, hs, coords2d, coords3d_rel, s);
+    case MTR_BF16: return mtr::dispatch_head_layout<__hip_bfloat16>(layout, features, pk, B, C, H, W, J, D, g, hs, coords2d, coords3d_rel, s);
     default: return MTR_E_DTYPE;
   }
 }

@@ -184,7 +184,12 @@ def warp_crops(pyramid, warp_params, res, antialias=1, out_dtype=torch.float32,
 def head_fused_supported(C, J, D, H, W, channels_last=False):
     """Shapes the fused projection+decode kernel covers; everything else goes through a library
     GEMM for the 1x1 conv followed by the HIP decode kernel (same results, logits via HBM)."""
-    return (not channels_last) and (H * W) % 4 == 0 and H * W <= 256 and (1 + D) <= 64
+    return (H * W) % 4 == 0 and H * W <= 256 and (1 + D) <= 64 and (not channels_last or C % 4 == 0)
+
+
+def _is_channels_last(t):
+    return (t.dim() == 4 and not t.is_contiguous()
+            and t.is_contiguous(memory_format=torch.channels_last))
 
 
 def head_pack_weights(weight2d, bias, n_points, depth, feat_dtype=torch.float32):
@@ -207,10 +212,13 @@ def head_pack_weights(weight2d, bias, n_points, depth, feat_dtype=torch.float32)
 
 
 def head_fused(features, packed, C, n_points, cfg, out=None):
-    """features [B,C,H,W] (f32/f16/bf16, NCHW contiguous) -> (coords2d, coords3d_rel)."""
+    """features [B,C,H,W] (f32/f16/bf16; NCHW-contiguous or torch channels_last = NHWC memory, which
+    is consumed in place) -> (coords2d, coords3d_rel)."""
     require_cuda(features, packed)
     lib = _lib.load()
-    features = features.contiguous()
+    nhwc = _is_channels_last(features)
+    if not nhwc:
+        features = features.contiguous()
     B, Cf, H, W = features.shape
     if Cf != C:
         raise ValueError(f'features have {Cf} channels, weights were packed for {C}')
@@ -222,7 +230,8 @@ def head_fused(features, packed, C, n_points, cfg, out=None):
         c2d, c3d = out
     hp = cfg.head_params()
     check(lib.mtr_head_fused(
-        _ptr(features), dtype_code(features.dtype), _lib.MTR_NCHW, B, C, H, W, _ptr(packed), J, D,
+        _ptr(features), dtype_code(features.dtype), _lib.MTR_NHWC if nhwc else _lib.MTR_NCHW, B, C,
+        H, W, _ptr(packed), J, D,
         ctypes.byref(hp), _ptr(c2d), _ptr(c3d), current_stream_ptr(features.device)),
         'mtr_head_fused')
     return c2d, c3d

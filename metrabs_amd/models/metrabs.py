@@ -48,7 +48,8 @@ class MetrabsHeads(torch.nn.Module):
                 self.conv_final.has_uninitialized_params():
             self.conv_final(inp[:1])  # materialise the lazy conv exactly like the reference would
         _, c_in, h, w = inp.shape
-        if self.fused and kernels.head_fused_supported(c_in, self.n_points, self.config.depth, h, w):
+        if self.fused and kernels.head_fused_supported(
+                c_in, self.n_points, self.config.depth, h, w, kernels._is_channels_last(inp)):
             return kernels.head_fused(inp, self._packed_weights(inp.dtype), c_in, self.n_points,
                                       self.config)
         logits = self.conv_final(inp)  # 1x1 conv as a library GEMM (rocBLAS / MIOpen)

@@ -127,3 +127,27 @@ def test_fused_head_full_size_properties(hip_lib):
     with torch.inference_mode():
         o2d, o3d = cpu_ref.heads_forward(feat[idx].cpu(), w, b, 17, cpu_ref.HeadConfig())
     assert cpu_ref.mpjpe(c3d[idx].cpu(), o3d) <= 1e-3
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+@pytest.mark.parametrize('shape', [(5, 1280, 17, 8, 8), (3, 100, 9, 12, 12), (2, 40, 17, 4, 4),
+                                   (2, 64, 5, 16, 16)])
+def test_fused_head_channels_last_features(shape, dtype, hip_lib):
+    """NHWC memory (torch channels_last; the TF twin's layout, tf models/metrabs.py:100-101) is
+    consumed in place and gives the SAME bits as the NCHW path: the k-order of every MFMA chain is
+    identical, only the staging differs."""
+    from metrabs_amd import kernels
+    B, C, J, H, W = shape
+    cfg = cpu_ref.HeadConfig(proc_side=H * 32)
+    g = cases.gen(8100 + sum(shape))
+    feat = torch.randn(B, C, H, W, generator=g).to(dtype).cuda()
+    w, b = cases.default_conv_init(J * 9, C, g)
+    packed = kernels.head_pack_weights(w.cuda() * 3, b.cuda() * 3, J, 8, dtype)
+    n2d, n3d = kernels.head_fused(feat, packed, C, J, mcfg(cfg))
+    feat_cl = feat.contiguous(memory_format=torch.channels_last)
+    assert kernels._is_channels_last(feat_cl)
+    c2d, c3d = kernels.head_fused(feat_cl, packed, C, J, mcfg(cfg))
+    assert torch.equal(c3d, n3d) and torch.equal(c2d, n2d)
+    with torch.inference_mode():
+        o2d, o3d = cpu_ref.heads_forward(feat.float().cpu(), w * 3, b * 3, J, cfg)
+    assert float((c3d.cpu() - o3d).abs().max()) <= 2e-3
