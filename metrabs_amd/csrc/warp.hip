@@ -299,8 +299,11 @@ __global__ __launch_bounds__(256) void warp_crops_kernel(
     OutT* __restrict__ out) {
   // ---- XCD-aware map (block id b runs on XCD b % 8): all row tiles of a crop share one XCD, so
   // the crop's source footprint is fetched into ONE L2 instead of eight.
-  const int row_tiles = (res + 3) / 4;
-  const int x_tiles = (res + 64 * PX - 1) / (64 * PX);
+  // a wave covers a 64-px x 4-row output tile (16 lanes x PX pixels per row); a block = 4 such
+  // tiles stacked (64 x 16): under the +-25 degree TTA rotations a 256 x 1 row per wave walked
+  // ~100 source rows, this keeps a wave's source footprint within ~30 rows
+  const int row_tiles = (res + 15) / 16;
+  const int x_tiles = (res + 16 * PX - 1) / (16 * PX);
   const int per_crop = row_tiles * x_tiles;
   const int id = blockIdx.x;
   const int crop = (id / (8 * per_crop)) * 8 + (id % 8);
@@ -324,8 +327,9 @@ __global__ __launch_bounds__(256) void warp_crops_kernel(
   const buffer_rsrc_t rsrc = make_rsrc(uniform_ptr(planes), (unsigned)(3 * plane_elems) * 4u);
   const bool tiny = W < 2 || H < 2;  // degenerate pyramid levels: per-tap path
 
-  const int u0 = (tx * 64 + (threadIdx.x & 63)) * PX;
-  const int v = ty * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int u0 = (tx * 16 + (lane & 15)) * PX;
+  const int v = ty * 16 + (threadIdx.x >> 6) * 4 + (lane >> 4);
   if (v >= res || u0 >= res) return;
 
   float acc[PX][3];
@@ -437,7 +441,7 @@ static int launch_warp(const float* l0, const float* l1, const float* l2, const 
                        const float* wp, int n_crops, int res, int nhwc, void* out,
                        hipStream_t stream) {
   constexpr int PX = 4;
-  const long long per_crop = (long long)((res + 64 * PX - 1) / (64 * PX)) * ((res + 3) / 4);
+  const long long per_crop = (long long)((res + 16 * PX - 1) / (16 * PX)) * ((res + 15) / 16);
   const long long blocks = (long long)((n_crops + 7) / 8) * 8 * per_crop;
   if (blocks > 0x7fffffffLL) return MTR_E_SHAPE;
   MTR_CLEAR_STALE();
