@@ -5,6 +5,8 @@
 // is_within_fov (ptu3d.py:113-121) and back_project (ptu3d.py:108-110): ~40 tiny launches and a
 // batched LAPACK call in the reference, two launches here.
 //
+//   0. small batches (B*J <= 16384, i.e. every internal batch of the reference): ONE launch, each
+//      workgroup recomputes the batch moments redundantly (recon_fused_small_kernel);
 //   1. moments kernel: sum(normalized2d^2) and sum(rel_backproj^2) over the WHOLE call batch --
 //      the reference's rms_normalize is batch-global (ptu3d.py:71-74).  <= 256 per-block fp64
 //      partials, combined in a fixed order (no atomics: run-to-run deterministic).
@@ -116,21 +118,19 @@ struct ReconArgs {
   float l2_reg, weight_eps;
 };
 
-__global__ __launch_bounds__(256) void recon_solve_kernel(
+// one wave solves one crop; m0/m1/m2 = sum(normalized2d^2), sum(rel_backproj^2), count
+__device__ __forceinline__ void recon_solve_crop(
     const float* __restrict__ coords2d, const float* __restrict__ rel,
-    const float* __restrict__ intr, int B, int J, ReconArgs a, const double* __restrict__ moments,
-    float* __restrict__ poses) {
-  const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (b >= B) return;
+    const float* __restrict__ intr, int b, int lane, int J, const ReconArgs& a, double m0, double m1,
+    double m2, float* __restrict__ poses) {
   const Cam cam = inverse_rows01(intr + (size_t)b * 9);
   const size_t base = (size_t)b * J;
 
   double ref0, ref1, ref2;
   if (!a.weak) {
     // rms over the whole call batch (ptu3d.py:71-74, 82, 90)
-    const double scale2d = sqrt(moments[0] / moments[2]);
-    const double scale_rb = sqrt(moments[1] / moments[2]);
+    const double scale2d = sqrt(m0 / m2);
+    const double scale_rb = sqrt(m1 / m2);
     double m02 = 0, m12 = 0, m22 = 0, sw = 0, v0 = 0, v1 = 0, v2 = 0;
     for (int j = lane; j < J; j += 64) {
       const float px = coords2d[(base + j) * 2], py = coords2d[(base + j) * 2 + 1];
@@ -233,6 +233,56 @@ __global__ __launch_bounds__(256) void recon_solve_kernel(
   }
 }
 
+
+__global__ __launch_bounds__(256) void recon_solve_kernel(
+    const float* __restrict__ coords2d, const float* __restrict__ rel,
+    const float* __restrict__ intr, int B, int J, ReconArgs a, const double* __restrict__ moments,
+    float* __restrict__ poses) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const double m0 = a.weak ? 0.0 : moments[0], m1 = a.weak ? 0.0 : moments[1],
+               m2 = a.weak ? 1.0 : moments[2];
+  recon_solve_crop(coords2d, rel, intr, b, lane, J, a, m0, m1, m2, poses);
+}
+
+// Small batches (B*J <= kFusedMaxElems): ONE launch.  Every workgroup recomputes the batch moments
+// itself (the whole batch's coordinates are a few tens of KB, L2-resident) in a fixed order, so all
+// workgroups hold bit-identical scalars without any inter-workgroup hand-off, then solves its 4 crops.
+constexpr int kFusedMaxElems = 16384;
+
+__global__ __launch_bounds__(256) void recon_fused_small_kernel(
+    const float* __restrict__ coords2d, const float* __restrict__ rel,
+    const float* __restrict__ intr, int B, int J, ReconArgs a, float* __restrict__ poses) {
+  __shared__ double red[2][4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  double m0 = 0.0, m1 = 0.0;
+  if (!a.weak) {
+    double s2d = 0.0, srb = 0.0;
+    for (int c = wid; c < B; c += 4) {
+      const Cam cam = inverse_rows01(intr + (size_t)c * 9);
+      for (int j = lane; j < J; j += 64) {
+        const size_t o = (size_t)c * J + j;
+        double nx, ny;
+        normalize2d(cam, coords2d[o * 2], coords2d[o * 2 + 1], nx, ny);
+        const double rx = rel[o * 3], ry = rel[o * 3 + 1], rz = rel[o * 3 + 2];
+        const double bx = nx * rz - rx, by = ny * rz - ry;
+        s2d += nx * nx + ny * ny;
+        srb += bx * bx + by * by;
+      }
+    }
+    s2d = group_sum<64>(s2d);
+    srb = group_sum<64>(srb);
+    if (lane == 0) { red[0][wid] = s2d; red[1][wid] = srb; }
+    __syncthreads();
+    m0 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    m1 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+  const int b = blockIdx.x * 4 + wid;
+  if (b >= B) return;
+  recon_solve_crop(coords2d, rel, intr, b, lane, J, a, m0, m1, (double)B * J * 2.0, poses);
+}
+
 static ReconArgs make_args(const mtr_recon_params& p) {
   ReconArgs a;
   // is_within_fov (ptu3d.py:113-121)
@@ -316,6 +366,15 @@ extern "C" int mtr_reconstruct_absolute(const float* coords2d, const float* coor
   if (rc) return rc;
   if (!p || !poses3d || !workspace) return MTR_E_NULL;
   if (B == 0) return MTR_OK;
+  if (p->proc_side <= 0 || p->stride_train <= 0) return MTR_E_PARAM;
+  if ((long long)B * J <= mtr::kFusedMaxElems) {
+    MTR_CLEAR_STALE();
+    hipLaunchKernelGGL(mtr::recon_fused_small_kernel, dim3((B + 3) / 4), dim3(256), 0,
+                       (hipStream_t)stream, coords2d, coords3d_rel, intrinsics, B, J,
+                       mtr::make_args(*p), poses3d);
+    MTR_CHECK_LAUNCH();
+    return MTR_OK;
+  }
   double* moments = (double*)workspace;
   if (!p->weak_perspective) {
     rc = mtr_reconstruct_moments(coords2d, coords3d_rel, intrinsics, B, J, moments, workspace,
