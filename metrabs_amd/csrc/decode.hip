@@ -69,13 +69,13 @@ __global__ __launch_bounds__(256) void decode_nchw_kernel(
     const int p0 = pos_ok ? p_raw : 0;
     // (h, w) of the VEC elements; the VEC=4 instantiations require W % 4 == 0, so no wrap there
     const int h0 = p0 / W, w0 = p0 - h0 * W;
-    double fx[VEC], fy[VEC];
+    float fx[VEC], fy[VEC];  // small integers, exact in f32; widened at use (saves 8 VGPRs)
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       int w = w0 + v, h = h0;
       if (w >= W) { w -= W; ++h; }
-      fx[v] = (double)w;
-      fy[v] = (double)h;
+      fx[v] = (float)w;
+      fy[v] = (float)h;
     }
     const int voff = (j * HW + p0) * (int)sizeof(T);
 
@@ -102,8 +102,8 @@ __global__ __launch_bounds__(256) void decode_nchw_kernel(
         for (int v = 0; v < VEC; ++v) {
           const double e = (double)exp_shifted(v2[v], nm);
           s2 += e;
-          sx2 += e * fx[v];
-          sy2 += e * fy[v];
+          sx2 += e * (double)fx[v];
+          sy2 += e * (double)fy[v];
         }
       }
       {
@@ -137,8 +137,8 @@ __global__ __launch_bounds__(256) void decode_nchw_kernel(
         for (int v = 0; v < VEC; ++v) {
           const double c = (double)col[v];
           s3 += c;
-          sx3 += c * fx[v];
-          sy3 += c * fy[v];
+          sx3 += c * (double)fx[v];
+          sy3 += c * (double)fy[v];
           sz3 += (double)colz[v];
         }
       }
