@@ -360,7 +360,7 @@ def main():
                                    (im_h // 4) * (im_w // 4) * 4)
     src_bytes = source_footprint_bytes(extras['wp'], args.res, im_h, im_w)
     head_flops = 2.0 * C * J * (1 + D) * hw * n_crops
-    mfma_peak = MFMA_F64_PEAK if args.precision == 'f32' else MFMA_F32_PEAK
+    mfma_peak = MFMA_F32_PEAK  # v_mfma_f32_16x16x4_f32 in both precision classes (f64 carry on the VALU)
     alg = {
         'pyramid': dict(kernel='build_pyramid_kernel<true>', bound='hbm', bytes=pyr_bytes),
         'warp': dict(kernel='warp_crops_kernel', bound='hbm',

@@ -10,15 +10,17 @@
 // J*(1+D) = 153, HW = 64, C = 1280 for EffNetV2-S/256): 25 MFLOP over 328 KB of features
 // = 76 FLOP/B, above the f32-MFMA ridge (157 TF / 6.3-8 TB/s = 20-25), so in fp32 this kernel is
 // MATRIX-bound.  Precision class follows the feature dtype:
-//   * f32 features (the reference's CPU path): v_mfma_f64_16x16x4_f64 on operands widened to f64
-//     in registers -- products exact, accumulation in f64.  A sequential f32 fmaf chain over
-//     K = 1280 was measured ~4x noisier than oneDNN's blocked accumulation (1.6e-3 mm vs 3.7e-4 mm
-//     from the fp64 truth on the golden cases), which breaks the 1e-3 mm parity gate; f64
-//     accumulation puts the logits at the centre of the reference's own noise band.  Peak for this
-//     mode is the f64 matrix rate (78.6 TF);
+//   * f32 features (the reference's CPU path): v_mfma_f32_16x16x4_f32 over SHORT chains (KS k-steps
+//     = 16 channels), each chain's result carried into f64 accumulators on the VALU.  Why not a
+//     plain f32 chain: over K = 1280 it is ~4x noisier than oneDNN's blocked accumulation (1.6e-3
+//     vs 3.7e-4 mm from the fp64 truth on the golden cases) and fails the 1e-3 mm gate.  Why not
+//     v_mfma_f64_16x16x4_f64 (round-1 first choice, exact products + f64 accumulate): a pure chain of
+//     it, operands in registers, measures 47.7 TF at 4 waves/SIMD and 33-35 TF at 1 wave/SIMD on
+//     this chip (tools/experiments/mfma_probe.hip) -- 61 % / 42 % of the 78.6 TF spec -- and the
+//     kernel already sat at 90-95 % of that ceiling (45 TF), whereas the f32 shape reaches 125 TF;
 //   * f16 / bf16 features (the autocast GPU path, where the reference itself rounds the logits to
-//     f16): v_mfma_f32_16x16x4_f32, exact f32 fmaf chain at the 157 TF f32 matrix rate; weights and
-//     logits stay f32, i.e. strictly more accurate than the reference's f16 logits.
+//     f16): one f32 fma chain over all of K; weights and logits stay f32, i.e. strictly more
+//     accurate than the reference's f16 logits.
 //
 // Decomposition
 //   * weights are re-packed once (mtr_head_pack_weights) joint-major: joint j owns rows
@@ -251,14 +253,21 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(
                             : Bb[((kb + k) * 4 + fk) * HWP + n * 16];                             \
       }                                                                                           \
       __builtin_amdgcn_sched_barrier(0); /* keep the reads batched ahead of the MFMAs */          \
-      _Pragma("unroll") for (int k = 0; k < KS; ++k) {                                            \
+      if constexpr (ACC64) {                                                                      \
+        /* f32 MFMA over a SHORT chain (KS k-steps = 4*KS channels), carried into f64 */          \
+        f32x4 part[NT];                                                                           \
+        _Pragma("unroll") for (int n = 0; n < NT; ++n) part[n] = f32x4{0.f, 0.f, 0.f, 0.f};       \
+        _Pragma("unroll") for (int k = 0; k < KS; ++k) {                                          \
+          _Pragma("unroll") for (int n = 0; n < NT; ++n)                                          \
+              part[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k], bf[k][n], part[n], 0, 0, 0);  \
+        }                                                                                         \
         _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                          \
-          if constexpr (ACC64) {                                                                  \
-            acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)af[k], (double)bf[k][n],        \
-                                                          acc[n], 0, 0, 0);                       \
-          } else {                                                                                \
-            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k], bf[k][n], acc[n], 0, 0, 0);      \
-          }                                                                                       \
+          _Pragma("unroll") for (int r = 0; r < 4; ++r) acc[n][r] += (double)part[n][r];          \
+        }                                                                                         \
+      } else {                                                                                    \
+        _Pragma("unroll") for (int k = 0; k < KS; ++k) {                                          \
+          _Pragma("unroll") for (int n = 0; n < NT; ++n)                                          \
+              acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k], bf[k][n], acc[n], 0, 0, 0);    \
         }                                                                                         \
       }                                                                                           \
     }                                                                                             \
@@ -267,8 +276,10 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(
     __syncthreads();                                                                              \
   }
 
-  // k-steps per fragment batch and prefetch depth are register-budget choices: f64 accumulators
-  // take 8 VGPRs per tile (128 at NT = 16, where only one stage can be prefetched)
+  // k-steps per fragment batch (= the f32 chain length / 4 in carry mode) and prefetch depth are
+  // register-budget choices: f64 carry accumulators take 8 VGPRs per tile (128 at NT = 16)
+  // (carry interval 16 vs 32 channels: 32 is 4-6 % faster but 3x less accurate on peaked logits --
+  //  1.6e-3 vs 4.9e-4 mm from fp64 on golden case s256_c1280_peaked; parity first)
   constexpr int KS = NT <= 4 ? (ACC64 ? 4 : 8) : (NT <= 9 ? 4 : 2);
   constexpr int kAhead = (NT >= 16 && ACC64) ? 1 : 2;
   StageRegs<B_VECS> regs0;
@@ -288,14 +299,14 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(
   }
 #undef HEAD_ITER
 
-  // ---- epilogue 1: logits (+bias) -> LDS [64][HWP].  C/D layout: col = l&15 and
-  //   f32 16x16x4: row = (l>>4)*4 + reg;   f64 16x16x4: row = (l>>4) + 4*reg
+  // ---- epilogue 1: logits (+bias) -> LDS [64][HWP].  C/D layout of f32 16x16x4: col = l&15,
+  //   row = (l>>4)*4 + reg (the f64 carry accumulators mirror it element for element)
   // (the final __syncthreads of the loop already separates the last MFMA reads from these writes)
 #pragma unroll
   for (int n = 0; n < NT; ++n)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = wid * 16 + (ACC64 ? fk + 4 * r : fk * 4 + r);
+      const int row = wid * 16 + fk * 4 + r;
       // bias joins in the accumulator's precision; one rounding to f32
       Ls[row * HWP + n * 16 + fr] = (float)(acc[n][r] + (decltype(acc[n][r] + 0))bgrp[row]);
     }
