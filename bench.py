@@ -177,7 +177,8 @@ def source_footprint_bytes(wp, res, im_h, im_w):
         w, h = (im_w >> lvl), (im_h >> lvl)
         x0, x1 = q[:, 0].min().clamp(0, w - 1), q[:, 0].max().clamp(0, w - 1)
         y0, y1 = q[:, 1].min().clamp(0, h - 1), q[:, 1].max().clamp(0, h - 1)
-        total += float((x1 - x0 + 1) * (y1 - y0 + 1)) * 3 * 4
+        # level 0 is sampled from the uint8 frame (1 B / texel); levels 1-2 are f32
+        total += float((x1 - x0 + 1) * (y1 - y0 + 1)) * 3 * (1 if lvl == 0 else 4)
     return total
 
 
@@ -356,13 +357,14 @@ def main():
     feat_bytes = 2 if args.precision != 'f32' else 4
     out_bytes = 2 if args.precision != 'f32' else 4
     n_crops = n_box * args.num_aug
-    pyr_bytes = args.frames * 3 * (im_h * im_w * (1 + 4) + (im_h // 2) * (im_w // 2) * 4 +
+    # pyramid: read the uint8 frames, write f32 levels 1 and 2 (level 0 stays uint8 + LUT)
+    pyr_bytes = args.frames * 3 * (im_h * im_w * 1 + (im_h // 2) * (im_w // 2) * 4 +
                                    (im_h // 4) * (im_w // 4) * 4)
     src_bytes = source_footprint_bytes(extras['wp'], args.res, im_h, im_w)
     head_flops = 2.0 * C * J * (1 + D) * hw * n_crops
     mfma_peak = MFMA_F32_PEAK  # v_mfma_f32_16x16x4_f32 in both precision classes (f64 carry on the VALU)
     alg = {
-        'pyramid': dict(kernel='build_pyramid_kernel<true>', bound='hbm', bytes=pyr_bytes),
+        'pyramid': dict(kernel='build_pyramid_kernel<true,false>', bound='hbm', bytes=pyr_bytes),
         'warp': dict(kernel='warp_crops_kernel', bound='hbm',
                      bytes=n_crops * 3 * args.res ** 2 * out_bytes + src_bytes),
         'head_fused': dict(kernel='head_fused_kernel', bound='mfma', flops=head_flops,

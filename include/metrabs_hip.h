@@ -169,6 +169,16 @@ int mtr_build_pyramid(const uint8_t* images_u8, int N, int Hi, int Wi, float* le
  * receives, warping.py:6-13): writes level1 / level2 only. */
 int mtr_pyramid_from_level0(const float* level0, int N, int Hi, int Wi, float* level1, float* level2,
                             mtr_stream_t stream);
+/* Level 0 left as the uint8 frame: the f32 level 0 is 64 % of the pyramid's bytes and is only ever
+ * sampled, so the fast path never materialises it.  mtr_build_pyramid_u8 writes level1 / level2 and
+ * the 256-entry gamma LUT (lut[v] = (v/255)**2.2); mtr_warp_crops_u8 samples level 0 from
+ * images_u8 through that LUT (bit-identical to mtr_warp_crops on the materialised level 0). */
+int mtr_build_pyramid_u8(const uint8_t* images_u8, int N, int Hi, int Wi, float* lut /*[256]*/,
+                         float* level1, float* level2, mtr_stream_t stream);
+int mtr_warp_crops_u8(const uint8_t* level0_u8, const float* lut, const float* level1,
+                      const float* level2, int N, int Hi, int Wi, const float* warp_params,
+                      int n_crops, int res, int antialias, int out_dtype, int out_layout, void* out,
+                      mtr_stream_t stream);
 int mtr_crop_geometry(const float* boxes, int box_stride, const float* intrinsics,
                       const float* distortion, const float* camspace_up, const int32_t* image_ids,
                       const float* aug_rotflipmat, const float* aug_scales, const float* aug_gammas,

@@ -21,14 +21,17 @@ namespace mtr {
 // ------------------------------------------------------------------------------------------------
 // pyramid: each thread owns a 4x4 block of level-0 pixels = 2x2 of level 1 = 1 pixel of level 2.
 // avg_pool2d accumulates row-major ((a+b)+c)+d and divides by 4 (exact in fp32).
-template <bool FROM_U8>
+// WRITE_L0 = false: the f32 level 0 (64 % of the pyramid's bytes) is NOT materialised; the sampler
+// reads level 0 straight from the uint8 frame through the 256-entry LUT exported to `lut_out`.
+template <bool FROM_U8, bool WRITE_L0>
 __global__ __launch_bounds__(256) void build_pyramid_kernel(
     const void* __restrict__ src_any, int planes, int Hi, int Wi, float* __restrict__ l0,
-    float* __restrict__ l1, float* __restrict__ l2) {
+    float* __restrict__ l1, float* __restrict__ l2, float* __restrict__ lut_out) {
   __shared__ float lut[256];
   if (FROM_U8) {
     // (v/255)**2.2: fp32 division like torch, pow evaluated in fp64 and rounded once
     lut[threadIdx.x] = (float)pow((double)__fdiv_rn((float)threadIdx.x, 255.0f), (double)2.2f);
+    if (lut_out != nullptr && blockIdx.x == 0) lut_out[threadIdx.x] = lut[threadIdx.x];
     __syncthreads();
   }
   const uint8_t* __restrict__ src = (const uint8_t*)src_any;
@@ -64,8 +67,9 @@ __global__ __launch_bounds__(256) void build_pyramid_kernel(
         v[r][1] = lut[(raw >> 8) & 0xff];
         v[r][2] = lut[(raw >> 16) & 0xff];
         v[r][3] = lut[raw >> 24];
-        *reinterpret_cast<float4*>(d0 + (size_t)(y0 + r) * Wi + x0) =
-            make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
+        if (WRITE_L0)
+          *reinterpret_cast<float4*>(d0 + (size_t)(y0 + r) * Wi + x0) =
+              make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
       }
     } else {
 #pragma unroll
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(256) void build_pyramid_kernel(
           float val = 0.0f;
           if (y < Hi && x < Wi) {
             val = lut[sp[(size_t)y * Wi + x]];
-            d0[(size_t)y * Wi + x] = val;
+            if (WRITE_L0) d0[(size_t)y * Wi + x] = val;
           }
           v[r][c] = val;
         }
@@ -292,11 +296,25 @@ __device__ __forceinline__ void pair_weights(int i, int s, int n, float t0, floa
   else if (i == n - 1) { w_second = t0; }            // only tap i = n-1 is inside (s = n-2)
 }
 
-template <typename OutT, int AA, int PX>
+__device__ __forceinline__ float tap_u8(const uint8_t* __restrict__ plane, const float* lut, int x,
+                                        int y, int W, int H) {
+  return (x >= 0 && x < W && y >= 0 && y < H) ? lut[plane[(size_t)y * W + x]] : 0.0f;
+}
+
+// L0U8: level 0 is the uint8 frame itself (l0 is then a uint8 pointer) decoded through a copy of
+// the gamma LUT in LDS.  One 8-byte load from the 4-byte-aligned address below the tap still
+// yields both x-taps of a row: bytes (off&3) and (off&3)+1 of the 64-bit word.
+template <typename OutT, int AA, int PX, bool L0U8>
 __global__ __launch_bounds__(256) void warp_crops_kernel(
-    const float* __restrict__ l0, const float* __restrict__ l1, const float* __restrict__ l2,
-    LevelDims dims, const float* __restrict__ wp_all, int n_crops, int res, int nhwc,
-    OutT* __restrict__ out) {
+    const void* __restrict__ l0_any, const float* __restrict__ l1, const float* __restrict__ l2,
+    const float* __restrict__ lut_g, LevelDims dims, unsigned u8_bytes,
+    const float* __restrict__ wp_all, int n_crops, int res, int nhwc, OutT* __restrict__ out) {
+  __shared__ float lut[L0U8 ? 256 : 1];
+  if (L0U8) {
+    lut[threadIdx.x] = lut_g[threadIdx.x];
+    __syncthreads();
+  }
+  const float* __restrict__ l0 = (const float*)l0_any;
   // ---- XCD-aware map (block id b runs on XCD b % 8): all row tiles of a crop share one XCD, so
   // the crop's source footprint is fetched into ONE L2 instead of eight.
   // a wave covers a 64-px x 4-row output tile (16 lanes x PX pixels per row); a block = 4 such
@@ -321,10 +339,17 @@ __global__ __launch_bounds__(256) void warp_crops_kernel(
   const int img = (int)wp[32];
   const float gexp = wp[33];
   const int W = dims.W[level], H = dims.H[level];
+  const bool bytes0 = L0U8 && level == 0;  // wave-uniform
   const float* __restrict__ lvl = level == 0 ? l0 : (level == 1 ? l1 : l2);
   const float* __restrict__ planes = lvl + (size_t)img * 3 * H * W;
+  const uint8_t* __restrict__ planes_u8 = (const uint8_t*)l0_any + (size_t)img * 3 * H * W;
   const int plane_elems = H * W;
-  const buffer_rsrc_t rsrc = make_rsrc(uniform_ptr(planes), (unsigned)(3 * plane_elems) * 4u);
+  // uint8 path: the descriptor spans the WHOLE frame tensor (its base is 4-byte aligned; an
+  // image's own base is not when 3*H*W is odd) and the image offset joins the byte offset
+  const int img_off = bytes0 ? img * 3 * plane_elems : 0;
+  const buffer_rsrc_t rsrc =
+      bytes0 ? make_rsrc(uniform_ptr((const uint8_t*)l0_any), (unsigned)u8_bytes)
+             : make_rsrc(uniform_ptr(planes), (unsigned)(3 * plane_elems) * 4u);
   const bool tiny = W < 2 || H < 2;  // degenerate pyramid levels: per-tap path
 
   const int lane = threadIdx.x & 63;
@@ -373,14 +398,37 @@ __global__ __launch_bounds__(256) void warp_crops_kernel(
           pair_weights(x0, xs, W, tx0, tx1, wl, wr);
           pair_weights(y0, ys, H, ty0, ty1, wt, wb);
           const float w00 = wl * wt, w01 = wr * wt, w10 = wl * wb, w11 = wr * wb;
-          const int off = (ys * W + xs) * 4;
+          if (!bytes0) {
+            const int off = (ys * W + xs) * 4;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const auto top = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, c * plane_elems * 4, 0);
+              const auto bot = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + W * 4, c * plane_elems * 4, 0);
+              struct F2 { float a, b; };
+              const F2 t = __builtin_bit_cast(F2, top), b2 = __builtin_bit_cast(F2, bot);
+              acc[p][c] += fmaf(b2.b, w11, fmaf(b2.a, w10, fmaf(t.b, w01, t.a * w00)));
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const int ot = img_off + c * plane_elems + ys * W + xs, ob = ot + W;  // byte offsets
+              const auto top = __builtin_amdgcn_raw_buffer_load_b64(rsrc, ot & ~3, 0, 0);
+              const auto bot = __builtin_amdgcn_raw_buffer_load_b64(rsrc, ob & ~3, 0, 0);
+              const unsigned long long tw = __builtin_bit_cast(unsigned long long, top) >> ((ot & 3) * 8);
+              const unsigned long long bw = __builtin_bit_cast(unsigned long long, bot) >> ((ob & 3) * 8);
+              const float ta = lut[tw & 0xff], tb = lut[(tw >> 8) & 0xff];
+              const float ba = lut[bw & 0xff], bb = lut[(bw >> 8) & 0xff];
+              acc[p][c] += fmaf(bb, w11, fmaf(ba, w10, fmaf(tb, w01, ta * w00)));
+            }
+          }
+        } else if (bytes0) {
+          const float wnw = tx0 * ty0, wne = tx1 * ty0, wsw = tx0 * ty1, wse = tx1 * ty1;
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            const auto top = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, c * plane_elems * 4, 0);
-            const auto bot = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + W * 4, c * plane_elems * 4, 0);
-            struct F2 { float a, b; };
-            const F2 t = __builtin_bit_cast(F2, top), b2 = __builtin_bit_cast(F2, bot);
-            acc[p][c] += fmaf(b2.b, w11, fmaf(b2.a, w10, fmaf(t.b, w01, t.a * w00)));
+            const uint8_t* __restrict__ pl = planes_u8 + (size_t)c * plane_elems;
+            const float nw = tap_u8(pl, lut, x0, y0, W, H), ne = tap_u8(pl, lut, x0 + 1, y0, W, H);
+            const float sw = tap_u8(pl, lut, x0, y0 + 1, W, H), se = tap_u8(pl, lut, x0 + 1, y0 + 1, W, H);
+            acc[p][c] += fmaf(se, wse, fmaf(sw, wsw, fmaf(ne, wne, nw * wnw)));
           }
         } else {
           const float wnw = tx0 * ty0, wne = tx1 * ty0, wsw = tx0 * ty1, wse = tx1 * ty1;
@@ -436,64 +484,120 @@ __global__ __launch_bounds__(256) void warp_crops_kernel(
   }
 }
 
-template <typename OutT, int AA>
-static int launch_warp(const float* l0, const float* l1, const float* l2, const LevelDims& dims,
-                       const float* wp, int n_crops, int res, int nhwc, void* out,
-                       hipStream_t stream) {
+template <typename OutT, int AA, bool L0U8>
+static int launch_warp(const void* l0, const float* l1, const float* l2, const float* lut,
+                       const LevelDims& dims, unsigned u8_bytes, const float* wp, int n_crops,
+                       int res, int nhwc, void* out, hipStream_t stream) {
   constexpr int PX = 4;
   const long long per_crop = (long long)((res + 16 * PX - 1) / (16 * PX)) * ((res + 15) / 16);
   const long long blocks = (long long)((n_crops + 7) / 8) * 8 * per_crop;
   if (blocks > 0x7fffffffLL) return MTR_E_SHAPE;
   MTR_CLEAR_STALE();
-  hipLaunchKernelGGL((warp_crops_kernel<OutT, AA, PX>), dim3((unsigned)blocks), dim3(256), 0, stream,
-                     l0, l1, l2, dims, wp, n_crops, res, nhwc, (OutT*)out);
+  hipLaunchKernelGGL((warp_crops_kernel<OutT, AA, PX, L0U8>), dim3((unsigned)blocks), dim3(256), 0,
+                     stream, l0, l1, l2, lut, dims, u8_bytes, wp, n_crops, res, nhwc, (OutT*)out);
   MTR_CHECK_LAUNCH();
   return MTR_OK;
 }
 
-template <typename OutT>
-static int dispatch_warp_aa(const float* l0, const float* l1, const float* l2,
-                            const LevelDims& dims, const float* wp, int n_crops, int res, int aa,
-                            int nhwc, void* out, hipStream_t stream) {
+template <typename OutT, bool L0U8>
+static int dispatch_warp_aa(const void* l0, const float* l1, const float* l2, const float* lut,
+                            const LevelDims& dims, unsigned u8_bytes, const float* wp, int n_crops,
+                            int res, int aa, int nhwc, void* out, hipStream_t stream) {
   switch (aa) {
-    case 1: return launch_warp<OutT, 1>(l0, l1, l2, dims, wp, n_crops, res, nhwc, out, stream);
-    case 2: return launch_warp<OutT, 2>(l0, l1, l2, dims, wp, n_crops, res, nhwc, out, stream);
-    case 4: return launch_warp<OutT, 4>(l0, l1, l2, dims, wp, n_crops, res, nhwc, out, stream);
+    case 1: return launch_warp<OutT, 1, L0U8>(l0, l1, l2, lut, dims, u8_bytes, wp, n_crops, res, nhwc, out, stream);
+    case 2: return launch_warp<OutT, 2, L0U8>(l0, l1, l2, lut, dims, u8_bytes, wp, n_crops, res, nhwc, out, stream);
+    case 4: return launch_warp<OutT, 4, L0U8>(l0, l1, l2, lut, dims, u8_bytes, wp, n_crops, res, nhwc, out, stream);
     default: return MTR_E_SHAPE;  // the reference needs torchvision for aa > 4 (:312-315)
+  }
+}
+
+template <bool L0U8>
+static int warp_entry(const void* level0, const float* lut, const float* level1, const float* level2,
+                      int N, int Hi, int Wi, const float* warp_params, int n_crops, int res,
+                      int antialias, int out_dtype, int out_layout, void* out, hipStream_t s) {
+  if (N <= 0 || Hi <= 0 || Wi <= 0 || n_crops < 0 || res <= 0) return MTR_E_SHAPE;
+  // a pyramid level of a tiny image may be empty: its pointer may then be NULL
+  const bool l1_empty = (Hi / 2) * (Wi / 2) == 0, l2_empty = (Hi / 4) * (Wi / 4) == 0;
+  if (!level0 || (!level1 && !l1_empty) || (!level2 && !l2_empty) || !warp_params || !out ||
+      (L0U8 && !lut))
+    return MTR_E_NULL;
+  if ((long long)N * 3 * Hi * Wi > 0xffffffffLL) return MTR_E_SHAPE;
+  // Range of the uint8 descriptor, rounded up so that the dword PAIR covering the last byte is in
+  // range (a dword straddling num_records reads as zero).  The <= 8 bytes past the tensor belong to
+  // the same allocation granule (torch: 512 B) and only ever meet zero tap weights.
+  const unsigned u8_bytes = (unsigned)((((long long)N * 3 * Hi * Wi + 3) & ~3LL) + 4);
+  if (out_layout != MTR_NCHW && out_layout != MTR_NHWC) return MTR_E_DTYPE;
+  if (n_crops == 0) return MTR_OK;
+  if ((uintptr_t)out % 16) return MTR_E_ALIGN;
+  if (L0U8 && ((uintptr_t)level0 % 4)) return MTR_E_ALIGN;
+  LevelDims dims;
+  dims.H[0] = Hi; dims.W[0] = Wi;
+  dims.H[1] = Hi / 2; dims.W[1] = Wi / 2;
+  dims.H[2] = dims.H[1] / 2; dims.W[2] = dims.W[1] / 2;
+  const int nhwc = out_layout == MTR_NHWC;
+  switch (out_dtype) {
+    case MTR_F32:
+      return dispatch_warp_aa<float, L0U8>(level0, level1, level2, lut, dims, u8_bytes, warp_params,
+                                           n_crops, res, antialias, nhwc, out, s);
+    case MTR_F16:
+      return dispatch_warp_aa<__half, L0U8>(level0, level1, level2, lut, dims, u8_bytes, warp_params,
+                                            n_crops, res, antialias, nhwc, out, s);
+    case MTR_BF16:
+      return dispatch_warp_aa<__hip_bfloat16, L0U8>(level0, level1, level2, lut, dims, u8_bytes,
+                                                    warp_params, n_crops, res, antialias, nhwc, out, s);
+    default: return MTR_E_DTYPE;
   }
 }
 
 }  // namespace mtr
 
-extern "C" int mtr_build_pyramid(const uint8_t* images_u8, int N, int Hi, int Wi, float* level0,
-                                 float* level1, float* level2, mtr_stream_t stream) {
-  if (!images_u8 || !level0 || !level1 || !level2) return MTR_E_NULL;
-  if (N < 0 || Hi <= 0 || Wi <= 0) return MTR_E_SHAPE;
-  if (N == 0) return MTR_OK;
-  if (((uintptr_t)level0 % 16) || ((uintptr_t)images_u8 % 4)) return MTR_E_ALIGN;
+static int pyramid_grid(int N, int Hi, int Wi) {
   const long long blocks4 = (long long)N * 3 * ((Hi + 3) / 4) * ((Wi + 3) / 4);
   long long grid = (blocks4 + 255) / 256;
   if (grid > 8192) grid = 8192;  // grid-stride the rest
+  return (int)grid;
+}
+
+extern "C" int mtr_build_pyramid(const uint8_t* images_u8, int N, int Hi, int Wi, float* level0,
+                                 float* level1, float* level2, mtr_stream_t stream) {
+  if (N < 0 || Hi <= 0 || Wi <= 0) return MTR_E_SHAPE;
+  if (!images_u8 || !level0 || (!level1 && (Hi / 2) * (Wi / 2) > 0) || (!level2 && (Hi / 4) * (Wi / 4) > 0))
+    return MTR_E_NULL;
+  if (N == 0) return MTR_OK;
+  if (((uintptr_t)level0 % 16) || ((uintptr_t)images_u8 % 4)) return MTR_E_ALIGN;
   MTR_CLEAR_STALE();
-  hipLaunchKernelGGL(mtr::build_pyramid_kernel<true>, dim3((unsigned)grid), dim3(256), 0,
-                     (hipStream_t)stream, (const void*)images_u8, N * 3, Hi, Wi, level0, level1,
-                     level2);
+  hipLaunchKernelGGL((mtr::build_pyramid_kernel<true, true>), dim3(pyramid_grid(N, Hi, Wi)), dim3(256),
+                     0, (hipStream_t)stream, (const void*)images_u8, N * 3, Hi, Wi, level0, level1,
+                     level2, (float*)nullptr);
+  MTR_CHECK_LAUNCH();
+  return MTR_OK;
+}
+
+extern "C" int mtr_build_pyramid_u8(const uint8_t* images_u8, int N, int Hi, int Wi, float* lut,
+                                    float* level1, float* level2, mtr_stream_t stream) {
+  if (N < 0 || Hi <= 0 || Wi <= 0) return MTR_E_SHAPE;
+  if (!images_u8 || !lut || (!level1 && (Hi / 2) * (Wi / 2) > 0) || (!level2 && (Hi / 4) * (Wi / 4) > 0))
+    return MTR_E_NULL;
+  if (N == 0) return MTR_OK;
+  if ((uintptr_t)images_u8 % 4) return MTR_E_ALIGN;
+  MTR_CLEAR_STALE();
+  hipLaunchKernelGGL((mtr::build_pyramid_kernel<true, false>), dim3(pyramid_grid(N, Hi, Wi)),
+                     dim3(256), 0, (hipStream_t)stream, (const void*)images_u8, N * 3, Hi, Wi,
+                     (float*)nullptr, level1, level2, lut);
   MTR_CHECK_LAUNCH();
   return MTR_OK;
 }
 
 extern "C" int mtr_pyramid_from_level0(const float* level0, int N, int Hi, int Wi, float* level1,
                                        float* level2, mtr_stream_t stream) {
-  if (!level0 || !level1 || !level2) return MTR_E_NULL;
   if (N < 0 || Hi <= 0 || Wi <= 0) return MTR_E_SHAPE;
+  if (!level0 || (!level1 && (Hi / 2) * (Wi / 2) > 0) || (!level2 && (Hi / 4) * (Wi / 4) > 0))
+    return MTR_E_NULL;
   if (N == 0) return MTR_OK;
-  const long long blocks4 = (long long)N * 3 * ((Hi + 3) / 4) * ((Wi + 3) / 4);
-  long long grid = (blocks4 + 255) / 256;
-  if (grid > 8192) grid = 8192;
   MTR_CLEAR_STALE();
-  hipLaunchKernelGGL(mtr::build_pyramid_kernel<false>, dim3((unsigned)grid), dim3(256), 0,
-                     (hipStream_t)stream, (const void*)level0, N * 3, Hi, Wi, (float*)nullptr,
-                     level1, level2);
+  hipLaunchKernelGGL((mtr::build_pyramid_kernel<false, false>), dim3(pyramid_grid(N, Hi, Wi)),
+                     dim3(256), 0, (hipStream_t)stream, (const void*)level0, N * 3, Hi, Wi,
+                     (float*)nullptr, level1, level2, (float*)nullptr);
   MTR_CHECK_LAUNCH();
   return MTR_OK;
 }
@@ -523,27 +627,14 @@ extern "C" int mtr_warp_crops(const float* level0, const float* level1, const fl
                               int Hi, int Wi, const float* warp_params, int n_crops, int res,
                               int antialias, int out_dtype, int out_layout, void* out,
                               mtr_stream_t stream) {
-  if (!level0 || !level1 || !level2 || !warp_params || !out) return MTR_E_NULL;
-  if (N <= 0 || Hi <= 0 || Wi <= 0 || n_crops < 0 || res <= 0) return MTR_E_SHAPE;
-  if (out_layout != MTR_NCHW && out_layout != MTR_NHWC) return MTR_E_DTYPE;
-  if (n_crops == 0) return MTR_OK;
-  if ((uintptr_t)out % 16) return MTR_E_ALIGN;
-  mtr::LevelDims dims;
-  dims.H[0] = Hi; dims.W[0] = Wi;
-  dims.H[1] = Hi / 2; dims.W[1] = Wi / 2;
-  dims.H[2] = dims.H[1] / 2; dims.W[2] = dims.W[1] / 2;
-  hipStream_t s = (hipStream_t)stream;
-  const int nhwc = out_layout == MTR_NHWC;
-  switch (out_dtype) {
-    case MTR_F32:
-      return mtr::dispatch_warp_aa<float>(level0, level1, level2, dims, warp_params, n_crops, res,
-                                          antialias, nhwc, out, s);
-    case MTR_F16:
-      return mtr::dispatch_warp_aa<__half>(level0, level1, level2, dims, warp_params, n_crops, res,
-                                           antialias, nhwc, out, s);
-    case MTR_BF16:
-      return mtr::dispatch_warp_aa<__hip_bfloat16>(level0, level1, level2, dims, warp_params,
-                                                   n_crops, res, antialias, nhwc, out, s);
-    default: return MTR_E_DTYPE;
-  }
+  return mtr::warp_entry<false>(level0, nullptr, level1, level2, N, Hi, Wi, warp_params, n_crops, res,
+                                antialias, out_dtype, out_layout, out, (hipStream_t)stream);
+}
+
+extern "C" int mtr_warp_crops_u8(const uint8_t* level0_u8, const float* lut, const float* level1,
+                                 const float* level2, int N, int Hi, int Wi, const float* warp_params,
+                                 int n_crops, int res, int antialias, int out_dtype, int out_layout,
+                                 void* out, mtr_stream_t stream) {
+  return mtr::warp_entry<true>(level0_u8, lut, level1, level2, N, Hi, Wi, warp_params, n_crops, res,
+                               antialias, out_dtype, out_layout, out, (hipStream_t)stream);
 }

@@ -95,12 +95,21 @@ def reconstruct_solve(coords2d, coords3d_rel, intrinsics, moments, cfg, mix_3d_i
 
 
 class Pyramid:
-    """Linear-light f32 image pyramid [level0, level1, level2], each [N,3,H_l,W_l]
-    (multiperson_model.py:196 + warping.py:10-13)."""
+    """Linear-light image pyramid of the reference (multiperson_model.py:196 + warping.py:10-13).
 
-    def __init__(self, levels):
+    Two representations of level 0:
+      * ``levels[0]`` f32 [N,3,H,W] (materialised -- what warping.warp_images_with_pyramid builds);
+      * ``images_u8`` + ``lut``: level 0 stays the uint8 frame, decoded through the 256-entry gamma
+        LUT inside the sampler (``levels[0]`` is None).  Same numbers, 64 % fewer pyramid bytes.
+    ``levels[1]``, ``levels[2]`` are always f32."""
+
+    def __init__(self, levels, images_u8=None, lut=None):
         self.levels = levels
-        self.n, _, self.h, self.w = levels[0].shape
+        self.images_u8 = images_u8
+        self.lut = lut
+        ref = images_u8 if levels[0] is None else levels[0]
+        self.n, _, self.h, self.w = ref.shape
+        self.device = ref.device
 
 
 def _alloc_levels(n, h, w, device, with_level0=True):
@@ -111,17 +120,26 @@ def _alloc_levels(n, h, w, device, with_level0=True):
     return l0, l1, l2
 
 
-def build_pyramid(images_u8):
-    """uint8 [N,3,H,W] -> Pyramid: fused gamma decode (u8/255)**2.2 + two 2x2 box levels."""
+def build_pyramid(images_u8, materialize_level0=False):
+    """uint8 [N,3,H,W] -> Pyramid: fused gamma decode (u8/255)**2.2 + two 2x2 box levels.  By
+    default level 0 is NOT written as f32 (the sampler reads the uint8 frame through the LUT)."""
     require_cuda(images_u8)
     if images_u8.dtype != torch.uint8 or images_u8.ndim != 4 or images_u8.shape[1] != 3:
         raise ValueError('images must be uint8 [N,3,H,W]')
     images_u8 = images_u8.contiguous()
     n, _, h, w = images_u8.shape
-    l0, l1, l2 = _alloc_levels(n, h, w, images_u8.device)
-    check(_lib.load().mtr_build_pyramid(_ptr(images_u8), n, h, w, _ptr(l0), _ptr(l1), _ptr(l2),
-                                        current_stream_ptr(images_u8.device)), 'mtr_build_pyramid')
-    return Pyramid([l0, l1, l2])
+    lib = _lib.load()
+    stream = current_stream_ptr(images_u8.device)
+    if materialize_level0:
+        l0, l1, l2 = _alloc_levels(n, h, w, images_u8.device)
+        check(lib.mtr_build_pyramid(_ptr(images_u8), n, h, w, _ptr(l0), _ptr(l1), _ptr(l2), stream),
+              'mtr_build_pyramid')
+        return Pyramid([l0, l1, l2])
+    _, l1, l2 = _alloc_levels(n, h, w, images_u8.device, with_level0=False)
+    lut = torch.empty(256, device=images_u8.device, dtype=torch.float32)
+    check(lib.mtr_build_pyramid_u8(_ptr(images_u8), n, h, w, _ptr(lut), _ptr(l1), _ptr(l2), stream),
+          'mtr_build_pyramid_u8')
+    return Pyramid([None, l1, l2], images_u8=images_u8, lut=lut)
 
 
 def pyramid_from_level0(images_linear):
@@ -173,11 +191,14 @@ def warp_crops(pyramid, warp_params, res, antialias=1, out_dtype=torch.float32,
         else:
             out = torch.empty(n, 3, res, res, device=dev, dtype=out_dtype)
     l0, l1, l2 = pyramid.levels
-    check(_lib.load().mtr_warp_crops(
-        _ptr(l0), _ptr(l1), _ptr(l2), pyramid.n, pyramid.h, pyramid.w, _ptr(warp_params), n,
-        int(res), int(antialias), dtype_code(out.dtype),
-        _lib.MTR_NHWC if channels_last else _lib.MTR_NCHW, _ptr(out), current_stream_ptr(dev)),
-        'mtr_warp_crops')
+    tail = (pyramid.n, pyramid.h, pyramid.w, _ptr(warp_params), n, int(res), int(antialias),
+            dtype_code(out.dtype), _lib.MTR_NHWC if channels_last else _lib.MTR_NCHW, _ptr(out),
+            current_stream_ptr(dev))
+    if l0 is None:
+        check(_lib.load().mtr_warp_crops_u8(_ptr(pyramid.images_u8), _ptr(pyramid.lut), _ptr(l1),
+                                            _ptr(l2), *tail), 'mtr_warp_crops_u8')
+    else:
+        check(_lib.load().mtr_warp_crops(_ptr(l0), _ptr(l1), _ptr(l2), *tail), 'mtr_warp_crops')
     return out
 
 

@@ -53,7 +53,7 @@ def warp_images_with_pyramid(images, intrinsic_matrix, new_invprojmats, distorti
     if output_shape[0] != output_shape[1]:
         raise NotImplementedError('square crops only (the reference only requests res x res)')
     pyr = images if isinstance(images, kernels.Pyramid) else kernels.pyramid_from_level0(images)
-    dev = pyr.levels[0].device
+    dev = pyr.device
     wp = make_warp_params(
         intrinsic_matrix.to(dev), new_invprojmats.to(dev), distortion_coeffs.to(dev),
         crop_scales.to(dev), image_ids.to(dev), None, n_pyramid_levels)

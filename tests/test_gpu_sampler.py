@@ -25,7 +25,12 @@ def test_pyramid_vs_oracle(shape, hip_lib):
     img = cases.synth_images(n, h, w, 9)
     lin = (img.float() / 255) ** 2.2
     ref = cpu_ref.build_pyramid(lin)
-    pyr = kernels.build_pyramid(img.cuda())
+    pyr = kernels.build_pyramid(img.cuda(), materialize_level0=True)
+    fast = kernels.build_pyramid(img.cuda())  # uint8 level 0 + LUT: levels 1-2 must be the same bits
+    assert fast.levels[0] is None and torch.equal(fast.levels[1], pyr.levels[1]) \
+        and torch.equal(fast.levels[2], pyr.levels[2])
+    lut_ref = (torch.arange(256).float() / 255) ** 2.2
+    assert float((fast.lut.cpu() - lut_ref).abs().max()) <= 6e-8
     for lvl in range(3):
         assert pyr.levels[lvl].shape == ref[lvl].shape
         if ref[lvl].numel():
@@ -169,3 +174,31 @@ def test_warp_full_size_properties(hip_lib):
     print(f'[parity] full-size crops: linear max-abs {float(d.max()):.2e} mean {float(d.mean()):.2e}')
     # 1080p coordinates (~2000 px) carry ~10x the rounding of the 160 px fixtures
     assert float(d.max()) <= 1.5e-3 and float(d.mean()) <= 4e-5
+
+
+@pytest.mark.parametrize('aa,dtype', [(1, torch.float32), (2, torch.float32), (1, torch.float16), (4, torch.float32)])
+def test_u8_level0_path_is_bit_identical(aa, dtype, hip_lib):
+    """The fast path (level 0 sampled from the uint8 frame through the LUT) gives the SAME BITS as
+    sampling a materialised f32 level 0 -- crops at all three pyramid levels, distortion, borders,
+    odd image sizes (W % 4 != 0 exercises the unaligned byte-pair extraction)."""
+    from metrabs_amd import kernels
+    for (h, w, seed) in [(120, 160, 1), (97, 131, 2), (3, 5, 3)]:
+        img = cases.synth_images(2, h, w, 60 + seed).cuda()
+        n, res = 12, 32
+        g = cases.gen(70 + seed)
+        boxes = torch.stack([torch.rand(n, generator=g) * w * 0.7 - 5, torch.rand(n, generator=g) * h * 0.6 - 5,
+                             (0.1 + torch.rand(n, generator=g)) * w, (0.2 + torch.rand(n, generator=g)) * h], 1)
+        K = cases.intrinsics_for(h, w, 55.0, seed)[None].repeat(n, 1, 1)
+        d12 = torch.zeros(n, 12)
+        d12[::2, :5] = torch.tensor(cases.DISTORTION_5)
+        tta = cpu_ref.tta_params(3)
+        up = torch.tensor([[0.0, -1.0, 0.0]]).repeat(n, 1)
+        ids = torch.arange(n) % 2
+        _, _, wp = kernels.crop_geometry(boxes.cuda(), K.cuda(), d12.cuda(), up.cuda(), ids.cuda(),
+                                         tta['rotflipmat'].cuda(), tta['scales'].cuda(),
+                                         tta['gammas'].cuda(), res, aa)
+        slow = kernels.warp_crops(kernels.build_pyramid(img, materialize_level0=True), wp, res, aa,
+                                  out_dtype=dtype)
+        fast = kernels.warp_crops(kernels.build_pyramid(img), wp, res, aa, out_dtype=dtype)
+        assert (wp[:, 31] == 0).any(), 'fixture must contain level-0 crops'
+        assert torch.equal(slow, fast), (h, w, float((slow.float() - fast.float()).abs().max()))

@@ -79,10 +79,11 @@ def bench_warp_pyramid():
     out = []
     g = torch.Generator().manual_seed(0)
     frames = torch.randint(0, 256, (8, 3, 1080, 1920), dtype=torch.uint8, generator=g).cuda()
-    t = timeit(lambda: kernels.build_pyramid(frames))
-    nbytes = 8 * 3 * (1080 * 1920 * 5 + 540 * 960 * 4 + 270 * 480 * 4)
-    out.append(dict(kernel='pyramid', case='8 x 1080p', us=round(t * 1e6, 1),
-                    GBps=round(nbytes / t / 1e9, 1), frac_hbm=round(nbytes / t / HBM, 3)))
+    for name, mat, l0b in [('8 x 1080p, f32 level 0 materialised', True, 4), ('8 x 1080p, uint8 level 0 (default)', False, 0)]:
+        t = timeit(lambda: kernels.build_pyramid(frames, materialize_level0=mat))
+        nbytes = 8 * 3 * (1080 * 1920 * (1 + l0b) + 540 * 960 * 4 + 270 * 480 * 4)
+        out.append(dict(kernel='pyramid', case=name, us=round(t * 1e6, 1),
+                        GBps=round(nbytes / t / 1e9, 1), frac_hbm=round(nbytes / t / HBM, 3)))
     pyr = kernels.build_pyramid(frames)
     for name, n, num_aug, aa, dt in [('64 crops 256px f32', 64, 1, 1, torch.float32),
                                      ('64 crops 256px f16', 64, 1, 1, torch.float16),
