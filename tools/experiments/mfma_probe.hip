@@ -56,6 +56,61 @@ __global__ __launch_bounds__(256) void probe_f32(const float* in, float* out, in
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// f32 16x16x4 fed from LDS exactly like the head kernel: per k-step 1 A + NACC B ds_read_b32
+template <int NACC, bool BATCH>
+__global__ __launch_bounds__(256) void probe_f32_lds(const float* in, float* out, int iters) {
+  __shared__ float lds[8192];
+  for (int i = threadIdx.x; i < 8192; i += 256) lds[i] = in[i & 4095];
+  __syncthreads();
+  f32x4 acc[NACC];
+  for (int n = 0; n < NACC; ++n) acc[n] = f32x4{0, 0, 0, 0};
+  const int lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4;
+  for (int it = 0; it < iters; it += 4) {
+    float a[4], b[4][NACC];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      a[k] = lds[((it + k) * 4 + fk) * 80 % 4096 + fr];
+#pragma unroll
+      for (int n = 0; n < NACC; ++n) b[k][n] = lds[4096 + (((it + k) * 4 + fk) * 80 + n * 16) % 4000 + fr];
+    }
+    if (BATCH) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int n = 0; n < NACC; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k], b[k][n], acc[n], 0, 0, 0);
+  }
+  float s = 0;
+  for (int n = 0; n < NACC; ++n) s += acc[n][0] + acc[n][1] + acc[n][2] + acc[n][3];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// f32 32x32x2: one 32x32 tile per wave, operands from registers or from LDS (1 A + 1 B read per MFMA)
+template <bool LDS>
+__global__ __launch_bounds__(256) void probe_f32_32(const float* in, float* out, int iters) {
+  __shared__ float lds[8192];
+  for (int i = threadIdx.x; i < 8192; i += 256) lds[i] = in[i & 4095];
+  __syncthreads();
+  f32x16 acc = {0};
+  const int lane = threadIdx.x & 63;
+  float af = in[threadIdx.x], bf = in[threadIdx.x + 256];
+  for (int it = 0; it < iters; it += 4) {
+    float a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      a[k] = LDS ? lds[(((it + k) * 2 + (lane >> 5)) * 80) % 4000 + (lane & 31)] : af;
+      b[k] = LDS ? lds[4096 + (((it + k) * 2 + (lane >> 5)) * 80) % 4000 + (lane & 31)] : bf;
+    }
+    if (LDS) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b[k], acc, 0, 0, 0);
+  }
+  float s = 0;
+  for (int r = 0; r < 16; ++r) s += acc[r];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 template <typename F>
 float time_ms(F launch) {
   hipEvent_t a, b;
@@ -86,6 +141,10 @@ int main() {
     rep("f64 + cvt", time_ms([&] { probe_f64<1, 4><<<blocks, 256>>>(in, outd, iters); }), 4, 2048);
     rep("f64 + cvt + lds", time_ms([&] { probe_f64<2, 4><<<blocks, 256>>>(in, outd, iters); }), 4, 2048);
     rep("f32 regs", time_ms([&] { probe_f32<4><<<blocks, 256>>>(in, outf, iters); }), 4, 2048);
+    rep("f32 16x16x4 + lds (jit reads)", time_ms([&] { probe_f32_lds<4, false><<<blocks, 256>>>(in, outf, iters); }), 4, 2048);
+    rep("f32 16x16x4 + lds (batched)", time_ms([&] { probe_f32_lds<4, true><<<blocks, 256>>>(in, outf, iters); }), 4, 2048);
+    rep("f32 32x32x2 regs", time_ms([&] { probe_f32_32<false><<<blocks, 256>>>(in, outf, iters); }), 1, 4096);
+    rep("f32 32x32x2 + lds", time_ms([&] { probe_f32_32<true><<<blocks, 256>>>(in, outf, iters); }), 1, 4096);
   }
   return 0;
 }
