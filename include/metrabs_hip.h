@@ -95,9 +95,11 @@ int mtr_softargmax_decode(const void* logits, int dtype, int layout, int B, int 
  * tiled layout the kernel streams; `packed` must hold
  * mtr_head_packed_bytes(...) bytes.  features: [B, C, H, W] (MTR_NCHW) or [B, H, W, C] (MTR_NHWC,
  * C % 4 == 0); H*W must be a multiple of 4 and <= 256, 1+D <= 64 (else: 1x1-conv GEMM +
- * mtr_softargmax_decode).  Arithmetic: v_mfma_f32_16x16x4_f32 with f32 weights; for f32 features the
- * f32 chains are 16 channels long and carried into f64 accumulators (parity with the fp32 CPU
- * reference), for f16/bf16 features one f32 chain runs over all of C.
+ * mtr_softargmax_decode).  Arithmetic: f32-input MFMA with f32 weights (v_mfma_f32_32x32x2_f32 for
+ * maps of 33..128 positions, v_mfma_f32_16x16x4_f32 otherwise; the packed blob holds the weights in
+ * both tile layouts); for f32 features the f32 chains are 16 channels long and carried into f64
+ * accumulators (parity with the fp32 CPU reference), for f16/bf16 features one f32 chain runs over
+ * all of C.
  */
 size_t mtr_head_packed_bytes(int C, int J, int D, int feat_dtype);
 int mtr_head_pack_weights(const float* weight /*[J*(1+D), C] f32*/, const float* bias /*[J*(1+D)]*/,

@@ -36,6 +36,7 @@
 //     (softmax over its D slices, fp64 moment sums; exp in the accumulator's precision class);
 //   * 1-D grid with an XCD-aware remap: the joint groups of one crop run on the same XCD so the
 //     crop's features are fetched from HBM once and re-read from that XCD's L2.
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -68,19 +69,33 @@ __host__ __device__ inline HeadGeom head_geom(int C, int J, int D) {
   return g;
 }
 
-// packed = [n_groups][c_pad][64] weights, then [n_groups][64] bias (all f32)
+// packed = [n_groups][c_pad][64] weights (16x16 core), [n_groups][64] bias,
+//          [n_groups][c_pad/32][64][32] weights (32x32 core)  -- all f32
 __global__ void head_pack_kernel(const float* __restrict__ w, const float* __restrict__ bias, int C,
                                  int J, int D, HeadGeom g, float* __restrict__ packed) {
   const int per = 1 + D;
   const size_t n_w = (size_t)g.n_groups * g.c_pad * kRows;
-  const size_t total = n_w + (size_t)g.n_groups * kRows;
+  const size_t n_b = (size_t)g.n_groups * kRows;
+  const size_t total = 2 * n_w + n_b;
   for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
        t += (size_t)gridDim.x * blockDim.x) {
-    const bool is_bias = t >= n_w;
-    const size_t u = is_bias ? t - n_w : t;
-    const int row = (int)(u % kRows);
-    const int c = is_bias ? 0 : (int)((u / kRows) % g.c_pad);
-    const int grp = is_bias ? (int)(u / kRows) : (int)(u / ((size_t)kRows * g.c_pad));
+    int row, c, grp;
+    const bool is_bias = t >= n_w && t < n_w + n_b;
+    if (t < n_w) {
+      row = (int)(t % kRows);
+      c = (int)((t / kRows) % g.c_pad);
+      grp = (int)(t / ((size_t)kRows * g.c_pad));
+    } else if (is_bias) {
+      row = (int)((t - n_w) % kRows);
+      c = 0;
+      grp = (int)((t - n_w) / kRows);
+    } else {
+      const size_t u = t - n_w - n_b;
+      row = (int)((u / kKC) % kRows);
+      const size_t st = u / ((size_t)kKC * kRows);  // global stage index = grp * n_stages + stage
+      grp = (int)(st / (g.c_pad / kKC));
+      c = (int)(st % (g.c_pad / kKC)) * kKC + (int)(u % kKC);
+    }
     const int jl = row / per, k = row % per;
     const int j = grp * g.jg + jl;
     float v = 0.0f;
@@ -93,9 +108,6 @@ __global__ void head_pack_kernel(const float* __restrict__ w, const float* __res
   }
 }
 
-// ---- global -> registers -> LDS staging of one 32-channel stage (weights tile + feature tile).
-// Plain structs + forceinline functions (a lambda capturing the register arrays by reference kept
-// them in scratch memory).
 // ---- global -> registers -> LDS staging of one 32-channel stage (weights tile + feature tile).
 // Native ext_vector loads/stores only: copying HIP's float4 *struct* between address spaces lowers
 // to llvm.memcpy (global -> private -> LDS), which SROA does not split, so the staged tile went
@@ -180,6 +192,79 @@ __device__ __forceinline__ void store_stage(const StageSrc<FeatT>& s, float* As_
     } else {
       const int row = v / s.vec_per_row, q = v - row * s.vec_per_row;
       if (v < s.b_total) *reinterpret_cast<v4f*>(Bs_buf + row * HWP + q * 4) = r.b[i];
+    }
+  }
+}
+
+// ---- decode epilogue shared by both GEMM kernels: logits of one joint group in LDS [64][HWP]
+// (row = jl*(1+D) + {0: 2D map, 1+d: depth slice d}); a half-wave (32 lanes) per joint (<= 8 joints
+// in flight).  The logits are on chip and the epilogue is a few % of the GEMM, so the f64-accumulate
+// mode also takes exp in f64: the decode error then is the f32 rounding of the outputs only, which
+// matters because reconstruct_absolute amplifies coords3d_rel errors ~7x.
+// PV = positions per lane and step: 4 for maps of more than 64 positions, 2 below (an 8x8 map
+// then keeps all 32 lanes of the half-wave busy instead of 16).
+template <bool ACC64, int PV>
+__device__ __forceinline__ void decode_group_from_lds(const float* Ls, int HWP, int grp,
+                                                      const HeadGeom& g, int crop, int J, int D,
+                                                      int H, int W, const HeadScale& hs,
+                                                      float* __restrict__ coords2d,
+                                                      float* __restrict__ coords3d_rel, int wid,
+                                                      int lane) {
+  using vecf = __attribute__((ext_vector_type(PV))) float;
+  const int HW = H * W;
+  const int per = 1 + D;
+  const int li = lane & 31;
+  for (int jl = wid * 2 + (lane >> 5); jl < g.jg; jl += 8) {
+    const int j = grp * g.jg + jl;
+    if (j >= J) continue;
+    const float* row2d = Ls + (size_t)(jl * per) * HWP;
+    const float* row3d = row2d + HWP;
+    float m2 = -INFINITY, m3 = -INFINITY;
+    for (int p = li * PV; p < HW; p += 32 * PV) {
+      const vecf v = *reinterpret_cast<const vecf*>(row2d + p);
+#pragma unroll
+      for (int q = 0; q < PV; ++q) m2 = fmaxf(m2, v[q]);
+      for (int d = 0; d < D; ++d) {
+        const vecf u = *reinterpret_cast<const vecf*>(row3d + (size_t)d * HWP + p);
+#pragma unroll
+        for (int q = 0; q < PV; ++q) m3 = fmaxf(m3, u[q]);
+      }
+    }
+    m2 = group_max<32>(m2);
+    m3 = group_max<32>(m3);
+    double s2 = 0, sx2 = 0, sy2 = 0, s3 = 0, sx3 = 0, sy3 = 0, sz3 = 0;
+    for (int p = li * PV; p < HW; p += 32 * PV) {
+      const vecf v2 = *reinterpret_cast<const vecf*>(row2d + p);
+      double col[PV];
+#pragma unroll
+      for (int q = 0; q < PV; ++q) col[q] = 0;
+      for (int d = 0; d < D; ++d) {
+        const vecf u3 = *reinterpret_cast<const vecf*>(row3d + (size_t)d * HWP + p);
+#pragma unroll
+        for (int q = 0; q < PV; ++q) {
+          const double e = ACC64 ? exp((double)u3[q] - (double)m3) : (double)expf(u3[q] - m3);
+          col[q] += e;
+          sz3 += e * (double)d;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < PV; ++q) {
+        const int h = (p + q) / W, w = (p + q) - h * W;  // narrow maps wrap more than once
+        const double e2 = ACC64 ? exp((double)v2[q] - (double)m2) : (double)expf(v2[q] - m2);
+        s2 += e2; sx2 += e2 * w; sy2 += e2 * h;
+        s3 += col[q]; sx3 += col[q] * w; sy3 += col[q] * h;
+      }
+    }
+    s2 = group_sum<32>(s2); sx2 = group_sum<32>(sx2); sy2 = group_sum<32>(sy2);
+    s3 = group_sum<32>(s3); sx3 = group_sum<32>(sx3); sy3 = group_sum<32>(sy3);
+    sz3 = group_sum<32>(sz3);
+    if (li == 0) {
+      const size_t o = (size_t)crop * J + j;
+      coords2d[o * 2 + 0] = heatmap_to_px(axis_coord(sx2, s2, W), hs);
+      coords2d[o * 2 + 1] = heatmap_to_px(axis_coord(sy2, s2, H), hs);
+      coords3d_rel[o * 3 + 0] = heatmap_to_mm_xy(axis_coord(sx3, s3, W), hs);
+      coords3d_rel[o * 3 + 1] = heatmap_to_mm_xy(axis_coord(sy3, s3, H), hs);
+      coords3d_rel[o * 3 + 2] = heatmap_to_mm_z(axis_coord(sz3, s3, D), hs);
     }
   }
 }
@@ -312,63 +397,377 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(
     }
   __syncthreads();
 
-  // ---- epilogue 2: a half-wave (32 lanes) per joint of this group (<= 8 joints in flight).
-  // The logits are on chip and the epilogue is a few % of the GEMM, so the f64-accumulate mode
-  // also takes exp in f64: the decode error then is the f32 rounding of the outputs only, which
-  // matters because reconstruct_absolute amplifies coords3d_rel errors ~7x.
-  const int per = 1 + D;
-  const int li = lane & 31;
-  for (int jl = wid * 2 + (lane >> 5); jl < g.jg; jl += 8) {
-    const int j = grp * g.jg + jl;
-    if (j >= J) continue;
-    const float* row2d = Ls + (size_t)(jl * per) * HWP;
-    const float* row3d = row2d + HWP;
-    float m2 = -INFINITY, m3 = -INFINITY;
-    for (int p = li * 4; p < HW; p += 128) {
-      const float4 v = *reinterpret_cast<const float4*>(row2d + p);
-      m2 = fmaxf(m2, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
-      for (int d = 0; d < D; ++d) {
-        const float4 u = *reinterpret_cast<const float4*>(row3d + (size_t)d * HWP + p);
-        m3 = fmaxf(m3, fmaxf(fmaxf(u.x, u.y), fmaxf(u.z, u.w)));
-      }
-    }
-    m2 = group_max<32>(m2);
-    m3 = group_max<32>(m3);
-    double s2 = 0, sx2 = 0, sy2 = 0, s3 = 0, sx3 = 0, sy3 = 0, sz3 = 0;
-    for (int p = li * 4; p < HW; p += 128) {
-      const float4 v = *reinterpret_cast<const float4*>(row2d + p);
-      const float v2[4] = {v.x, v.y, v.z, v.w};
-      double col[4] = {0, 0, 0, 0};
-      for (int d = 0; d < D; ++d) {
-        const float4 u = *reinterpret_cast<const float4*>(row3d + (size_t)d * HWP + p);
-        const float u3[4] = {u.x, u.y, u.z, u.w};
+  decode_group_from_lds<ACC64, (NT > 4 ? 4 : 2)>(Ls, HWP, grp, g, crop, J, D, H, W, hs, coords2d, coords3d_rel, wid,
+                               lane);
+}
+
+// =====================================================================================
+// 32x32 variant (maps of 33..160 positions, i.e. every shipped configuration).
+//
+// Why a second GEMM core: with one workgroup per CU (B = 64 crops -> 256 workgroups) every SIMD
+// holds ONE wave, and in that regime (a) a single wave gets about a fifth of the LDS rate on
+// ds_read_b32 but the full rate on ds_read_b128 (MI355X_MICROARCH.md, LDS), and (b) a dependent
+// v_mfma_f32_32x32x2_f32 chain runs at 149 TF from registers where 16x16x4 chains reach 101
+// (tools/experiments/mfma_probe.hip).  So:
+//   * both LDS tiles are K-CONTIGUOUS: weights [64 rows][32 ch], features [position][32 ch], one
+//     128-byte row per output row / position and stage;
+//   * the k index of the MFMA is a free permutation (A and B only have to agree): MFMA (u, s) of a
+//     stage contracts channels {8u + s, 8u + 4 + s}; lane (i, g) therefore needs channels
+//     8u + 4g .. + 3 of row i for s = 0..3 = ONE ds_read_b128 per operand per four MFMAs (was: one
+//     ds_read_b32 per operand per MFMA);
+//   * rows are XOR-swizzled in 16-byte slots, slot ^= swz(row), which makes those reads conflict-
+//     free for the b128 lane groups {0-3,12-15,20-27},... and the transposing ds_write_b32 of NCHW
+//     features at most 2-way (HW = 64; free) / 4-way;
+//   * wave w owns row tile w & 1 and column tiles (w >> 1) + 2t; f32 chains of 16 channels
+//     (8 MFMAs) are carried into f64 exactly as in the 16x16 core, from two alternating partial
+//     sets so the VALU carry of one chain runs under the MFMAs of the next.
+// Weights for this core are packed [group][stage][64 rows][32 ch] (appended to the 16x16 layout
+// by mtr_head_pack_weights).
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// developer-only timing ablations of the 32x32 core (tools/experiments/ablate_head.sh); 0 in the product
+#ifndef MTR_ABLATE
+#define MTR_ABLATE 0
+#endif
+
+__device__ __forceinline__ int swz(int row) { return ((row >> 1) & 7) ^ ((row >> 4) & 1); }
+
+// Staged registers of the 32x32 core hold the bits as loaded (8 bytes for four f16 / bf16 values);
+// the conversion to f32 happens at store time, next to the zeroing, for the same reason.
+using v2u = __attribute__((ext_vector_type(2))) unsigned;
+template <typename T> struct RawVec { using type = v2u; };
+template <> struct RawVec<float> { using type = v4f; };
+
+template <typename T>
+__device__ __forceinline__ typename RawVec<T>::type load4_raw(const T* p) {
+  return *reinterpret_cast<const typename RawVec<T>::type*>(p);
+}
+__device__ __forceinline__ v4f raw_to_f32(v4f v, const float*) { return v; }
+template <typename T>
+__device__ __forceinline__ v4f raw_to_f32(v2u v, const T*) {
+  struct Pack { T h[4]; };
+  const Pack pk = __builtin_bit_cast(Pack, v);
+  return v4f{to_f32(pk.h[0]), to_f32(pk.h[1]), to_f32(pk.h[2]), to_f32(pk.h[3])};
+}
+template <typename FeatT, int B_VECS>
+struct StageRegs32 {
+  v4f a[2];
+  typename RawVec<FeatT>::type b[B_VECS];
+};
+
+// Raw loads only (addresses clamped into the crop): the zeroing of channels >= C / positions
+// >= HW happens in store_stage32, one iteration later -- a select placed here makes the compiler
+// wait for the load right behind the barrier, in front of the MFMAs it is meant to hide under.
+template <typename FeatT, int B_VECS, bool NHWC>
+__device__ __forceinline__ void load_stage32(const StageSrc<FeatT>& s, const float* w32, int stage,
+                                             StageRegs32<FeatT, B_VECS>& r) {
+  const int c0 = stage * kKC;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const double e = ACC64 ? exp((double)u3[q] - (double)m3) : (double)expf(u3[q] - m3);
-          col[q] += e;
-          sz3 += e * (double)d;
-        }
-      }
+  for (int i = 0; i < 2; ++i)  // 64 rows x 32 ch of this stage: contiguous 8 KiB
+    r.a[i] = *reinterpret_cast<const v4f*>(w32 + (size_t)stage * (kRows * kKC) + (size_t)(s.tid + i * 256) * 4);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int h = (p + q) / W, w = (p + q) - h * W;  // W < 4 maps wrap more than once
-        const double e2 = ACC64 ? exp((double)v2[q] - (double)m2) : (double)expf(v2[q] - m2);
-        s2 += e2; sx2 += e2 * w; sy2 += e2 * h;
-        s3 += col[q]; sx3 += col[q] * w; sy3 += col[q] * h;
-      }
+  for (int i = 0; i < B_VECS; ++i) {
+    const int v = s.tid + i * 256;
+    bool ok;
+    size_t off;
+    if constexpr (NHWC) {
+      const int pos = v >> 3, c4 = v & 7;
+      ok = pos < s.HW && c0 + c4 * 4 < s.C;
+      off = (size_t)pos * s.C + c0 + c4 * 4;
+    } else {
+      const int row = v / s.vec_per_row, q = v - row * s.vec_per_row;
+      ok = v < s.b_total && c0 + row < s.C;
+      off = (size_t)(c0 + row) * s.HW + q * 4;
     }
-    s2 = group_sum<32>(s2); sx2 = group_sum<32>(sx2); sy2 = group_sum<32>(sy2);
-    s3 = group_sum<32>(s3); sx3 = group_sum<32>(sx3); sy3 = group_sum<32>(sy3);
-    sz3 = group_sum<32>(sz3);
-    if (li == 0) {
-      const size_t o = (size_t)crop * J + j;
-      coords2d[o * 2 + 0] = heatmap_to_px(axis_coord(sx2, s2, W), hs);
-      coords2d[o * 2 + 1] = heatmap_to_px(axis_coord(sy2, s2, H), hs);
-      coords3d_rel[o * 3 + 0] = heatmap_to_mm_xy(axis_coord(sx3, s3, W), hs);
-      coords3d_rel[o * 3 + 1] = heatmap_to_mm_xy(axis_coord(sy3, s3, H), hs);
-      coords3d_rel[o * 3 + 2] = heatmap_to_mm_z(axis_coord(sz3, s3, D), hs);
+    r.b[i] = load4_raw<FeatT>(s.fcrop + (ok ? off : 0));
+  }
+}
+
+// The stage body has to stay ONE basic block (the MFMA / carry interleave is a scheduling-region
+// property), so lanes without a valid element do not branch around their store: they aim it at a
+// per-lane dump slot behind the tiles (`dump`, word offset from the buffer base).
+template <int B_VECS, bool NHWC, typename FeatT>
+__device__ __forceinline__ void store_stage32(const StageSrc<FeatT>& s, float* As_buf, float* Bs_buf,
+                                              int dump, int stage,
+                                              const StageRegs32<FeatT, B_VECS>& r) {
+  const int c0 = stage * kKC;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int v = s.tid + i * 256;
+    const int row = v >> 3, slot = v & 7;
+    *reinterpret_cast<v4f*>(As_buf + row * kKC + ((slot ^ swz(row)) << 2)) = r.a[i];
+  }
+  const v4f zero = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < B_VECS; ++i) {
+    const int v = s.tid + i * 256;
+    if constexpr (NHWC) {
+      const int pos = v >> 3, slot = v & 7;
+      const int o = pos < s.HW ? pos * kKC + ((slot ^ swz(pos)) << 2) : dump;
+      *reinterpret_cast<v4f*>(Bs_buf + o) =
+          (c0 + slot * 4 < s.C) ? raw_to_f32(r.b[i], s.fcrop) : zero;
+    } else {
+      // transpose on the way in: this thread holds channel `row` of positions 4q .. 4q+3
+      const int row = v / s.vec_per_row, q = v - row * s.vec_per_row;
+      const bool ok = v < s.b_total;
+      const v4f val = (c0 + row < s.C) ? raw_to_f32(r.b[i], s.fcrop) : zero;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int pos = q * 4 + e;
+        const int o = pos * kKC + ((((row >> 2) ^ swz(pos)) << 2) | (row & 3));
+        Bs_buf[ok ? o : dump + e] = val[e];
+      }
     }
   }
+}
+
+template <int CT>
+__host__ __device__ constexpr int hw_pad32() { return CT * 32 + 4; }
+
+template <typename FeatT, int CT, bool ACC64, bool NHWC>
+__global__ __launch_bounds__(256, 2) void head_fused32_kernel(
+    const FeatT* __restrict__ feat, const float* __restrict__ packed, int B, int C, int H, int W,
+    int J, int D, HeadGeom g, HeadScale hs, float* __restrict__ coords2d,
+    float* __restrict__ coords3d_rel) {
+  constexpr int TPW = (CT + 1) / 2;                  // column tiles per wave (upper bound)
+  constexpr int HWP = hw_pad32<CT>();
+  constexpr int A_STAGE = kRows * kKC;               // floats
+  constexpr int B_STAGE = CT * 32 * kKC;             // floats
+  constexpr int B_VECS = (CT * 32 * kKC / 4 + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                 // [2][64][32]
+  float* Bs = smem + 2 * A_STAGE;   // [2][CT*32][32], then 256 x 16-byte dump slots (store_stage32)
+  float* Ls = smem;                 // epilogue alias: [64][HWP]
+
+  const int HW = H * W;
+  const int chunk = 8 * g.n_groups;  // XCD-aware remap, as in the 16x16 core
+  const int id = blockIdx.x;
+  const int crop = (id / chunk) * 8 + (id % 8);
+  const int grp = (id % chunk) / 8;
+  if (crop >= B) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int n_stages = g.c_pad / kKC;
+  const FeatT* fcrop = feat + (size_t)crop * C * HW;
+  const size_t n_w = (size_t)g.n_groups * g.c_pad * kRows;
+  const float* w32 = packed + n_w + (size_t)g.n_groups * kRows + (size_t)grp * g.c_pad * kRows;
+  const float* bgrp = packed + n_w + (size_t)grp * kRows;
+  const int vec_per_row = HW / 4;
+  const StageSrc<FeatT> src{nullptr, fcrop, C, HW, vec_per_row, kKC * vec_per_row, tid};
+
+  // rows >= HW of the feature tile are never written: zero both buffers once
+  for (int v = tid; v < 2 * B_STAGE; v += 256) Bs[v] = 0.0f;
+
+  const int rt = wid & 1, ct0 = wid >> 1;
+  const int fi = lane & 31, fg = lane >> 5;
+  const int a_row = rt * 32 + fi;
+  const int a_off = a_row * kKC + ((fg ^ swz(a_row)) << 2);  // ^ (u << 3) selects slot 2u + g
+  int b_off[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int pos = (ct0 + 2 * t < CT ? ct0 + 2 * t : 0) * 32 + fi;  // (absent tile: any valid row)
+    b_off[t] = pos * kKC + ((fg ^ swz(pos)) << 2);
+  }
+
+  // Register budget (256 VGPRs at 2 waves/SIMD): f64 carry accumulators take 32 per tile.
+  //   1 tile/wave : two partial sets (the carry of chain n-1 runs under chain n of the same tile);
+  //   2 tiles/wave: one partial set (chain n-1 is the other tile).
+  static_assert(TPW <= 2, "3 tiles per wave do not fit the register file in carry mode");
+  constexpr int PS = (ACC64 && TPW == 1) ? 2 : 1;
+  constexpr int NCH = 2 * TPW;  // chains per stage: (chunk h, tile t), n = h * TPW + t
+
+  using AccT = typename std::conditional<ACC64, double, float>::type;
+  AccT acc[ACC64 ? TPW : 1][16];
+  if constexpr (ACC64) {
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0;
+  }
+  // Two sub-accumulators per chain (even / odd MFMA) where the registers allow it: anything
+  // issued between two MFMAs on the SAME accumulator costs ~40 cycles (MI355X_MICROARCH.md,
+  // instruction timings), and this loop puts the carry VALU, the fragment reads, the global loads
+  // and the LDS stores exactly there; neighbours on different accumulators make those slots free.
+  constexpr int NSUB = (TPW == 1 && !ACC64) ? 2 : 1;  // (carry mode: measured slower, more VALU)
+  f32x16 part[PS][TPW][NSUB];  // ACC64: short-chain partials; else part[0] is the accumulator
+#pragma unroll
+  for (int h = 0; h < PS; ++h)
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+      for (int e = 0; e < NSUB; ++e) part[h][t][e] = f32x16{0};
+
+  auto tile_on = [&](int t) { return (CT % 2 == 0) || (ct0 + 2 * t < CT); };
+
+  // fragments: [0..1] = channels 0..15 of the stage (chunk 0), [2..3] = channels 16..31 (chunk 1).
+  // Chunk 1 is consumed one iteration late (see the loop), so it starts as zeros.
+  v4f af[4], bf[TPW][4];
+#pragma unroll
+  for (int u = 2; u < 4; ++u) {
+    af[u] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) bf[t][u] = v4f{0.f, 0.f, 0.f, 0.f};
+  }
+
+#define HEAD32_READ(U0, U1)                                                                       \
+  _Pragma("unroll") for (int u = (U0); u < (U1); ++u) {                                           \
+    af[u] = *reinterpret_cast<const v4f*>(Ab + (a_off ^ (u << 3)));                               \
+    _Pragma("unroll") for (int t = 0; t < TPW; ++t)                                               \
+        bf[t][u] = *reinterpret_cast<const v4f*>(Bb + (b_off[t] ^ (u << 3)));                     \
+  }
+// (odd CT: the waves of the second column-tile pair run their last tile on tile 0's data and drop
+//  the result -- branch-free, and the stage barrier waits for the 2-tile waves anyway)
+#define HEAD32_MFMA1(P_, T_, E_, U_, S_, FIRST_)                                                  \
+  part[P_][T_][E_] = __builtin_amdgcn_mfma_f32_32x32x2f32(                                        \
+      af[U_][S_], bf[T_][U_][S_], (FIRST_) ? f32x16{0} : part[P_][T_][E_], 0, 0, 0);
+// two elements of a finished chain into the f64 accumulators; the empty asm pins the add inside
+// this basic block (otherwise it is sunk past the barrier, where no MFMA is in flight to hide it)
+#define HEAD32_CARRY(P_, T_, R0, R1)                                                              \
+  _Pragma("unroll") for (int r = (R0); r < (R1); ++r) {                                           \
+    if constexpr (NSUB == 2)                                                                      \
+      acc[T_][r] += (double)(part[P_][T_][0][r] + part[P_][T_][1][r]);                            \
+    else                                                                                          \
+      acc[T_][r] += (double)part[P_][T_][0][r];                                                   \
+    asm volatile("" : "+v"(acc[T_][r]));                                                          \
+  }
+// MFMAs K0..K1-1 of chain (chunk H_, tile T_) = 16 channels of one tile.  In carry mode the
+// previous chain's 16 elements are folded into f64 under the matrix pipe: nothing behind MFMA 0
+// (the previous chain's last MFMA is still in flight then), 2-3 elements behind each of the other
+// seven, and a scheduling fence per slot so that the even spread survives the compiler (a slot
+// holding more VALU than one MFMA lasts -- 64 cycles -- idles the matrix pipe).
+#define HEAD32_CHAIN(H_, T_, K0, K1)                                                              \
+  {                                                                                               \
+    constexpr int n_ = (H_) * TPW + (T_), pn_ = (n_ + NCH - 1) % NCH, pt_ = pn_ % TPW;            \
+    constexpr int ps_ = PS == 2 ? (H_) : 0, pps_ = PS == 2 ? pn_ / TPW : 0;                       \
+    _Pragma("unroll") for (int k = (K0); k < (K1); ++k) {                                         \
+      HEAD32_MFMA1(ps_, T_, k % NSUB, 2 * (H_) + k / 4, k % 4, ACC64 && k < NSUB)                 \
+      if constexpr (ACC64 && !(MTR_ABLATE & 8)) {                                                 \
+        constexpr int e0_[9] = {0, 0, 2, 4, 6, 8, 11, 14, 16};                                    \
+        HEAD32_CARRY(pps_, pt_, e0_[k], e0_[k + 1])                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+      }                                                                                           \
+    }                                                                                             \
+  }
+
+  // One iteration = one 32-channel stage, ONE barrier, and the matrix pipe never drains across it:
+  //   barrier                      stage s visible in LDS buffer s & 1
+  //   read chunk-0 fragments of s  \  the LDS latency is covered by the chunk-1 chains of stage
+  //   issue the global loads of    |  s-1, whose fragments were read before the barrier
+  //     stage s+kAhead (set LD)    |
+  //   chunk-1 chains of stage s-1  /
+  //   read chunk-1 fragments of s
+  //   chunk-0 chains of stage s, with the LDS stores of stage s+1 (register set ST, landed
+  //   iterations ago) issued in the middle -- not at the end, where they would sit between the
+  //   last MFMA and the barrier.
+  // With one workgroup per CU (B = 64: one wave per SIMD) nothing else hides those gaps; ending
+  // the stage with stores + barrier + fragment reads measured 8 us of 32 (ablation).
+#define HEAD32_ITER(S, LD, ST)                                                                    \
+  {                                                                                               \
+    const int s_ = (S);                                                                           \
+    const int buf = s_ & 1;                                                                       \
+    const float* Ab = As + buf * A_STAGE;                                                         \
+    const float* Bb = Bs + buf * B_STAGE;                                                         \
+    __syncthreads();                                                                              \
+    if (!(MTR_ABLATE & 2)) {                                                                      \
+      HEAD32_READ(0, 2)                                                                           \
+      __builtin_amdgcn_sched_barrier(0); /* fragment reads first, then the load addresses */      \
+    }                                                                                             \
+    /* (past the end: reload the last stage, never consumed -- keeps the body branch-free) */     \
+    if (!(MTR_ABLATE & (4 | 32)))                                                                 \
+      load_stage32<FeatT, B_VECS, NHWC>(src, w32, min(s_ + kAhead, n_stages - 1), LD);            \
+    if (!(MTR_ABLATE & 2)) {                                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                          \
+      HEAD32_CHAIN(1, 0, 0, 8)                                                                    \
+      if constexpr (TPW == 2) HEAD32_CHAIN(1, 1, 0, 8)                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                          \
+      HEAD32_READ(2, 4)                                                                           \
+      if constexpr (TPW == 2) HEAD32_CHAIN(0, 0, 0, 8) else HEAD32_CHAIN(0, 0, 0, 4)              \
+      __builtin_amdgcn_sched_barrier(0);                                                          \
+    }                                                                                             \
+    if (!(MTR_ABLATE & (4 | 16)))                                                                 \
+      store_stage32<B_VECS, NHWC>(src, As + (buf ^ 1) * A_STAGE, Bs + (buf ^ 1) * B_STAGE,        \
+                                  (1 + buf) * B_STAGE + tid * 4, min(s_ + 1, n_stages - 1), ST);  \
+    if (MTR_ABLATE & 16) { /* loads only: wait for them where the stores would have */           \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(ST.a[i]));              \
+      _Pragma("unroll") for (int i = 0; i < B_VECS; ++i) asm volatile("" ::"v"(ST.b[i]));         \
+    }                                                                                             \
+    if (!(MTR_ABLATE & 2)) {                                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                          \
+      if constexpr (TPW == 2) HEAD32_CHAIN(0, 1, 0, 8) else HEAD32_CHAIN(0, 0, 4, 8)              \
+    }                                                                                             \
+  }
+
+  // kAhead stages of global loads in flight per workgroup (register sets, rotated statically):
+  // a load is issued right behind the barrier of iteration s and consumed in the middle of
+  // iteration s + kAhead - 1, which has to cover ~1-2 us of latency when nothing else runs on the CU
+  constexpr int kAhead = 2;  // (3 measured no better: the loop is not load-latency bound)
+  StageRegs32<FeatT, B_VECS> regs[kAhead];
+#pragma unroll
+  for (int i = 0; i < kAhead; ++i)
+    load_stage32<FeatT, B_VECS, NHWC>(src, w32, min(i, n_stages - 1), regs[i]);
+  __syncthreads();  // zero fill done
+  store_stage32<B_VECS, NHWC>(src, As, Bs, 2 * B_STAGE + tid * 4, 0, regs[0]);
+  if constexpr (kAhead == 3) {
+    for (int s = 0; s < n_stages; s += 3) {
+      HEAD32_ITER(s, regs[0], regs[1])
+      if (s + 1 < n_stages) HEAD32_ITER(s + 1, regs[1], regs[2])
+      if (s + 2 < n_stages) HEAD32_ITER(s + 2, regs[2], regs[0])
+    }
+  } else {
+    for (int s = 0; s < n_stages; s += 2) {
+      HEAD32_ITER(s, regs[0], regs[1])
+      if (s + 1 < n_stages) HEAD32_ITER(s + 1, regs[1], regs[0])
+    }
+  }
+  // drain: chunk 1 of the last stage, then the last chain's carry
+  HEAD32_CHAIN(1, 0, 0, 8)
+  if constexpr (TPW == 2) HEAD32_CHAIN(1, 1, 0, 8)
+  if constexpr (ACC64) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = part[PS - 1][TPW - 1][0][r];
+      if constexpr (NSUB == 2) v += part[PS - 1][TPW - 1][1][r];
+      acc[TPW - 1][r] += (double)v;
+    }
+  }
+  __syncthreads();  // every wave is done reading the tiles: the logits may overwrite them
+#undef HEAD32_ITER
+#undef HEAD32_CHAIN
+#undef HEAD32_MFMA1
+#undef HEAD32_CARRY
+#undef HEAD32_READ
+
+  // ---- epilogue 1: logits (+bias) -> LDS [64][HWP].  C/D layout of f32 32x32x2: col = l & 31,
+  //   row = 8 * (reg / 4) + 4 * (l >> 5) + reg % 4
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    if (!tile_on(t)) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rt * 32 + 8 * (r >> 2) + 4 * fg + (r & 3);
+      const int col = (ct0 + 2 * t) * 32 + fi;
+      if constexpr (ACC64)
+        Ls[row * HWP + col] = (float)(acc[t][r] + (double)bgrp[row]);
+      else
+        Ls[row * HWP + col] =
+            part[0][t][0][r] + (NSUB == 2 ? part[0][t][NSUB - 1][r] : 0.0f) + bgrp[row];
+    }
+  }
+  __syncthreads();
+
+  if (MTR_ABLATE & 1) {  // no decode: one store per workgroup keeps the GEMM alive
+    if (tid == 0) coords2d[(size_t)crop * J * 2 + grp] = Ls[tid];
+    return;
+  }
+  decode_group_from_lds<ACC64, (CT > 2 ? 4 : 2)>(Ls, HWP, grp, g, crop, J, D, H, W, hs, coords2d, coords3d_rel, wid,
+                               lane);
+}
+
+template <int CT>
+constexpr size_t head32_lds_bytes() {
+  constexpr size_t stage = 2 * ((size_t)kRows * kKC + (size_t)CT * 32 * kKC) + 256 * 4;  // + dump slots
+  constexpr size_t logits = (size_t)kRows * hw_pad32<CT>();
+  return (stage > logits ? stage : logits) * sizeof(float);
 }
 
 template <int NT, bool NHWC>
@@ -401,11 +800,46 @@ static int launch_head(const void* feat, const float* packed, int B, int C, int 
   return MTR_OK;
 }
 
+template <typename FeatT, int CT, bool NHWC>
+static int launch_head32(const void* feat, const float* packed, int B, int C, int H, int W, int J,
+                         int D, const HeadGeom& g, const HeadScale& hs, float* c2d, float* c3d,
+                         hipStream_t stream) {
+  constexpr size_t lds = head32_lds_bytes<CT>();
+  auto kern = head_fused32_kernel<FeatT, CT, std::is_same<FeatT, float>::value, NHWC>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int chunk = 8 * g.n_groups;
+  const long long blocks = (long long)((B + 7) / 8) * chunk;
+  if (blocks > 0x7fffffffLL) return MTR_E_SHAPE;
+  MTR_CLEAR_STALE();
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, (const FeatT*)feat,
+                     packed, B, C, H, W, J, D, g, hs, c2d, c3d);
+  MTR_CHECK_LAUNCH();
+  return MTR_OK;
+}
+
+// MTR_HEAD_CORE=16 forces the 16x16x4 core for every shape (A/B measurements, tools/microbench.py)
+static bool force_core16() {
+  static const bool v = [] {
+    const char* e = getenv("MTR_HEAD_CORE");
+    return e && e[0] == '1' && e[1] == '6';
+  }();
+  return v;
+}
+
 template <typename FeatT, bool NHWC>
 static int dispatch_head(const void* feat, const float* packed, int B, int C, int H, int W, int J,
                          int D, const HeadGeom& g, const HeadScale& hs, float* c2d, float* c3d,
                          hipStream_t stream) {
   const int HW = H * W;
+  if (HW > 32 && HW <= 128 && !force_core16()) {
+    if (HW <= 64) return launch_head32<FeatT, 2, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+    if (HW <= 96) return launch_head32<FeatT, 3, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+    return launch_head32<FeatT, 4, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+  }
   if (HW <= 16) return launch_head<FeatT, 1, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
   if (HW <= 32) return launch_head<FeatT, 2, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
   if (HW <= 64) return launch_head<FeatT, 4, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
@@ -435,7 +869,7 @@ extern "C" size_t mtr_head_packed_bytes(int C, int J, int D, int feat_dtype) {
   (void)feat_dtype;  // weights stay f32 for every feature dtype (exact-f32 MFMA)
   if (mtr::check_head_dims(C, J, D)) return 0;
   const mtr::HeadGeom g = mtr::head_geom(C, J, D);
-  return ((size_t)g.n_groups * g.c_pad * mtr::kRows + (size_t)g.n_groups * mtr::kRows) * sizeof(float);
+  return (2 * (size_t)g.n_groups * g.c_pad * mtr::kRows + (size_t)g.n_groups * mtr::kRows) * sizeof(float);
 }
 
 extern "C" int mtr_head_pack_weights(const float* weight, const float* bias, int C, int J, int D,
@@ -446,7 +880,7 @@ extern "C" int mtr_head_pack_weights(const float* weight, const float* bias, int
   if (rc) return rc;
   if ((uintptr_t)packed % 16) return MTR_E_ALIGN;
   const mtr::HeadGeom g = mtr::head_geom(C, J, D);
-  const size_t total = (size_t)g.n_groups * g.c_pad * mtr::kRows + (size_t)g.n_groups * mtr::kRows;
+  const size_t total = 2 * (size_t)g.n_groups * g.c_pad * mtr::kRows + (size_t)g.n_groups * mtr::kRows;
   size_t blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   MTR_CLEAR_STALE();

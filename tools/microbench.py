@@ -52,14 +52,25 @@ def bench_decode():
 def bench_head():
     out = []
     g = torch.Generator(device='cuda').manual_seed(0)
-    for name, B, C, J, H, dt in [('cfg2 B=64 f32', 64, 1280, 17, 8, torch.float32),
-                                 ('B=1024 f32', 1024, 1280, 17, 8, torch.float32),
-                                 ('B=1024 f16 feats', 1024, 1280, 17, 8, torch.float16),
-                                 ('cfg3 B=32 384px f32', 32, 1280, 17, 12, torch.float32),
-                                 ('cfg5 B=32 J=122 f16', 32, 1280, 122, 12, torch.float16),
-                                 ('cfg5 B=256 J=122 f16', 256, 1280, 122, 12, torch.float16)]:
+    core = os.environ.get('MTR_HEAD_CORE', 'auto')
+    for name, B, C, J, H, dt, nhwc in [('cfg2 B=64 f32', 64, 1280, 17, 8, torch.float32, False),
+                                       ('cfg2 B=64 f32 nhwc', 64, 1280, 17, 8, torch.float32, True),
+                                       ('cfg2 B=64 f16', 64, 1280, 17, 8, torch.float16, False),
+                                       ('B=1024 f32', 1024, 1280, 17, 8, torch.float32, False),
+                                       ('B=1024 f32 nhwc', 1024, 1280, 17, 8, torch.float32, True),
+                                       ('B=1024 f16 feats', 1024, 1280, 17, 8, torch.float16, False),
+                                       ('B=1024 f16 nhwc', 1024, 1280, 17, 8, torch.float16, True),
+                                       ('HW=100 B=64 f32', 64, 1280, 17, 10, torch.float32, False),
+                                       ('HW=100 B=512 f32', 512, 1280, 17, 10, torch.float32, False),
+                                       ('HW=100 B=512 f16', 512, 1280, 17, 10, torch.float16, False),
+                                       ('cfg3 B=32 384px f32', 32, 1280, 17, 12, torch.float32, False),
+                                       ('cfg3 B=256 384px f32', 256, 1280, 17, 12, torch.float32, False),
+                                       ('cfg5 B=32 J=122 f16', 32, 1280, 122, 12, torch.float16, False),
+                                       ('cfg5 B=256 J=122 f16', 256, 1280, 122, 12, torch.float16, False)]:
         cfg = MetrabsConfig(proc_side=H * 32)
         feat = torch.randn(B, C, H, H, device='cuda', generator=g).to(dt)
+        if nhwc:
+            feat = feat.contiguous(memory_format=torch.channels_last)
         w = torch.randn(J * 9, C, device='cuda', generator=g) * 0.03
         b = torch.zeros(J * 9, device='cuda')
         packed = kernels.head_pack_weights(w, b, J, 8, dt)
@@ -68,7 +79,7 @@ def bench_head():
         flops = 2.0 * C * J * 9 * H * H * B
         peak = 157.3e12  # f32-input MFMA (both precision classes use v_mfma_f32_16x16x4_f32)
         nbytes = feat.numel() * feat.element_size()
-        out.append(dict(kernel='head_fused', case=name, us=round(t * 1e6, 1),
+        out.append(dict(kernel='head_fused', core=core, case=name, us=round(t * 1e6, 1),
                         TFLOPs=round(flops / t / 1e12, 2), frac_mfma=round(flops / t / peak, 3),
                         GBps=round(nbytes / t / 1e9, 1)))
     return out
