@@ -573,7 +573,15 @@ __global__ __launch_bounds__(256, 2) void head_fused32_kernel(
   //   1 tile/wave : two partial sets (the carry of chain n-1 runs under chain n of the same tile);
   //   2 tiles/wave: one partial set (chain n-1 is the other tile).
   static_assert(TPW <= 2, "3 tiles per wave do not fit the register file in carry mode");
-  constexpr int PS = (ACC64 && TPW == 1) ? 2 : 1;
+  //   1 tile/wave, carry mode ("SC"): ONE carry per 32-channel stage.  The stage's two 16-channel
+  //     chunks run as independent f32 chains (sub-accumulators a, b), are added in f32 (one more
+  //     rounding, at the magnitude of a 32-channel sum) and that sum goes into f64: half the
+  //     f64 converts/adds of carrying each 16-channel chain, which is what the carry costs
+  //     (ablation: +8 us of 33 at B = 64, however evenly it is spread under the MFMAs).
+  //     A single 32-channel chain would halve them too but is 3x less accurate (16 dependent
+  //     roundings; 1.6e-3 vs 4.9e-4 mm on golden case s256_c1280_peaked).
+  constexpr bool SC = ACC64 && TPW == 1;
+  constexpr int PS = SC ? 2 : 1;
   constexpr int NCH = 2 * TPW;  // chains per stage: (chunk h, tile t), n = h * TPW + t
 
   using AccT = typename std::conditional<ACC64, double, float>::type;
@@ -588,7 +596,7 @@ __global__ __launch_bounds__(256, 2) void head_fused32_kernel(
   // issued between two MFMAs on the SAME accumulator costs ~40 cycles (MI355X_MICROARCH.md,
   // instruction timings), and this loop puts the carry VALU, the fragment reads, the global loads
   // and the LDS stores exactly there; neighbours on different accumulators make those slots free.
-  constexpr int NSUB = (TPW == 1 && !ACC64) ? 2 : 1;  // (carry mode: measured slower, more VALU)
+  constexpr int NSUB = TPW == 1 ? 2 : 1;  // (SC mode: sub-accumulator = chunk; f16 mode: even/odd MFMA)
   f32x16 part[PS][TPW][NSUB];  // ACC64: short-chain partials; else part[0] is the accumulator
 #pragma unroll
   for (int h = 0; h < PS; ++h)
@@ -649,6 +657,54 @@ __global__ __launch_bounds__(256, 2) void head_fused32_kernel(
     }                                                                                             \
   }
 
+// ---- SC mode.  Chunk H_ (sub-accumulator H_) of the stage with parity P_, MFMAs K0..K1-1; with
+// CP_ >= 0 the finished stage held in partial set CP_ is folded into f64 underneath (nothing
+// behind MFMA 0: the set's last MFMA is still in flight then; 2-3 elements behind the others).
+#define HEAD32_SC_CHUNK(P_, H_, K0, K1, CP_)                                                      \
+  _Pragma("unroll") for (int k = (K0); k < (K1); ++k) {                                           \
+    part[P_][0][H_] = __builtin_amdgcn_mfma_f32_32x32x2f32(                                       \
+        af[2 * (H_) + k / 4][k % 4], bf[0][2 * (H_) + k / 4][k % 4],                              \
+        k == 0 ? f32x16{0} : part[P_][0][H_], 0, 0, 0);                                           \
+    if constexpr ((CP_) >= 0 && !(MTR_ABLATE & 8)) {                                              \
+      constexpr int e0_[9] = {0, 0, 2, 4, 6, 8, 11, 14, 16};                                      \
+      constexpr int cp_ = (CP_) >= 0 ? (CP_) : 0;                                                 \
+      _Pragma("unroll") for (int r = e0_[k]; r < e0_[k + 1]; ++r) {                               \
+        acc[0][r] += (double)(part[cp_][0][0][r] + part[cp_][0][1][r]);                           \
+        asm volatile("" : "+v"(acc[0][r]));                                                       \
+      }                                                                                           \
+      __builtin_amdgcn_sched_barrier(0);                                                          \
+    }                                                                                             \
+  }
+// Same iteration structure as HEAD32_ITER below; PAR = parity of the stage (a literal: the
+// partial sets must be indexed statically).
+// Same iteration structure as HEAD32_ITER below; PAR = parity of the stage (a literal: the
+// partial sets must be indexed statically).
+// (Staggering the LDS stores by wave -- one wave at a time on the CU's store path -- measured
+//  slower, 40.9 vs 38.3 us at B = 64: the ~6 us the stores cost is not queueing between waves.)
+#define HEAD32_ITER_SC(S, PAR, LD, ST)                                                            \
+  {                                                                                               \
+    const int s_ = (S);                                                                           \
+    const float* Ab = As + (PAR) * A_STAGE;                                                       \
+    const float* Bb = Bs + (PAR) * B_STAGE;                                                       \
+    __syncthreads();                                                                              \
+    HEAD32_READ(0, 2)                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    if (!(MTR_ABLATE & (4 | 32)))                                                                 \
+      load_stage32<FeatT, B_VECS, NHWC>(src, w32, min(s_ + 2, n_stages - 1), LD);                 \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    HEAD32_SC_CHUNK((PAR) ^ 1, 1, 0, 8, -1)                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    HEAD32_READ(2, 4)                                                                             \
+    HEAD32_SC_CHUNK(PAR, 0, 0, 4, (PAR) ^ 1)                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    if (!(MTR_ABLATE & (4 | 16)))                                                                 \
+      store_stage32<B_VECS, NHWC>(src, As + ((PAR) ^ 1) * A_STAGE, Bs + ((PAR) ^ 1) * B_STAGE,    \
+                                  (1 + (PAR)) * B_STAGE + tid * 4, min(s_ + 1, n_stages - 1),     \
+                                  ST);                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    HEAD32_SC_CHUNK(PAR, 0, 4, 8, (PAR) ^ 1)                                                      \
+  }
+
   // One iteration = one 32-channel stage, ONE barrier, and the matrix pipe never drains across it:
   //   barrier                      stage s visible in LDS buffer s & 1
   //   read chunk-0 fragments of s  \  the LDS latency is covered by the chunk-1 chains of stage
@@ -707,31 +763,38 @@ __global__ __launch_bounds__(256, 2) void head_fused32_kernel(
     load_stage32<FeatT, B_VECS, NHWC>(src, w32, min(i, n_stages - 1), regs[i]);
   __syncthreads();  // zero fill done
   store_stage32<B_VECS, NHWC>(src, As, Bs, 2 * B_STAGE + tid * 4, 0, regs[0]);
-  if constexpr (kAhead == 3) {
-    for (int s = 0; s < n_stages; s += 3) {
-      HEAD32_ITER(s, regs[0], regs[1])
-      if (s + 1 < n_stages) HEAD32_ITER(s + 1, regs[1], regs[2])
-      if (s + 2 < n_stages) HEAD32_ITER(s + 2, regs[2], regs[0])
+  if constexpr (SC) {
+    for (int s = 0; s < n_stages; s += 2) {
+      HEAD32_ITER_SC(s, 0, regs[0], regs[1])
+      if (s + 1 < n_stages) HEAD32_ITER_SC(s + 1, 1, regs[1], regs[0])
+    }
+    // drain: chunk 1 of the last stage, then that stage's carry (its parity is a run-time value)
+    if ((n_stages - 1) & 1) {
+      HEAD32_SC_CHUNK(1, 1, 0, 8, -1)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][r] += (double)(part[1][0][0][r] + part[1][0][1][r]);
+    } else {
+      HEAD32_SC_CHUNK(0, 1, 0, 8, -1)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][r] += (double)(part[0][0][0][r] + part[0][0][1][r]);
     }
   } else {
     for (int s = 0; s < n_stages; s += 2) {
       HEAD32_ITER(s, regs[0], regs[1])
       if (s + 1 < n_stages) HEAD32_ITER(s + 1, regs[1], regs[0])
     }
-  }
-  // drain: chunk 1 of the last stage, then the last chain's carry
-  HEAD32_CHAIN(1, 0, 0, 8)
-  if constexpr (TPW == 2) HEAD32_CHAIN(1, 1, 0, 8)
-  if constexpr (ACC64) {
+    // drain: chunk 1 of the last stage, then the last chain's carry
+    HEAD32_CHAIN(1, 0, 0, 8)
+    if constexpr (TPW == 2) HEAD32_CHAIN(1, 1, 0, 8)
+    if constexpr (ACC64) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float v = part[PS - 1][TPW - 1][0][r];
-      if constexpr (NSUB == 2) v += part[PS - 1][TPW - 1][1][r];
-      acc[TPW - 1][r] += (double)v;
+      for (int r = 0; r < 16; ++r) acc[TPW - 1][r] += (double)part[PS - 1][TPW - 1][0][r];
     }
   }
   __syncthreads();  // every wave is done reading the tiles: the logits may overwrite them
 #undef HEAD32_ITER
+#undef HEAD32_ITER_SC
+#undef HEAD32_SC_CHUNK
 #undef HEAD32_CHAIN
 #undef HEAD32_MFMA1
 #undef HEAD32_CARRY
