@@ -103,6 +103,76 @@ __global__ __launch_bounds__(256) void build_pyramid_kernel(
   }
 }
 
+// Wide variant for uint8 frames whose width and height are multiples of 8 (every video format),
+// level 0 not materialised: one thread owns an 8x8 tile = four of the blocks above, laid out so
+// that EVERY access of a wave is lane-contiguous -- 8-byte loads of 8 pixels (512 B per wave and
+// row), float4 stores to level 1 (1 KiB per wave and row), float2 stores to level 2.  (The 4x4
+// kernel reads 4 B and writes 8 B / 4 B per lane; a 16x4 strip per thread had 16-byte loads but
+// 32-byte-strided level-1 stores and was slower.)  Same values, same addition order.
+// The gamma LUT is replicated once per LDS bank ([value][32]): lanes l and l+32 of a ds_read_b32
+// are serviced separately and lane l always reads bank l & 31, so the lookups are conflict-free
+// whatever the pixel values (random pixels averaged ~3.5 ways on the shared 256-entry table).
+__global__ __launch_bounds__(256) void build_pyramid_u8_wide_kernel(
+    const uint8_t* __restrict__ src, int planes, int Hi, int Wi, float* __restrict__ l1,
+    float* __restrict__ l2, float* __restrict__ lut_out) {
+  __shared__ __attribute__((aligned(16))) float lut[256 * 32];
+  {
+    const float v = (float)pow((double)__fdiv_rn((float)threadIdx.x, 255.0f), (double)2.2f);
+    if (lut_out != nullptr && blockIdx.x == 0) lut_out[threadIdx.x] = v;
+    const float4 v4 = make_float4(v, v, v, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) reinterpret_cast<float4*>(lut + threadIdx.x * 32)[j] = v4;
+    __syncthreads();
+  }
+  const float* mylut = lut + (threadIdx.x & 31);
+  const int W1 = Wi / 2, W2 = Wi / 4, H1 = Hi / 2, H2 = Hi / 4;
+  const int tw = Wi / 8, th = Hi / 8;  // tiles per row / tile rows
+  const long long total = (long long)planes * th * tw;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int tx = (int)(t % tw);
+    const int ty = (int)((t / tw) % th);
+    const int pl = (int)(t / ((long long)tw * th));
+    const uint8_t* sp = src + ((size_t)pl * Hi + (size_t)ty * 8) * Wi + (size_t)tx * 8;
+    uint2 raw[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) raw[r] = *reinterpret_cast<const uint2*>(sp + (size_t)r * Wi);
+    float q[4][4];  // level 1: 4 rows x 4 px
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v[2][8];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const uint32_t w0 = raw[2 * r + i].x, w1 = raw[2 * r + i].y;
+        v[i][0] = mylut[(w0 & 0xff) << 5];
+        v[i][1] = mylut[((w0 >> 8) & 0xff) << 5];
+        v[i][2] = mylut[((w0 >> 16) & 0xff) << 5];
+        v[i][3] = mylut[(w0 >> 24) << 5];
+        v[i][4] = mylut[(w1 & 0xff) << 5];
+        v[i][5] = mylut[((w1 >> 8) & 0xff) << 5];
+        v[i][6] = mylut[((w1 >> 16) & 0xff) << 5];
+        v[i][7] = mylut[(w1 >> 24) << 5];
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        q[r][c] = __fadd_rn(__fadd_rn(__fadd_rn(v[0][2 * c], v[0][2 * c + 1]), v[1][2 * c]),
+                            v[1][2 * c + 1]) * 0.25f;
+      *reinterpret_cast<float4*>(l1 + ((size_t)pl * H1 + (size_t)ty * 4 + r) * W1 + (size_t)tx * 4) =
+          make_float4(q[r][0], q[r][1], q[r][2], q[r][3]);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      float o[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        o[c] = __fadd_rn(__fadd_rn(__fadd_rn(q[2 * r][2 * c], q[2 * r][2 * c + 1]), q[2 * r + 1][2 * c]),
+                         q[2 * r + 1][2 * c + 1]) * 0.25f;
+      *reinterpret_cast<float2*>(l2 + ((size_t)pl * H2 + (size_t)ty * 2 + r) * W2 + (size_t)tx * 2) =
+          make_float2(o[0], o[1]);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // geometry: one thread per (aug, box); fp64 internally, fp32 in/out.
 
@@ -551,6 +621,18 @@ static int warp_entry(const void* level0, const float* lut, const float* level1,
 
 }  // namespace mtr
 
+// wide path: whole 8x8 tiles, rows aligned for the 8 / 16 / 8-byte vectors of the three levels
+static bool pyramid_wide_ok(const void* src, const void* l1, const void* l2, int Hi, int Wi) {
+  return Wi % 8 == 0 && Hi % 8 == 0 && ((uintptr_t)src % 8) == 0 && ((uintptr_t)l1 % 16) == 0 &&
+         ((uintptr_t)l2 % 8) == 0;
+}
+static int pyramid_wide_grid(int N, int Hi, int Wi) {
+  const long long tiles = (long long)N * 3 * (Hi / 8) * (Wi / 8);
+  long long grid = (tiles + 255) / 256;
+  if (grid > 256 * 5) grid = 256 * 5;  // persistent: 5 workgroups per CU (32 KiB LUT each)
+  return (int)grid;
+}
+
 static int pyramid_grid(int N, int Hi, int Wi) {
   const long long blocks4 = (long long)N * 3 * ((Hi + 3) / 4) * ((Wi + 3) / 4);
   long long grid = (blocks4 + 255) / 256;
@@ -581,6 +663,12 @@ extern "C" int mtr_build_pyramid_u8(const uint8_t* images_u8, int N, int Hi, int
   if (N == 0) return MTR_OK;
   if ((uintptr_t)images_u8 % 4) return MTR_E_ALIGN;
   MTR_CLEAR_STALE();
+  if (pyramid_wide_ok(images_u8, level1, level2, Hi, Wi)) {
+    hipLaunchKernelGGL(mtr::build_pyramid_u8_wide_kernel, dim3(pyramid_wide_grid(N, Hi, Wi)), dim3(256),
+                       0, (hipStream_t)stream, images_u8, N * 3, Hi, Wi, level1, level2, lut);
+    MTR_CHECK_LAUNCH();
+    return MTR_OK;
+  }
   hipLaunchKernelGGL((mtr::build_pyramid_kernel<true, false>), dim3(pyramid_grid(N, Hi, Wi)),
                      dim3(256), 0, (hipStream_t)stream, (const void*)images_u8, N * 3, Hi, Wi,
                      (float*)nullptr, level1, level2, lut);

@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 LIN_MAX, LIN_MEAN = 6e-5, 4e-6
 
 
-@pytest.mark.parametrize('shape', [(2, 120, 160), (1, 37, 53), (3, 64, 66), (1, 5, 7), (1, 1080, 1920)])
+@pytest.mark.parametrize('shape', [(2, 120, 160), (1, 37, 53), (3, 64, 66), (1, 5, 7), (1, 1080, 1920),
+                                   (2, 8, 16), (1, 40, 48), (1, 36, 48)])
 def test_pyramid_vs_oracle(shape, hip_lib):
     """(u8/255)**2.2 and the 2x2 box pyramid incl. odd sizes.  Level 0 may differ from torch's CPU
     pow by 1 ulp (LUT is evaluated in fp64); levels 1-2 inherit that: bound 2.4e-7 abs (2 ulp at 1)."""
@@ -37,6 +38,12 @@ def test_pyramid_vs_oracle(shape, hip_lib):
             d = float((pyr.levels[lvl].cpu() - ref[lvl]).abs().max())
             print(f'[parity] pyramid {shape} level {lvl}: max-abs {d:.2e}')
             assert d <= 2.4e-7
+    # the uint8 path runs the 8x8-tile kernel when width and height are multiples of 8 (asserted
+    # equal to the materialising 4x4 kernel above); the float entry point (4x4 kernel, any size)
+    # must give the same bits again from the materialised level 0
+    gen = kernels.pyramid_from_level0(pyr.levels[0])
+    for lvl in (1, 2):
+        assert torch.equal(gen.levels[lvl], fast.levels[lvl])
     # float entry point: exactly avg_pool2d of what it is given
     pyr2 = kernels.pyramid_from_level0(lin.cuda())
     for lvl in (1, 2):
