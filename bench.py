@@ -373,12 +373,13 @@ def main():
                                    (im_h // 4) * (im_w // 4) * 4)
     src_bytes = source_footprint_bytes(extras['wp'], args.res, im_h, im_w)
     head_flops = 2.0 * C * J * (1 + D) * hw * n_crops
-    mfma_peak = MFMA_F32_PEAK  # v_mfma_f32_16x16x4_f32 in both precision classes (f64 carry on the VALU)
+    mfma_peak = MFMA_F32_PEAK  # f32-input MFMA in both precision classes (f64 carry on the VALU)
     alg = {
-        'pyramid': dict(kernel='build_pyramid_kernel<true,false>', bound='hbm', bytes=pyr_bytes),
+        'pyramid': dict(kernel='build_pyramid_u8_wide_kernel', bound='hbm', bytes=pyr_bytes),
         'warp': dict(kernel='warp_crops_kernel', bound='hbm',
                      bytes=n_crops * 3 * args.res ** 2 * out_bytes + src_bytes),
-        'head_fused': dict(kernel='head_fused_kernel', bound='mfma', flops=head_flops,
+        'head_fused': dict(kernel='head_fused32_kernel' if 32 < hw <= 128 else 'head_fused_kernel',
+                           bound='mfma', flops=head_flops,
                            bytes=n_crops * (C * hw * feat_bytes + 20 * J)),
     }
     ours = {k: stages[k] for k in ('pyramid', 'geometry', 'warp', 'head_fused', 'reconstruct',
