@@ -209,6 +209,33 @@ int mtr_postprocess_poses(const float* poses_crop, const float* rot, const uint8
                           const float* distortion, const float* inv_extrinsics, int A, int n, int J,
                           int average_aug, float* poses3d, float* poses2d, mtr_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * K9: detector pre-processing, the step in front of the hot path.
+ * Replaces PersonDetector.forward minus the network (metrabs_pytorch/multiperson/person_detector.py):
+ *   :15-20,26-29  target size / padding arithmetic in float32        -> mtr_detector_geometry (host)
+ *   :21-33        (u8/255)**2.2, torchvision bilinear resize (antialiased when shrinking),
+ *                 **(1/2.2), pad to multiples of 32 with 0.5           -> mtr_detector_preprocess
+ *   :47-54        scale_boxes (network frame -> image frame)          -> mtr_detector_scale_boxes
+ * The resize mirrors aten's separable CPU kernels operation for operation (bit-exact in linear
+ * light); shrink factors above 19x are rejected (MTR_E_SHAPE).
+ */
+typedef struct mtr_detector_geom {
+  int32_t target_h, target_w; /* resized extent: int32(factor * h), int32(factor * w)          */
+  int32_t antialias;          /* factor < 1                                                    */
+  int32_t pad_top, pad_left;  /* half_pad_h, half_pad_w                                        */
+  int32_t out_h, out_w;       /* padded extent (multiples of 32)                               */
+  float x_factor, y_factor;   /* w / target_w, h / target_h                                    */
+} mtr_detector_geom;
+
+/* host-only, no GPU work: fills `g` (a HOST pointer) for frames of H x W */
+int mtr_detector_geometry(int H, int W, int input_size /*416*/, mtr_detector_geom* g);
+/* images_u8 [N,3,H,W] uint8 -> out [N,3,g->out_h,g->out_w] f32 (what the network is fed); g: host */
+int mtr_detector_preprocess(const uint8_t* images_u8, int N, int H, int W, const mtr_detector_geom* g,
+                            float* out, mtr_stream_t stream);
+/* xyxy_conf [n,5] (x1,y1,x2,y2,conf; network frame) -> boxes_out [n,5] (x,y,w,h,conf; image frame) */
+int mtr_detector_scale_boxes(const float* xyxy_conf, int n, const mtr_detector_geom* g,
+                             float* boxes_out, mtr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

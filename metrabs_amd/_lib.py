@@ -28,6 +28,13 @@ class ReconParams(ctypes.Structure):
                 ('fov_border_factor', c_float)]
 
 
+class DetectorGeom(ctypes.Structure):
+    """mtr_detector_geom (include/metrabs_hip.h)."""
+    _fields_ = [('target_h', c_int32), ('target_w', c_int32), ('antialias', c_int32),
+                ('pad_top', c_int32), ('pad_left', c_int32), ('out_h', c_int32), ('out_w', c_int32),
+                ('x_factor', c_float), ('y_factor', c_float)]
+
+
 # name -> (restype, argtypes); must list EVERY symbol the header declares
 # (tests/test_capi_symbols.py cross-checks this table against include/metrabs_hip.h).
 SIGNATURES = {
@@ -63,6 +70,10 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_void_p]),
     'mtr_warp_crops': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
                                c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'mtr_detector_geometry': (c_int, [c_int, c_int, c_int, POINTER(DetectorGeom)]),
+    'mtr_detector_preprocess': (c_int, [c_void_p, c_int, c_int, c_int, POINTER(DetectorGeom), c_void_p,
+                                        c_void_p]),
+    'mtr_detector_scale_boxes': (c_int, [c_void_p, c_int, POINTER(DetectorGeom), c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -285,3 +285,43 @@ def postprocess_poses(poses_crop, rot, should_flip, mirror_mapping, intrinsics, 
         _ptr(inv_extrinsics.contiguous().float()), A, n, J, int(bool(average_aug)), _ptr(p3),
         _ptr(p2), current_stream_ptr(dev)), 'mtr_postprocess_poses')
     return p3, p2
+
+
+# ------------------------------------------------------------------------------------------------
+# K9: detector pre-processing (person_detector.py:14-54 minus the network)
+
+def detector_geometry(h, w, input_size=416):
+    """person_detector.py:15-20,26-29 -> _lib.DetectorGeom (host arithmetic, no GPU work)."""
+    g = _lib.DetectorGeom()
+    check(_lib.load().mtr_detector_geometry(int(h), int(w), int(input_size), ctypes.byref(g)),
+          'mtr_detector_geometry')
+    return g
+
+
+def detector_preprocess(images_u8, geom=None, input_size=416, out=None):
+    """images_u8 [N,3,H,W] uint8 (cuda) -> ([N,3,out_h,out_w] f32 as fed to the detector network,
+    geometry).  person_detector.py:21-33."""
+    if images_u8.dtype != torch.uint8 or images_u8.dim() != 4 or images_u8.shape[1] != 3:
+        raise ValueError('images must be uint8 [N,3,H,W]')
+    require_cuda(images_u8)
+    images_u8 = images_u8.contiguous()
+    N, _, H, W = images_u8.shape
+    g = geom if geom is not None else detector_geometry(H, W, input_size)
+    if out is None:
+        out = torch.empty(N, 3, g.out_h, g.out_w, device=images_u8.device, dtype=torch.float32)
+    check(_lib.load().mtr_detector_preprocess(_ptr(images_u8), N, H, W, ctypes.byref(g), _ptr(out),
+                                              current_stream_ptr(images_u8.device)),
+          'mtr_detector_preprocess')
+    return out, g
+
+
+def detector_scale_boxes(xyxy_conf, geom):
+    """[n,5] (x1,y1,x2,y2,conf) in the padded network frame -> [n,5] (x,y,w,h,conf) in the image
+    frame.  person_detector.py:47-54."""
+    require_cuda(xyxy_conf)
+    b = xyxy_conf.float().contiguous()
+    out = torch.empty_like(b)
+    check(_lib.load().mtr_detector_scale_boxes(_ptr(b), b.shape[0], ctypes.byref(geom), _ptr(out),
+                                               current_stream_ptr(b.device)),
+          'mtr_detector_scale_boxes')
+    return out

@@ -335,3 +335,34 @@ def warp_case(name):
             else torch.zeros(n, 5))
     return dict(images_u8=images_u8, images=images, K=K, hinv=hinv, dist=dist,
                 crop_scales=crop_scales, image_ids=image_ids, res=res)
+
+
+# ------------------------------------------------------------------------- detector pre-processing
+
+# name -> (n_images, h, w, seed): shrinking (antialiased) landscape / portrait / odd sizes, exact fit,
+# enlarging (plain bilinear), and a size whose target is already a multiple of 32 (no padding)
+DETPRE_CASES = {
+    'qhd_270x480': (2, 270, 480, 21),
+    'portrait_320x180': (1, 320, 180, 22),
+    'odd_211x307': (2, 211, 307, 23),
+    'exact_416x416': (1, 416, 416, 24),
+    'small_100x64': (2, 100, 64, 25),
+    'tiny_37x53': (1, 37, 53, 26),
+    'nopad_512x832': (1, 512, 832, 27),
+}
+
+
+def detpre_case(name):
+    n, h, w, seed = DETPRE_CASES[name]
+    images = synth_images(n, h, w, seed)
+    g = gen(seed + 1000)
+    # detector answers in the padded network frame (x1, y1, x2, y2, conf); image 0 may be empty
+    boxes = []
+    for i in range(n):
+        k = int(torch.randint(0 if i else 1, 5, (1,), generator=g))
+        x1 = torch.rand(k, generator=g) * 300
+        y1 = torch.rand(k, generator=g) * 300
+        boxes.append(torch.stack([x1, y1, x1 + 20 + 100 * torch.rand(k, generator=g),
+                                  y1 + 30 + 100 * torch.rand(k, generator=g),
+                                  torch.rand(k, generator=g)], dim=1).float())
+    return dict(images=images, net_boxes=boxes)

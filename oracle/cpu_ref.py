@@ -611,3 +611,47 @@ def postprocess_from_crop_outputs(poses_flat, rot, should_flip, mirror_mapping, 
     if average_aug:
         p3, p2 = torch.mean(p3, dim=-3), torch.mean(p2, dim=-3)
     return p3, p2
+
+
+# ------------------------------------------------------------------------------------------------
+# Row f.3 -- detector pre-processing and box rescale (the step BEFORE the hot path)
+# metrabs_pytorch/multiperson/person_detector.py:14-54.  The detector network itself (ultralytics
+# YOLOv8, third party) is out of scope; `detector_preprocess` produces what it is fed and
+# `detector_scale_boxes` maps its boxes back to the frame.
+
+def detector_target_size(h, w, input_size=416):
+    """person_detector.py:15-20,26-29 -- numpy float32 arithmetic exactly as written there."""
+    h32, w32 = np.float32(h), np.float32(w)
+    max_side = np.maximum(h32, w32)
+    factor = input_size / max_side
+    target_w = int(np.int32(factor * w32))
+    target_h = int(np.int32(factor * h32))
+    pad_h = -target_h % 32
+    pad_w = -target_w % 32
+    return dict(target_h=target_h, target_w=target_w, antialias=bool(factor < 1),
+                pad_top=pad_h // 2, pad_left=pad_w // 2, out_h=target_h + pad_h, out_w=target_w + pad_w,
+                x_factor=float(w32 / np.float32(target_w)), y_factor=float(h32 / np.float32(target_h)))
+
+
+def detector_preprocess(images_u8, input_size=416):
+    """person_detector.py:21-33: gamma-decode, bilinear resize (antialiased when shrinking; torchvision's
+    tensor path = F.interpolate(bilinear, align_corners=False, antialias)), gamma-encode, pad with 0.5
+    to multiples of 32.  images_u8 [N,3,H,W] uint8 -> ([N,3,out_h,out_w] f32, geometry dict)."""
+    m = detector_target_size(images_u8.shape[2], images_u8.shape[3], input_size)
+    x = (images_u8.float() / 255) ** 2.2
+    x = F.interpolate(x, size=[m['target_h'], m['target_w']], mode='bilinear', align_corners=False,
+                      antialias=m['antialias'])
+    x = x ** (1 / 2.2)
+    pad_h, pad_w = m['out_h'] - m['target_h'], m['out_w'] - m['target_w']
+    x = F.pad(x, (m['pad_left'], pad_w - m['pad_left'], m['pad_top'], pad_h - m['pad_top']), value=0.5)
+    return x, m
+
+
+def detector_scale_boxes(xyxy_conf, m):
+    """person_detector.py:47-54: boxes [n,5] (x1,y1,x2,y2,conf) in the padded network frame ->
+    (x, y, w, h, conf) in the original frame."""
+    hw, hh = np.float32(m['pad_left']), np.float32(m['pad_top'])
+    xf, yf = np.float32(m['x_factor']), np.float32(m['y_factor'])
+    b = xyxy_conf
+    return torch.stack([(b[:, 0] - hw) * xf, (b[:, 1] - hh) * yf, (b[:, 2] - b[:, 0]) * xf,
+                        (b[:, 3] - b[:, 1]) * yf, b[:, 4]], dim=1)

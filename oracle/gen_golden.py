@@ -11,6 +11,7 @@ were computed from.  Nothing here is used by the product.
 import os
 import platform
 import sys
+import warnings
 
 import numpy as np
 import torch
@@ -122,6 +123,27 @@ def gen_warp(ref):
                  c['images_u8'], c['K'], c['hinv'], c['dist'], c['crop_scales'], c['image_ids'])))
 
 
+def gen_detpre(ref):
+    """Detector pre-processing + box rescale: the reference's own PersonDetector.forward with the
+    network replaced by a recording stub (oracle/ref_harness.py: torchvision.resize -> its published
+    F.interpolate path, ultralytics.YOLO -> recorder)."""
+    import ultralytics
+    det = ref.person_detector.PersonDetector()
+    for name in cases.DETPRE_CASES:
+        c = cases.detpre_case(name)
+        ultralytics.YOLO.fake_boxes_xyxy_conf = c['net_boxes']
+        with torch.inference_mode(), warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            boxes = det(c['images'], 0.3, 0.7, 150)
+        fed = ultralytics.YOLO.last_source
+        n_box = np.array([len(b) for b in boxes])
+        # the full tensor is 1-2.5 MB per case: keep every 7th row / 5th column plus a digest of all
+        save(f'detpre_{name}', network_input_sample=fed[:, :, ::7, ::5].contiguous(),
+             network_input_shape=np.array(fed.shape), network_input_sha256=np.array(cases.sha256_of(fed)),
+             boxes=torch.cat(boxes), n_box=n_box,
+             input_sha256=np.array(cases.sha256_of(c['images'], *c['net_boxes'])))
+
+
 def gen_tta(ref):
     """TTA parameter tables computed by the reference's own expressions:
     run _estimate_poses_batched with a recording stub for _predict_in_batches."""
@@ -209,14 +231,13 @@ def gen_e2e(ref):
 
 
 def main():
+    """python oracle/gen_golden.py [group ...]   (default: every group)"""
     torch.manual_seed(0)
     ref = rh.load()
-    gen_heads(ref)
-    gen_headconv(ref)
-    gen_recon(ref)
-    gen_warp(ref)
-    gen_tta(ref)
-    gen_e2e(ref)
+    groups = dict(heads=gen_heads, headconv=gen_headconv, recon=gen_recon, warp=gen_warp,
+                  tta=gen_tta, e2e=gen_e2e, detpre=gen_detpre)
+    for name in (sys.argv[1:] or groups):
+        groups[name](ref)
 
 
 if __name__ == '__main__':

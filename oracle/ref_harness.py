@@ -112,14 +112,46 @@ def _install_stubs():
     tvt.__path__ = []
     tvf = types.ModuleType('torchvision.transforms.functional')
     tv.transforms, tvt.functional = tvt, tvf
+
+    def tv_resize(img, size, interpolation=None, max_size=None, antialias=True):
+        """torchvision.transforms.functional.resize on a float tensor with a (h, w) size (torchvision is
+        not installed; its published tensor path is `torch.nn.functional.interpolate(img, size=size,
+        mode='bilinear', align_corners=False, antialias=antialias)` -- transforms/_functional_tensor.py
+        `resize`, default InterpolationMode.BILINEAR), which is what person_detector.py:23-24 reaches."""
+        import torch.nn.functional as F
+        return F.interpolate(img, size=[int(size[0]), int(size[1])], mode='bilinear',
+                             align_corners=False, antialias=bool(antialias))
+
+    tvf.resize = tv_resize
     sys.modules.update({'torchvision': tv, 'torchvision.transforms': tvt,
                         'torchvision.transforms.functional': tvf})
 
     ul = types.ModuleType('ultralytics')
 
-    class YOLO:  # the detector is out of scope; boxes are supplied by the caller
+    class YOLO:  # the detector network is out of scope; boxes are supplied by the caller
+        """Stand-in for ultralytics.YOLO: records what person_detector.py:38-41 feeds the network and
+        answers with the boxes in `YOLO.fake_boxes_xyxy_conf` (one [n, 5] tensor per image, in the
+        network's padded input frame), wrapped in the attribute layout the reference reads
+        (`r.boxes.xyxy`, `.xywh`, `.conf`)."""
+        fake_boxes_xyxy_conf = None
+        last_source = None
+        last_kwargs = None
+
         def __init__(self, *a, **k):
             pass
+
+        def predict(self, source, **kw):
+            type(self).last_source = source.detach().clone()
+            type(self).last_kwargs = dict(kw)
+            out = []
+            for b in type(self).fake_boxes_xyxy_conf:
+                boxes = types.SimpleNamespace(
+                    xyxy=b[:, :4],
+                    xywh=torch.stack([(b[:, 0] + b[:, 2]) / 2, (b[:, 1] + b[:, 3]) / 2,
+                                      b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], dim=1),
+                    conf=b[:, 4])
+                out.append(types.SimpleNamespace(boxes=boxes))
+            return out
 
     ul.YOLO = YOLO
     sys.modules['ultralytics'] = ul
@@ -140,7 +172,7 @@ def _install_stubs():
 
 def load():
     """Returns a namespace with the reference modules (ptu, ptu3d, model_util, metrabs_model,
-    warping, multiperson_model)."""
+    warping, multiperson_model, person_detector)."""
     if _loaded:
         return types.SimpleNamespace(**_loaded)
     if not reference_available():
@@ -154,5 +186,7 @@ def load():
     _loaded['warping'] = importlib.import_module('metrabs_pytorch.multiperson.warping')
     _loaded['multiperson_model'] = importlib.import_module(
         'metrabs_pytorch.multiperson.multiperson_model')
+    _loaded['person_detector'] = importlib.import_module(
+        'metrabs_pytorch.multiperson.person_detector')
     _loaded['JointInfo'] = _JointInfoStub
     return types.SimpleNamespace(**_loaded)

@@ -99,3 +99,31 @@ def test_backbone_shapes():
         with torch.inference_mode():
             y = net(torch.rand(1, 3, res, res))
         assert y.shape == (1, c, res // 32, res // 32) and net.out_channels == c
+
+
+def test_detector_geometry_matches_the_reference_arithmetic():
+    """mtr_detector_geometry is host-only C (no GPU): person_detector.py:15-20,26-29 in float32 must
+    give the oracle's numbers on every frame size, including the ones where float32 and float64
+    would disagree about int(factor * w)."""
+    import random
+    from metrabs_amd import kernels
+    from oracle import cpu_ref
+    rnd = random.Random(0)
+    sizes = [(1080, 1920), (1920, 1080), (270, 480), (416, 416), (100, 64), (37, 53), (512, 832),
+             (2160, 3840), (1, 1), (415, 417)] + [(rnd.randint(8, 3000), rnd.randint(8, 4000))
+                                                   for _ in range(2000)]
+    import pytest
+    for h, w in sizes:
+        m = cpu_ref.detector_target_size(h, w)
+        if min(m['target_h'], m['target_w']) <= 0:  # the reference's resize fails there too
+            with pytest.raises(RuntimeError):
+                kernels.detector_geometry(h, w)
+            continue
+        g = kernels.detector_geometry(h, w)
+        assert (g.target_h, g.target_w, bool(g.antialias), g.pad_top, g.pad_left, g.out_h, g.out_w) == \
+            (m['target_h'], m['target_w'], m['antialias'], m['pad_top'], m['pad_left'], m['out_h'],
+             m['out_w']), (h, w)
+        assert g.x_factor == m['x_factor'] and g.y_factor == m['y_factor'], (h, w)
+        assert g.out_h % 32 == 0 and g.out_w % 32 == 0
+    with pytest.raises(RuntimeError):
+        kernels.detector_geometry(5000, 3)  # target width 0

@@ -117,6 +117,37 @@ def test_e2e_vs_golden(name):
     check(torch.cat(res['poses2d']), g['poses2d'], g, atol=5e-4, exact_ok=False)
 
 
+@pytest.mark.parametrize('name', list(cases.DETPRE_CASES))
+def test_detector_preprocess_vs_golden(name):
+    """Row f.3: what the reference's PersonDetector.forward feeds the network (recorded from the
+    real person_detector.py with a stub network) and the boxes it returns."""
+    g = load_golden(f'detpre_{name}')
+    c = cases.detpre_case(name)
+    assert cases.sha256_of(c['images'], *c['net_boxes']) == str(g['input_sha256']), 'input RNG drifted'
+    with torch.inference_mode():
+        fed, m = cpu_ref.detector_preprocess(c['images'])
+        boxes = torch.cat([cpu_ref.detector_scale_boxes(b, m) for b in c['net_boxes']])
+    assert list(fed.shape) == list(g['network_input_shape'])
+    check(fed[:, :, ::7, ::5], g['network_input_sample'], g, atol=2e-6)
+    if same_cpu_as_golden(g):
+        assert cases.sha256_of(fed) == str(g['network_input_sha256'])
+    check(boxes, g['boxes'], g, atol=1e-4)
+
+
+def test_detector_target_size_known_answers():
+    """person_detector.py:15-29 in numpy float32: 1080p -> 234 x 416 padded to 256 x 416 (11 rows of
+    0.5 above and below), antialiased; frames at or below 416 px are enlarged without antialiasing."""
+    m = cpu_ref.detector_target_size(1080, 1920)
+    assert (m['target_h'], m['target_w'], m['out_h'], m['out_w'], m['pad_top'], m['pad_left']) == \
+        (234, 416, 256, 416, 11, 0) and m['antialias']
+    assert abs(m['x_factor'] - 1920 / 416) < 1e-6 and abs(m['y_factor'] - 1080 / 234) < 1e-6
+    m = cpu_ref.detector_target_size(100, 64)
+    assert (m['target_h'], m['target_w'], m['out_h'], m['out_w'], m['pad_top'], m['pad_left']) == \
+        (416, 266, 416, 288, 0, 11) and not m['antialias']
+    m = cpu_ref.detector_target_size(416, 416)
+    assert (m['target_h'], m['target_w'], m['out_h'], m['out_w']) == (416, 416, 416, 416) and not m['antialias']
+
+
 @pytest.mark.skipif(not rh.reference_available(), reason='/root/reference not mounted')
 class TestAgainstLiveReference:
     """Bit-for-bit against the reference modules executed in place."""

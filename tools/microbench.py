@@ -134,8 +134,25 @@ def bench_recon():
     return out
 
 
+def bench_detector_pre():
+    """K9: detector pre-processing (person_detector.py:21-33).  Algorithmic bytes: the uint8 frames
+    once + the f32 network input once."""
+    out = []
+    g = torch.Generator().manual_seed(0)
+    for name, n, h, w in [('8 x 1080p -> 256x416', 8, 1080, 1920), ('2 x 2160p -> 256x416', 2, 2160, 3840),
+                          ('8 x 480x640 -> 320x416', 8, 480, 640)]:
+        frames = torch.randint(0, 256, (n, 3, h, w), dtype=torch.uint8, generator=g).cuda()
+        geom = kernels.detector_geometry(h, w)
+        o = torch.empty(n, 3, geom.out_h, geom.out_w, device='cuda')
+        t = timeit(lambda: kernels.detector_preprocess(frames, geom=geom, out=o))
+        nbytes = frames.numel() + o.numel() * 4
+        out.append(dict(kernel='detector_pre', case=name, us=round(t * 1e6, 1),
+                        GBps=round(nbytes / t / 1e9, 1), frac_hbm=round(nbytes / t / HBM, 3)))
+    return out
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['decode', 'head', 'warp', 'recon']
+    which = sys.argv[1:] or ['decode', 'head', 'warp', 'recon', 'detector']
     res = []
     if 'decode' in which:
         res += bench_decode()
@@ -145,5 +162,7 @@ if __name__ == '__main__':
         res += bench_warp_pyramid()
     if 'recon' in which:
         res += bench_recon()
+    if 'detector' in which:
+        res += bench_detector_pre()
     for r in res:
         print(json.dumps(r))
