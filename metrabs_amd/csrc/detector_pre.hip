@@ -18,20 +18,29 @@
 // (plain bilinear).  This kernel mirrors that arithmetic, so the linear-light resize is bit-exact
 // and the result differs from the reference only by the two pow roundings (<= 2 ulp).
 //
-// One workgroup walks output tiles of TY x 64 (persistent grid): per tile it derives the weights of
-// its 64 columns and TY rows, runs the horizontal pass for the input rows the tile needs straight
-// from the uint8 frame (gamma LUT in LDS) into an LDS intermediate, then the vertical pass, the
-// re-gamma and the store; pad pixels are written as 0.5 by the same tile walk.
-// Bound: HBM read of the uint8 frames (6.2 MB per 1080p frame) -- in practice LDS/ALU-limited, the
-// taps of neighbouring outputs overlap 2x in each direction.
+// One workgroup walks output tiles of TY x 64 (persistent grid).  Per tile:
+//   1. weights of its 64 columns and TY rows, raw taps in parallel (4 threads per column), the
+//      in-order float sum + division per column by one thread each;
+//   2. the uint8 region the tile needs (rows y_lo.., bytes x_lo..) is staged into LDS with aligned
+//      4-byte loads, many in flight -- the first version read each tap from global memory in a
+//      dependent load -> LUT -> fma chain and spent 150 us on 8 x 1080p;
+//   3. horizontal pass out of LDS (byte read + gamma LUT + fma, weights in registers, tap loop
+//      unrolled to the template bound KT) into an f32 LDS intermediate [rows][64];
+//   4. vertical pass, re-gamma, store; pad pixels are written as 0.5 by the same tile walk.
+// Bound: HBM read of the uint8 frames (6.2 MB per 1080p frame); in practice the LDS pipe (two LDS
+// reads per horizontal tap, ~10 taps per intermediate value at 1080p).
 #include "common.h"
+
+// developer-only timing ablations (tools/experiments/ablate_detector.py); 0 in the product
+#ifndef MTR_DET_ABLATE
+#define MTR_DET_ABLATE 0
+#endif
 
 namespace mtr {
 
 constexpr int kDTX = 64;     // output columns per tile
 constexpr int kDTYMax = 8;   // output rows per tile (host picks <= this)
 constexpr int kDTaps = 40;   // taps per output index: ceil(2 * scale) + 2 <= 40 (scale <= 19)
-constexpr int kDRows = 128;  // input rows of the LDS intermediate per tile
 
 struct AxisGeom {
   int in_size, out_size;  // frame / resized extent along this axis
@@ -39,127 +48,256 @@ struct AxisGeom {
 };
 
 // aten/native/cpu/UpSampleKernel.cpp: _compute_indices_min_size_weights_aa (antialias) and
-// compute_indices_weights / guard_index_and_lambda (plain).  `w` has stride `ws` floats.
-__device__ __forceinline__ void axis_weights(int i, const AxisGeom& g, int& imin, int& isize, float* w,
-                                             int ws) {
+// compute_indices_weights / guard_index_and_lambda (plain).  Split in two so that the taps can be
+// evaluated in parallel: axis_span (per output index) and axis_raw_weight (per tap).
+struct AxisSpan {
+  int imin, isize;
+  float center, invscale, l1;  // l1: plain-bilinear lambda
+};
+__device__ __forceinline__ AxisSpan axis_span(int i, const AxisGeom& g) {
+  AxisSpan s;
   const float scale = (float)g.in_size / (float)g.out_size;
   if (g.aa) {
     const float support = scale >= 1.0f ? scale : 1.0f;
-    const float invscale = scale >= 1.0f ? (float)(1.0 / (double)scale) : 1.0f;
-    const float center = (float)((double)scale * ((double)i + 0.5));
-    long long lo = (long long)((double)(center - support) + 0.5);
-    long long hi = (long long)((double)(center + support) + 0.5);
+    s.invscale = scale >= 1.0f ? (float)(1.0 / (double)scale) : 1.0f;
+    s.center = (float)((double)scale * ((double)i + 0.5));
+    long long lo = (long long)((double)(s.center - support) + 0.5);
+    long long hi = (long long)((double)(s.center + support) + 0.5);
     if (lo < 0) lo = 0;
     if (hi > g.in_size) hi = g.in_size;
-    imin = (int)lo;
-    isize = (int)(hi - lo);
-    if (isize > kDTaps) isize = kDTaps;  // (host rejects scales that need more)
-    float total = 0.0f;
-    for (int j = 0; j < isize; ++j) {
-      float x = (float)(((double)((float)(j + imin) - center) + 0.5) * (double)invscale);
-      x = x < 0.0f ? -x : x;
-      const float wj = x < 1.0f ? 1.0f - x : 0.0f;
-      w[j * ws] = wj;
-      total = __fadd_rn(total, wj);
-    }
-    if (total != 0.0f)
-      for (int j = 0; j < isize; ++j) w[j * ws] = __fdiv_rn(w[j * ws], total);
+    s.imin = (int)lo;
+    s.isize = min((int)(hi - lo), kDTaps);  // (host rejects scales that need more)
+    s.l1 = 0.0f;
   } else {
     float real = (float)((double)scale * ((double)i + 0.5) - 0.5);
     if (real < 0.0f) real = 0.0f;
     int i0 = (int)floorf(real);
     if (i0 > g.in_size - 1) i0 = g.in_size - 1;
-    float l1 = real - (float)i0;
-    l1 = fminf(fmaxf(l1, 0.0f), 1.0f);
-    imin = i0;
-    isize = 2;  // tap 1 is read at min(i0 + 1, in_size - 1)
-    w[0] = 1.0f - l1;
-    w[ws] = l1;
+    s.imin = i0;
+    s.isize = 2;  // tap 1 is read at min(i0 + 1, in_size - 1)
+    s.l1 = fminf(fmaxf(real - (float)i0, 0.0f), 1.0f);
+    s.center = s.invscale = 0.0f;
   }
+  return s;
+}
+// tap j before normalisation (antialias) / final weight (plain bilinear)
+__device__ __forceinline__ float axis_raw_weight(const AxisSpan& s, int j, int aa) {
+  if (!aa) return j == 0 ? 1.0f - s.l1 : s.l1;
+  float x = (float)(((double)((float)(j + s.imin) - s.center) + 0.5) * (double)s.invscale);
+  x = x < 0.0f ? -x : x;
+  return x < 1.0f ? 1.0f - x : 0.0f;
 }
 
+// dynamic LDS: stage [rows_cap][pitch] uint8, then temp [rows_cap][64] f32
+template <int KT, bool TAIL>
 __global__ __launch_bounds__(256) void detector_pre_kernel(
-    const uint8_t* __restrict__ src, int planes, AxisGeom gx, AxisGeom gy, int pad_top, int pad_left,
-    int out_h, int out_w, int ty_rows, float* __restrict__ out) {
-  __shared__ float lut[256];
-  __shared__ float wx[kDTaps][kDTX];        // [tap][column]: conflict-free across columns
-  __shared__ float wy[kDTYMax][kDTaps];
+    const uint8_t* __restrict__ src, size_t src_bytes, int planes, AxisGeom gx, AxisGeom gy,
+    int pad_top, int pad_left, int out_h, int out_w, int ty_rows, int rows_cap, int pitch,
+    float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
+  // gamma LUT replicated 16x ([value][16], lane l reads copy l & 15): two lanes of a 32-lane LDS
+  // group share a copy, so a random-pixel lookup is ~1.5-way instead of ~3.5-way on one shared table
+  __shared__ __attribute__((aligned(16))) float lut[256 * 16];
+  __shared__ float wx[KT][kDTX];  // raw taps [tap][column]
+  __shared__ float wy[kDTYMax][KT];
+  __shared__ float xtotal[kDTX], ytotal[kDTYMax];
   __shared__ int xmin[kDTX], xsize[kDTX], ymin[kDTYMax], ysize[kDTYMax];
-  __shared__ float temp[kDRows][kDTX];
-  __shared__ int yrange[2];
+
+  uint8_t* stage = dyn;
+  float* temp = reinterpret_cast<float*>(dyn + (size_t)rows_cap * pitch);
 
   const int tid = threadIdx.x;
-  lut[tid] = (float)pow((double)__fdiv_rn((float)tid, 255.0f), (double)2.2f);
-
+  {
+    const float v = (float)pow((double)__fdiv_rn((float)tid, 255.0f), (double)2.2f);
+    const float4 v4 = make_float4(v, v, v, v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) reinterpret_cast<float4*>(lut + tid * 16)[j] = v4;
+  }
+  const float* mylut = lut + (tid & 15);
+  // A workgroup owns ONE column tile tx for its whole life (grid = tiles_x * G): the column weights
+  // are derived once and stay in registers; the loop walks (plane, row tile) pairs.
   const int tiles_x = (out_w + kDTX - 1) / kDTX, tiles_y = (out_h + ty_rows - 1) / ty_rows;
-  const long long n_tiles = (long long)planes * tiles_y * tiles_x;
+  const int tx = blockIdx.x % tiles_x, lane0 = blockIdx.x / tiles_x, lanes = gridDim.x / tiles_x;
   const int c = tid & (kDTX - 1), rg = tid >> 6;  // column of the tile, row group 0..3
 
-  for (long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    const int tx = (int)(t % tiles_x), tyi = (int)((t / tiles_x) % tiles_y);
-    const int pl = (int)(t / ((long long)tiles_x * tiles_y));
-    __syncthreads();  // previous tile fully consumed (and the LUT written, first time)
-    // ---- weights of this tile's columns (threads 0..63) and rows (threads 64..64+TY-1)
-    if (tid < kDTX) {
-      const int ox = tx * kDTX + tid - pad_left;  // column in the resized image
-      int mn = 0, sz = 0;
-      if (ox >= 0 && ox < gx.out_size) axis_weights(ox, gx, mn, sz, &wx[0][tid], kDTX);
-      xmin[tid] = mn;
-      xsize[tid] = sz;  // 0 = pad column
-    } else if (tid < kDTX + ty_rows) {
-      const int r = tid - kDTX;
+  // ---- column weights (once): raw taps by 4 threads per column, in-order sum by one, division by all
+  AxisSpan sp{0, 0, 0.f, 0.f, 0.f};
+  {
+    const int ox = tx * kDTX + c - pad_left;  // column in the resized image
+    if (ox >= 0 && ox < gx.out_size) sp = axis_span(ox, gx);
+    sp.isize = min(sp.isize, KT);  // (cannot bind: the host sized KT from the support)
+    for (int j = rg; j < sp.isize; j += 4) wx[j][c] = axis_raw_weight(sp, j, gx.aa);
+    if (rg == 0) {
+      xmin[c] = sp.imin;
+      xsize[c] = sp.isize;  // 0 = pad column
+    }
+  }
+  __syncthreads();
+  if (tid < kDTX) {
+    float total = 0.0f;
+    for (int j = 0; j < xsize[tid]; ++j) total = __fadd_rn(total, wx[j][tid]);
+    xtotal[tid] = total;
+  }
+  __syncthreads();
+  const int xs = sp.isize, xm = sp.imin;
+  float wreg[KT];
+  {
+    const float total = xtotal[c];
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+      const float raw = j < xs ? wx[j][c] : 0.0f;
+      wreg[j] = (gx.aa && total != 0.0f) ? __fdiv_rn(raw, total) : raw;
+    }
+  }
+  // bytes of the frame rows this column tile reads: xmin and xmin + xsize are monotone in the column
+  int x_lo = 0, x_hi = 0;
+  {
+    const int c0 = max(0, pad_left - tx * kDTX), c1 = min(kDTX - 1, pad_left + gx.out_size - 1 - tx * kDTX);
+    if (c1 >= c0) {
+      x_lo = xmin[c0];
+      x_hi = min(xmin[c1] + (gx.aa ? xsize[c1] : 2), gx.in_size);
+    }
+  }
+  const int vecs = x_hi > x_lo ? (x_hi - x_lo + 15 + 15) / 16 : 0;  // <= pitch / 16 (host sized it)
+
+  for (long long t = lane0; t < (long long)planes * tiles_y; t += lanes) {
+    const int tyi = (int)(t % tiles_y), pl = (int)(t / tiles_y);
+    __syncthreads();  // previous tile fully consumed
+    // ---- 1. row weights of this tile: thread (r, k) evaluates tap k of row r
+    for (int e = tid; e < ty_rows * KT; e += 256) {
+      const int r = e / KT, k = e - r * KT;
       const int oy = tyi * ty_rows + r - pad_top;
-      int mn = 0, sz = 0;
-      if (oy >= 0 && oy < gy.out_size) axis_weights(oy, gy, mn, sz, &wy[r][0], 1);
-      ymin[r] = mn;
-      ysize[r] = sz;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      int lo = 0x7fffffff, hi = 0;
-      for (int r = 0; r < ty_rows; ++r)
-        if (ysize[r] > 0) {
-          lo = min(lo, ymin[r]);
-          hi = max(hi, min(ymin[r] + ysize[r], gy.in_size));
-        }
-      yrange[0] = lo;
-      yrange[1] = hi > lo ? hi - lo : 0;
-    }
-    __syncthreads();
-    const int y_lo = yrange[0], n_rows = min(yrange[1], kDRows);
-    // ---- horizontal pass: input rows y_lo .. y_lo + n_rows - 1, this thread's column
-    const int xs = xsize[c], xm = xmin[c];
-    if (xs > 0) {
-      const uint8_t* plane = src + (size_t)pl * gy.in_size * gx.in_size;
-      for (int r = rg; r < n_rows; r += 4) {
-        const uint8_t* row = plane + (size_t)(y_lo + r) * gx.in_size;
-        float acc;
-        if (gx.aa) {
-          acc = __fmul_rn(lut[row[xm]], wx[0][c]);
-          for (int j = 1; j < xs; ++j) acc = __fmaf_rn(lut[row[xm + j]], wx[j][c], acc);
-        } else {
-          const float v0 = lut[row[xm]], v1 = lut[row[min(xm + 1, gx.in_size - 1)]];
-          acc = __fmaf_rn(v0, wx[0][c], __fmul_rn(v1, wx[1][c]));
-        }
-        temp[r][c] = acc;
+      AxisSpan sy{0, 0, 0.f, 0.f, 0.f};
+      if (oy >= 0 && oy < gy.out_size) sy = axis_span(oy, gy);
+      sy.isize = min(sy.isize, KT);
+      wy[r][k] = k < sy.isize ? axis_raw_weight(sy, k, gy.aa) : 0.0f;
+      if (k == 0) {
+        ymin[r] = sy.imin;
+        ysize[r] = sy.isize;
       }
     }
     __syncthreads();
-    // ---- vertical pass + re-gamma + store (pad pixels: 0.5)
+    if (tid < ty_rows) {  // in-order float sum per row (the normalisation aten applies)
+      float total = 0.0f;
+      for (int k = 0; k < ysize[tid]; ++k) total = __fadd_rn(total, wy[tid][k]);
+      ytotal[tid] = total;
+    }
+    __syncthreads();
+    if (gy.aa)
+      for (int e = tid; e < ty_rows * KT; e += 256) {
+        const int r = e / KT, k = e - r * KT;
+        if (ytotal[r] != 0.0f) wy[r][k] = __fdiv_rn(wy[r][k], ytotal[r]);
+      }
+    __syncthreads();
+    // rows of the frame this tile reads (ymin, ymin + ysize monotone in the row)
+    int y_lo = 0, n_rows = 0;
+    {
+      const int r0 = max(0, pad_top - tyi * ty_rows);
+      const int r1 = min(ty_rows - 1, pad_top + gy.out_size - 1 - tyi * ty_rows);
+      if (r1 >= r0) {
+        y_lo = ymin[r0];
+        n_rows = min(min(ymin[r1] + (gy.aa ? ysize[r1] : 2), gy.in_size) - y_lo, rows_cap);
+      }
+    }
+    // ---- 2. stage rows y_lo.., bytes x_lo..x_hi-1 with aligned 16-byte loads.  Row r of the stage
+    // starts at the frame byte a_r = (row start + x_lo) & ~15; its taps sit at offset
+    // (row start + x_lo) & 15.
+    const size_t plane_off = (size_t)pl * gy.in_size * gx.in_size;
+    // 16-byte loads, two per thread in flight before either is stored (a load-store loop with a
+    // bounds branch in it serialised one ~1 us global round trip per word).
+    const int n_vecs = (MTR_DET_ABLATE & 1) ? 0 : n_rows * vecs;
+    for (int e0 = tid; e0 < n_vecs; e0 += 2 * 256) {
+      uint4 v[2];
+      int dst[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int e = min(e0 + i * 256, n_vecs - 1);  // clamped duplicates are never stored
+        const int r = e / vecs, k = e - r * vecs;
+        const size_t row0 = plane_off + (size_t)(y_lo + r) * gx.in_size + x_lo;
+        const size_t a = (row0 & ~(size_t)15) + (size_t)k * 16;
+        dst[i] = r * pitch + k * 16;
+        if (TAIL) {  // tensor size not a multiple of 16: its last vector is assembled from bytes
+          if (a + 16 <= src_bytes) {
+            v[i] = *reinterpret_cast<const uint4*>(src + a);
+          } else {
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (int q = 0; q < 16; ++q)
+              if (a + q < src_bytes) w[q >> 2] |= (uint32_t)src[a + q] << (8 * (q & 3));
+            v[i] = make_uint4(w[0], w[1], w[2], w[3]);
+          }
+        } else {
+          v[i] = *reinterpret_cast<const uint4*>(src + a);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        if (e0 + i * 256 < n_vecs) *reinterpret_cast<uint4*>(stage + dst[i]) = v[i];
+    }
+    __syncthreads();
+    // ---- 3. horizontal pass out of LDS.  The taps of a column are KT consecutive bytes of the
+    // staged row: read them as KT/4 + 1 aligned words, realign with v_alignbyte, split with static
+    // shifts (one LDS read per 4 taps instead of one per tap), then LUT + fma per tap.
+    // RU rows per thread are in flight together: each row is a dependent read -> LUT -> fma chain,
+    // and with 3 workgroups per CU there are not enough waves to hide it otherwise.
+    if (xs > 0 && !(MTR_DET_ABLATE & 2)) {
+      constexpr int NW = (KT + 3) / 4;  // realigned words
+      constexpr int RU = KT <= 12 ? 4 : 2;
+      for (int rb = rg; rb < n_rows; rb += 4 * RU) {
+        uint32_t al[RU][NW];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+          const int r = min(rb + 4 * u, n_rows - 1);  // clamped duplicates are not stored
+          const size_t row0 = plane_off + (size_t)(y_lo + r) * gx.in_size + x_lo;
+          const int off = (int)(row0 & 15) + (xm - x_lo);  // byte offset of tap 0 in the staged row
+          const uint32_t* wrow = reinterpret_cast<const uint32_t*>(stage + (size_t)r * pitch) + (off >> 2);
+          uint32_t raw[NW + 1];
+#pragma unroll
+          for (int i = 0; i <= NW; ++i) raw[i] = wrow[i];
+#pragma unroll
+          for (int i = 0; i < NW; ++i) al[u][i] = __builtin_amdgcn_alignbyte(raw[i + 1], raw[i], off & 3);
+        }
+        float acc[RU];
+        if (gx.aa) {
+#pragma unroll
+          for (int u = 0; u < RU; ++u) acc[u] = __fmul_rn(mylut[(al[u][0] & 0xff) << 4], wreg[0]);
+#pragma unroll
+          for (int j = 1; j < KT; ++j)
+            if (j < xs) {
+#pragma unroll
+              for (int u = 0; u < RU; ++u)
+                acc[u] = __fmaf_rn(mylut[((al[u][j >> 2] >> (8 * (j & 3))) & 0xff) << 4], wreg[j], acc[u]);
+            }
+        } else {
+          const int j1 = min(xm + 1, gx.in_size - 1) - xm;  // 0 or 1
+#pragma unroll
+          for (int u = 0; u < RU; ++u) {
+            const float v0 = mylut[(al[u][0] & 0xff) << 4], v1 = mylut[((al[u][0] >> (8 * j1)) & 0xff) << 4];
+            acc[u] = __fmaf_rn(v0, wreg[0], __fmul_rn(v1, wreg[1]));
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u)
+          if (rb + 4 * u < n_rows) temp[(rb + 4 * u) * kDTX + c] = acc[u];
+      }
+    }
+    __syncthreads();
+    // ---- 4. vertical pass + re-gamma + store (pad pixels: 0.5)
     for (int r = rg; r < ty_rows; r += 4) {
       const int py = tyi * ty_rows + r, px = tx * kDTX + c;  // position in the padded output
       if (py >= out_h || px >= out_w) continue;
       float v = 0.5f;
       const int ys = ysize[r];
-      if (ys > 0 && xs > 0) {
+      if (ys > 0 && xs > 0 && !(MTR_DET_ABLATE & 4)) {
         const int y0 = ymin[r] - y_lo;
         float acc;
         if (gy.aa) {
-          acc = __fmul_rn(temp[y0][c], wy[r][0]);
-          for (int k = 1; k < ys; ++k) acc = __fmaf_rn(temp[y0 + k][c], wy[r][k], acc);
+          acc = __fmul_rn(temp[y0 * kDTX + c], wy[r][0]);
+#pragma unroll
+          for (int k = 1; k < KT; ++k)
+            if (k < ys) acc = __fmaf_rn(temp[(y0 + k) * kDTX + c], wy[r][k], acc);
         } else {
           const int y1 = min(ymin[r] + 1, gy.in_size - 1) - y_lo;
-          acc = __fmaf_rn(temp[y0][c], wy[r][0], __fmul_rn(temp[y1][c], wy[r][1]));
+          acc = __fmaf_rn(temp[y0 * kDTX + c], wy[r][0], __fmul_rn(temp[y1 * kDTX + c], wy[r][1]));
         }
         v = powf(acc, (float)(1.0 / 2.2));
       }
@@ -207,6 +345,60 @@ extern "C" int mtr_detector_geometry(int H, int W, int input_size, mtr_detector_
   return MTR_OK;
 }
 
+// compute units of the current device (queried once per device and process; read-only)
+static int device_cu_count() {
+  static int cache[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cache[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    cache[dev] = n;
+  }
+  return cache[dev];
+}
+
+template <int KT, bool TAIL>
+static int launch_detector_pre_t(const uint8_t* images_u8, int N, int H, int W, const mtr_detector_geom* g,
+                               int ty, int rows_cap, int pitch, float* out, hipStream_t stream) {
+  const mtr::AxisGeom gx{W, g->target_w, g->antialias}, gy{H, g->target_h, g->antialias};
+  const size_t lds = (size_t)rows_cap * pitch + (size_t)rows_cap * mtr::kDTX * sizeof(float);
+  auto kern = mtr::detector_pre_kernel<KT, TAIL>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  // persistent: every workgroup keeps one column tile; G workgroups share its (plane, row tile)
+  // pairs.  The grid is sized to what is RESIDENT at once (a workgroup that has to wait for a slot
+  // makes a second round: 128 -> 80 us on 8 x 1080p).
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 256, lds) != hipSuccess ||
+      per_cu < 1)
+    per_cu = 1;
+  const int n_cu = device_cu_count();
+  const int tiles_x = (g->out_w + mtr::kDTX - 1) / mtr::kDTX;
+  const long long pairs = (long long)N * 3 * ((g->out_h + ty - 1) / ty);
+  long long G = (long long)per_cu * n_cu / tiles_x;
+  if (G < 1) G = 1;
+  if (G > pairs) G = pairs;
+  const int grid = (int)(G * tiles_x);
+  MTR_CLEAR_STALE();
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, images_u8, (size_t)N * 3 * H * W, N * 3,
+                     gx, gy, g->pad_top, g->pad_left, g->out_h, g->out_w, ty, rows_cap, pitch, out);
+  MTR_CHECK_LAUNCH();
+  return MTR_OK;
+}
+
+template <int KT>
+static int launch_detector_pre(const uint8_t* images_u8, int N, int H, int W, const mtr_detector_geom* g,
+                               int ty, int rows_cap, int pitch, float* out, hipStream_t stream) {
+  if (((size_t)N * 3 * H * W) % 16)
+    return launch_detector_pre_t<KT, true>(images_u8, N, H, W, g, ty, rows_cap, pitch, out, stream);
+  return launch_detector_pre_t<KT, false>(images_u8, N, H, W, g, ty, rows_cap, pitch, out, stream);
+}
+
 extern "C" int mtr_detector_preprocess(const uint8_t* images_u8, int N, int H, int W,
                                        const mtr_detector_geom* g, float* out, mtr_stream_t stream) {
   if (!images_u8 || !g || !out) return MTR_E_NULL;
@@ -215,23 +407,26 @@ extern "C" int mtr_detector_preprocess(const uint8_t* images_u8, int N, int H, i
       g->pad_top < 0 || g->pad_left < 0 || g->pad_top + g->target_h > g->out_h ||
       g->pad_left + g->target_w > g->out_w)
     return MTR_E_PARAM;
+  if ((uintptr_t)images_u8 % 16) return MTR_E_ALIGN;
   if (N == 0) return MTR_OK;
   const float sx = (float)W / (float)g->target_w, sy = (float)H / (float)g->target_h;
   const float supx = (g->antialias && sx >= 1.0f) ? sx : 1.0f, supy = (g->antialias && sy >= 1.0f) ? sy : 1.0f;
-  if (2.0f * supx + 2.0f > (float)mtr::kDTaps || 2.0f * supy + 2.0f > (float)mtr::kDTaps)
-    return MTR_E_SHAPE;  // > 19x shrink: resize in two steps
-  // rows of the intermediate a tile needs: TY * scale + 2 * support + 2 <= kDRows
-  int ty = (int)(((float)mtr::kDRows - 2.0f * supy - 3.0f) / (sy > 1.0f ? sy : 1.0f));
-  if (ty > mtr::kDTYMax) ty = mtr::kDTYMax;
+  const int taps = (int)(2.0f * (supx > supy ? supx : supy)) + 2;  // isize <= 2 * support + 1
+  if (taps > mtr::kDTaps) return MTR_E_SHAPE;  // > 19x shrink: resize in two steps
+  // bytes of a staged row: 64 columns' worth of source + both supports + alignment slack
+  const int pitch = (((int)(mtr::kDTX * (sx > 1.0f ? sx : 1.0f) + 2.0f * supx) + 40) + 15) / 16 * 16;
+  // rows a tile of TY output rows needs: TY * scale + 2 * support + 2; fit stage + temp in 60 KiB
+  int ty = mtr::kDTYMax, rows_cap = 0;
+  for (; ty >= 1; --ty) {
+    rows_cap = (int)((float)ty * (sy > 1.0f ? sy : 1.0f) + 2.0f * supy) + 3;
+    if ((size_t)rows_cap * (pitch + mtr::kDTX * sizeof(float)) <= 60 * 1024) break;
+  }
   if (ty < 1) return MTR_E_SHAPE;
-  const mtr::AxisGeom gx{W, g->target_w, g->antialias}, gy{H, g->target_h, g->antialias};
-  const long long tiles = (long long)N * 3 * ((g->out_h + ty - 1) / ty) * ((g->out_w + mtr::kDTX - 1) / mtr::kDTX);
-  const int grid = (int)(tiles < 256 * 3 ? tiles : 256 * 3);  // persistent, 3 workgroups per CU
-  MTR_CLEAR_STALE();
-  hipLaunchKernelGGL(mtr::detector_pre_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, images_u8,
-                     N * 3, gx, gy, g->pad_top, g->pad_left, g->out_h, g->out_w, ty, out);
-  MTR_CHECK_LAUNCH();
-  return MTR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (!g->antialias) return launch_detector_pre<2>(images_u8, N, H, W, g, ty, rows_cap, pitch, out, s);
+  if (taps <= 12) return launch_detector_pre<12>(images_u8, N, H, W, g, ty, rows_cap, pitch, out, s);
+  if (taps <= 24) return launch_detector_pre<24>(images_u8, N, H, W, g, ty, rows_cap, pitch, out, s);
+  return launch_detector_pre<mtr::kDTaps>(images_u8, N, H, W, g, ty, rows_cap, pitch, out, s);
 }
 
 extern "C" int mtr_detector_scale_boxes(const float* xyxy_conf, int n, const mtr_detector_geom* g,
