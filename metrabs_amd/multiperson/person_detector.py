@@ -41,6 +41,9 @@ class PersonDetector(torch.nn.Module):
         return list(self.network(x, threshold, nms_iou_threshold, max_detections))
 
     def forward(self, images, threshold, nms_iou_threshold, max_detections):
+        images = torch.as_tensor(images)
+        if not images.is_cuda:
+            images = images.cuda()
         x, geom = self.preprocess(images)
         per_image = self._run_network(x, threshold, nms_iou_threshold, max_detections)
         n_per_image = [len(b) for b in per_image]

@@ -80,3 +80,36 @@ def test_shrink_factor_limit_is_reported(hip_lib):
     img = torch.zeros(1, 3, 16, 9000, dtype=torch.uint8).cuda()  # 21.6x shrink
     with pytest.raises(RuntimeError):
         kernels.detector_preprocess(img)
+
+
+def test_detect_poses_runs_detector_then_the_hot_path(hip_lib):
+    """detect_poses_batched (multiperson_model.py:56-75 of the reference) = PersonDetector + the
+    per-crop path: with a stub network the result must equal estimate on the rescaled boxes."""
+    from test_gpu_e2e import build_estimator
+    from metrabs_amd.multiperson.person_detector import PersonDetector
+    case = cases.e2e_case('aug5')
+    est = build_estimator(case, fused_head=True)
+    n_img, _, h, w = case['images'].shape
+    geom = cpu_ref.detector_target_size(h, w)
+    g = cases.gen(99)
+    net_boxes = []
+    for i in range(n_img):  # boxes well inside the network frame, one image without detections
+        k = 0 if i == 1 else 2
+        x1 = geom['pad_left'] + torch.rand(k, generator=g) * geom['target_w'] * 0.4
+        y1 = geom['pad_top'] + torch.rand(k, generator=g) * geom['target_h'] * 0.3
+        net_boxes.append(torch.stack([x1, y1, x1 + 0.3 * geom['target_w'], y1 + 0.6 * geom['target_h'],
+                                      0.5 + 0.5 * torch.rand(k, generator=g)], dim=1).float())
+    est.detector = PersonDetector(lambda x, t, i, m: [b.cuda() for b in net_boxes])
+    with torch.inference_mode():
+        got = est.detect_poses_batched(case['images'], case['K'], case['dist'], case['extr'], case['world_up'],
+                                       55, case['ibs'], case['aa'], case['num_aug'], case['average_aug'], '',
+                                       0.3, 0.7, 150, False, False)
+        boxes = [cpu_ref.detector_scale_boxes(b, geom) for b in net_boxes]
+        want = est._estimate_poses_batched(
+            case['images'], boxes, case['K'], case['dist'], case['extr'], case['world_up'], 55, case['ibs'],
+            case['aa'], case['num_aug'], case['average_aug'], '', False)
+    assert [len(b) for b in got['boxes']] == [len(b) for b in net_boxes]
+    for a, b in zip(got['boxes'], boxes):
+        assert torch.equal(a.cpu(), b)
+    for a, b in zip(got['poses3d'], want['poses3d']):
+        assert torch.equal(a, b)
