@@ -236,6 +236,38 @@ int mtr_detector_preprocess(const uint8_t* images_u8, int N, int H, int W, const
 int mtr_detector_scale_boxes(const float* xyxy_conf, int n, const mtr_detector_geom* g,
                              float* boxes_out, mtr_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * K8: plausibility filter + pose NMS, one launch per call (one
+ * workgroup per image).  Replaces _filter_poses (metrabs_tf/multiperson/multiperson_model.py:441-459)
+ * and plausibility_check.py (TF :9-96; PyTorch port metrabs_pytorch/multiperson/
+ * plausibility_check.py:8-119, whose call site multiperson_model.py:158-163 is commented out):
+ * is_pose_plausible, are_augmentation_results_consistent, is_pose_consistent_with_box,
+ * compute_pose_similarity, pose_non_max_suppression.
+ *   poses3d [P,A,J,3] camera-space mm (all model joints, before the skeleton selection),
+ *   poses2d [P,A,J,2] px, boxes [P,5] (x,y,w,h,score); poses of image i are rows
+ *   row_start[i] .. row_start[i+1]-1; sim_offsets[i] = sum_{k<i} n_k^2 (floats);
+ *   edges [n_bones,2] + mean_bones [n_bones] of the first J_model joints (n_bones = 0: no bone test).
+ *   -> valid [P] (u8, the three plausibility tests), keep_idx [P] (per image: the kept poses as
+ *      global row indices, then -1), keep_count [n_images].
+ */
+typedef struct mtr_filter_params {
+  float rel_small, rel_big, abs_diff_mm; /* 0.1, 3, 300   plausibility_check.py:22-24            */
+  float stdev_mm;                        /* 200           :64-66                                 */
+  float box_fraction;                    /* 0.5           TF :84                                  */
+  float sim_scale_mm, sim_threshold;     /* 300, 0.4      :83, :59                                */
+  int32_t max_output;                    /* 150 (TF max_output_size; used when order_by_score)     */
+  int32_t var_correction;                /* 0 = population variance (TF), 1 = torch.var default    */
+  int32_t order_by_score;                /* 1 = TF order (score descending), 0 = PyTorch port (index) */
+} mtr_filter_params;
+
+size_t mtr_filter_poses_workspace_bytes(int P, int J, int max_per_image);
+int mtr_filter_poses(const float* poses3d, const float* poses2d, const float* boxes,
+                     const int32_t* row_start, const int32_t* sim_offsets, int n_images, int P, int A,
+                     int J, const int32_t* edges, const float* mean_bones, int n_bones, int J_model,
+                     const mtr_filter_params* params /*host*/, void* workspace, size_t workspace_bytes,
+                     int max_per_image, uint8_t* valid, int32_t* keep_idx, int32_t* keep_count,
+                     mtr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

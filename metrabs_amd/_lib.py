@@ -35,6 +35,14 @@ class DetectorGeom(ctypes.Structure):
                 ('x_factor', c_float), ('y_factor', c_float)]
 
 
+class FilterParams(ctypes.Structure):
+    """mtr_filter_params (include/metrabs_hip.h); defaults = the reference's constants."""
+    _fields_ = [('rel_small', c_float), ('rel_big', c_float), ('abs_diff_mm', c_float),
+                ('stdev_mm', c_float), ('box_fraction', c_float), ('sim_scale_mm', c_float),
+                ('sim_threshold', c_float), ('max_output', c_int32), ('var_correction', c_int32),
+                ('order_by_score', c_int32)]
+
+
 # name -> (restype, argtypes); must list EVERY symbol the header declares
 # (tests/test_capi_symbols.py cross-checks this table against include/metrabs_hip.h).
 SIGNATURES = {
@@ -74,6 +82,10 @@ SIGNATURES = {
     'mtr_detector_preprocess': (c_int, [c_void_p, c_int, c_int, c_int, POINTER(DetectorGeom), c_void_p,
                                         c_void_p]),
     'mtr_detector_scale_boxes': (c_int, [c_void_p, c_int, POINTER(DetectorGeom), c_void_p, c_void_p]),
+    'mtr_filter_poses_workspace_bytes': (ctypes.c_size_t, [c_int, c_int, c_int]),
+    'mtr_filter_poses': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                 c_int, c_void_p, c_void_p, c_int, c_int, POINTER(FilterParams), c_void_p,
+                                 ctypes.c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None

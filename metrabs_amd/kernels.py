@@ -325,3 +325,51 @@ def detector_scale_boxes(xyxy_conf, geom):
                                                current_stream_ptr(b.device)),
           'mtr_detector_scale_boxes')
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# K8: plausibility filter + pose NMS (plausibility_check.py / TF _filter_poses)
+
+def filter_poses(poses3d, poses2d, boxes, n_per_image, edges, mean_bones, n_joints=None,
+                 unbiased=False, order='index', max_output=150):
+    """poses3d [P,A,J,3] (camera space, all model joints), poses2d [P,A,J,2], boxes [P,5], poses of
+    image i contiguous with n_per_image[i] rows.  edges [n_bones,2] / mean_bones [n_bones] may be
+    None (no bone-length test).  -> (keep_idx [P] i32: per image its kept rows then -1,
+    keep_count [n_images] i32, valid [P] bool) -- all on the GPU, no host sync."""
+    require_cuda(poses3d, poses2d, boxes)
+    P, A, J, _ = poses3d.shape
+    dev = poses3d.device
+    n_images = len(n_per_image)
+    counts = [int(x) for x in n_per_image]
+    if sum(counts) != P:
+        raise ValueError('n_per_image does not add up to the number of poses')
+    row_start = torch.tensor([0] + list(torch.tensor(counts).cumsum(0).tolist()) if counts else [0],
+                             dtype=torch.int32, device=dev)
+    sq = [c * c for c in counts]
+    sim_off = torch.tensor([sum(sq[:i]) for i in range(n_images)], dtype=torch.int32, device=dev)
+    max_n = max(counts) if counts else 0
+    lib = _lib.load()
+    ws_bytes = lib.mtr_filter_poses_workspace_bytes(P, J, max_n)
+    ws = torch.empty(ws_bytes // 8 + 1, dtype=torch.float64, device=dev)
+    valid = torch.zeros(P, dtype=torch.uint8, device=dev)
+    keep_idx = torch.full((P,), -1, dtype=torch.int32, device=dev)
+    keep_count = torch.zeros(n_images, dtype=torch.int32, device=dev)
+    if edges is not None and len(edges):
+        e = torch.as_tensor(edges, dtype=torch.int32, device=dev).contiguous()
+        mb = torch.as_tensor(mean_bones, dtype=torch.float32, device=dev).contiguous()
+        n_bones = e.shape[0]
+    else:
+        e = mb = None
+        n_bones = 0
+    fp = _lib.FilterParams(0.1, 3.0, 300.0, 200.0, 0.5, 300.0, 0.4, int(max_output),
+                           1 if unbiased else 0, 1 if order == 'score' else 0)
+    p3 = poses3d.float().contiguous()
+    p2 = poses2d.float().contiguous()
+    bx = boxes.float().contiguous()
+    check(lib.mtr_filter_poses(_ptr(p3), _ptr(p2), _ptr(bx), _ptr(row_start), _ptr(sim_off), n_images,
+                               P, A, J, _ptr(e) if e is not None else None,
+                               _ptr(mb) if mb is not None else None, n_bones,
+                               int(n_joints or J), ctypes.byref(fp), _ptr(ws), ws.numel() * 8, max_n,
+                               _ptr(valid), _ptr(keep_idx), _ptr(keep_count),
+                               current_stream_ptr(dev)), 'mtr_filter_poses')
+    return keep_idx, keep_count, valid.bool()

@@ -80,6 +80,14 @@ class Pose3dEstimator(torch.nn.Module):
         self.shard_across_ranks = False
         # K7: one HIP launch for everything after the crop model (False = the torch-op sequence)
         self.fused_postprocess = True
+        # Mean bone lengths (mm, one per joint_info.stick_figure_edges entry) switch on the
+        # plausibility filter + pose NMS for detect_poses*(suppress_implausible_poses=True) -- the TF
+        # reference's behaviour (FLAGS.bone_length_file, plausibility_check.py:13-16).  None (the
+        # default) = the PyTorch reference's behaviour: the flag is accepted and ignored
+        # (multiperson_model.py:158-163 is commented out there).
+        self.mean_bone_lengths = None
+        self.filter_unbiased_variance = False  # True: torch.var's default, as the PyTorch port
+        self.filter_order = 'index'            # 'score': tf.image.non_max_suppression_overlaps order
 
     # ------------------------------------------------------------------ public API (reference names)
 
@@ -223,7 +231,8 @@ class Pose3dEstimator(torch.nn.Module):
         tta = self._tta(num_aug, dev)
         n_joints = self.joint_info.n_joints
         idx = self.skeleton_joint_indices_table[skeleton]
-        if self.fused_postprocess:
+        suppress = bool(suppress_implausible_poses) and self.mean_bone_lengths is not None
+        if self.fused_postprocess and not suppress:
             n_out = len(idx)
             if sum(counts) == 0:
                 shape = (0, n_out) if average_aug else (0, num_aug, n_out)
@@ -252,6 +261,21 @@ class Pose3dEstimator(torch.nn.Module):
                 distort_points(ptu3d.project(poses3d_flat), distortion_b))
             poses2d_flat = torch.einsum(
                 'bank,bjk->banj', poses2d_flat_normalized, intrinsic_matrix_b[:, :2, :])
+            if suppress and sum(counts):
+                # TF multiperson_model.py:404-409,441-459: filter on the camera-space poses of all
+                # joints, before the world transform and the skeleton selection (K8, one launch)
+                from metrabs_amd.multiperson import plausibility_check
+                boxes_dev = list(torch.split(boxes_flat, counts))
+                keep = plausibility_check.filter_poses(
+                    boxes_dev, list(torch.split(poses3d_flat, counts)),
+                    list(torch.split(poses2d_flat, counts)), self.joint_info, self.mean_bone_lengths,
+                    unbiased=self.filter_unbiased_variance, order=self.filter_order)
+                offsets = np.cumsum([0] + counts[:-1])
+                sel = torch.cat([k + int(o) for k, o in zip(keep, offsets)])
+                boxes_out = [b[k] for b, k in zip(boxes_dev, keep)]
+                poses3d_flat, poses2d_flat = poses3d_flat[sel], poses2d_flat[sel]
+                inv_extrinsics_b = inv_extrinsics_b[sel]
+                counts = [len(k) for k in keep]
             poses3d_flat = torch.einsum(
                 'bank,bjk->banj', ptu3d.to_homogeneous(poses3d_flat), inv_extrinsics_b[:, :3, :])
             poses3d_flat = poses3d_flat[..., idx, :]

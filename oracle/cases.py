@@ -366,3 +366,87 @@ def detpre_case(name):
                                   y1 + 30 + 100 * torch.rand(k, generator=g),
                                   torch.rand(k, generator=g)], dim=1).float())
     return dict(images=images, net_boxes=boxes)
+
+
+# ------------------------------------------------------------------ plausibility filter + pose NMS
+
+# a standing person in camera space, mm (x right, y down, z forward): COCO-17 order
+_TEMPLATE17 = [(0, -1650, 0), (30, -1680, -20), (-30, -1680, -20), (70, -1660, 40), (-70, -1660, 40),
+               (180, -1400, 0), (-180, -1400, 0), (250, -1100, 20), (-250, -1100, 20),
+               (270, -850, -30), (-270, -850, -30), (110, -900, 0), (-110, -900, 0),
+               (120, -480, 10), (-120, -480, 10), (125, -60, 0), (-125, -60, 0)]
+
+# name -> (n_images, max poses per image, num_aug, n_joints, seed)
+FILTER_CASES = {
+    'coco17_aug5': (3, 7, 5, 17, 41),
+    'coco17_aug1': (2, 5, 1, 17, 42),
+    'chain40_aug3': (2, 6, 3, 40, 43),
+    'crowd_aug2': (1, 40, 2, 17, 44),
+}
+
+
+def filter_case(name):
+    """Per image: distinct people, near-duplicates of some of them (same person detected twice:
+    must be suppressed by the pose NMS), and poses that must fail each plausibility test (a bone
+    5x too long, augmentation results that disagree, a pose far outside its detection box).
+    Decisions are placed well away from the thresholds, so float summation order cannot flip them."""
+    n_images, max_poses, A, J, seed = FILTER_CASES[name]
+    g = gen(seed)
+    if J == 17:
+        template = torch.tensor(_TEMPLATE17, dtype=torch.float32)
+        edges = list(COCO17_EDGES)
+    else:  # a chain skeleton with J joints
+        template = torch.cumsum(torch.randn(J, 3, generator=g) * torch.tensor([60.0, 90.0, 40.0]), dim=0)
+        edges = [(i, i + 1) for i in range(J - 1)]
+    tj = torch.tensor(edges)
+    mean_bones = torch.norm(template[tj[:, 0]] - template[tj[:, 1]], dim=-1) * \
+        (0.9 + 0.2 * torch.rand(len(edges), generator=g))
+    f = 1000.0
+    boxes, poses3d, poses2d, kinds = [], [], [], []
+    for i in range(n_images):
+        n_people = int(torch.randint(1, max(2, max_poses // 2) + 1, (1,), generator=g)) if i != 1 else 0
+        items = []  # (pose [A,J,3], score, kind)
+        for _ in range(n_people):
+            base = template * (0.85 + 0.3 * torch.rand(1, generator=g)) + \
+                torch.tensor([0.0, 900.0, 0.0]) + \
+                (torch.rand(3, generator=g) - 0.5) * torch.tensor([3000.0, 300.0, 0.0]) + \
+                torch.tensor([0.0, 0.0, 3000.0 + 3000.0 * float(torch.rand(1, generator=g))])
+            pose = base[None] + torch.randn(A, J, 3, generator=g) * 8
+            items.append((pose, 0.5 + 0.5 * float(torch.rand(1, generator=g)), 'person'))
+            r = float(torch.rand(1, generator=g))
+            if r < 0.4:  # the same person detected twice
+                items.append((base[None] + torch.randn(A, J, 3, generator=g) * 12,
+                              0.3 + 0.2 * float(torch.rand(1, generator=g)), 'duplicate'))
+            elif r < 0.55:  # one bone far too long
+                bad = pose.clone()
+                bad[:, edges[3][0]] += torch.tensor([0.0, -2500.0, 0.0])
+                items.append((bad + torch.tensor([900.0, 0.0, 400.0]), 0.6, 'long_bone'))
+            elif r < 0.7 and A > 1:  # augmentation results disagree
+                items.append((base[None] + torch.tensor([1500.0, 0.0, 800.0]) +
+                              torch.randn(A, J, 3, generator=g) * 900, 0.55, 'inconsistent'))
+            elif r < 0.85:  # plausible pose, but nowhere near its detection box
+                items.append((pose + torch.tensor([-1200.0, 0.0, 300.0]), 0.7, 'off_box'))
+        if i == 0 and items:  # every case holds at least one stretched skeleton
+            bad = items[0][0].clone()
+            bad[:, edges[3][0]] += torch.tensor([0.0, -2500.0, 0.0])
+            items.insert(1, (bad + torch.tensor([900.0, 0.0, 400.0]), 0.6, 'long_bone'))
+        items = items[:max_poses]
+        order = torch.randperm(len(items), generator=g).tolist()
+        items = [items[k] for k in order]
+        if items:
+            p3 = torch.stack([it[0] for it in items])
+            p2 = f * p3[..., :2] / p3[..., 2:] + torch.tensor([960.0, 540.0])
+            m2 = p2.mean(dim=1)
+            lo, hi = m2.min(dim=1).values, m2.max(dim=1).values
+            bx = torch.cat([lo - 20, hi - lo + 40, torch.tensor([[it[1]] for it in items])], dim=1)
+            for k, it in enumerate(items):
+                if it[2] == 'off_box':
+                    bx[k, 0] += 3 * bx[k, 2]
+        else:
+            p3, p2, bx = torch.zeros(0, A, J, 3), torch.zeros(0, A, J, 2), torch.zeros(0, 5)
+        boxes.append(bx.float())
+        poses3d.append(p3.float())
+        poses2d.append(p2.float())
+        kinds.append([it[2] for it in items])
+    return dict(boxes=boxes, poses3d=poses3d, poses2d=poses2d, edges=edges, mean_bones=mean_bones.float(),
+                n_joints=J, kinds=kinds)

@@ -655,3 +655,132 @@ def detector_scale_boxes(xyxy_conf, m):
     b = xyxy_conf
     return torch.stack([(b[:, 0] - hw) * xf, (b[:, 1] - hh) * yf, (b[:, 2] - b[:, 0]) * xf,
                         (b[:, 3] - b[:, 1]) * yf, b[:, 4]], dim=1)
+
+
+# ------------------------------------------------------------------------------------------------
+# Row f.2 -- plausibility filter + pose NMS (the step AFTER the hot path inside detect_poses)
+# TF: metrabs_tf/multiperson/multiperson_model.py:441-459 (_filter_poses), plausibility_check.py:9-96.
+# PyTorch: metrabs_pytorch/multiperson/plausibility_check.py:8-119 is a port of the same functions,
+# but the call site is commented out (multiperson_model.py:158-163,357-378) and
+# is_pose_consistent_with_box (:86-103) does not run (torch.min(dim=) returns a tuple).  The
+# functions below follow the shared algorithm; where the twins differ the default is noted.
+
+def joint2bone_mat(edges, n_joints):
+    """posepile.joint_info.get_joint2bone_mat (third party; published algorithm): one row per
+    stick-figure edge, +1 at its first joint and -1 at its second."""
+    m = torch.zeros(len(edges), n_joints)
+    for b, (j1, j2) in enumerate(edges):
+        m[b, int(j1)] = 1
+        m[b, int(j2)] = -1
+    return m
+
+
+def is_pose_plausible(poses, edges, mean_bones, n_joints=None):
+    """plausibility_check.py:8-29.  poses [...,J,3]; a pose is implausible when some bone is
+    (< 0.1x or > 3x its mean length) AND more than 300 mm off."""
+    n_joints = n_joints or poses.shape[-2]
+    bones = joint2bone_mat(edges, n_joints) @ poses[..., :n_joints, :]
+    bone_lengths = torch.norm(bones, dim=-1)
+    mean_bones = torch.as_tensor(mean_bones, dtype=torch.float32)
+    rel = bone_lengths / mean_bones
+    diff = torch.abs(bone_lengths - mean_bones)
+    bad = torch.any(((rel > 3) | (rel < 0.1)) & (diff > 300), dim=-1)
+    return ~bad
+
+
+def scale_align(poses):
+    """plausibility_check.py:111-114."""
+    square_scales = torch.mean(torch.square(poses), dim=(-2, -1), keepdim=True)
+    mean_square_scale = torch.mean(square_scales, dim=-3, keepdim=True)
+    return poses * torch.sqrt(mean_square_scale / square_scales)
+
+
+def point_stdev(poses, item_dim, coord_dim, unbiased=False):
+    """plausibility_check.py:117-119.  TF's reduce_variance is the population variance
+    (unbiased=False, the default here: with num_aug=1 every pose is consistent); the PyTorch port's
+    torch.var defaults to the unbiased estimator (NaN at num_aug=1, x sqrt(A/(A-1)) otherwise)."""
+    var = torch.var(poses, dim=item_dim, keepdim=True, unbiased=unbiased)
+    return torch.squeeze(torch.sqrt(torch.sum(var, dim=coord_dim, keepdim=True)), (item_dim, coord_dim))
+
+
+def are_augmentation_results_consistent(poses3d, unbiased=False):
+    """plausibility_check.py:62-66: at least one fourth of the joints have a stdev under 200 mm."""
+    n_joints = poses3d.shape[-2]
+    stdevs = point_stdev(scale_align(poses3d), item_dim=1, coord_dim=-1, unbiased=unbiased)
+    return torch.count_nonzero(stdevs < 200, dim=1) > (n_joints // 4)
+
+
+def compute_pose_similarity(poses):
+    """plausibility_check.py:69-83 (both twins take the k LARGEST distances)."""
+    square_scales = torch.mean(torch.square(poses), dim=(-2, -1), keepdim=True)
+    s1, s2 = square_scales.unsqueeze(0), square_scales.unsqueeze(1)
+    mean_square_scales = (s1 + s2) / 2
+    f1, f2 = torch.sqrt(mean_square_scales / s1), torch.sqrt(mean_square_scales / s2)
+    dists = torch.linalg.norm(f1 * poses.unsqueeze(0) - f2 * poses.unsqueeze(1), dim=-1)
+    best = torch.topk(dists, k=poses.shape[-2] // 4, sorted=False).values
+    return torch.mean(torch.relu(1 - best / 300), dim=-1)
+
+
+def non_max_suppression_overlaps(overlaps, scores, overlap_threshold, max_output_size=150,
+                                 order='index'):
+    """Greedy NMS on a similarity matrix, highest score first (stable).  PyTorch port
+    (plausibility_check.py:32-52): survivors in ascending index order, no cap (order='index');
+    tf.image.non_max_suppression_overlaps (TF :37-39): survivors in descending score order, at most
+    max_output_size (order='score')."""
+    n = len(overlaps)
+    by_score = torch.argsort(scores, stable=True, dim=0, descending=True)
+    suppressed = torch.zeros(n, dtype=torch.bool)
+    kept = []
+    for _i in range(n):
+        i = int(by_score[_i])
+        if suppressed[i]:
+            continue
+        if order == 'score' and len(kept) >= max_output_size:
+            break
+        kept.append(i)
+        for _j in range(_i + 1, n):
+            j = int(by_score[_j])
+            if not suppressed[j] and overlaps[i, j] > overlap_threshold:
+                suppressed[j] = True
+    kept = torch.tensor(kept, dtype=torch.int64)
+    return kept if order == 'score' else torch.sort(kept).values
+
+
+def pose_non_max_suppression(poses, scores, is_pose_valid, order='index'):
+    """plausibility_check.py:55-59."""
+    idx = torch.squeeze(torch.argwhere(is_pose_valid), 1)
+    sim = compute_pose_similarity(poses[idx])
+    keep = non_max_suppression_overlaps(sim, scores[idx], 0.4, order=order)
+    return idx[keep]
+
+
+def is_pose_consistent_with_box(pose2d, box):
+    """TF plausibility_check.py:66-84 (the PyTorch port :86-103 raises TypeError as written): the
+    intersection of the 2D pose's bounding box with the detection covers more than half of the
+    detection."""
+    posebox_start = torch.min(pose2d, dim=-2).values
+    posebox_end = torch.max(pose2d, dim=-2).values
+    box_start, box_end = box[..., :2], box[..., :2] + box[..., 2:4]
+    box_area = torch.prod(box[..., 2:4], dim=-1)
+    inter = torch.relu(torch.minimum(box_end, posebox_end) - torch.maximum(box_start, posebox_start))
+    return torch.prod(inter, dim=-1) > 0.5 * box_area
+
+
+def filter_poses(boxes, poses3d, poses2d, edges, mean_bones, n_joints=None, unbiased=False,
+                 order='index'):
+    """TF multiperson_model.py:441-459.  boxes: list of [n_i,5]; poses3d: list of [n_i,A,J,3]
+    (camera space, before the skeleton selection); poses2d: list of [n_i,A,J,2].
+    -> (list of kept index tensors, list of plausibility masks)."""
+    keep, masks = [], []
+    for b, p3, p2 in zip(boxes, poses3d, poses2d):
+        if len(b) == 0:
+            keep.append(torch.zeros(0, dtype=torch.int64))
+            masks.append(torch.zeros(0, dtype=torch.bool))
+            continue
+        p3m, p2m = p3.mean(dim=-3), p2.mean(dim=-3)
+        mask = is_pose_plausible(p3m, edges, mean_bones, n_joints) \
+            & are_augmentation_results_consistent(p3, unbiased) \
+            & is_pose_consistent_with_box(p2m, b)
+        masks.append(mask)
+        keep.append(pose_non_max_suppression(p3m, b[:, 4], mask, order=order))
+    return keep, masks

@@ -144,6 +144,37 @@ def gen_detpre(ref):
              input_sha256=np.array(cases.sha256_of(c['images'], *c['net_boxes'])))
 
 
+def gen_filter(ref):
+    """Plausibility filter + pose NMS (row f.2).  The PyTorch reference never calls these functions
+    (multiperson_model.py:158-163 is commented out) and is_pose_consistent_with_box does not run as
+    written, so the vectors hold the outputs of the reference functions that DO run, on the case
+    inputs: is_pose_plausible, are_augmentation_results_consistent (torch.var: unbiased),
+    compute_pose_similarity, and pose_non_max_suppression given the oracle's validity mask."""
+    import simplepyutils
+    from oracle import cpu_ref
+    pc = ref.plausibility_check
+    for name in cases.FILTER_CASES:
+        c = cases.filter_case(name)
+        simplepyutils.mean_bones = c['mean_bones']
+        ji = ref.JointInfo([f'j{i}' for i in range(c['n_joints'])], c['edges'])
+        _, masks = cpu_ref.filter_poses(c['boxes'], c['poses3d'], c['poses2d'], c['edges'], c['mean_bones'])
+        out = {}
+        for i, (b, p3, mask) in enumerate(zip(c['boxes'], c['poses3d'], masks)):
+            if len(b) == 0:
+                continue
+            with torch.inference_mode():
+                m3 = p3.mean(dim=-3)
+                out[f'plausible_{i}'] = pc.is_pose_plausible(m3, ji)
+                if p3.shape[1] > 1:
+                    out[f'aug_consistent_unbiased_{i}'] = pc.are_augmentation_results_consistent(p3)
+                out[f'similarity_{i}'] = pc.compute_pose_similarity(m3)
+                out[f'valid_mask_{i}'] = mask
+                out[f'keep_{i}'] = pc.pose_non_max_suppression(m3, b[:, 4], mask)
+        save(f'filter_{name}', n_images=np.array(len(c['boxes'])),
+             input_sha256=np.array(cases.sha256_of(*c['boxes'], *c['poses3d'], *c['poses2d'], c['mean_bones'])),
+             **out)
+
+
 def gen_tta(ref):
     """TTA parameter tables computed by the reference's own expressions:
     run _estimate_poses_batched with a recording stub for _predict_in_batches."""
@@ -235,7 +266,7 @@ def main():
     torch.manual_seed(0)
     ref = rh.load()
     groups = dict(heads=gen_heads, headconv=gen_headconv, recon=gen_recon, warp=gen_warp,
-                  tta=gen_tta, e2e=gen_e2e, detpre=gen_detpre)
+                  tta=gen_tta, e2e=gen_e2e, detpre=gen_detpre, filter=gen_filter)
     for name in (sys.argv[1:] or groups):
         groups[name](ref)
 

@@ -103,8 +103,31 @@ def _install_stubs():
     ji = types.ModuleType('posepile.joint_info')
     ji.JointInfo = _JointInfoStub
     posepile.paths, posepile.joint_info = paths, ji
+
+    def get_joint2bone_mat(joint_info):
+        """posepile.joint_info.get_joint2bone_mat (third party, not vendored; published algorithm,
+        posepile/joint_info.py): one row per stick-figure edge, +1 at its first joint, -1 at its
+        second, so `mat @ pose` is the bone vector."""
+        import numpy as np
+        edges = joint_info.stick_figure_edges
+        mat = np.zeros([len(edges), joint_info.n_joints], np.float32)
+        for i_bone, (j1, j2) in enumerate(edges):
+            mat[i_bone, j1] = 1
+            mat[i_bone, j2] = -1
+        return torch.from_numpy(mat)
+
+    ji.get_joint2bone_mat = get_joint2bone_mat
+    ds3d = types.ModuleType('posepile.datasets3d')
+    posepile.datasets3d = ds3d
+    spu = types.ModuleType('simplepyutils')
+    # plausibility_check.py:13-16 reads FLAGS.bone_length_dataset / FLAGS.bone_length_file; the tests
+    # set `simplepyutils.mean_bones` and leave the dataset name empty
+    spu.FLAGS = types.SimpleNamespace(bone_length_dataset='', bone_length_file='<stub>')
+    spu.mean_bones = None
+    spu.load_pickle = lambda path: spu.mean_bones
     sys.modules.update({'posepile': posepile, 'posepile.paths': paths,
-                        'posepile.joint_info': ji})
+                        'posepile.joint_info': ji, 'posepile.datasets3d': ds3d,
+                        'simplepyutils': spu})
 
     tv = types.ModuleType('torchvision')
     tv.__path__ = []
@@ -188,5 +211,7 @@ def load():
         'metrabs_pytorch.multiperson.multiperson_model')
     _loaded['person_detector'] = importlib.import_module(
         'metrabs_pytorch.multiperson.person_detector')
+    _loaded['plausibility_check'] = importlib.import_module(
+        'metrabs_pytorch.multiperson.plausibility_check')
     _loaded['JointInfo'] = _JointInfoStub
     return types.SimpleNamespace(**_loaded)

@@ -134,6 +134,49 @@ def test_detector_preprocess_vs_golden(name):
     check(boxes, g['boxes'], g, atol=1e-4)
 
 
+@pytest.mark.parametrize('name', list(cases.FILTER_CASES))
+def test_pose_filter_vs_golden(name):
+    """Row f.2: the oracle's restatement against the outputs of the reference functions that run
+    (metrabs_pytorch/multiperson/plausibility_check.py: is_pose_plausible, compute_pose_similarity,
+    pose_non_max_suppression, are_augmentation_results_consistent with torch.var's unbiased default)."""
+    g = load_golden(f'filter_{name}')
+    c = cases.filter_case(name)
+    assert cases.sha256_of(*c['boxes'], *c['poses3d'], *c['poses2d'], c['mean_bones']) == str(g['input_sha256'])
+    keep, masks = cpu_ref.filter_poses(c['boxes'], c['poses3d'], c['poses2d'], c['edges'], c['mean_bones'])
+    for i, (b, p3) in enumerate(zip(c['boxes'], c['poses3d'])):
+        if len(b) == 0:
+            assert len(keep[i]) == 0
+            continue
+        m3 = p3.mean(dim=-3)
+        assert np.array_equal(cpu_ref.is_pose_plausible(m3, c['edges'], c['mean_bones']).numpy(), g[f'plausible_{i}'])
+        if p3.shape[1] > 1:
+            assert np.array_equal(cpu_ref.are_augmentation_results_consistent(p3, unbiased=True).numpy(),
+                                  g[f'aug_consistent_unbiased_{i}'])
+        check(cpu_ref.compute_pose_similarity(m3), g[f'similarity_{i}'], g, atol=1e-6)
+        assert np.array_equal(masks[i].numpy(), g[f'valid_mask_{i}'])
+        assert np.array_equal(keep[i].numpy(), g[f'keep_{i}'])
+
+
+def test_pose_filter_known_answers():
+    """Analytic cases for the parts the PyTorch reference cannot run: box consistency (TF
+    plausibility_check.py:66-84) and the TF ordering / cap of the NMS."""
+    pose2d = torch.tensor([[[10.0, 10.0], [50.0, 90.0]]])            # pose box (10,10)-(50,90)
+    assert bool(cpu_ref.is_pose_consistent_with_box(pose2d, torch.tensor([[0.0, 0.0, 60.0, 100.0, 1.0]])))   # 3200 > 3000
+    assert not bool(cpu_ref.is_pose_consistent_with_box(pose2d, torch.tensor([[0.0, 0.0, 100.0, 100.0, 1.0]])))  # 3200 < 5000
+    assert not bool(cpu_ref.is_pose_consistent_with_box(pose2d, torch.tensor([[200.0, 0.0, 50.0, 50.0, 1.0]])))   # disjoint
+    sim = torch.tensor([[1.0, 0.9, 0.0], [0.9, 1.0, 0.0], [0.0, 0.0, 1.0]])
+    sc = torch.tensor([0.5, 0.8, 0.6])
+    assert cpu_ref.non_max_suppression_overlaps(sim, sc, 0.4, order='index').tolist() == [1, 2]
+    assert cpu_ref.non_max_suppression_overlaps(sim, sc, 0.4, order='score').tolist() == [1, 2]
+    sc = torch.tensor([0.5, 0.8, 0.9])
+    assert cpu_ref.non_max_suppression_overlaps(sim, sc, 0.4, order='score').tolist() == [2, 1]
+    assert cpu_ref.non_max_suppression_overlaps(sim, sc, 0.4, max_output_size=1, order='score').tolist() == [2]
+    # num_aug = 1: population variance 0 -> consistent (TF); the PyTorch port's unbiased variance is NaN
+    p = torch.randn(3, 1, 17, 3) * 100
+    assert bool(cpu_ref.are_augmentation_results_consistent(p).all())
+    assert not bool(cpu_ref.are_augmentation_results_consistent(p, unbiased=True).any())
+
+
 def test_detector_target_size_known_answers():
     """person_detector.py:15-29 in numpy float32: 1080p -> 234 x 416 padded to 256 x 416 (11 rows of
     0.5 above and below), antialiased; frames at or below 416 px are enlarged without antialiasing."""

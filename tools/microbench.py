@@ -151,8 +151,30 @@ def bench_detector_pre():
     return out
 
 
+def bench_filter():
+    """K8: plausibility filter + pose NMS, one launch per call; beside it the oracle's torch-op
+    formulation (what the reference runs) on the host."""
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import cases, cpu_ref
+    out = []
+    for name, reps in [('coco17_aug5', 8), ('crowd_aug2', 8)]:
+        c = cases.filter_case(name)
+        boxes, p3, p2 = c['boxes'] * reps, c['poses3d'] * reps, c['poses2d'] * reps
+        counts = [len(b) for b in boxes]
+        P3, P2, BX = torch.cat(p3).cuda(), torch.cat(p2).cuda(), torch.cat(boxes).cuda()
+        t = timeit(lambda: kernels.filter_poses(P3, P2, BX, counts, c['edges'], c['mean_bones']))
+        t0 = time.perf_counter()
+        for _ in range(3):
+            cpu_ref.filter_poses(boxes, p3, p2, c['edges'], c['mean_bones'])
+        tc = (time.perf_counter() - t0) / 3
+        out.append(dict(kernel='pose_filter', case=f'{name} x{reps}: {len(counts)} images, {sum(counts)} poses',
+                        us=round(t * 1e6, 1), cpu_torch_ops_us=round(tc * 1e6, 1)))
+    return out
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['decode', 'head', 'warp', 'recon', 'detector']
+    which = sys.argv[1:] or ['decode', 'head', 'warp', 'recon', 'detector', 'filter']
     res = []
     if 'decode' in which:
         res += bench_decode()
@@ -164,5 +186,7 @@ if __name__ == '__main__':
         res += bench_recon()
     if 'detector' in which:
         res += bench_detector_pre()
+    if 'filter' in which:
+        res += bench_filter()
     for r in res:
         print(json.dumps(r))
