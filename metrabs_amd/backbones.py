@@ -10,13 +10,19 @@ metrabs_tf/backbones/resnet.py:746-754 (ResNet-18) and metrabs_tf/backbones/mobi
 (MobileNetV3-Large, last_point_ch 1280).  Padding is symmetric k//2 (the reference uses TF-'SAME'
 fixed padding, efficientnet.py:1127-1161; irrelevant for throughput).
 """
+import collections
+
 import torch
 from torch import nn
 
 
 class ConvBNAct(nn.Sequential):
-    def __init__(self, cin, cout, k=3, s=1, groups=1, act=nn.SiLU, eps=1e-3):
-        layers = [nn.Conv2d(cin, cout, k, s, k // 2, groups=groups, bias=False),
+    """conv '0' + batch norm '1' (+ activation '2'): the parameter names of torchvision's
+    Conv2dNormActivation, which the reference's checkpoints use."""
+
+    def __init__(self, cin, cout, k=3, s=1, groups=1, act=nn.SiLU, eps=1e-3, padding=None):
+        layers = [nn.Conv2d(cin, cout, k, s, k // 2 if padding is None else padding, groups=groups,
+                            bias=False),
                   nn.BatchNorm2d(cout, eps=eps)]
         if act is not None:
             layers.append(act())
@@ -35,16 +41,38 @@ class SqueezeExcite(nn.Module):
         return x * self.gate(self.fc2(self.act(self.fc1(s))))
 
 
+def _padded_conv(layers, name, cin, cout, k, stride, groups=1, act=nn.SiLU, bottomright=False):
+    """The reference pads explicitly (TF 'SAME' independent of the input size,
+    efficientnet.py:1127-1161: (k-1)//2 before, the rest after, shifted one pixel to the bottom
+    right for the `bottomright_stride` layer) and convolves unpadded.  Symmetric padding is folded
+    into the convolution (same zeros, one op less); the asymmetric case keeps a ZeroPad2d, which
+    has no parameters, so the checkpoint keys are unaffected either way."""
+    total = k - 1
+    beg, end = total // 2, total - total // 2
+    if bottomright:
+        layers['padding'] = nn.ZeroPad2d((beg - 1, end + 1, beg - 1, end + 1))
+        layers[name] = ConvBNAct(cin, cout, k, stride, groups=groups, act=act, padding=0)
+    elif beg == end:
+        layers[name] = ConvBNAct(cin, cout, k, stride, groups=groups, act=act, padding=beg)
+    else:
+        layers['padding'] = nn.ZeroPad2d((beg, end, beg, end))
+        layers[name] = ConvBNAct(cin, cout, k, stride, groups=groups, act=act, padding=0)
+
+
 class FusedMBConv(nn.Module):
-    def __init__(self, cin, cout, expand, stride):
+    """efficientnet.py:176-234 (module names '0' [, '1'] inside `block`)."""
+
+    def __init__(self, cin, cout, expand, stride, bottomright=False):
         super().__init__()
         self.residual = stride == 1 and cin == cout
         mid = cin * expand
+        layers = collections.OrderedDict()
         if expand == 1:
-            self.block = ConvBNAct(cin, cout, 3, stride)
+            _padded_conv(layers, '0', cin, cout, 3, stride, bottomright=bottomright)
         else:
-            self.block = nn.Sequential(ConvBNAct(cin, mid, 3, stride),
-                                       ConvBNAct(mid, cout, 1, 1, act=None))
+            _padded_conv(layers, '0', cin, mid, 3, stride, bottomright=bottomright)
+            layers['1'] = ConvBNAct(mid, cout, 1, 1, act=None)
+        self.block = nn.Sequential(layers)
 
     def forward(self, x):
         y = self.block(x)
@@ -52,13 +80,21 @@ class FusedMBConv(nn.Module):
 
 
 class MBConv(nn.Module):
-    def __init__(self, cin, cout, expand, stride, k=3):
+    """efficientnet.py:110-173: '0' expand 1x1, '1' depthwise, '2' squeeze-excite (fc1, fc2),
+    '3' project."""
+
+    def __init__(self, cin, cout, expand, stride, k=3, bottomright=False):
         super().__init__()
         self.residual = stride == 1 and cin == cout
         mid = cin * expand
-        self.block = nn.Sequential(
-            ConvBNAct(cin, mid, 1, 1), ConvBNAct(mid, mid, k, stride, groups=mid),
-            SqueezeExcite(mid, max(1, cin // 4)), ConvBNAct(mid, cout, 1, 1, act=None))
+        layers = collections.OrderedDict()
+        if mid != cin:
+            layers['0'] = ConvBNAct(cin, mid, 1, 1)
+        n = len(layers)
+        _padded_conv(layers, str(n), mid, mid, k, stride, groups=mid, bottomright=bottomright)
+        layers[str(n + 1)] = SqueezeExcite(mid, max(1, cin // 4))
+        layers[str(n + 2)] = ConvBNAct(mid, cout, 1, 1, act=None)
+        self.block = nn.Sequential(layers)
 
     def forward(self, x):
         y = self.block(x)
@@ -73,25 +109,37 @@ class Preproc(nn.Module):
 
 
 EFFNETV2 = {
-    # (block, expand, stride, cin, cout, n_layers)
+    # (block, expand, stride, cin, cout, n_layers); efficientnet.py:399-431.  The LAST stride-2 stage
+    # is the `bottomright_stride=FLAGS.centered_stride` one.
     's': dict(stem=24, stages=[('f', 1, 1, 24, 24, 2), ('f', 4, 2, 24, 48, 4), ('f', 4, 2, 48, 64, 4),
                                ('m', 4, 2, 64, 128, 6), ('m', 6, 1, 128, 160, 9),
                                ('m', 6, 2, 160, 256, 15)], head=1280),
+    'm': dict(stem=24, stages=[('f', 1, 1, 24, 24, 3), ('f', 4, 2, 24, 48, 5), ('f', 4, 2, 48, 80, 5),
+                               ('m', 4, 2, 80, 160, 7), ('m', 6, 1, 160, 176, 14),
+                               ('m', 6, 2, 176, 304, 18), ('m', 6, 1, 304, 512, 5)], head=1280),
     'l': dict(stem=32, stages=[('f', 1, 1, 32, 32, 4), ('f', 4, 2, 32, 64, 7), ('f', 4, 2, 64, 96, 7),
                                ('m', 4, 2, 96, 192, 10), ('m', 6, 1, 192, 224, 19),
                                ('m', 6, 2, 224, 384, 25), ('m', 6, 1, 384, 640, 7)], head=1280),
 }
 
 
-def efficientnetv2(size='s'):
+def efficientnetv2(size='s', centered_stride=True):
+    """`Sequential(PreprocLayer(), efficientnet_v2_<size>().features)` of the reference
+    (scripts/demo_image.py:63-66) with the same module tree, hence the same state_dict keys
+    ('1.0.0.weight' = stem conv, '1.<stage>.<i>.block.<k>....', '1.<last>.0.weight' = 1x1 head conv)
+    and the same arithmetic (checked against the reference's own class on shared weights,
+    tests/test_oracle_pin.py)."""
     cfg = EFFNETV2[size]
-    layers = [Preproc(), ConvBNAct(3, cfg['stem'], 3, 2)]
-    for kind, expand, stride, cin, cout, n in cfg['stages']:
-        for i in range(n):
-            blk = FusedMBConv if kind == 'f' else MBConv
-            layers.append(blk(cin if i == 0 else cout, cout, expand, stride if i == 0 else 1))
-    layers.append(ConvBNAct(cfg['stages'][-1][4], cfg['head'], 1, 1))
-    net = nn.Sequential(*layers)
+    feats = collections.OrderedDict()
+    _padded_conv(feats, '0', 3, cfg['stem'], 3, 2)
+    last_s2 = max(i for i, st in enumerate(cfg['stages']) if st[2] == 2)
+    for si, (kind, expand, stride, cin, cout, n) in enumerate(cfg['stages']):
+        blk = FusedMBConv if kind == 'f' else MBConv
+        stage = [blk(cin if i == 0 else cout, cout, expand, stride if i == 0 else 1,
+                     bottomright=(centered_stride and si == last_s2 and i == 0)) for i in range(n)]
+        feats[str(si + 1)] = nn.Sequential(*stage)
+    feats[str(len(cfg['stages']) + 1)] = ConvBNAct(cfg['stages'][-1][4], cfg['head'], 1, 1)
+    net = nn.Sequential(Preproc(), nn.Sequential(feats))
     net.out_channels = cfg['head']
     return net
 

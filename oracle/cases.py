@@ -450,3 +450,35 @@ def filter_case(name):
         kinds.append([it[2] for it in items])
     return dict(boxes=boxes, poses3d=poses3d, poses2d=poses2d, edges=edges, mean_bones=mean_bones.float(),
                 n_joints=J, kinds=kinds)
+
+
+# ------------------------------------------------------------------ checkpoint format (row f.4)
+
+def deterministic_state(state_dict, seed=0):
+    """Fills a state_dict with values that depend only on each entry's NAME and shape (so two
+    implementations with the same keys get the same weights regardless of construction order):
+    conv weights ~ N(0, 1/fan_in), BN scale 0.8..1.2, BN var 0.5..1.5, everything else small."""
+    import hashlib
+    out = {}
+    for k, v in state_dict.items():
+        if v.dtype == torch.int64:  # num_batches_tracked
+            out[k] = torch.zeros_like(v)
+            continue
+        h = int(hashlib.sha256(f'{seed}:{k}'.encode()).hexdigest()[:8], 16)
+        g = torch.Generator().manual_seed(h)
+        if k.endswith('running_var'):
+            out[k] = 0.5 + torch.rand(v.shape, generator=g)
+        elif k.endswith('running_mean'):
+            out[k] = 0.1 * torch.randn(v.shape, generator=g)
+        elif v.dim() == 4:
+            fan_in = v.shape[1] * v.shape[2] * v.shape[3]
+            out[k] = torch.randn(v.shape, generator=g) * (1.0 / fan_in) ** 0.5
+        elif k.endswith('.1.weight') or k.endswith('bn.weight'):
+            out[k] = 0.8 + 0.4 * torch.rand(v.shape, generator=g)
+        else:
+            out[k] = 0.05 * torch.randn(v.shape, generator=g)
+    return out
+
+
+def backbone_probe_input():
+    return torch.rand(2, 3, 96, 96, generator=gen(314))

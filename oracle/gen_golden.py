@@ -175,6 +175,22 @@ def gen_filter(ref):
              **out)
 
 
+def gen_backbone(ref):
+    """Checkpoint format (row f.4): parameter names / shapes of the reference's backbone stack
+    `Sequential(PreprocLayer(), efficientnet_v2_<size>().features)` (scripts/demo_image.py:63-66) and
+    its output on name-determined weights (oracle/cases.py:deterministic_state)."""
+    for size in ('s', 'l'):
+        with rh.config():
+            net = getattr(ref.efficientnet, f'efficientnet_v2_{size}')()
+        stack = torch.nn.Sequential(ref.efficientnet.PreprocLayer(), net.features).eval()
+        sd = stack.state_dict()
+        stack.load_state_dict(cases.deterministic_state(sd))
+        with torch.inference_mode():
+            y = stack(cases.backbone_probe_input())
+        save(f'backbone_effnetv2_{size}', keys=np.array(list(sd)),
+             shapes=np.array([','.join(map(str, v.shape)) for v in sd.values()]), output=y)
+
+
 def gen_tta(ref):
     """TTA parameter tables computed by the reference's own expressions:
     run _estimate_poses_batched with a recording stub for _predict_in_batches."""
@@ -266,7 +282,7 @@ def main():
     torch.manual_seed(0)
     ref = rh.load()
     groups = dict(heads=gen_heads, headconv=gen_headconv, recon=gen_recon, warp=gen_warp,
-                  tta=gen_tta, e2e=gen_e2e, detpre=gen_detpre, filter=gen_filter)
+                  tta=gen_tta, e2e=gen_e2e, detpre=gen_detpre, filter=gen_filter, backbone=gen_backbone)
     for name in (sys.argv[1:] or groups):
         groups[name](ref)
 

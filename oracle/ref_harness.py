@@ -146,6 +146,91 @@ def _install_stubs():
                              align_corners=False, antialias=bool(antialias))
 
     tvf.resize = tv_resize
+
+    # ---- what metrabs_pytorch/backbones/efficientnet.py imports from torchvision (row f.4: the
+    # backbone's parameter names and TF-'SAME' padding are part of the checkpoint format).  The three
+    # classes with behaviour restate torchvision's published definitions (ops/misc.py,
+    # ops/stochastic_depth.py, models/_utils.py); the rest are inert placeholders for the ImageNet
+    # weight registry, which the reference never uses.
+    class Conv2dNormActivation(torch.nn.Sequential):
+        def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=None, groups=1,
+                     norm_layer=torch.nn.BatchNorm2d, activation_layer=torch.nn.ReLU, dilation=1,
+                     inplace=True, bias=None):
+            if padding is None:
+                padding = (kernel_size - 1) // 2 * dilation
+            if bias is None:
+                bias = norm_layer is None
+            layers = [torch.nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding,
+                                      dilation=dilation, groups=groups, bias=bias)]
+            if norm_layer is not None:
+                layers.append(norm_layer(out_channels))
+            if activation_layer is not None:
+                params = {} if inplace is None else {'inplace': inplace}
+                layers.append(activation_layer(**params))
+            super().__init__(*layers)
+            self.out_channels = out_channels
+
+    class SqueezeExcitation(torch.nn.Module):
+        def __init__(self, input_channels, squeeze_channels, activation=torch.nn.ReLU,
+                     scale_activation=torch.nn.Sigmoid):
+            super().__init__()
+            self.avgpool = torch.nn.AdaptiveAvgPool2d(1)
+            self.fc1 = torch.nn.Conv2d(input_channels, squeeze_channels, 1)
+            self.fc2 = torch.nn.Conv2d(squeeze_channels, input_channels, 1)
+            self.activation = activation()
+            self.scale_activation = scale_activation()
+
+        def forward(self, x):
+            scale = self.scale_activation(self.fc2(self.activation(self.fc1(self.avgpool(x)))))
+            return scale * x
+
+    class StochasticDepth(torch.nn.Module):  # identity at inference
+        def __init__(self, p, mode):
+            super().__init__()
+            self.p, self.mode = p, mode
+
+        def forward(self, x):
+            if self.training and self.p > 0:
+                raise NotImplementedError('training-time stochastic depth is not stubbed')
+            return x
+
+    def _make_divisible(v, divisor, min_value=None):
+        if min_value is None:
+            min_value = divisor
+        new_v = max(min_value, int(v + divisor / 2) // divisor * divisor)
+        if new_v < 0.9 * v:
+            new_v += divisor
+        return new_v
+
+    class Weights:
+        def __init__(self, url=None, transforms=None, meta=None):
+            self.url, self.transforms, self.meta = url, transforms, meta
+
+    class WeightsEnum:
+        @classmethod
+        def verify(cls, obj):
+            return None
+
+    def _mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    tv.models = _mod('torchvision.models')
+    _mod('torchvision.models._api', Weights=Weights, WeightsEnum=WeightsEnum)
+    _mod('torchvision.models._meta', _IMAGENET_CATEGORIES=[])
+    _mod('torchvision.models._utils', _make_divisible=_make_divisible,
+         _ovewrite_named_param=lambda kwargs, param, new_value: kwargs.__setitem__(param, new_value),
+         handle_legacy_interface=lambda **kw: (lambda fn: fn), _ModelURLs=dict)
+    tv.ops = _mod('torchvision.ops', StochasticDepth=StochasticDepth)
+    _mod('torchvision.ops.misc', Conv2dNormActivation=Conv2dNormActivation,
+         SqueezeExcitation=SqueezeExcitation)
+    _mod('torchvision.transforms._presets', ImageClassification=object,
+         InterpolationMode=types.SimpleNamespace(BICUBIC='bicubic', BILINEAR='bilinear'))
+    tv.utils = _mod('torchvision.utils', _log_api_usage_once=lambda *a, **k: None)
     sys.modules.update({'torchvision': tv, 'torchvision.transforms': tvt,
                         'torchvision.transforms.functional': tvf})
 
@@ -213,5 +298,6 @@ def load():
         'metrabs_pytorch.multiperson.person_detector')
     _loaded['plausibility_check'] = importlib.import_module(
         'metrabs_pytorch.multiperson.plausibility_check')
+    _loaded['efficientnet'] = importlib.import_module('metrabs_pytorch.backbones.efficientnet')
     _loaded['JointInfo'] = _JointInfoStub
     return types.SimpleNamespace(**_loaded)
