@@ -49,6 +49,7 @@ constexpr int kDppXor1 = 0xB1;    // quad_perm [1,0,3,2]
 constexpr int kDppXor2 = 0x4E;    // quad_perm [2,3,0,1]
 constexpr int kDppRor4 = 0x124;   // row_ror:4
 constexpr int kDppRor8 = 0x128;   // row_ror:8
+constexpr int kDppHalfMirror = 0x141;  // row_half_mirror: lane i <-> 7 - i inside each 8 lanes
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_move(float v) {
@@ -63,12 +64,15 @@ __device__ __forceinline__ double dpp_move(double v) {
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
-// every lane of an aligned group of WIDTH lanes (16 or 64) receives the group's sum / max
+// every lane of an aligned group of WIDTH lanes (8, 16, 32 or 64) receives the group's sum / max.
+// WIDTH 8: after the two quad steps every lane holds its quad's value, and row_half_mirror pairs
+// each lane with one of the other quad of its 8.
 template <int WIDTH, typename T>
 __device__ __forceinline__ T group_sum(T v) {
-  static_assert(WIDTH == 16 || WIDTH == 32 || WIDTH == 64, "groups are DPP rows / half / whole waves");
+  static_assert(WIDTH == 8 || WIDTH == 16 || WIDTH == 32 || WIDTH == 64, "DPP-row fractions / waves");
   v += dpp_move<kDppXor1>(v);
   v += dpp_move<kDppXor2>(v);
+  if (WIDTH == 8) return v + dpp_move<kDppHalfMirror>(v);
   v += dpp_move<kDppRor4>(v);
   v += dpp_move<kDppRor8>(v);
   if (WIDTH >= 32) v += __shfl_xor(v, 16, kWave);
@@ -77,9 +81,10 @@ __device__ __forceinline__ T group_sum(T v) {
 }
 template <int WIDTH>
 __device__ __forceinline__ float group_max(float v) {
-  static_assert(WIDTH == 16 || WIDTH == 32 || WIDTH == 64, "groups are DPP rows / half / whole waves");
+  static_assert(WIDTH == 8 || WIDTH == 16 || WIDTH == 32 || WIDTH == 64, "DPP-row fractions / waves");
   v = fmaxf(v, dpp_move<kDppXor1>(v));
   v = fmaxf(v, dpp_move<kDppXor2>(v));
+  if (WIDTH == 8) return fmaxf(v, dpp_move<kDppHalfMirror>(v));
   v = fmaxf(v, dpp_move<kDppRor4>(v));
   v = fmaxf(v, dpp_move<kDppRor8>(v));
   if (WIDTH >= 32) v = fmaxf(v, __shfl_xor(v, 16, kWave));
@@ -155,6 +160,13 @@ __device__ __forceinline__ void buffer_load_vec(buffer_rsrc_t rsrc, int voff_byt
     static_assert(sizeof(raw) == 16, "b128 load");
     const float4 f = __builtin_bit_cast(float4, raw);
     out[0] = f.x; out[1] = f.y; out[2] = f.z; out[3] = f.w;
+  } else if constexpr (VEC == 8 && sizeof(T) == 2) {
+    const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_bytes, soff_bytes, AUX);
+    static_assert(sizeof(raw) == 16, "b128 load");
+    struct Pack8 { T h[8]; };
+    const Pack8 pk = __builtin_bit_cast(Pack8, raw);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = to_f32(pk.h[i]);
   } else if constexpr (VEC == 4 && sizeof(T) == 2) {
     const auto raw = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff_bytes, soff_bytes, AUX);
     static_assert(sizeof(raw) == 8, "b64 load");

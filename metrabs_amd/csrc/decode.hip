@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void decode_nchw_kernel(
     const int p_raw = (it * LPJ + li) * VEC;
     const bool pos_ok = p_raw < HW;     // lanes past the map re-read position 0 with weight 0
     const int p0 = pos_ok ? p_raw : 0;
-    // (h, w) of the VEC elements; the VEC=4 instantiations require W % 4 == 0, so no wrap there
+    // (h, w) of the VEC elements; the VEC=4 / 8 instantiations require W % VEC == 0: no wrap there
     const int h0 = p0 / W, w0 = p0 - h0 * W;
     float fx[VEC], fy[VEC];  // small integers, exact in f32; widened at use (saves 8 VGPRs)
 #pragma unroll
@@ -181,7 +181,7 @@ static int launch_decode(const void* logits, int B, int J, int D, int H, int W, 
   // Non-temporal loads pay when every wave-wide load covers whole 128-B lines (8x8 f32 rows are
   // 256 B: +3 % at D=8, 73 -> 83 % of HBM at D=72); when map rows straddle lines (12x12: 576 B)
   // the neighbouring load re-fetches the evicted line (69 -> 58 %), so those keep the default policy.
-  const bool whole_lines = ((size_t)H * W * sizeof(T)) % 128 == 0 && VEC == 4;
+  const bool whole_lines = ((size_t)H * W * sizeof(T)) % 128 == 0 && VEC * sizeof(T) == 16;
   if (whole_lines) return launch_decode_aux<T, VEC, LPJ, 2>(logits, B, J, D, H, W, hs, c2d, c3d, stream);
   return launch_decode_aux<T, VEC, LPJ, 0>(logits, B, J, D, H, W, hs, c2d, c3d, stream);
 }
@@ -190,6 +190,17 @@ template <typename T>
 static int dispatch_decode(const void* logits, int B, int J, int D, int H, int W,
                            const HeadScale& hs, float* c2d, float* c3d, hipStream_t stream) {
   const int HW = H * W;
+  if constexpr (sizeof(T) == 2) {
+    // 16-bit logits (the reference's autocast GPU path): 8 elements = 16 bytes per lane, so that a
+    // wave keeps as many BYTES in flight as with f32 (8 x 16-B loads per lane); with 4-element
+    // loads the same kernel was latency-starved: 372 us = 3.5 TB/s on the 0.64 GB shape
+    const bool vec8 = (W % 8 == 0) && (((uintptr_t)logits) % 16 == 0);
+    if (vec8) {
+      if (HW <= 64) return launch_decode<T, 8, 8>(logits, B, J, D, H, W, hs, c2d, c3d, stream);
+      if (HW <= 512) return launch_decode<T, 8, 16>(logits, B, J, D, H, W, hs, c2d, c3d, stream);
+      return launch_decode<T, 8, 64>(logits, B, J, D, H, W, hs, c2d, c3d, stream);
+    }
+  }
   const bool vec4 = (W % 4 == 0) && (((uintptr_t)logits) % (4 * sizeof(T)) == 0);
   if (vec4) {
     // 16 lanes x 4 elements cover 64 positions per round; wider maps use the whole wave per joint
