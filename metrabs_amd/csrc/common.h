@@ -192,6 +192,32 @@ __device__ __forceinline__ double fast_rcp64(double x) {
   return r;
 }
 
+// exp(x) for x <= 0 in fp64, ~2e-13 relative: t = x*log2(e) = n + f, |f| <= 1/2, 2^f by a degree-11
+// Taylor polynomial of exp(f ln2) in Horner form (11 fma), scaled by 2^n through the exponent
+// field.  ocml's exp() spends ~4x the instructions on special cases and the last ulp, which a
+// softmax weight does not need (its error is relative to a term that is then summed in fp64 and
+// rounded to fp32).  Terms below 2^-1000 are flushed to 0.
+__device__ __forceinline__ double exp_neg64(double x) {
+  const double t = x * 1.4426950408889634;  // log2(e)
+  if (!(t > -1000.0)) return 0.0;            // also catches -inf / NaN
+  const double n = rint(t);
+  const double z = (t - n) * 0.6931471805599453;  // f * ln2, |z| <= 0.347
+  double p = 2.505210838544172e-08;               // 1/11!
+  p = fma(p, z, 2.755731922398589e-07);
+  p = fma(p, z, 2.755731922398589e-06);
+  p = fma(p, z, 2.48015873015873e-05);
+  p = fma(p, z, 1.984126984126984e-04);
+  p = fma(p, z, 1.388888888888889e-03);
+  p = fma(p, z, 8.333333333333333e-03);
+  p = fma(p, z, 4.166666666666666e-02);
+  p = fma(p, z, 1.666666666666667e-01);
+  p = fma(p, z, 0.5);
+  p = fma(p, z, 1.0);
+  p = fma(p, z, 1.0);
+  const long long bits = __builtin_bit_cast(long long, p) + ((long long)n << 52);  // p * 2^n, n <= 0
+  return __builtin_bit_cast(double, bits);
+}
+
 // Expectation of an axis index -> [0,1]: ptu.decode_heatmap dots with linspace(0,1,n)
 // (ptu.py:68-70); ptu.linspace(num==1) is the midpoint 0.5 (ptu.py:83-84).
 __device__ __forceinline__ float axis_coord(double weighted_index_sum, double total, int n) {

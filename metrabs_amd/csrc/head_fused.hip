@@ -242,7 +242,7 @@ __device__ __forceinline__ void decode_group_from_lds(const float* Ls, int HWP, 
         const vecf u3 = *reinterpret_cast<const vecf*>(row3d + (size_t)d * HWP + p);
 #pragma unroll
         for (int q = 0; q < PV; ++q) {
-          const double e = ACC64 ? exp((double)u3[q] - (double)m3) : (double)expf(u3[q] - m3);
+          const double e = ACC64 ? exp_neg64((double)u3[q] - (double)m3) : (double)expf(u3[q] - m3);
           col[q] += e;
           sz3 += e * (double)d;
         }
@@ -250,7 +250,7 @@ __device__ __forceinline__ void decode_group_from_lds(const float* Ls, int HWP, 
 #pragma unroll
       for (int q = 0; q < PV; ++q) {
         const int h = (p + q) / W, w = (p + q) - h * W;  // narrow maps wrap more than once
-        const double e2 = ACC64 ? exp((double)v2[q] - (double)m2) : (double)expf(v2[q] - m2);
+        const double e2 = ACC64 ? exp_neg64((double)v2[q] - (double)m2) : (double)expf(v2[q] - m2);
         s2 += e2; sx2 += e2 * w; sy2 += e2 * h;
         s3 += col[q]; sx3 += col[q] * w; sy3 += col[q] * h;
       }
@@ -728,7 +728,8 @@ __global__ __launch_bounds__(256, 2) void head_fused32_kernel(
       HEAD32_READ(0, 2)                                                                           \
       __builtin_amdgcn_sched_barrier(0); /* fragment reads first, then the load addresses */      \
     }                                                                                             \
-    /* (past the end: reload the last stage, never consumed -- keeps the body branch-free) */     \
+    /* (past the end: reload the last stage, never consumed -- keeps the body branch-free; a    \
+       uniform branch around the load measured no better) */                                      \
     if (!(MTR_ABLATE & (4 | 32)))                                                                 \
       load_stage32<FeatT, B_VECS, NHWC>(src, w32, min(s_ + kAhead, n_stages - 1), LD);            \
     if (!(MTR_ABLATE & 2)) {                                                                      \
