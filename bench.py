@@ -85,6 +85,12 @@ def build_model(args, dev):
     from metrabs_amd.joint_info import JointInfo
     from metrabs_amd.models.metrabs import Metrabs
     from metrabs_amd.multiperson.multiperson_model import Pose3dEstimator
+    # MIOpen's immediate mode (PyTorch's default) falls back to its naive direct convolution for
+    # the depthwise layers on this stack (44 % of the step's GPU time in profiles/r01d_kernel_trace).
+    # Benchmark mode (MIOpen times its applicable solvers per layer shape) was tried: 2 minutes of
+    # search on a fresh box and the same 14.1 ms step, so it stays off (MTR_BENCH_MIOPEN_FIND=1).
+    if os.environ.get('MTR_BENCH_MIOPEN_FIND', '0') == '1':
+        torch.backends.cudnn.benchmark = True
     torch.manual_seed(1234)
     cfg = MetrabsConfig(proc_side=args.res)
     names = JOINT_NAMES if args.joints == 17 else [f'j{i}' for i in range(args.joints)]
@@ -97,12 +103,14 @@ def build_model(args, dev):
     model = model.to(dev)
     calibrate_batchnorm(model.backbone, args.res, dev)
     model = model.eval()
-    if autocast is not None:
+    channels_last = autocast is not None or os.environ.get('MTR_BENCH_CHANNELS_LAST') == '1'
+    if channels_last:
         model = model.to(memory_format=torch.channels_last)
     skel = {'': dict(indices=list(range(args.joints)), names=names, edges=edges)}
     est = Pose3dEstimator(model, skel, None)
     if autocast is not None:
         est.crop_dtype = autocast
+    if channels_last:
         est.crop_channels_last = True
     return est, cfg
 
