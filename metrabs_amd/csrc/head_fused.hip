@@ -10,8 +10,8 @@
 // J*(1+D) = 153, HW = 64, C = 1280 for EffNetV2-S/256): 25 MFLOP over 328 KB of features
 // = 76 FLOP/B, above the f32-MFMA ridge (157 TF / 6.3-8 TB/s = 20-25), so in fp32 this kernel is
 // MATRIX-bound.  Precision class follows the feature dtype:
-//   * f32 features (the reference's CPU path): v_mfma_f32_16x16x4_f32 over SHORT chains (KS k-steps
-//     = 16 channels), each chain's result carried into f64 accumulators on the VALU.  Why not a
+//   * f32 features (the reference's CPU path): f32-input MFMA over SHORT chains (16 channels),
+//     each chain's result carried into f64 accumulators on the VALU.  Why not a
 //     plain f32 chain: over K = 1280 it is ~4x noisier than oneDNN's blocked accumulation (1.6e-3
 //     vs 3.7e-4 mm from the fp64 truth on the golden cases) and fails the 1e-3 mm gate.  Why not
 //     v_mfma_f64_16x16x4_f64 (round-1 first choice, exact products + f64 accumulate): a pure chain of
@@ -22,7 +22,11 @@
 //     f16): one f32 fma chain over all of K; weights and logits stay f32, i.e. strictly more
 //     accurate than the reference's f16 logits.
 //
-// Decomposition
+// Two GEMM cores share the packing, the grid mapping and the decode epilogue: the 16x16x4 core
+// described next (maps of <= 32 or 129..256 positions) and the 32x32x2 core further down (33..128
+// positions, i.e. the 8x8 maps of the 256-px models), which is the faster one where it applies.
+//
+// Decomposition (16x16x4 core)
 //   * weights are re-packed once (mtr_head_pack_weights) joint-major: joint j owns rows
 //     [2D chan j, depth 0 .. D-1] so a JOINT GROUP is a contiguous <=64-row block that can be
 //     decoded without leaving the workgroup; layout [group][c][64 rows] (k-major) so that the
@@ -570,9 +574,8 @@ __global__ __launch_bounds__(256, 2) void head_fused32_kernel(
   }
 
   // Register budget (256 VGPRs at 2 waves/SIMD): f64 carry accumulators take 32 per tile.
-  //   1 tile/wave : two partial sets (the carry of chain n-1 runs under chain n of the same tile);
-  //   2 tiles/wave: one partial set (chain n-1 is the other tile).
-  static_assert(TPW <= 2, "3 tiles per wave do not fit the register file in carry mode");
+  //   2 tiles/wave, carry mode: one f32 partial per tile, 16-channel chains, the carry of a chain
+  //     runs under the other tile's next chain.
   //   1 tile/wave, carry mode ("SC"): ONE carry per 32-channel stage.  The stage's two 16-channel
   //     chunks run as independent f32 chains (sub-accumulators a, b), are added in f32 (one more
   //     rounding, at the magnitude of a 32-channel sum) and that sum goes into f64: half the
@@ -592,11 +595,12 @@ __global__ __launch_bounds__(256, 2) void head_fused32_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0;
   }
-  // Two sub-accumulators per chain (even / odd MFMA) where the registers allow it: anything
-  // issued between two MFMAs on the SAME accumulator costs ~40 cycles (MI355X_MICROARCH.md,
-  // instruction timings), and this loop puts the carry VALU, the fragment reads, the global loads
-  // and the LDS stores exactly there; neighbours on different accumulators make those slots free.
-  constexpr int NSUB = TPW == 1 ? 2 : 1;  // (SC mode: sub-accumulator = chunk; f16 mode: even/odd MFMA)
+  // 1 tile/wave: two f32 accumulators per tile.  SC mode: sub-accumulator h = chunk h of the stage
+  // (two independent 16-channel chains).  16-bit features (no carry): even / odd MFMAs of the one
+  // long chain -- anything issued between two MFMAs on the SAME accumulator costs ~40 cycles
+  // (MI355X_MICROARCH.md, instruction timings) and this loop puts fragment reads, global loads and
+  // LDS stores exactly there; measured 34.6 -> 33.2 us at B = 64.
+  constexpr int NSUB = TPW == 1 ? 2 : 1;
   f32x16 part[PS][TPW][NSUB];  // ACC64: short-chain partials; else part[0] is the accumulator
 #pragma unroll
   for (int h = 0; h < PS; ++h)
@@ -645,13 +649,14 @@ __global__ __launch_bounds__(256, 2) void head_fused32_kernel(
 // holding more VALU than one MFMA lasts -- 64 cycles -- idles the matrix pipe).
 #define HEAD32_CHAIN(H_, T_, K0, K1)                                                              \
   {                                                                                               \
+    /* (used with one partial set: 2 tiles/wave in carry mode -- the previous chain is the other  \
+       tile's -- and the carry-free 16-bit mode) */                                               \
     constexpr int n_ = (H_) * TPW + (T_), pn_ = (n_ + NCH - 1) % NCH, pt_ = pn_ % TPW;            \
-    constexpr int ps_ = PS == 2 ? (H_) : 0, pps_ = PS == 2 ? pn_ / TPW : 0;                       \
     _Pragma("unroll") for (int k = (K0); k < (K1); ++k) {                                         \
-      HEAD32_MFMA1(ps_, T_, k % NSUB, 2 * (H_) + k / 4, k % 4, ACC64 && k < NSUB)                 \
+      HEAD32_MFMA1(0, T_, k % NSUB, 2 * (H_) + k / 4, k % 4, ACC64 && k < NSUB)                   \
       if constexpr (ACC64 && !(MTR_ABLATE & 8)) {                                                 \
         constexpr int e0_[9] = {0, 0, 2, 4, 6, 8, 11, 14, 16};                                    \
-        HEAD32_CARRY(pps_, pt_, e0_[k], e0_[k + 1])                                               \
+        HEAD32_CARRY(0, pt_, e0_[k], e0_[k + 1])                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                        \
       }                                                                                           \
     }                                                                                             \
@@ -675,8 +680,6 @@ __global__ __launch_bounds__(256, 2) void head_fused32_kernel(
       __builtin_amdgcn_sched_barrier(0);                                                          \
     }                                                                                             \
   }
-// Same iteration structure as HEAD32_ITER below; PAR = parity of the stage (a literal: the
-// partial sets must be indexed statically).
 // Same iteration structure as HEAD32_ITER below; PAR = parity of the stage (a literal: the
 // partial sets must be indexed statically).
 // (Staggering the LDS stores by wave -- one wave at a time on the CU's store path -- measured
