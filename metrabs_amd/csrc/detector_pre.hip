@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void detector_pre_kernel(
   __shared__ __attribute__((aligned(16))) float lut[256 * 16];
   __shared__ float wx[KT][kDTX];  // raw taps [tap][column]
   __shared__ float wy[kDTYMax][KT];
-  __shared__ float xtotal[kDTX], ytotal[kDTYMax];
+  __shared__ float xtotal[kDTX];
   __shared__ int xmin[kDTX], xsize[kDTX], ymin[kDTYMax], ysize[kDTYMax];
 
   uint8_t* stage = dyn;
@@ -163,31 +163,26 @@ __global__ __launch_bounds__(256) void detector_pre_kernel(
   for (long long t = lane0; t < (long long)planes * tiles_y; t += lanes) {
     const int tyi = (int)(t % tiles_y), pl = (int)(t / tiles_y);
     __syncthreads();  // previous tile fully consumed
-    // ---- 1. row weights of this tile: thread (r, k) evaluates tap k of row r
+    // ---- 1. row weights of this tile: thread (r, k) evaluates tap k of row r and, redundantly,
+    // the row's in-order float sum (<= KT cheap evaluations; saves two barriers per tile)
     for (int e = tid; e < ty_rows * KT; e += 256) {
       const int r = e / KT, k = e - r * KT;
       const int oy = tyi * ty_rows + r - pad_top;
       AxisSpan sy{0, 0, 0.f, 0.f, 0.f};
       if (oy >= 0 && oy < gy.out_size) sy = axis_span(oy, gy);
       sy.isize = min(sy.isize, KT);
-      wy[r][k] = k < sy.isize ? axis_raw_weight(sy, k, gy.aa) : 0.0f;
+      float w = k < sy.isize ? axis_raw_weight(sy, k, gy.aa) : 0.0f;
+      if (gy.aa) {
+        float total = 0.0f;
+        for (int q = 0; q < sy.isize; ++q) total = __fadd_rn(total, axis_raw_weight(sy, q, 1));
+        if (total != 0.0f) w = __fdiv_rn(w, total);
+      }
+      wy[r][k] = w;
       if (k == 0) {
         ymin[r] = sy.imin;
         ysize[r] = sy.isize;
       }
     }
-    __syncthreads();
-    if (tid < ty_rows) {  // in-order float sum per row (the normalisation aten applies)
-      float total = 0.0f;
-      for (int k = 0; k < ysize[tid]; ++k) total = __fadd_rn(total, wy[tid][k]);
-      ytotal[tid] = total;
-    }
-    __syncthreads();
-    if (gy.aa)
-      for (int e = tid; e < ty_rows * KT; e += 256) {
-        const int r = e / KT, k = e - r * KT;
-        if (ytotal[r] != 0.0f) wy[r][k] = __fdiv_rn(wy[r][k], ytotal[r]);
-      }
     __syncthreads();
     // rows of the frame this tile reads (ymin, ymin + ysize monotone in the row)
     int y_lo = 0, n_rows = 0;
@@ -281,27 +276,41 @@ __global__ __launch_bounds__(256) void detector_pre_kernel(
       }
     }
     __syncthreads();
-    // ---- 4. vertical pass + re-gamma + store (pad pixels: 0.5)
-    for (int r = rg; r < ty_rows; r += 4) {
-      const int py = tyi * ty_rows + r, px = tx * kDTX + c;  // position in the padded output
-      if (py >= out_h || px >= out_w) continue;
-      float v = 0.5f;
-      const int ys = ysize[r];
-      if (ys > 0 && xs > 0 && !(MTR_DET_ABLATE & 4)) {
-        const int y0 = ymin[r] - y_lo;
-        float acc;
-        if (gy.aa) {
-          acc = __fmul_rn(temp[y0 * kDTX + c], wy[r][0]);
+    // ---- 4. vertical pass + re-gamma + store (pad pixels: 0.5); a thread's rows (r, r+4) run
+    // as independent chains
+    {
+      constexpr int VU = (kDTYMax + 3) / 4;
+      float acc[VU];
+      bool live[VU], inside[VU];
 #pragma unroll
-          for (int k = 1; k < KT; ++k)
-            if (k < ys) acc = __fmaf_rn(temp[(y0 + k) * kDTX + c], wy[r][k], acc);
-        } else {
-          const int y1 = min(ymin[r] + 1, gy.in_size - 1) - y_lo;
-          acc = __fmaf_rn(temp[y0 * kDTX + c], wy[r][0], __fmul_rn(temp[y1 * kDTX + c], wy[r][1]));
+      for (int u = 0; u < VU; ++u) {
+        const int r = rg + 4 * u;
+        const int py = tyi * ty_rows + r, px = tx * kDTX + c;
+        inside[u] = r < ty_rows && py < out_h && px < out_w;
+        const int rr = min(r, ty_rows - 1);
+        const int ys = ysize[rr];
+        live[u] = inside[u] && ys > 0 && xs > 0 && !(MTR_DET_ABLATE & 4);
+        acc[u] = 0.5f;
+        if (live[u]) {
+          const int y0 = ymin[rr] - y_lo;
+          if (gy.aa) {
+            float a = __fmul_rn(temp[y0 * kDTX + c], wy[rr][0]);
+#pragma unroll
+            for (int k = 1; k < KT; ++k)
+              if (k < ys) a = __fmaf_rn(temp[(y0 + k) * kDTX + c], wy[rr][k], a);
+            acc[u] = a;
+          } else {
+            const int y1 = min(ymin[rr] + 1, gy.in_size - 1) - y_lo;
+            acc[u] = __fmaf_rn(temp[y0 * kDTX + c], wy[rr][0], __fmul_rn(temp[y1 * kDTX + c], wy[rr][1]));
+          }
         }
-        v = powf(acc, (float)(1.0 / 2.2));
       }
-      out[((size_t)pl * out_h + py) * out_w + px] = v;
+#pragma unroll
+      for (int u = 0; u < VU; ++u) {
+        if (!inside[u]) continue;
+        const int py = tyi * ty_rows + rg + 4 * u, px = tx * kDTX + c;
+        out[((size_t)pl * out_h + py) * out_w + px] = live[u] ? powf(acc[u], (float)(1.0 / 2.2)) : 0.5f;
+      }
     }
   }
 }
