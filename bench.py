@@ -115,6 +115,16 @@ def build_model(args, dev):
     return est, cfg
 
 
+def head_kernel_name(hw, n_crops, J, D):
+    """Which GEMM kernel mtr_head_fused dispatches to (metrabs_amd/csrc/head_fused.hip:dispatch_head)."""
+    if not 32 < hw <= 128:
+        return 'head_fused_kernel'
+    jg_max = 64 // (1 + D)
+    n_groups = -(-J // jg_max)
+    blocks = -(-n_crops // 8) * 8 * n_groups
+    return 'head_fused32w8_kernel' if hw <= 64 and blocks <= 512 else 'head_fused32_kernel'
+
+
 def time_stage(fn, iters, warm=3):
     for _ in range(warm):
         fn()
@@ -386,8 +396,7 @@ def main():
         'pyramid': dict(kernel='build_pyramid_u8_wide_kernel', bound='hbm', bytes=pyr_bytes),
         'warp': dict(kernel='warp_crops_kernel', bound='hbm',
                      bytes=n_crops * 3 * args.res ** 2 * out_bytes + src_bytes),
-        'head_fused': dict(kernel='head_fused32_kernel' if 32 < hw <= 128 else 'head_fused_kernel',
-                           bound='mfma', flops=head_flops,
+        'head_fused': dict(kernel=head_kernel_name(hw, n_crops, J, D), bound='mfma', flops=head_flops,
                            bytes=n_crops * (C * hw * feat_bytes + 20 * J)),
     }
     ours = {k: stages[k] for k in ('pyramid', 'geometry', 'warp', 'head_fused', 'reconstruct',

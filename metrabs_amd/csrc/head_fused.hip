@@ -830,6 +830,256 @@ __global__ __launch_bounds__(256, 2) void head_fused32_kernel(
                                lane);
 }
 
+// =====================================================================================
+// 8-wave variant of the 32x32 core for SMALL launches (fewer workgroups than ~2 per CU; config 2's
+// B = 64 gives 192 workgroups on 256 CUs).  There the 4-wave kernel leaves one wave per SIMD and
+// every in-order stall of that wave (LDS store issue, carry VALU, waits) idles the matrix pipe.
+// Here a workgroup has two waves per SIMD: waves 0-3 take channels 0..15 of every 32-channel
+// stage, waves 4-7 channels 16..31 (same 2x2 tile assignment), so each wave issues 8 of the
+// stage's 16 MFMAs per tile and the other wave's MFMAs fill its stalls; the two K-halves are
+// added through LDS once, before the decode.  Same LDS tiles, same staging volume, same f32
+// chains: a wave's chain is 16 channels (8 MFMAs), chains of two consecutive stages are added in
+// f32 and carried once (the SC pairing, over stages instead of chunks).
+template <typename FeatT, bool ACC64, bool NHWC>
+__global__ __launch_bounds__(512, 2) void head_fused32w8_kernel(
+    const FeatT* __restrict__ feat, const float* __restrict__ packed, int B, int C, int H, int W,
+    int J, int D, HeadGeom g, HeadScale hs, float* __restrict__ coords2d,
+    float* __restrict__ coords3d_rel) {
+  constexpr int CT = 2;
+  constexpr int HWP = hw_pad32<CT>();
+  constexpr int A_STAGE = kRows * kKC;    // floats
+  constexpr int B_STAGE = CT * 32 * kKC;  // floats
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                // [2][64][32]
+  float* Bs = smem + 2 * A_STAGE;  // [2][64][32], then 512 x 16-byte dump slots
+  float* Ls = smem;                // epilogue alias: [64][HWP]
+
+  const int HW = H * W;
+  const int chunk = 8 * g.n_groups;
+  const int id = blockIdx.x;
+  const int crop = (id / chunk) * 8 + (id % 8);
+  const int grp = (id % chunk) / 8;
+  if (crop >= B) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int kh = wid >> 2, wt = wid & 3;  // K-half, tile
+  const int n_stages = g.c_pad / kKC;
+  const FeatT* fcrop = feat + (size_t)crop * C * HW;
+  const size_t n_w = (size_t)g.n_groups * g.c_pad * kRows;
+  const float* w32 = packed + n_w + (size_t)g.n_groups * kRows + (size_t)grp * g.c_pad * kRows;
+  const float* bgrp = packed + n_w + (size_t)grp * kRows;
+  const int vec_per_row = HW / 4;
+
+  for (int v = tid; v < 2 * B_STAGE; v += 512) Bs[v] = 0.0f;
+
+  const int rt = wt & 1, ct0 = wt >> 1;
+  const int fi = lane & 31, fg = lane >> 5;
+  const int a_row = rt * 32 + fi, b_pos = ct0 * 32 + fi;
+  // slot 2u + g with u = 2 kh + {0, 1}
+  const int a_off = a_row * kKC + (((fg ^ swz(a_row)) << 2) ^ (kh << 4));
+  const int b_off = b_pos * kKC + (((fg ^ swz(b_pos)) << 2) ^ (kh << 4));
+
+  // ---- staging: one 16-byte vector of each tile per thread and stage
+  using RawT = typename RawVec<FeatT>::type;
+  struct Regs { v4f a; RawT b; };
+  const int b_total = kKC * vec_per_row;  // NCHW vectors per stage (<= 512 at 8x8)
+  auto load_stage = [&](int stage, Regs& r) {
+    const int c0 = stage * kKC;
+    r.a = *reinterpret_cast<const v4f*>(w32 + (size_t)stage * (kRows * kKC) + (size_t)tid * 4);
+    bool ok;
+    size_t off;
+    if constexpr (NHWC) {
+      const int pos = tid >> 3, c4 = tid & 7;
+      ok = pos < HW && c0 + c4 * 4 < C;
+      off = (size_t)pos * C + c0 + c4 * 4;
+    } else {
+      const int row = tid / vec_per_row, q = tid - row * vec_per_row;
+      ok = tid < b_total && c0 + row < C;
+      off = (size_t)(c0 + row) * HW + q * 4;
+    }
+    r.b = load4_raw<FeatT>(fcrop + (ok ? off : 0));
+  };
+  auto store_stage = [&](int stage, int buf, const Regs& r) {
+    const int c0 = stage * kKC;
+    float* Ab = As + buf * A_STAGE;
+    float* Bb = Bs + buf * B_STAGE;
+    const int dump = (2 - buf) * B_STAGE + tid * 4;
+    {
+      const int row = tid >> 3, slot = tid & 7;
+      *reinterpret_cast<v4f*>(Ab + row * kKC + ((slot ^ swz(row)) << 2)) = r.a;
+    }
+    const v4f zero = v4f{0.f, 0.f, 0.f, 0.f};
+    if constexpr (NHWC) {
+      const int pos = tid >> 3, slot = tid & 7;
+      const int o = pos < HW ? pos * kKC + ((slot ^ swz(pos)) << 2) : dump;
+      *reinterpret_cast<v4f*>(Bb + o) = (c0 + slot * 4 < C) ? raw_to_f32(r.b, fcrop) : zero;
+    } else {
+      const int row = tid / vec_per_row, q = tid - row * vec_per_row;
+      const bool ok = tid < b_total;
+      const v4f val = (c0 + row < C) ? raw_to_f32(r.b, fcrop) : zero;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int pos = q * 4 + e;
+        const int o = pos * kKC + ((((row >> 2) ^ swz(pos)) << 2) | (row & 3));
+        Bb[ok ? o : dump + e] = val[e];
+      }
+    }
+  };
+
+  // ---- accumulators
+  double acc[ACC64 ? 16 : 1];
+  if constexpr (ACC64) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0;
+  }
+  // ACC64: part[Q][sub]: pair Q = (stage / 2) & 1, sub = stage & 1; else part[0][k & 1] accumulate
+  f32x16 part[2][2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) part[q][e] = f32x16{0};
+  v4f af[2], bf[2];  // [0]: channels 0..7 of this wave's chunk, [1]: channels 8..15 (used one iteration late)
+  af[1] = bf[1] = v4f{0.f, 0.f, 0.f, 0.f};
+
+#define W8_MFMA(Q_, E_, U_, S_, FIRST_)                                                            \
+  part[Q_][E_] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[U_][S_], bf[U_][S_],                     \
+                                                      (FIRST_) ? f32x16{0} : part[Q_][E_], 0, 0, 0);
+#define W8_CARRY(Q_, R0, R1)                                                                      \
+  _Pragma("unroll") for (int r = (R0); r < (R1); ++r) {                                           \
+    acc[r] += (double)(part[Q_][0][r] + part[Q_][1][r]);                                          \
+    asm volatile("" : "+v"(acc[r]));                                                              \
+  }
+// Iteration of stage S with literal phase PH = S & 3 (pair Q = PH >> 1, sub E = PH & 1):
+//   barrier; read the first fragment pair of S; the SECOND half (4 MFMAs) of the previous stage's
+//   chain from the fragments read before the barrier; read the second pair; issue the global
+//   loads of S+2; first half of S's chain with the LDS stores of S+1 in the middle.
+//   Carry mode: a pair (stages 2m, 2m+1) is complete after the deferred half at the top of
+//   iteration 2m+2 and is folded into f64 under that iteration's four first-half MFMAs.
+#define W8_ITER(S, PH, LD, ST)                                                                    \
+  {                                                                                               \
+    const int s_ = (S);                                                                           \
+    constexpr int q_ = (PH) >> 1, e_ = (PH) & 1;                                                  \
+    constexpr int pq_ = (((PH) + 3) & 3) >> 1, pe_ = (((PH) + 3) & 3) & 1; /* previous stage */   \
+    const float* Ab = As + e_ * A_STAGE;                                                          \
+    const float* Bb = Bs + e_ * B_STAGE;                                                          \
+    __syncthreads();                                                                              \
+    af[0] = *reinterpret_cast<const v4f*>(Ab + a_off);                                            \
+    bf[0] = *reinterpret_cast<const v4f*>(Bb + b_off);                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    load_stage(min(s_ + 2, n_stages - 1), LD);                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                               \
+      if constexpr (ACC64) {                                                                      \
+        W8_MFMA(pq_, pe_, 1, k, false)                                                            \
+      } else {                                                                                    \
+        W8_MFMA(0, k & 1, 1, k, false)                                                            \
+      }                                                                                           \
+    }                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    af[1] = *reinterpret_cast<const v4f*>(Ab + (a_off ^ 8));                                      \
+    bf[1] = *reinterpret_cast<const v4f*>(Bb + (b_off ^ 8));                                      \
+    _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                               \
+      if constexpr (ACC64) {                                                                      \
+        W8_MFMA(q_, e_, 0, k, k == 0)                                                             \
+        /* the pair finished by the deferred half above (stages S-2, S-1 when S is even) */       \
+        if constexpr (e_ == 0) { W8_CARRY(q_ ^ 1, 4 * k, 4 * k + 4) __builtin_amdgcn_sched_barrier(0); } \
+      } else {                                                                                    \
+        W8_MFMA(0, k & 1, 0, k, false)                                                            \
+      }                                                                                           \
+    }                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    store_stage(min(s_ + 1, n_stages - 1), e_ ^ 1, ST);                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    _Pragma("unroll") for (int k = 2; k < 4; ++k) {                                               \
+      if constexpr (ACC64) {                                                                      \
+        W8_MFMA(q_, e_, 0, k, false)                                                              \
+        if constexpr (e_ == 0) { W8_CARRY(q_ ^ 1, 4 * k, 4 * k + 4) __builtin_amdgcn_sched_barrier(0); } \
+      } else {                                                                                    \
+        W8_MFMA(0, k & 1, 0, k, false)                                                            \
+      }                                                                                           \
+    }                                                                                             \
+  }
+
+  Regs regs0, regs1;
+  load_stage(0, regs0);
+  load_stage(min(1, n_stages - 1), regs1);
+  __syncthreads();  // zero fill done
+  store_stage(0, 0, regs0);
+  for (int s = 0; s < n_stages; s += 4) {
+    W8_ITER(s, 0, regs0, regs1)
+    if (s + 1 < n_stages) W8_ITER(s + 1, 1, regs1, regs0)
+    if (s + 2 < n_stages) W8_ITER(s + 2, 2, regs0, regs1)
+    if (s + 3 < n_stages) W8_ITER(s + 3, 3, regs1, regs0)
+  }
+  // ---- drain: second half of the last stage's chain, then the open pair(s)
+  {
+    const int last = (n_stages - 1) & 3;  // phase of the last stage (run-time)
+#define W8_DRAIN(PH)                                                                              \
+    {                                                                                             \
+      constexpr int q_ = (PH) >> 1, e_ = (PH) & 1;                                                \
+      _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                             \
+        if constexpr (ACC64) { W8_MFMA(q_, e_, 1, k, false) } else { W8_MFMA(0, k & 1, 1, k, false) } \
+      }                                                                                           \
+      if constexpr (ACC64) {                                                                      \
+        /* pair q_ holds the last one or two stages; when the last stage is even the previous    \
+           pair (q_^1) was already folded in during that stage */                                 \
+        if constexpr (e_ == 0) {                                                                  \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[r] += (double)part[q_][0][r];        \
+        } else {                                                                                  \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r)                                          \
+              acc[r] += (double)(part[q_][0][r] + part[q_][1][r]);                                \
+        }                                                                                         \
+      }                                                                                           \
+    }
+    if (last == 0) W8_DRAIN(0) else if (last == 1) W8_DRAIN(1) else if (last == 2) W8_DRAIN(2) else W8_DRAIN(3)
+#undef W8_DRAIN
+  }
+#undef W8_ITER
+#undef W8_CARRY
+#undef W8_MFMA
+  __syncthreads();  // every wave is done reading the tiles
+
+  // ---- add the two K-halves through LDS (waves 4-7 publish, waves 0-3 add), logits -> Ls
+  {
+    using XT = typename std::conditional<ACC64, double, float>::type;
+    XT* X = reinterpret_cast<XT*>(smem);  // [4 tiles][16 regs][64 lanes]
+    if (kh == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        XT v;
+        if constexpr (ACC64) v = acc[r]; else v = part[0][0][r] + part[0][1][r];
+        X[(wt * 16 + r) * 64 + lane] = v;
+      }
+    }
+    __syncthreads();
+    XT tot[16];
+    if (kh == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        XT v;
+        if constexpr (ACC64) v = acc[r]; else v = part[0][0][r] + part[0][1][r];
+        tot[r] = v + X[(wt * 16 + r) * 64 + lane];
+      }
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rt * 32 + 8 * (r >> 2) + 4 * fg + (r & 3);
+        const int col = ct0 * 32 + fi;
+        if constexpr (ACC64)
+          Ls[row * HWP + col] = (float)(tot[r] + (double)bgrp[row]);
+        else
+          Ls[row * HWP + col] = tot[r] + bgrp[row];
+      }
+    }
+    __syncthreads();
+  }
+  if (wid < 4)
+    decode_group_from_lds<ACC64, 2>(Ls, HWP, grp, g, crop, J, D, H, W, hs, coords2d, coords3d_rel, wid,
+                                    lane);
+}
+
 template <int CT>
 constexpr size_t head32_lds_bytes() {
   constexpr size_t stage = 2 * ((size_t)kRows * kKC + (size_t)CT * 32 * kKC) + 256 * 4;  // + dump slots
@@ -888,6 +1138,30 @@ static int launch_head32(const void* feat, const float* packed, int B, int C, in
   return MTR_OK;
 }
 
+template <typename FeatT, bool NHWC>
+static int launch_head32w8(const void* feat, const float* packed, int B, int C, int H, int W, int J,
+                           int D, const HeadGeom& g, const HeadScale& hs, float* c2d, float* c3d,
+                           hipStream_t stream) {
+  constexpr size_t lds = (2 * ((size_t)kRows * kKC + 64 * kKC) + 512 * 4) * sizeof(float);
+  auto kern = head_fused32w8_kernel<FeatT, std::is_same<FeatT, float>::value, NHWC>;
+  const int chunk = 8 * g.n_groups;
+  const long long blocks = (long long)((B + 7) / 8) * chunk;
+  MTR_CLEAR_STALE();
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, stream, (const FeatT*)feat, packed,
+                     B, C, H, W, J, D, g, hs, c2d, c3d);
+  MTR_CHECK_LAUNCH();
+  return MTR_OK;
+}
+
+// MTR_HEAD_W8=0 / 1 forces the 4-wave / 8-wave 32x32 kernel (default: 8 waves for small launches)
+static int force_w8() {
+  static const int v = [] {
+    const char* e = getenv("MTR_HEAD_W8");
+    return e ? (e[0] == '1' ? 1 : 0) : -1;
+  }();
+  return v;
+}
+
 // MTR_HEAD_CORE=16 forces the 16x16x4 core for every shape (A/B measurements, tools/microbench.py)
 static bool force_core16() {
   static const bool v = [] {
@@ -903,7 +1177,14 @@ static int dispatch_head(const void* feat, const float* packed, int B, int C, in
                          hipStream_t stream) {
   const int HW = H * W;
   if (HW > 32 && HW <= 128 && !force_core16()) {
-    if (HW <= 64) return launch_head32<FeatT, 2, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+    if (HW <= 64) {
+      // fewer than ~2 workgroups per CU: two waves per SIMD inside the workgroup instead
+      const long long blocks = (long long)((B + 7) / 8) * 8 * g.n_groups;
+      const bool small = blocks <= 512;
+      if (force_w8() == 1 || (force_w8() < 0 && small))
+        return launch_head32w8<FeatT, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+      return launch_head32<FeatT, 2, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+    }
     if (HW <= 96) return launch_head32<FeatT, 3, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
     return launch_head32<FeatT, 4, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
   }

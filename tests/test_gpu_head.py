@@ -156,18 +156,20 @@ def test_fused_head_channels_last_features(shape, dtype, hip_lib):
     assert float((c3d.cpu() - o3d).abs().max()) <= 2e-3
 
 
-def test_16x16_core_on_all_shapes_subprocess(hip_lib):
-    """The 32x32 core took over maps of 33..128 positions; MTR_HEAD_CORE=16 (read once per process)
-    routes them through the 16x16 core again, which stays the path for the other sizes.  Re-run
-    this file's parity tests that way so both cores are held to the same bounds on every shape."""
+@pytest.mark.parametrize('env', [{'MTR_HEAD_CORE': '16'}, {'MTR_HEAD_W8': '0'}, {'MTR_HEAD_W8': '1'}],
+                         ids=['core16', 'w4', 'w8'])
+def test_every_gemm_variant_on_all_shapes_subprocess(env, hip_lib):
+    """Three GEMM kernels sit behind mtr_head_fused: the 16x16x4 core, the 4-wave 32x32x2 kernel and
+    its 8-wave K-split variant for small launches.  The dispatch picks by map size and launch size;
+    the MTR_HEAD_CORE / MTR_HEAD_W8 switches (read once per process) force one of them.  Re-run this
+    file's parity tests under each, so every kernel is held to the same bounds on every shape."""
     import os
     import subprocess
     import sys
-    if os.environ.get('MTR_HEAD_CORE'):
-        pytest.skip('already inside the forced-core run')
-    env = dict(os.environ, MTR_HEAD_CORE='16')
+    if os.environ.get('MTR_HEAD_CORE') or os.environ.get('MTR_HEAD_W8'):
+        pytest.skip('already inside a forced-variant run')
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-m', 'gpu',
-                        '-k', 'golden or odd_shapes or 16bit or channels_last'],
-                       env=env, capture_output=True, text=True, timeout=900,
+                        '-k', 'golden or odd_shapes or 16bit or channels_last or full_size'],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=900,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
