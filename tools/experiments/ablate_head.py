@@ -34,6 +34,7 @@ def build():
 
 
 def run_one(mask):
+    os.environ['MTR_HEAD_W8'] = '0'  # the hooks live in the 4-wave kernel; small launches default to 8 waves
     sys.path.insert(0, ROOT)
     import torch
     from metrabs_amd import _lib
