@@ -425,10 +425,15 @@ extern "C" int mtr_detector_preprocess(const uint8_t* images_u8, int N, int H, i
   // bytes of a staged row: 64 columns' worth of source + both supports + alignment slack
   const int pitch = (((int)(mtr::kDTX * (sx > 1.0f ? sx : 1.0f) + 2.0f * supx) + 40) + 15) / 16 * 16;
   // rows a tile of TY output rows needs: TY * scale + 2 * support + 2; fit stage + temp in 60 KiB
+  // (budget 60 KiB keeps 2-3 workgroups per CU; extreme shrinks on both axes take up to 120 KiB
+  //  for a single output row per tile rather than being rejected)
   int ty = mtr::kDTYMax, rows_cap = 0;
-  for (; ty >= 1; --ty) {
-    rows_cap = (int)((float)ty * (sy > 1.0f ? sy : 1.0f) + 2.0f * supy) + 3;
-    if ((size_t)rows_cap * (pitch + mtr::kDTX * sizeof(float)) <= 60 * 1024) break;
+  for (size_t budget : {(size_t)60 * 1024, (size_t)120 * 1024}) {
+    for (ty = mtr::kDTYMax; ty >= 1; --ty) {
+      rows_cap = (int)((float)ty * (sy > 1.0f ? sy : 1.0f) + 2.0f * supy) + 3;
+      if ((size_t)rows_cap * (pitch + mtr::kDTX * sizeof(float)) <= budget) break;
+    }
+    if (ty >= 1) break;
   }
   if (ty < 1) return MTR_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;

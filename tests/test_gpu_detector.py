@@ -38,10 +38,11 @@ def test_detector_preprocess_vs_golden(name, hip_lib):
 
 
 @pytest.mark.parametrize('shape', [(1, 1080, 1920), (2, 720, 1280), (1, 2160, 3840), (1, 333, 1999),
-                                   (1, 64, 416), (2, 8, 8), (1, 417, 200)])
+                                   (1, 64, 416), (2, 8, 8), (1, 417, 200), (1, 200, 6000), (1, 4500, 300)])
 def test_detector_preprocess_vs_oracle_full_tensor(shape, hip_lib):
-    """Full-size frames (1080p = BASELINE configs, 4K), extreme aspect ratios, tiny frames: every
-    element against the oracle, and the pad region exactly 0.5."""
+    """Full-size frames (1080p = BASELINE configs, 4K), extreme aspect ratios (14x shrink: the
+    40-tap instantiation), tiny frames, tensor sizes that are not multiples of 16 (byte-wise tail):
+    every element against the oracle, and the pad region exactly 0.5."""
     from metrabs_amd import kernels
     n, h, w = shape
     img = cases.synth_images(n, h, w, 31)
