@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256) void pose_filter_kernel(
     int32_t* __restrict__ keep_idx,   // [P]: per image its kept poses (global indices), then -1
     int32_t* __restrict__ keep_count  // [n_images]
 ) {
-  extern __shared__ __attribute__((aligned(16))) float dynf[];  // [4 waves][J] distances
+  // dynamic LDS: [4 waves][J rounded up to even] float distances, then [4 waves][A] double factors
+  extern __shared__ __attribute__((aligned(16))) float dynf[];
   __shared__ int s_valid[1024], s_list[1024], s_rank[1024], s_sel[1024];
   __shared__ float s_scale[1024];
   __shared__ int s_nv, s_nsel;
@@ -91,12 +92,12 @@ __global__ __launch_bounds__(256) void pose_filter_kernel(
       if ((rel > fa.rel_big || rel < fa.rel_small) && diff > fa.abs_diff_mm) bad = 1;
     }
     bad = __any(bad);
-    // (b) augmentation consistency: scale-align the A results, stdev of every joint over A
+    // (b) augmentation consistency: scale-align the A results, stdev of every joint over A.
+    // The per-aug scale factors sqrt(mean_sq / sq_a) go through this wave's slice of LDS.
     int n_stable = 0;
     {
-      // square scale of each aug (mean of squares over J*3) -- lanes split the elements
+      double* fac = reinterpret_cast<double*>(dynf + 4 * ((J + 1) & ~1)) + wid * A;
       double msq = 0.0;
-      double sq_a[8];  // A <= 8 handled in registers; larger A recomputes (see loop below)
       for (int a = 0; a < A; ++a) {
         double s = 0.0;
         for (int e = lane; e < J * 3; e += 64) {
@@ -104,43 +105,22 @@ __global__ __launch_bounds__(256) void pose_filter_kernel(
           s += v * v;
         }
         s = wave_sum(s) / (double)(J * 3);
-        if (a < 8) sq_a[a] = s;
+        if (lane == 0) fac[a] = s;
         msq += s;
       }
       msq /= (double)A;
+      __builtin_amdgcn_wave_barrier();
+      for (int a = lane; a < A; a += 64) fac[a] = sqrt(msq / fac[a]);
+      __builtin_amdgcn_wave_barrier();
       for (int j = lane; j < J; j += 64) {
         double var_sum = 0.0;
         for (int cdim = 0; cdim < 3; ++cdim) {
           double mean = 0.0;
-          for (int a = 0; a < A; ++a) {
-            double sa;
-            if (a < 8) {
-              sa = sq_a[a];
-            } else {  // rare: recompute this aug's scale serially
-              sa = 0.0;
-              for (int e = 0; e < J * 3; ++e) {
-                const double v = P3[(size_t)a * J * 3 + e];
-                sa += v * v;
-              }
-              sa /= (double)(J * 3);
-            }
-            mean += (double)P3[((size_t)a * J + j) * 3 + cdim] * sqrt(msq / sa);
-          }
+          for (int a = 0; a < A; ++a) mean += (double)P3[((size_t)a * J + j) * 3 + cdim] * fac[a];
           mean /= (double)A;
           double ss = 0.0;
           for (int a = 0; a < A; ++a) {
-            double sa;
-            if (a < 8) {
-              sa = sq_a[a];
-            } else {
-              sa = 0.0;
-              for (int e = 0; e < J * 3; ++e) {
-                const double v = P3[(size_t)a * J * 3 + e];
-                sa += v * v;
-              }
-              sa /= (double)(J * 3);
-            }
-            const double d = (double)P3[((size_t)a * J + j) * 3 + cdim] * sqrt(msq / sa) - mean;
+            const double d = (double)P3[((size_t)a * J + j) * 3 + cdim] * fac[a] - mean;
             ss += d * d;
           }
           var_sum += ss / (double)(A - fa.var_correction);  // A == 1 with correction 1: NaN, as torch
@@ -200,7 +180,7 @@ __global__ __launch_bounds__(256) void pose_filter_kernel(
   const int nv = s_nv;
   // ---- 3. similarity matrix of the valid poses: one wave per ordered pair (u <= v mirrored)
   float* S = ws_sim + sim_off[img];
-  float* dist = dynf + wid * J;
+  float* dist = dynf + wid * ((J + 1) & ~1);
   const int k = J / 4;
   for (int pr = wid; pr < nv * nv; pr += 4) {
     const int u = pr / nv, v = pr - u * nv;
@@ -316,7 +296,7 @@ extern "C" int mtr_filter_poses(const float* poses3d, const float* poses2d, cons
   fa.order_by_score = fp->order_by_score;
   float* ws_mean = (float*)workspace;
   float* ws_sim = ws_mean + (size_t)P * J * 3;
-  const size_t lds = (size_t)4 * J * sizeof(float);
+  const size_t lds = (size_t)4 * ((J + 1) & ~1) * sizeof(float) + (size_t)4 * A * sizeof(double);
   if (lds > 48 * 1024) return MTR_E_SHAPE;
   MTR_CLEAR_STALE();
   hipLaunchKernelGGL(mtr::pose_filter_kernel, dim3(n_images), dim3(256), lds, (hipStream_t)stream,

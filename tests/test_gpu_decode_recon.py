@@ -56,6 +56,28 @@ def test_decode_vs_oracle_odd_shapes(shape, hip_lib):
     assert float((c2d.cpu() - o2d).abs().max()) <= 2e-4
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(5, 17, 8, 8, 8), (3, 23, 8, 12, 12), (9, 17, 8, 16, 16),
+                                   (2, 5, 8, 8, 16), (2, 3, 4, 24, 24), (2, 6, 8, 7, 9), (3, 9, 16, 32, 32),
+                                   (70, 17, 72, 8, 8)])
+def test_decode_16bit_logits_every_load_shape(shape, dtype, hip_lib):
+    """16-bit logits (the reference's autocast GPU path keeps them in f16): the kernel reads 8, 4 or
+    1 elements per lane depending on the map width (16-byte loads with 8-, 16- or 64-lane joint
+    groups; 8-byte loads; scalars) and computes in f32/f64 -- compared with the oracle on the SAME
+    rounded logits, so the bounds of the f32 tests apply."""
+    from metrabs_amd import kernels
+    B, J, D, H, W = shape
+    cfg = cpu_ref.HeadConfig(depth=D, proc_side=max(H, W) * 8, stride_test=8, stride_train=8)
+    g = cases.gen(7100 + sum(shape))
+    logits = (torch.randn(B, J * (1 + D), H, W, generator=g) * 3).to(dtype)
+    with torch.inference_mode():
+        o2d, o3d = cpu_ref.heads_from_logits(logits.float(), J, cfg)
+    c2d, c3d = kernels.softargmax_decode(logits.cuda(), J, mcfg(cfg))
+    report(f'decode {dtype} {shape}', c3d.cpu(), o3d)
+    assert float((c3d.cpu() - o3d).abs().max()) <= 1e-3
+    assert float((c2d.cpu() - o2d).abs().max()) <= 2e-4
+
+
 def test_decode_kat_spike_uniform(hip_lib):
     from metrabs_amd import kernels
     from metrabs_amd.config import MetrabsConfig

@@ -101,3 +101,33 @@ def test_detect_poses_applies_the_filter_when_bone_lengths_are_set(hip_lib):
         assert len(pf) <= len(pp) and len(bf) == len(pf)
         for row in pf:  # every surviving pose is one of the unfiltered ones, bit for bit
             assert bool((pp == row).flatten(1).all(1).any())
+
+
+@pytest.mark.parametrize('A,J,n', [(10, 17, 6), (3, 122, 20), (2, 40, 130), (1, 6, 3)])
+def test_filter_sizes_beyond_the_common_ones(A, J, n, hip_lib):
+    """More augmentations than the 8 kept in registers, multi-skeleton joint counts, > 128 poses in
+    one image (several rounds of the 4-wave pose loop), tiny skeletons: vs the oracle on noise-free
+    far-apart people plus exact duplicates (decisions far from the thresholds)."""
+    g = cases.gen(600 + A + J + n)
+    edges = [(i, i + 1) for i in range(J - 1)]
+    template = torch.cumsum(torch.randn(J, 3, generator=g) * torch.tensor([60.0, 90.0, 40.0]), dim=0)
+    tj = torch.tensor(edges)
+    mean_bones = torch.norm(template[tj[:, 0]] - template[tj[:, 1]], dim=-1)
+    people = []
+    for i in range(n):
+        base = template + torch.tensor([(i % 16) * 2500.0 - 20000.0, (i // 16) * 3000.0, 9000.0])
+        if i % 5 == 4:  # an exact duplicate of the previous person, lower score
+            base = people[-1][0][0].clone()
+        people.append((base[None].repeat(A, 1, 1) + torch.randn(A, J, 3, generator=g) * 2.0, 0.9 - 0.001 * i))
+    p3 = torch.stack([p for p, _ in people])
+    p2 = 1500.0 * p3[..., :2] / p3[..., 2:] + torch.tensor([960.0, 540.0])
+    m2 = p2.mean(1)
+    lo, hi = m2.min(1).values, m2.max(1).values
+    bx = torch.cat([lo - 10, hi - lo + 20, torch.tensor([[s] for _, s in people])], dim=1)
+    c = dict(boxes=[bx], poses3d=[p3], poses2d=[p2], edges=edges, mean_bones=mean_bones, n_joints=J)
+    want, want_masks = cpu_ref.filter_poses(c['boxes'], c['poses3d'], c['poses2d'], edges, mean_bones)
+    got, masks = run_kernel(c)
+    assert torch.equal(masks[0], want_masks[0])
+    assert got[0].tolist() == want[0].tolist()
+    if J >= 17:  # (the 6-joint chain is too narrow for its own box test: all rejected, on both sides)
+        assert len(got[0]) == n - n // 5  # every fifth pose is a duplicate
