@@ -125,7 +125,12 @@ extern "C" int mtr_postprocess_poses(const float* poses_crop, const float* rot,
   a.S = a.has_skeleton ? S : a.Jt;
   a.average = average_aug != 0;
   const size_t lds = (size_t)A * J * 3 * sizeof(double);
-  if (lds > 64 * 1024) return MTR_E_SHAPE;  // A*J <= 2730
+  if (lds > 144 * 1024) return MTR_E_SHAPE;  // A*J <= 6144 (one box's poses live in LDS)
+  if (lds > 48 * 1024) {  // e.g. the 555-point multi-skeleton heads with num_aug = 5
+    hipError_t e = hipFuncSetAttribute((const void*)mtr::postprocess_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
   MTR_CLEAR_STALE();
   hipLaunchKernelGGL(mtr::postprocess_kernel, dim3(n), dim3(256), lds, (hipStream_t)stream,
                      poses_crop, rot, should_flip, mirror_mapping, joint_transform, skeleton,

@@ -40,6 +40,8 @@ def make_inputs(n, A, J, seed, dist, jt, skeleton):
     dict(n=5, A=5, J=17, dist=cases.DISTORTION_5, jt=0, skeleton=[0, 5, 6, 11, 12], avg=True),
     dict(n=3, A=4, J=17, dist=cases.DISTORTION_12, jt=24, skeleton=[1, 3, 23, 7], avg=False),
     dict(n=2, A=5, J=122, dist=None, jt=40, skeleton=None, avg=True),
+    dict(n=3, A=5, J=555, dist=cases.DISTORTION_5, jt=0, skeleton=list(range(0, 555, 7)), avg=True),
+    dict(n=2, A=10, J=300, dist=None, jt=64, skeleton=None, avg=False),
     dict(n=64, A=2, J=17, dist=None, jt=0, skeleton=None, avg=False),
 ])
 def test_postprocess_vs_oracle(cfg, hip_lib):
@@ -57,7 +59,10 @@ def test_postprocess_vs_oracle(cfg, hip_lib):
     assert p3.shape == o3.shape and p2.shape == o2.shape
     e3, e2 = float((p3.cpu() - o3).abs().max()), float((p2.cpu() - o2).abs().max())
     print(f'[parity] postprocess {cfg}: poses3d max {e3:.2e} mm, poses2d max {e2:.2e} px')
-    assert e3 <= 1.5e-3 and e2 <= 2e-3
+    # the joint transform is an f32 matmul over J terms in the reference (f64 here): its own rounding
+    # grows with J, so the bound does too beyond the largest shipped joint set
+    grow = max(1.0, cfg['J'] / 122) if cfg['jt'] else 1.0
+    assert e3 <= 1.5e-3 * grow and e2 <= 2e-3 * grow
 
 
 def test_fused_equals_torch_path_in_estimator(hip_lib):
