@@ -76,3 +76,55 @@ def test_reconstruct_fuzz(i, hip_lib):
         o = cpu_ref.reconstruct_absolute(c2d, rel, K, cfg)
     ours = kernels.reconstruct_absolute(c2d.cuda(), rel.cuda(), K.cuda(), mcfg(cfg)).cpu()
     assert cpu_ref.mpjpe(ours, o) <= 1e-3 and float((ours - o).abs().max()) <= 5e-3, (B, J, P)
+
+
+def _e2e_fuzz_cfgs(n, seed):
+    import random
+    rnd = random.Random(seed)
+    out = []
+    for i in range(n):
+        out.append(dict(
+            seed=9100 + i, n_images=rnd.randint(1, 3), imh=rnd.choice([96, 121, 150, 240]),
+            imw=rnd.choice([128, 161, 200, 320]), res=rnd.choice([32, 64]), num_aug=rnd.randint(1, 6),
+            aa=rnd.choice([1, 1, 2, 4]), dist=rnd.choice([None, cases.DISTORTION_5, cases.DISTORTION_12]),
+            ibs=rnd.choice([2, 5, 64]), average_aug=rnd.random() < 0.5, extr=rnd.random() < 0.5,
+            skeleton=rnd.random() < 0.5, jtm=rnd.random() < 0.5, known_k=rnd.random() < 0.7, i=i))
+    return out
+
+
+@pytest.mark.parametrize('c', _e2e_fuzz_cfgs(10, 77), ids=lambda c: f"{c['i']}")
+def test_estimator_fuzz_vs_oracle(c, hip_lib):
+    """Whole path from images (tiny backbone): random frame sizes (odd widths: the scalar pyramid and
+    byte-tail paths), 1-6 augmentations, antialias 1/2/4, 0/5/12 distortion coefficients, internal
+    batches that split a box's augmentations, extrinsics, skeleton selection, joint transform,
+    unknown intrinsics -- against the oracle's restatement of _estimate_poses_batched on the CPU."""
+    from test_gpu_e2e import build_estimator
+    name = f"fuzz{c['i']}"
+    cases.E2E_CASES[name] = {k: v for k, v in c.items() if k != 'i'}
+    try:
+        case = cases.e2e_case(name)
+        backbone_cpu = cases.e2e_case(name)['backbone']
+    finally:
+        del cases.E2E_CASES[name]
+    est = build_estimator(case, fused_head=True)
+    with torch.inference_mode():
+        ours = est._estimate_poses_batched(
+            case['images'], case['boxes'], case['K'], case['dist'], case['extr'], case['world_up'],
+            55, case['ibs'], case['aa'], case['num_aug'], case['average_aug'], '', False)
+        mm = cases.mirror_mapping(cases.COCO17)
+
+        def crop_model(inp):
+            crops, K = inp
+            return cpu_ref.crop_model_from_features(
+                backbone_cpu(crops), case['head_w'], case['head_b'], K, 17, case['cfg'])
+
+        ref = cpu_ref.estimate_poses_batched(
+            crop_model, mm, 17, case['res'], case['images'], case['boxes'], case['K'], case['dist'],
+            case['extr'], case['world_up'], 55, case['ibs'], case['aa'], case['num_aug'],
+            case['average_aug'], joint_transform_matrix=case['jtm'], skeleton_indices=case['skeleton'])
+    assert [len(p) for p in ours['poses3d']] == [len(p) for p in ref['poses3d']]
+    p3, r3 = torch.cat(ours['poses3d']).cpu(), torch.cat(ref['poses3d'])
+    assert p3.shape == r3.shape
+    if p3.numel():
+        print(f"[parity] e2e fuzz {c['i']}: MPJPE {cpu_ref.mpjpe(p3, r3):.2e} mm max {float((p3 - r3).abs().max()):.2e}")
+        assert cpu_ref.mpjpe(p3, r3) <= 0.05 and float((p3 - r3).abs().max()) <= 0.5
