@@ -16,6 +16,11 @@
 // per crop) plus the clipped source footprint, which normally stays in L2 / Infinity Cache.
 #include "common.h"
 
+// developer-only timing ablations of warp_crops_kernel (tools/experiments/ablate_warp.py); 0 in the product
+#ifndef MTR_WARP_ABLATE
+#define MTR_WARP_ABLATE 0
+#endif
+
 namespace mtr {
 
 // ------------------------------------------------------------------------------------------------
@@ -482,12 +487,24 @@ __global__ __launch_bounds__(256) void warp_crops_kernel(
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
               const int ot = img_off + c * plane_elems + ys * W + xs, ob = ot + W;  // byte offsets
-              const auto top = __builtin_amdgcn_raw_buffer_load_b64(rsrc, ot & ~3, 0, 0);
-              const auto bot = __builtin_amdgcn_raw_buffer_load_b64(rsrc, ob & ~3, 0, 0);
-              const unsigned long long tw = __builtin_bit_cast(unsigned long long, top) >> ((ot & 3) * 8);
-              const unsigned long long bw = __builtin_bit_cast(unsigned long long, bot) >> ((ob & 3) * 8);
-              const float ta = lut[tw & 0xff], tb = lut[(tw >> 8) & 0xff];
-              const float ba = lut[bw & 0xff], bb = lut[(bw >> 8) & 0xff];
+              unsigned long long tw, bw;
+              if (MTR_WARP_ABLATE & 1) {
+                tw = (unsigned long long)(unsigned)ot * 2654435761ull;
+                bw = (unsigned long long)(unsigned)ob * 2654435761ull;
+              } else {
+                const auto top = __builtin_amdgcn_raw_buffer_load_b64(rsrc, ot & ~3, 0, 0);
+                const auto bot = __builtin_amdgcn_raw_buffer_load_b64(rsrc, ob & ~3, 0, 0);
+                tw = __builtin_bit_cast(unsigned long long, top) >> ((ot & 3) * 8);
+                bw = __builtin_bit_cast(unsigned long long, bot) >> ((ob & 3) * 8);
+              }
+              float ta, tb, ba, bb;
+              if (MTR_WARP_ABLATE & 2) {
+                ta = (float)(tw & 0xff); tb = (float)((tw >> 8) & 0xff);
+                ba = (float)(bw & 0xff); bb = (float)((bw >> 8) & 0xff);
+              } else {
+                ta = lut[tw & 0xff]; tb = lut[(tw >> 8) & 0xff];
+                ba = lut[bw & 0xff]; bb = lut[(bw >> 8) & 0xff];
+              }
               acc[p][c] += fmaf(bb, w11, fmaf(ba, w10, fmaf(tb, w01, ta * w00)));
             }
           }
@@ -522,10 +539,11 @@ __global__ __launch_bounds__(256) void warp_crops_kernel(
     for (int c = 0; c < 3; ++c) {
       float val = acc[p][c];
       if (AA > 1) val = val * (1.0f / (AA * AA));
-      res_v[p][c] = (gexp == 1.0f) ? val : fast_pow_unit(val, gexp);
+      res_v[p][c] = (gexp == 1.0f || (MTR_WARP_ABLATE & 4)) ? val : fast_pow_unit(val, gexp);
     }
 
   const bool full = (u0 + PX <= res) && (res % PX == 0);
+  if ((MTR_WARP_ABLATE & 8) && (res_v[0][0] != 12345.0f || lane != 0)) return;
   if (!nhwc) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {

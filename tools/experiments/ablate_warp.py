@@ -1,0 +1,81 @@
+"""Timing ablations of warp_crops_kernel (developer tool).  build here, run on the GPU box.
+MTR_WARP_ABLATE bits: 1 = no tap loads (uint8 path), 2 = no LUT lookups, 4 = no gamma pow,
+8 = no output stores."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+OUT = os.path.join(ROOT, 'tools', 'experiments', '_build')
+MASKS = [0, 1, 2, 3, 4, 8, 15]
+
+
+def build():
+    os.makedirs(OUT, exist_ok=True)
+    csrc = os.path.join(ROOT, 'metrabs_amd', 'csrc')
+    srcs = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith('.hip'))
+    procs = [subprocess.Popen(['hipcc', '-O3', '-std=c++17', '-fPIC', '-shared', '--offload-arch=gfx950',
+                               f'-DMTR_WARP_ABLATE={m}', '-I', os.path.join(ROOT, 'include'), *srcs, '-o',
+                               os.path.join(OUT, f'libmtr_warp{m}.so')], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.PIPE) for m in MASKS]
+    for p in procs:
+        _, err = p.communicate()
+        if p.returncode:
+            sys.exit(err.decode())
+
+
+def run_one(mask):
+    sys.path.insert(0, ROOT)
+    import torch
+    from metrabs_amd import _lib
+    _lib.load(os.path.join(OUT, f'libmtr_warp{mask}.so'))
+    from metrabs_amd import kernels
+    from metrabs_amd.multiperson.multiperson_model import tta_parameters
+    g = torch.Generator().manual_seed(0)
+    frames = torch.randint(0, 256, (8, 3, 1080, 1920), dtype=torch.uint8, generator=g).cuda()
+    pyr = kernels.build_pyramid(frames)
+    n = 64
+    tta = {k: v.cuda() for k, v in tta_parameters(1).items()}
+    bw = 60 + 340 * torch.rand(n, generator=g)
+    bh = 150 + 750 * torch.rand(n, generator=g)
+    boxes = torch.stack([torch.rand(n, generator=g) * (1920 - bw),
+                         torch.rand(n, generator=g) * (1080 - bh).clamp_min(1), bw, bh], 1).cuda()
+    K = torch.tensor([[1844.0, 0, 960], [0, 1844.0, 540], [0, 0, 1]]).repeat(n, 1, 1).cuda()
+    up = torch.tensor([0.0, -1, 0]).repeat(n, 1).cuda()
+    ids = (torch.arange(n) % 8).int().cuda()
+    _, _, wp = kernels.crop_geometry(boxes, K, torch.zeros(n, 12).cuda(), up, ids, tta['rotflipmat'],
+                                     tta['scales'], tta['gammas'], 256, 1)
+    o = torch.empty(n, 3, 256, 256, device='cuda')
+    for _ in range(5):
+        kernels.warp_crops(pyr, wp, 256, 1, out=o)
+    torch.cuda.synchronize()
+    # 20 launches per graph replay: GPU time per launch without the Python / ctypes call floor
+    n = 20
+    st = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        kernels.warp_crops(pyr, wp, 256, 1, out=o)
+        st.synchronize()
+        with torch.cuda.graph(graph, stream=st):
+            for _ in range(n):
+                kernels.warp_crops(pyr, wp, 256, 1, out=o)
+    graph.replay()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(10):
+        graph.replay()
+    b.record()
+    torch.cuda.synchronize()
+    print(json.dumps({'mask': mask, 'us': round(a.elapsed_time(b) / (n * 10) * 1e3, 1)}), flush=True)
+
+
+if __name__ == '__main__':
+    if sys.argv[1] == 'build':
+        build()
+    elif sys.argv[1] == 'run':
+        for m in MASKS:
+            subprocess.run([sys.executable, __file__, 'one', str(m)])
+    else:
+        run_one(int(sys.argv[2]))
