@@ -103,7 +103,9 @@ def build_model(args, dev):
     model = model.to(dev)
     calibrate_batchnorm(model.backbone, args.res, dev)
     model = model.eval()
-    channels_last = autocast is not None or os.environ.get('MTR_BENCH_CHANNELS_LAST') == '1'
+    # (channels_last measured slower than NCHW on this MIOpen for both dtypes: 19.1 vs 14.0 ms in f32,
+    #  15.0 vs 11.4 ms under f16 autocast -- tools/experiments/backbone_f16_probe.py)
+    channels_last = os.environ.get('MTR_BENCH_CHANNELS_LAST') == '1'
     if channels_last:
         model = model.to(memory_format=torch.channels_last)
     skel = {'': dict(indices=list(range(args.joints)), names=names, edges=edges)}
