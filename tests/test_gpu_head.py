@@ -112,6 +112,30 @@ def test_fused_equals_unfused_and_module(hip_lib):
     assert set(sd) == {'conv_final.weight', 'conv_final.bias'} and sd['conv_final.weight'].shape == (153, 128, 1, 1)
 
 
+def test_depth72_goes_through_gemm_plus_decode(hip_lib):
+    """72 depth bins (the metric string of BASELINE.json): a joint's 73 rows do not fit the fused
+    head's 64-row tile, so MetrabsHeads runs the 1x1 conv as a library GEMM and the HIP decode
+    kernel on the logits -- still no CPU, and the oracle's bounds hold."""
+    from metrabs_amd import kernels
+    from metrabs_amd.config import MetrabsConfig
+    from metrabs_amd.models.metrabs import MetrabsHeads
+    cfg = MetrabsConfig(depth=72)
+    assert not kernels.head_fused_supported(256, 17, 72, 8, 8)
+    heads = MetrabsHeads(17, cfg, in_channels=256, fused=True).cuda()
+    g = cases.gen(72)
+    w, b = cases.default_conv_init(17 * 73, 256, g)
+    with torch.no_grad():
+        heads.conv_final.weight.copy_((w * 3)[:, :, None, None])
+        heads.conv_final.bias.copy_(b * 3)
+    feat = torch.randn(5, 256, 8, 8, generator=g)
+    with torch.inference_mode():
+        c2d, c3d = heads(feat.cuda())
+        o2d, o3d = cpu_ref.heads_forward(feat, w * 3, b * 3, 17, cpu_ref.HeadConfig(depth=72))
+    assert c3d.shape == (5, 17, 3)
+    assert float((c3d.cpu() - o3d).abs().max()) <= 2e-3 and cpu_ref.mpjpe(c3d.cpu(), o3d) <= 1e-3
+    assert float((c2d.cpu() - o2d).abs().max()) <= 4e-4
+
+
 def test_fused_head_full_size_properties(hip_lib):
     """BASELINE config 2 (B=64, C=1280, 8x8, J=17): permutation equivariance over crops (each crop
     is computed independently and deterministically) + sampled crops equal the oracle."""
