@@ -1080,6 +1080,261 @@ __global__ __launch_bounds__(512, 2) void head_fused32w8_kernel(
                                     lane);
 }
 
+// =====================================================================================
+// 16-bit features (the autocast backbone output): f16 / bf16 MFMA, f32 accumulate.
+// The reference's GPU path runs conv_final under autocast, i.e. f16 x f16 products, f32 sums and
+// logits rounded to f16 ("precision classes"); here the products and sums are
+// the same and the logits stay f32 on chip.  v_mfma_f32_32x32x16_{f16,bf16} has 16x the rate of
+// the f32 32x32x2 core, so this kernel is a staging loop: 64-channel stages, one 16-byte LDS read
+// per operand and MFMA, one barrier per stage.
+//   LDS tiles are K-contiguous, [row][64 ch] = 128 B rows of eight 16-byte slots, slot ^= swz(row)
+//   (same swizzle, same conflict analysis as the f32 32x32 core: a slot is one lane's operand);
+//   lane (i = l & 31, g = l >> 5) of MFMA u reads slot 2u + g of row i: channels 16u + 8g .. + 7.
+//   NHWC features are copied 16 B at a time.  NCHW features are transposed in registers: a thread
+//   loads one dword (positions 2p, 2p + 1) from each of 8 consecutive channels -- a wave reads
+//   whole 128-byte rows -- and v_perm_b32 packs the low / high halves into the two positions'
+//   8-channel slots: two ds_write_b128 instead of sixteen ds_write_b16.
+using v4u = __attribute__((ext_vector_type(4))) unsigned;
+using h16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+template <typename T> struct Mfma16;
+template <> struct Mfma16<__half> {
+  static __device__ __forceinline__ f32x16 run(v4u a, v4u b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a),
+                                                  __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mfma16<__hip_bfloat16> {
+  static __device__ __forceinline__ f32x16 run(v4u a, v4u b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+
+constexpr int kKH = 64;  // channels per stage of the 16-bit core
+
+// packed (16-bit feature dtypes) = the f32 sections above, then
+//   [n_groups][ceil(C / 64)][64 rows][64 ch] weights rounded to the feature dtype
+template <typename T>
+__global__ void head_pack16_kernel(const float* __restrict__ w, int C, int J, int D, HeadGeom g,
+                                   int n_st, T* __restrict__ w16) {
+  const int per = 1 + D;
+  const size_t total = (size_t)g.n_groups * n_st * kRows * kKH;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)((t / ((size_t)kKH * kRows)) % n_st) * kKH + (int)(t % kKH);
+    const int row = (int)((t / kKH) % kRows);
+    const int grp = (int)(t / ((size_t)kKH * kRows * n_st));
+    const int jl = row / per, k = row % per;
+    const int j = grp * g.jg + jl;
+    float v = 0.0f;
+    if (jl < g.jg && j < J && c < C) v = w[(size_t)((k == 0) ? j : J + (k - 1) * J + j) * C + c];
+    w16[t] = T(v);
+  }
+}
+
+template <int B_UNITS, bool NHWC>
+struct StageRegs16 {
+  v4u a[2];
+  // NHWC: one 16-byte slot per unit.  NCHW: 8 dwords per unit (8 channels x 2 positions).
+  unsigned b[B_UNITS][NHWC ? 4 : 8];
+};
+
+template <typename FeatT, int B_UNITS, bool NHWC>
+__device__ __forceinline__ void load_stage16(const FeatT* fcrop, const FeatT* w16, int C, int HW,
+                                             int tid, int stage, StageRegs16<B_UNITS, NHWC>& r) {
+  const int c0 = stage * kKH;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)  // 64 rows x 64 ch of this stage: contiguous 8 KiB
+    r.a[i] = *reinterpret_cast<const v4u*>(w16 + (size_t)stage * (kRows * kKH) + (size_t)(tid + i * 256) * 8);
+#pragma unroll
+  for (int i = 0; i < B_UNITS; ++i) {
+    const int v = tid + i * 256;
+    if constexpr (NHWC) {
+      const int pos = v >> 3, slot = v & 7;
+      const bool ok = pos < HW && c0 + slot * 8 < C;
+      const v4u x = *reinterpret_cast<const v4u*>(fcrop + (ok ? (size_t)pos * C + c0 + slot * 8 : 0));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r.b[i][e] = x[e];
+    } else {
+      const int pairs = HW >> 1;
+      const int kg = v / pairs, pp = v - kg * pairs;  // 8-channel group, position pair
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = c0 + kg * 8 + e;
+        const bool ok = kg < 8 && c < C;
+        r.b[i][e] = *reinterpret_cast<const unsigned*>(fcrop + (ok ? (size_t)c * HW + 2 * pp : 0));
+      }
+    }
+  }
+}
+
+template <typename FeatT, int B_UNITS, bool NHWC>
+__device__ __forceinline__ void store_stage16(char* As_buf, char* Bs_buf, int dump, int C, int HW,
+                                              int tid, int stage,
+                                              const StageRegs16<B_UNITS, NHWC>& r) {
+  const int c0 = stage * kKH;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int v = tid + i * 256;
+    const int row = v >> 3, slot = v & 7;
+    *reinterpret_cast<v4u*>(As_buf + row * 128 + ((slot ^ swz(row)) << 4)) = r.a[i];
+  }
+  const v4u zero = v4u{0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int i = 0; i < B_UNITS; ++i) {
+    const int v = tid + i * 256;
+    if constexpr (NHWC) {
+      const int pos = v >> 3, slot = v & 7;
+      const int o = pos < HW ? pos * 128 + ((slot ^ swz(pos)) << 4) : dump;
+      const v4u x = v4u{r.b[i][0], r.b[i][1], r.b[i][2], r.b[i][3]};
+      *reinterpret_cast<v4u*>(Bs_buf + o) = (c0 + slot * 8 < C) ? x : zero;
+    } else {
+      const int pairs = HW >> 1;
+      const int kg = v / pairs, pp = v - kg * pairs;
+      unsigned d[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d[e] = (c0 + kg * 8 + e < C) ? r.b[i][e] : 0u;
+      v4u lo, hi;  // position 2pp: low halves; 2pp + 1: high halves; channel e at half e
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        lo[e] = __builtin_amdgcn_perm(d[2 * e + 1], d[2 * e], 0x05040100u);
+        hi[e] = __builtin_amdgcn_perm(d[2 * e + 1], d[2 * e], 0x07060302u);
+      }
+      const int p0 = 2 * pp, p1 = 2 * pp + 1;
+      const bool ok = kg < 8;
+      *reinterpret_cast<v4u*>(Bs_buf + (ok ? p0 * 128 + ((kg ^ swz(p0)) << 4) : dump)) = lo;
+      *reinterpret_cast<v4u*>(Bs_buf + (ok ? p1 * 128 + ((kg ^ swz(p1)) << 4) : dump)) = hi;
+    }
+  }
+}
+
+template <int CT, bool NHWC>
+__host__ __device__ constexpr int h16_b_units() {
+  // NHWC: CT*32 positions x 8 slots.  NCHW: (HW / 2 <= CT*16) pairs x 8 channel groups.
+  return ((NHWC ? CT * 32 * 8 : CT * 16 * 8) + 255) / 256;
+}
+
+template <typename FeatT, int CT, bool NHWC>
+__global__ __launch_bounds__(256) void head_fused16_kernel(
+    const FeatT* __restrict__ feat, const float* __restrict__ packed, int B, int C, int H, int W,
+    int J, int D, HeadGeom g, HeadScale hs, float* __restrict__ coords2d,
+    float* __restrict__ coords3d_rel) {
+  constexpr int TPW = (CT + 1) / 2;
+  constexpr int HWP = hw_pad32<CT>();
+  constexpr int A_STAGE = kRows * 128;        // bytes
+  constexpr int B_STAGE = CT * 32 * 128;      // bytes
+  constexpr int B_UNITS = h16_b_units<CT, NHWC>();
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* As = reinterpret_cast<char*>(smem);   // [2][64][128 B]
+  char* Bs = As + 2 * A_STAGE;                // [2][CT*32][128 B], then 256 x 16-byte dump slots
+  float* Ls = smem;                           // epilogue alias: [64][HWP]
+
+  const int HW = H * W;
+  const int chunk = 8 * g.n_groups;  // XCD-aware remap, as in the f32 cores
+  const int id = blockIdx.x;
+  const int crop = (id / chunk) * 8 + (id % 8);
+  const int grp = (id % chunk) / 8;
+  if (crop >= B) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int n_st = (C + kKH - 1) / kKH;
+  const FeatT* fcrop = feat + (size_t)crop * C * HW;
+  const size_t n_w = (size_t)g.n_groups * g.c_pad * kRows;
+  const float* bgrp = packed + n_w + (size_t)grp * kRows;
+  const FeatT* w16 = reinterpret_cast<const FeatT*>(packed + 2 * n_w + (size_t)g.n_groups * kRows) +
+                     (size_t)grp * n_st * (kRows * kKH);
+
+  // rows >= HW of the feature tile are never written: zero both buffers once
+  for (int v = tid; v < 2 * B_STAGE / 16; v += 256)
+    reinterpret_cast<v4u*>(Bs)[v] = v4u{0u, 0u, 0u, 0u};
+
+  const int rt = wid & 1, ct0 = wid >> 1;
+  const int fi = lane & 31, fg = lane >> 5;
+  const int a_row = rt * 32 + fi;
+  const int a_off = a_row * 128 + ((fg ^ swz(a_row)) << 4);  // ^ (u << 5) selects slot 2u + g
+  int b_off[TPW];
+  bool on[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    on[t] = ct0 + 2 * t < CT;
+    const int pos = (on[t] ? ct0 + 2 * t : 0) * 32 + fi;
+    b_off[t] = pos * 128 + ((fg ^ swz(pos)) << 4);
+  }
+
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) acc[t] = f32x16{0};
+
+  // kAhead stages of global loads in flight per workgroup (register sets, rotated statically).  A
+  // stage is only a few hundred cycles of MFMA here, so a small launch (one workgroup per CU) needs
+  // several stages in flight to cover the ~1.5 us a load takes on an otherwise idle CU.
+  constexpr int kAhead = CT <= 2 ? 4 : (CT <= 4 ? 3 : 2);
+  const int dump = 2 * B_STAGE + tid * 16;  // byte offset from Bs of this lane's dump slot
+  StageRegs16<B_UNITS, NHWC> regs[kAhead];
+#pragma unroll
+  for (int k = 0; k < kAhead; ++k)
+    load_stage16<FeatT, B_UNITS, NHWC>(fcrop, w16, C, HW, tid, min(k, n_st - 1), regs[k]);
+  __syncthreads();  // zero fill done
+  store_stage16<FeatT, B_UNITS, NHWC>(As, Bs, dump, C, HW, tid, 0, regs[0]);
+
+  // iteration s = s0 + k: regs[k] held stage s (stored during iteration s - 1) and is refilled
+  // with stage s + kAhead; regs[k + 1] holds stage s + 1 and is stored into the other buffer,
+  // which every wave finished reading before this iteration's barrier.
+  for (int s0 = 0; s0 < n_st; s0 += kAhead) {
+#pragma unroll
+    for (int k = 0; k < kAhead; ++k) {
+      const int st = s0 + k;
+      if (st >= n_st) break;
+      __syncthreads();
+      const int cur = st & 1, nxt = cur ^ 1;
+      if (st + kAhead < n_st)
+        load_stage16<FeatT, B_UNITS, NHWC>(fcrop, w16, C, HW, tid, st + kAhead, regs[k]);
+      const char* Ab = As + cur * A_STAGE;
+      const char* Bb = Bs + cur * B_STAGE;
+      v4u af[4], bf[TPW][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        af[u] = *reinterpret_cast<const v4u*>(Ab + (a_off ^ (u << 5)));
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+          bf[t][u] = *reinterpret_cast<const v4u*>(Bb + (b_off[t] ^ (u << 5)));
+      }
+      if (st + 1 < n_st)
+        store_stage16<FeatT, B_UNITS, NHWC>(As + nxt * A_STAGE, Bs + nxt * B_STAGE,
+                                            dump - nxt * B_STAGE, C, HW, tid, st + 1,
+                                            regs[(k + 1) % kAhead]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+          if (on[t]) acc[t] = Mfma16<FeatT>::run(af[u], bf[t][u], acc[t]);
+    }
+  }
+  __syncthreads();  // every wave is done reading the tiles: the logits may overwrite them
+
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    if (!on[t]) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rt * 32 + 8 * (r >> 2) + 4 * fg + (r & 3);
+      Ls[row * HWP + (ct0 + 2 * t) * 32 + fi] = acc[t][r] + bgrp[row];
+    }
+  }
+  __syncthreads();
+  decode_group_from_lds<false, (CT > 2 ? 4 : 2)>(Ls, HWP, grp, g, crop, J, D, H, W, hs, coords2d,
+                                                 coords3d_rel, wid, lane);
+}
+
+template <int CT>
+constexpr size_t head16_lds_bytes() {
+  constexpr size_t stage = 2 * ((size_t)kRows * 128 + (size_t)CT * 32 * 128) + 256 * 16;
+  constexpr size_t logits = (size_t)kRows * hw_pad32<CT>() * sizeof(float);
+  return stage > logits ? stage : logits;
+}
+
 template <int CT>
 constexpr size_t head32_lds_bytes() {
   constexpr size_t stage = 2 * ((size_t)kRows * kKC + (size_t)CT * 32 * kKC) + 256 * 4;  // + dump slots
@@ -1153,6 +1408,40 @@ static int launch_head32w8(const void* feat, const float* packed, int B, int C, 
   return MTR_OK;
 }
 
+template <typename FeatT, int CT, bool NHWC>
+static int launch_head16(const void* feat, const float* packed, int B, int C, int H, int W, int J,
+                         int D, const HeadGeom& g, const HeadScale& hs, float* c2d, float* c3d,
+                         hipStream_t stream) {
+  if constexpr (std::is_same<FeatT, float>::value) {
+    return MTR_E_DTYPE;
+  } else {
+    constexpr size_t lds = head16_lds_bytes<CT>();
+    auto kern = head_fused16_kernel<FeatT, CT, NHWC>;
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    const int chunk = 8 * g.n_groups;
+    const long long blocks = (long long)((B + 7) / 8) * chunk;
+    if (blocks > 0x7fffffffLL) return MTR_E_SHAPE;
+    MTR_CLEAR_STALE();
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, (const FeatT*)feat,
+                       packed, B, C, H, W, J, D, g, hs, c2d, c3d);
+    MTR_CHECK_LAUNCH();
+    return MTR_OK;
+  }
+}
+
+// MTR_HEAD_H16=0: 16-bit features go through the f32 cores (widened in staging, f32 weights)
+static bool use_h16() {
+  static const bool v = [] {
+    const char* e = getenv("MTR_HEAD_H16");
+    return !(e && e[0] == '0');
+  }();
+  return v;
+}
+
 // MTR_HEAD_W8=0 / 1 forces the 4-wave / 8-wave 32x32 kernel (default: 8 waves for small launches)
 static int force_w8() {
   static const int v = [] {
@@ -1176,6 +1465,17 @@ static int dispatch_head(const void* feat, const float* packed, int B, int C, in
                          int D, const HeadGeom& g, const HeadScale& hs, float* c2d, float* c3d,
                          hipStream_t stream) {
   const int HW = H * W;
+  if (!std::is_same<FeatT, float>::value && use_h16() && !force_core16() && C % 8 == 0) {
+    switch ((HW + 31) / 32) {
+      case 1: return launch_head16<FeatT, 1, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+      case 2: return launch_head16<FeatT, 2, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+      case 3: return launch_head16<FeatT, 3, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+      case 4: return launch_head16<FeatT, 4, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+      case 5: return launch_head16<FeatT, 5, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+      case 6: return launch_head16<FeatT, 6, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+      default: return launch_head16<FeatT, 8, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+    }
+  }
   if (HW > 32 && HW <= 128 && !force_core16()) {
     if (HW <= 64) {
       // fewer than ~2 workgroups per CU: two waves per SIMD inside the workgroup instead
@@ -1214,10 +1514,13 @@ static int check_head_dims(int C, int J, int D) {
 }  // namespace mtr
 
 extern "C" size_t mtr_head_packed_bytes(int C, int J, int D, int feat_dtype) {
-  (void)feat_dtype;  // weights stay f32 for every feature dtype (exact-f32 MFMA)
   if (mtr::check_head_dims(C, J, D)) return 0;
   const mtr::HeadGeom g = mtr::head_geom(C, J, D);
-  return (2 * (size_t)g.n_groups * g.c_pad * mtr::kRows + (size_t)g.n_groups * mtr::kRows) * sizeof(float);
+  size_t n = (2 * (size_t)g.n_groups * g.c_pad * mtr::kRows + (size_t)g.n_groups * mtr::kRows) * sizeof(float);
+  // 16-bit feature dtypes: + the weights rounded to that dtype, for the f16 / bf16 MFMA kernel
+  if (feat_dtype == MTR_F16 || feat_dtype == MTR_BF16)
+    n += (size_t)g.n_groups * ((C + mtr::kKH - 1) / mtr::kKH) * mtr::kRows * mtr::kKH * 2;
+  return n;
 }
 
 extern "C" int mtr_head_pack_weights(const float* weight, const float* bias, int C, int J, int D,
@@ -1235,6 +1538,20 @@ extern "C" int mtr_head_pack_weights(const float* weight, const float* bias, int
   hipLaunchKernelGGL(mtr::head_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                      weight, bias, C, J, D, g, (float*)packed);
   MTR_CHECK_LAUNCH();
+  if (feat_dtype != MTR_F32) {
+    const int n_st = (C + mtr::kKH - 1) / mtr::kKH;
+    const size_t total16 = (size_t)g.n_groups * n_st * mtr::kRows * mtr::kKH;
+    size_t blocks16 = (total16 + 255) / 256;
+    if (blocks16 > 4096) blocks16 = 4096;
+    void* w16 = (float*)packed + total;
+    if (feat_dtype == MTR_F16)
+      hipLaunchKernelGGL(mtr::head_pack16_kernel<__half>, dim3((unsigned)blocks16), dim3(256), 0,
+                         (hipStream_t)stream, weight, C, J, D, g, n_st, (__half*)w16);
+    else
+      hipLaunchKernelGGL(mtr::head_pack16_kernel<__hip_bfloat16>, dim3((unsigned)blocks16), dim3(256),
+                         0, (hipStream_t)stream, weight, C, J, D, g, n_st, (__hip_bfloat16*)w16);
+    MTR_CHECK_LAUNCH();
+  }
   return MTR_OK;
 }
 

@@ -21,6 +21,18 @@ def mcfg(cfg):
     return MetrabsConfig.from_any(cfg.as_dict())
 
 
+def kernel_weights(w, dtype):
+    """The weights as the GEMM sees them: 16-bit features go through the f16 / bf16 MFMA kernel with
+    the weights rounded to the feature dtype (what autocast does to conv_final in the reference's
+    GPU path), unless C % 8 != 0 or a switch forces the f32 cores (f32 weights, features widened
+    in staging)."""
+    import os
+    forced_f32 = os.environ.get('MTR_HEAD_H16') == '0' or os.environ.get('MTR_HEAD_CORE') == '16'
+    if dtype == torch.float32 or forced_f32 or w.shape[1] % 8:  # (16-byte channel vectors: C % 8 == 0)
+        return w
+    return w.to(dtype).float()
+
+
 def run_fused(feat, w, b, J, cfg):
     from metrabs_amd import kernels
     packed = kernels.head_pack_weights(w.cuda(), b.cuda(), J, cfg.depth, feat.dtype)
@@ -80,15 +92,46 @@ def test_fused_head_odd_shapes_vs_oracle(shape, hip_lib):
 
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 def test_fused_head_16bit_features(dtype, hip_lib):
-    """f16 / bf16 features (the autocast backbone output) are widened to f32 in LDS staging; weights
-    and logits stay f32.  Equals the oracle evaluated on the rounded features."""
+    """f16 / bf16 features (the autocast backbone output): f16 / bf16 MFMA on features and weights
+    of that dtype, f32 accumulation, f32 logits.  Equals the oracle's f32 conv + decode evaluated on
+    the same rounded features and weights (products of two 16-bit values are exact in f32)."""
     feat, w, b, J, cfg = cases.headconv_case('s256_c1280')
     feat16 = feat.to(dtype)
     with torch.inference_mode():
-        o2d, o3d = cpu_ref.heads_forward(feat16.float(), w, b, J, cfg)
+        o2d, o3d = cpu_ref.heads_forward(feat16.float(), kernel_weights(w, dtype), b, J, cfg)
     c2d, c3d = run_fused(feat16, w, b, J, cfg)
     print(f'[parity] fused head {dtype}: max {float((c3d - o3d).abs().max()):.2e} mm')
     assert float((c3d - o3d).abs().max()) <= 2e-3 and cpu_ref.mpjpe(c3d, o3d) <= 1e-3
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(3, 40, 17, 8, 8, 8), (2, 24, 5, 8, 4, 4), (2, 136, 17, 8, 12, 12),
+                                   (1, 64, 3, 8, 16, 16), (2, 96, 30, 4, 10, 10), (9, 32, 1, 8, 8, 8),
+                                   (2, 100, 7, 8, 2, 8), (3, 72, 17, 8, 6, 6), (2, 33, 9, 8, 8, 12),
+                                   (2, 65, 17, 8, 8, 16), (10, 31, 17, 8, 8, 8), (2, 200, 4, 8, 14, 14),
+                                   (3, 128, 11, 8, 10, 16), (2, 1280, 122, 8, 12, 12)])
+def test_fused_head_16bit_odd_shapes(shape, dtype, hip_lib):
+    """The 16-bit MFMA kernel on every column-tile count (1 .. 8 tiles of 32 positions), C not a
+    multiple of its 64-channel stage (fewer stages than the prefetch depth included), ragged joint
+    groups, both layouts; C % 8 != 0 takes the f32 cores."""
+    from metrabs_amd import kernels
+    B, C, J, D, H, W = shape
+    cfg = cpu_ref.HeadConfig(depth=D, proc_side=max(H, W) * 8, stride_test=8, stride_train=8)
+    g = cases.gen(8300 + sum(shape))
+    feat = torch.randn(B, C, H, W, generator=g).to(dtype)
+    w, b = cases.default_conv_init(J * (1 + D), C, g)
+    w, b = w * 3, b * 3
+    with torch.inference_mode():
+        o2d, o3d = cpu_ref.heads_forward(feat.float(), kernel_weights(w, dtype), b, J, cfg)
+    c2d, c3d = run_fused(feat, w, b, J, cfg)
+    print(f'[parity] fused head 16-bit {shape} {dtype}: max {float((c3d - o3d).abs().max()):.2e} mm')
+    assert float((c3d - o3d).abs().max()) <= 2e-3 and cpu_ref.mpjpe(c3d, o3d) <= 1e-3
+    assert float((c2d - o2d).abs().max()) <= 4e-4
+    if C % 4 == 0:
+        packed = kernels.head_pack_weights(w.cuda(), b.cuda(), J, D, dtype)
+        l2d, l3d = kernels.head_fused(feat.cuda().contiguous(memory_format=torch.channels_last),
+                                      packed, C, J, mcfg(cfg))
+        assert float((l3d.cpu() - o3d).abs().max()) <= 2e-3 and float((l2d.cpu() - o2d).abs().max()) <= 4e-4
 
 
 def test_fused_equals_unfused_and_module(hip_lib):
@@ -176,12 +219,13 @@ def test_fused_head_channels_last_features(shape, dtype, hip_lib):
     c2d, c3d = kernels.head_fused(feat_cl, packed, C, J, mcfg(cfg))
     assert torch.equal(c3d, n3d) and torch.equal(c2d, n2d)
     with torch.inference_mode():
-        o2d, o3d = cpu_ref.heads_forward(feat.float().cpu(), w * 3, b * 3, J, cfg)
+        o2d, o3d = cpu_ref.heads_forward(feat.float().cpu(), kernel_weights(w * 3, dtype), b * 3, J, cfg)
     assert float((c3d.cpu() - o3d).abs().max()) <= 2e-3
 
 
-@pytest.mark.parametrize('env', [{'MTR_HEAD_CORE': '16'}, {'MTR_HEAD_W8': '0'}, {'MTR_HEAD_W8': '1'}],
-                         ids=['core16', 'w4', 'w8'])
+@pytest.mark.parametrize('env', [{'MTR_HEAD_CORE': '16'}, {'MTR_HEAD_W8': '0'}, {'MTR_HEAD_W8': '1'},
+                                 {'MTR_HEAD_H16': '0'}],
+                         ids=['core16', 'w4', 'w8', 'f32core_on_16bit'])
 def test_every_gemm_variant_on_all_shapes_subprocess(env, hip_lib):
     """Three GEMM kernels sit behind mtr_head_fused: the 16x16x4 core, the 4-wave 32x32x2 kernel and
     its 8-wave K-split variant for small launches.  The dispatch picks by map size and launch size;
@@ -190,7 +234,7 @@ def test_every_gemm_variant_on_all_shapes_subprocess(env, hip_lib):
     import os
     import subprocess
     import sys
-    if os.environ.get('MTR_HEAD_CORE') or os.environ.get('MTR_HEAD_W8'):
+    if os.environ.get('MTR_HEAD_CORE') or os.environ.get('MTR_HEAD_W8') or os.environ.get('MTR_HEAD_H16'):
         pytest.skip('already inside a forced-variant run')
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-m', 'gpu',
                         '-k', 'golden or odd_shapes or 16bit or channels_last or full_size'],

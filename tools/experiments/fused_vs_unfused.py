@@ -25,7 +25,9 @@ def timed(fn, n=20, reps=10):
     return a.elapsed_time(b) / (n * reps) * 1e3
 
 for (B, C, J, D, H, dt) in [(64, 1280, 17, 8, 8, torch.float32), (1024, 1280, 17, 8, 8, torch.float32),
-                            (64, 1280, 17, 8, 8, torch.float16), (32, 1280, 122, 8, 12, torch.float16),
+                            (64, 1280, 17, 8, 8, torch.float16), (1024, 1280, 17, 8, 8, torch.float16),
+                            (64, 1280, 17, 8, 8, torch.bfloat16), (32, 1280, 122, 8, 12, torch.float16),
+                            (256, 1280, 122, 8, 12, torch.float16), (256, 2048, 24, 8, 8, torch.float16),
                             (64, 1280, 17, 72, 8, torch.float32)]:
     cfg = MetrabsConfig(depth=D, proc_side=H * 32)
     heads = MetrabsHeads(J, cfg, in_channels=C, fused=True).cuda()
