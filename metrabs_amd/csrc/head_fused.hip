@@ -1134,68 +1134,83 @@ __global__ void head_pack16_kernel(const float* __restrict__ w, int C, int J, in
   }
 }
 
-template <int B_UNITS, bool NHWC>
+// GPW = joint groups (64-row blocks) per workgroup.  One group per workgroup re-stages the crop's
+// feature tile once per group and reads 2 KiB of LDS per MFMA; with GPW groups a wave holds GPW
+// weight fragments against each feature fragment (GPW x TPW MFMAs from GPW + TPW fragment reads)
+// and the feature tile is staged once for all of them.  Small launches keep GPW = 1 (more, smaller
+// workgroups to fill 256 CUs); the dispatch picks.
+template <int GPW, int B_UNITS, bool NHWC>
 struct StageRegs16 {
-  v4u a[2];
+  v4u a[2 * GPW];
   // NHWC: one 16-byte slot per unit.  NCHW: 8 dwords per unit (8 channels x 2 positions).
   unsigned b[B_UNITS][NHWC ? 4 : 8];
 };
 
-template <typename FeatT, int B_UNITS, bool NHWC>
-__device__ __forceinline__ void load_stage16(const FeatT* fcrop, const FeatT* w16, int C, int HW,
-                                             int tid, int stage, StageRegs16<B_UNITS, NHWC>& r) {
+template <typename FeatT>
+struct StageSrc16 {
+  const FeatT* fcrop;   // this crop's features
+  const FeatT* w16[3];  // 16-bit weights of the workgroup's groups (absent group: a valid one)
+  int C, HW, tid;
+};
+
+template <typename FeatT, int GPW, int B_UNITS, bool NHWC>
+__device__ __forceinline__ void load_stage16(const StageSrc16<FeatT>& s, int stage,
+                                             StageRegs16<GPW, B_UNITS, NHWC>& r) {
   const int c0 = stage * kKH;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)  // 64 rows x 64 ch of this stage: contiguous 8 KiB
-    r.a[i] = *reinterpret_cast<const v4u*>(w16 + (size_t)stage * (kRows * kKH) + (size_t)(tid + i * 256) * 8);
+  for (int i = 0; i < 2 * GPW; ++i)  // 64 rows x 64 ch of this stage and group: contiguous 8 KiB
+    r.a[i] = *reinterpret_cast<const v4u*>(s.w16[i >> 1] + (size_t)stage * (kRows * kKH) +
+                                           (size_t)(s.tid + (i & 1) * 256) * 8);
 #pragma unroll
   for (int i = 0; i < B_UNITS; ++i) {
-    const int v = tid + i * 256;
+    const int v = s.tid + i * 256;
     if constexpr (NHWC) {
       const int pos = v >> 3, slot = v & 7;
-      const bool ok = pos < HW && c0 + slot * 8 < C;
-      const v4u x = *reinterpret_cast<const v4u*>(fcrop + (ok ? (size_t)pos * C + c0 + slot * 8 : 0));
+      const bool ok = pos < s.HW && c0 + slot * 8 < s.C;
+      const v4u x = *reinterpret_cast<const v4u*>(s.fcrop + (ok ? (size_t)pos * s.C + c0 + slot * 8 : 0));
 #pragma unroll
       for (int e = 0; e < 4; ++e) r.b[i][e] = x[e];
     } else {
-      const int pairs = HW >> 1;
+      const int pairs = s.HW >> 1;
       const int kg = v / pairs, pp = v - kg * pairs;  // 8-channel group, position pair
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int c = c0 + kg * 8 + e;
-        const bool ok = kg < 8 && c < C;
-        r.b[i][e] = *reinterpret_cast<const unsigned*>(fcrop + (ok ? (size_t)c * HW + 2 * pp : 0));
+        const bool ok = kg < 8 && c < s.C;
+        r.b[i][e] = *reinterpret_cast<const unsigned*>(s.fcrop + (ok ? (size_t)c * s.HW + 2 * pp : 0));
       }
     }
   }
 }
 
-template <typename FeatT, int B_UNITS, bool NHWC>
-__device__ __forceinline__ void store_stage16(char* As_buf, char* Bs_buf, int dump, int C, int HW,
-                                              int tid, int stage,
-                                              const StageRegs16<B_UNITS, NHWC>& r) {
+// `dump`: byte offset from Bs_buf of this lane's 16-byte dump slot (lanes without a valid element
+// store there instead of branching)
+template <typename FeatT, int GPW, int B_UNITS, bool NHWC>
+__device__ __forceinline__ void store_stage16(const StageSrc16<FeatT>& s, char* As_buf, char* Bs_buf,
+                                              int dump, int stage,
+                                              const StageRegs16<GPW, B_UNITS, NHWC>& r) {
   const int c0 = stage * kKH;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int v = tid + i * 256;
-    const int row = v >> 3, slot = v & 7;
+  for (int i = 0; i < 2 * GPW; ++i) {
+    const int v = s.tid + (i & 1) * 256;
+    const int row = (i >> 1) * kRows + (v >> 3), slot = v & 7;
     *reinterpret_cast<v4u*>(As_buf + row * 128 + ((slot ^ swz(row)) << 4)) = r.a[i];
   }
   const v4u zero = v4u{0u, 0u, 0u, 0u};
 #pragma unroll
   for (int i = 0; i < B_UNITS; ++i) {
-    const int v = tid + i * 256;
+    const int v = s.tid + i * 256;
     if constexpr (NHWC) {
       const int pos = v >> 3, slot = v & 7;
-      const int o = pos < HW ? pos * 128 + ((slot ^ swz(pos)) << 4) : dump;
+      const int o = pos < s.HW ? pos * 128 + ((slot ^ swz(pos)) << 4) : dump;
       const v4u x = v4u{r.b[i][0], r.b[i][1], r.b[i][2], r.b[i][3]};
-      *reinterpret_cast<v4u*>(Bs_buf + o) = (c0 + slot * 8 < C) ? x : zero;
+      *reinterpret_cast<v4u*>(Bs_buf + o) = (c0 + slot * 8 < s.C) ? x : zero;
     } else {
-      const int pairs = HW >> 1;
+      const int pairs = s.HW >> 1;
       const int kg = v / pairs, pp = v - kg * pairs;
       unsigned d[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) d[e] = (c0 + kg * 8 + e < C) ? r.b[i][e] : 0u;
+      for (int e = 0; e < 8; ++e) d[e] = (c0 + kg * 8 + e < s.C) ? r.b[i][e] : 0u;
       v4u lo, hi;  // position 2pp: low halves; 2pp + 1: high halves; channel e at half e
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -1216,72 +1231,96 @@ __host__ __device__ constexpr int h16_b_units() {
   return ((NHWC ? CT * 32 * 8 : CT * 16 * 8) + 255) / 256;
 }
 
-template <typename FeatT, int CT, bool NHWC>
-__global__ __launch_bounds__(256) void head_fused16_kernel(
+// developer-only build knobs (tools/experiments/ablate_head16.py); all 0 in the product
+#ifndef MTR_H16_AHEAD
+#define MTR_H16_AHEAD 0     // prefetch depth override
+#endif
+#ifndef MTR_H16_ABLATE
+#define MTR_H16_ABLATE 0    // 1: no global loads in the K loop, 2: no MFMA, 4: no LDS stores, 8: no LDS reads
+#endif
+#ifndef MTR_H16_MINWAVES
+#define MTR_H16_MINWAVES 1  // __launch_bounds__ second argument
+#endif
+
+template <typename FeatT, int CT, int GPW, bool NHWC>
+__global__ __launch_bounds__(256, MTR_H16_MINWAVES) void head_fused16_kernel(
     const FeatT* __restrict__ feat, const float* __restrict__ packed, int B, int C, int H, int W,
     int J, int D, HeadGeom g, HeadScale hs, float* __restrict__ coords2d,
     float* __restrict__ coords3d_rel) {
   constexpr int TPW = (CT + 1) / 2;
   constexpr int HWP = hw_pad32<CT>();
-  constexpr int A_STAGE = kRows * 128;        // bytes
+  constexpr int A_STAGE = GPW * kRows * 128;  // bytes
   constexpr int B_STAGE = CT * 32 * 128;      // bytes
   constexpr int B_UNITS = h16_b_units<CT, NHWC>();
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  char* As = reinterpret_cast<char*>(smem);   // [2][64][128 B]
+  char* As = reinterpret_cast<char*>(smem);   // [2][GPW*64][128 B]
   char* Bs = As + 2 * A_STAGE;                // [2][CT*32][128 B], then 256 x 16-byte dump slots
-  float* Ls = smem;                           // epilogue alias: [64][HWP]
+  float* Ls = smem;                           // epilogue alias: [64][HWP], one group at a time
 
   const int HW = H * W;
-  const int chunk = 8 * g.n_groups;  // XCD-aware remap, as in the f32 cores
+  const int wg_per_crop = (g.n_groups + GPW - 1) / GPW;
+  const int chunk = 8 * wg_per_crop;  // XCD-aware remap, as in the f32 cores
   const int id = blockIdx.x;
   const int crop = (id / chunk) * 8 + (id % 8);
-  const int grp = (id % chunk) / 8;
+  const int grp0 = ((id % chunk) / 8) * GPW;
   if (crop >= B) return;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int n_st = (C + kKH - 1) / kKH;
-  const FeatT* fcrop = feat + (size_t)crop * C * HW;
   const size_t n_w = (size_t)g.n_groups * g.c_pad * kRows;
-  const float* bgrp = packed + n_w + (size_t)grp * kRows;
-  const FeatT* w16 = reinterpret_cast<const FeatT*>(packed + 2 * n_w + (size_t)g.n_groups * kRows) +
-                     (size_t)grp * n_st * (kRows * kKH);
+  const float* bias = packed + n_w;
+  const FeatT* w16 = reinterpret_cast<const FeatT*>(packed + 2 * n_w + (size_t)g.n_groups * kRows);
+  StageSrc16<FeatT> src;
+  src.fcrop = feat + (size_t)crop * C * HW;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    src.w16[k] = w16 + (size_t)min(grp0 + (k < GPW ? k : 0), g.n_groups - 1) * n_st * (kRows * kKH);
+  src.C = C; src.HW = HW; src.tid = tid;
 
   // rows >= HW of the feature tile are never written: zero both buffers once
   for (int v = tid; v < 2 * B_STAGE / 16; v += 256)
     reinterpret_cast<v4u*>(Bs)[v] = v4u{0u, 0u, 0u, 0u};
 
-  const int rt = wid & 1, ct0 = wid >> 1;
+  // wave (rp, cp): row tiles rp, rp + 2, .. (one per group), column tiles cp, cp + 2, ..
+  const int rp = wid & 1, cp = wid >> 1;
   const int fi = lane & 31, fg = lane >> 5;
-  const int a_row = rt * 32 + fi;
-  const int a_off = a_row * 128 + ((fg ^ swz(a_row)) << 4);  // ^ (u << 5) selects slot 2u + g
-  int b_off[TPW];
+  int a_off[GPW], b_off[TPW];  // ^ (u << 5) selects slot 2u + g
   bool on[TPW];
 #pragma unroll
+  for (int k = 0; k < GPW; ++k) {
+    const int row = (2 * k + rp) * 32 + fi;
+    a_off[k] = row * 128 + ((fg ^ swz(row)) << 4);
+  }
+#pragma unroll
   for (int t = 0; t < TPW; ++t) {
-    on[t] = ct0 + 2 * t < CT;
-    const int pos = (on[t] ? ct0 + 2 * t : 0) * 32 + fi;
+    on[t] = cp + 2 * t < CT;
+    const int pos = (on[t] ? cp + 2 * t : 0) * 32 + fi;
     b_off[t] = pos * 128 + ((fg ^ swz(pos)) << 4);
   }
 
-  f32x16 acc[TPW];
+  f32x16 acc[GPW][TPW];
 #pragma unroll
-  for (int t = 0; t < TPW; ++t) acc[t] = f32x16{0};
+  for (int k = 0; k < GPW; ++k)
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[k][t] = f32x16{0};
 
-  // kAhead stages of global loads in flight per workgroup (register sets, rotated statically).  A
-  // stage is only a few hundred cycles of MFMA here, so a small launch (one workgroup per CU) needs
-  // several stages in flight to cover the ~1.5 us a load takes on an otherwise idle CU.
-  constexpr int kAhead = CT <= 2 ? 4 : (CT <= 4 ? 3 : 2);
+  // kAhead register sets of global loads in flight (rotated statically).  Measured on MI355X
+  // (tools/experiments/ablate_head16.py): depth 2 - 4 is no faster than 1 at any launch
+  // size, and the registers it takes cost a resident workgroup on the wide tiles (J = 122, 12x12:
+  // 505 us at depth 2 vs 324 us at depth 1) -- what hides the load latency of this short loop is a
+  // second workgroup on the CU, not a deeper queue in this one.
+  constexpr int kAhead = MTR_H16_AHEAD ? MTR_H16_AHEAD : 1;
   const int dump = 2 * B_STAGE + tid * 16;  // byte offset from Bs of this lane's dump slot
-  StageRegs16<B_UNITS, NHWC> regs[kAhead];
+  StageRegs16<GPW, B_UNITS, NHWC> regs[kAhead];
 #pragma unroll
   for (int k = 0; k < kAhead; ++k)
-    load_stage16<FeatT, B_UNITS, NHWC>(fcrop, w16, C, HW, tid, min(k, n_st - 1), regs[k]);
+    load_stage16<FeatT, GPW, B_UNITS, NHWC>(src, min(k, n_st - 1), regs[k]);
   __syncthreads();  // zero fill done
-  store_stage16<FeatT, B_UNITS, NHWC>(As, Bs, dump, C, HW, tid, 0, regs[0]);
+  store_stage16<FeatT, GPW, B_UNITS, NHWC>(src, As, Bs, dump, 0, regs[0]);
 
   // iteration s = s0 + k: regs[k] held stage s (stored during iteration s - 1) and is refilled
-  // with stage s + kAhead; regs[k + 1] holds stage s + 1 and is stored into the other buffer,
-  // which every wave finished reading before this iteration's barrier.
+  // with stage s + kAhead; regs[(k + 1) % kAhead] holds stage s + 1 and is stored into the other
+  // buffer, which every wave finished reading before this iteration's barrier.
   for (int s0 = 0; s0 < n_st; s0 += kAhead) {
 #pragma unroll
     for (int k = 0; k < kAhead; ++k) {
@@ -1289,48 +1328,73 @@ __global__ __launch_bounds__(256) void head_fused16_kernel(
       if (st >= n_st) break;
       __syncthreads();
       const int cur = st & 1, nxt = cur ^ 1;
-      if (st + kAhead < n_st)
-        load_stage16<FeatT, B_UNITS, NHWC>(fcrop, w16, C, HW, tid, st + kAhead, regs[k]);
+      // unconditional (clamped) loads and stores: a load inside a branch makes the compiler merge
+      // "issued" and "not issued" at the join, and the vmcnt it then puts in front of the stores
+      // waits for the loads just issued -- the prefetch distance collapses to zero
+      if (!(MTR_H16_ABLATE & 1))
+        load_stage16<FeatT, GPW, B_UNITS, NHWC>(src, min(st + kAhead, n_st - 1), regs[k]);
       const char* Ab = As + cur * A_STAGE;
       const char* Bb = Bs + cur * B_STAGE;
-      v4u af[4], bf[TPW][4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        af[u] = *reinterpret_cast<const v4u*>(Ab + (a_off ^ (u << 5)));
+      for (int uh = 0; uh < 2; ++uh) {  // two 32-channel halves: half the live fragment registers
+        v4u af[GPW][2], bf[TPW][2];
 #pragma unroll
-        for (int t = 0; t < TPW; ++t)
-          bf[t][u] = *reinterpret_cast<const v4u*>(Bb + (b_off[t] ^ (u << 5)));
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+          for (int q = 0; q < GPW; ++q)
+            af[q][u] = (MTR_H16_ABLATE & 8) ? v4u{(unsigned)a_off[q], 1u, 2u, (unsigned)st}
+                : *reinterpret_cast<const v4u*>(Ab + (a_off[q] ^ ((2 * uh + u) << 5)));
+#pragma unroll
+          for (int t = 0; t < TPW; ++t)
+            bf[t][u] = (MTR_H16_ABLATE & 8) ? v4u{(unsigned)b_off[t], 1u, 2u, (unsigned)st}
+                : *reinterpret_cast<const v4u*>(Bb + (b_off[t] ^ ((2 * uh + u) << 5)));
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int t = 0; t < TPW; ++t)  // (an absent tile recomputes tile 0: no branch; the
+#pragma unroll                           //  other waves' tiles bound the stage anyway)
+            for (int q = 0; q < GPW; ++q) {
+              if (MTR_H16_ABLATE & 2) {
+                acc[q][t][0] += __builtin_bit_cast(float, af[q][u][0] ^ bf[t][u][0]);
+              } else {
+                acc[q][t] = Mfma16<FeatT>::run(af[q][u], bf[t][u], acc[q][t]);
+              }
+            }
       }
-      if (st + 1 < n_st)
-        store_stage16<FeatT, B_UNITS, NHWC>(As + nxt * A_STAGE, Bs + nxt * B_STAGE,
-                                            dump - nxt * B_STAGE, C, HW, tid, st + 1,
-                                            regs[(k + 1) % kAhead]);
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int t = 0; t < TPW; ++t)
-          if (on[t]) acc[t] = Mfma16<FeatT>::run(af[u], bf[t][u], acc[t]);
+      // behind the MFMA issue: the wait for the loads overlaps the matrix pipe draining
+      // (after the last stage: a clamped stage into the idle buffer)
+      if (!(MTR_H16_ABLATE & 4))
+        store_stage16<FeatT, GPW, B_UNITS, NHWC>(src, As + nxt * A_STAGE, Bs + nxt * B_STAGE,
+                                                 dump - nxt * B_STAGE, st + 1, regs[(k + 1) % kAhead]);
     }
   }
-  __syncthreads();  // every wave is done reading the tiles: the logits may overwrite them
 
+  // ---- epilogue, one group at a time (the logits of one group alias the staging tiles):
+  //   logits (+bias) -> LDS [64][HWP]; this wave's row tile of group q is 2q + rp
 #pragma unroll
-  for (int t = 0; t < TPW; ++t) {
-    if (!on[t]) continue;
+  for (int q = 0; q < GPW; ++q) {
+    __syncthreads();  // the tiles (q = 0) / the previous group's logits are no longer read
+    if (grp0 + q >= g.n_groups) break;
+    const float* bgrp = bias + (size_t)(grp0 + q) * kRows;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = rt * 32 + 8 * (r >> 2) + 4 * fg + (r & 3);
-      Ls[row * HWP + (ct0 + 2 * t) * 32 + fi] = acc[t][r] + bgrp[row];
+    for (int t = 0; t < TPW; ++t) {
+      if (!on[t]) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rp * 32 + 8 * (r >> 2) + 4 * fg + (r & 3);
+        Ls[row * HWP + (cp + 2 * t) * 32 + fi] = acc[q][t][r] + bgrp[row];
+      }
     }
+    __syncthreads();
+    decode_group_from_lds<false, (CT > 2 ? 4 : 2)>(Ls, HWP, grp0 + q, g, crop, J, D, H, W, hs,
+                                                   coords2d, coords3d_rel, wid, lane);
   }
-  __syncthreads();
-  decode_group_from_lds<false, (CT > 2 ? 4 : 2)>(Ls, HWP, grp, g, crop, J, D, H, W, hs, coords2d,
-                                                 coords3d_rel, wid, lane);
 }
 
-template <int CT>
+template <int CT, int GPW>
 constexpr size_t head16_lds_bytes() {
-  constexpr size_t stage = 2 * ((size_t)kRows * 128 + (size_t)CT * 32 * 128) + 256 * 16;
+  constexpr size_t stage = 2 * ((size_t)GPW * kRows * 128 + (size_t)CT * 32 * 128) + 256 * 16;
   constexpr size_t logits = (size_t)kRows * hw_pad32<CT>() * sizeof(float);
   return stage > logits ? stage : logits;
 }
@@ -1408,21 +1472,21 @@ static int launch_head32w8(const void* feat, const float* packed, int B, int C, 
   return MTR_OK;
 }
 
-template <typename FeatT, int CT, bool NHWC>
+template <typename FeatT, int CT, int GPW, bool NHWC>
 static int launch_head16(const void* feat, const float* packed, int B, int C, int H, int W, int J,
                          int D, const HeadGeom& g, const HeadScale& hs, float* c2d, float* c3d,
                          hipStream_t stream) {
   if constexpr (std::is_same<FeatT, float>::value) {
     return MTR_E_DTYPE;
   } else {
-    constexpr size_t lds = head16_lds_bytes<CT>();
-    auto kern = head_fused16_kernel<FeatT, CT, NHWC>;
+    constexpr size_t lds = head16_lds_bytes<CT, GPW>();
+    auto kern = head_fused16_kernel<FeatT, CT, GPW, NHWC>;
     if (lds > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute((const void*)kern,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return (int)e;
     }
-    const int chunk = 8 * g.n_groups;
+    const int chunk = 8 * ((g.n_groups + GPW - 1) / GPW);
     const long long blocks = (long long)((B + 7) / 8) * chunk;
     if (blocks > 0x7fffffffLL) return MTR_E_SHAPE;
     MTR_CLEAR_STALE();
@@ -1431,6 +1495,37 @@ static int launch_head16(const void* feat, const float* packed, int B, int C, in
     MTR_CHECK_LAUNCH();
     return MTR_OK;
   }
+}
+
+// MTR_HEAD_GPW=1/2/3 forces the joint groups per workgroup of the 16-bit kernel
+static int force_gpw() {
+  static const int v = [] {
+    const char* e = getenv("MTR_HEAD_GPW");
+    return e && e[0] >= '1' && e[0] <= '3' ? e[0] - '0' : 0;
+  }();
+  return v;
+}
+
+template <typename FeatT, int CT, bool NHWC>
+static int dispatch_head16(const void* feat, const float* packed, int B, int C, int H, int W, int J,
+                           int D, const HeadGeom& g, const HeadScale& hs, float* c2d, float* c3d,
+                           hipStream_t stream) {
+  // accumulators: GPW x ceil(CT / 2) tiles of 16 registers per wave
+  constexpr int kMaxGpw = CT <= 2 ? 3 : (CT <= 6 ? 2 : 1);
+  int gpw = 1;
+  const long long crops8 = (long long)((B + 7) / 8) * 8;
+  for (int cand = 2; cand <= kMaxGpw; ++cand) {
+    // several groups per workgroup once the launch still fills the chip (>= 4 workgroups per CU)
+    // and the groups divide without an idle remainder worse than the gain
+    const int wgs = (g.n_groups + cand - 1) / cand;
+    if (crops8 * wgs >= 1024 && wgs * cand - g.n_groups <= (g.n_groups >= 6 ? 1 : 0)) gpw = cand;
+  }
+  if (force_gpw()) gpw = force_gpw() < kMaxGpw ? force_gpw() : kMaxGpw;
+  if constexpr (kMaxGpw >= 3)
+    if (gpw == 3) return launch_head16<FeatT, CT, 3, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+  if constexpr (kMaxGpw >= 2)
+    if (gpw == 2) return launch_head16<FeatT, CT, 2, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+  return launch_head16<FeatT, CT, 1, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
 }
 
 // MTR_HEAD_H16=0: 16-bit features go through the f32 cores (widened in staging, f32 weights)
@@ -1467,13 +1562,13 @@ static int dispatch_head(const void* feat, const float* packed, int B, int C, in
   const int HW = H * W;
   if (!std::is_same<FeatT, float>::value && use_h16() && !force_core16() && C % 8 == 0) {
     switch ((HW + 31) / 32) {
-      case 1: return launch_head16<FeatT, 1, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
-      case 2: return launch_head16<FeatT, 2, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
-      case 3: return launch_head16<FeatT, 3, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
-      case 4: return launch_head16<FeatT, 4, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
-      case 5: return launch_head16<FeatT, 5, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
-      case 6: return launch_head16<FeatT, 6, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
-      default: return launch_head16<FeatT, 8, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+      case 1: return dispatch_head16<FeatT, 1, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+      case 2: return dispatch_head16<FeatT, 2, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+      case 3: return dispatch_head16<FeatT, 3, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+      case 4: return dispatch_head16<FeatT, 4, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+      case 5: return dispatch_head16<FeatT, 5, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+      case 6: return dispatch_head16<FeatT, 6, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
+      default: return dispatch_head16<FeatT, 8, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
     }
   }
   if (HW > 32 && HW <= 128 && !force_core16()) {

@@ -482,3 +482,15 @@ def deterministic_state(state_dict, seed=0):
 
 def backbone_probe_input():
     return torch.rand(2, 3, 96, 96, generator=gen(314))
+
+
+def head_weights_as_consumed(w, feat_dtype):
+    """The conv_final weights as the fused head's GEMM consumes them, for building the expected
+    value on the CPU: 16-bit features go through the f16 / bf16 MFMA kernel with the weights
+    rounded to the feature dtype (what autocast does to conv_final in the reference's GPU path,
+    SURVEY.md section 0), unless C % 8 != 0 or a developer switch forces the f32 cores."""
+    import os
+    forced_f32 = os.environ.get('MTR_HEAD_H16') == '0' or os.environ.get('MTR_HEAD_CORE') == '16'
+    if feat_dtype == torch.float32 or forced_f32 or w.shape[1] % 8:
+        return w
+    return w.to(feat_dtype).float()

@@ -23,8 +23,9 @@ def _head_and_recon(B, C, J, hw, proc_side, dtype, seed, gain=2.0):
     ocfg = cpu_ref.HeadConfig(proc_side=proc_side)
     cfg = MetrabsConfig(proc_side=proc_side)
     with torch.inference_mode():
-        ref = cpu_ref.crop_model_from_features(feat.float(), w, b, K, J, ocfg)
-        truth = cpu_ref.crop_model_from_features_fp64(feat.float(), w, b, K, J, ocfg)
+        wk = cases.head_weights_as_consumed(w, dtype)  # (f16 features: f16 weights, as under autocast)
+        ref = cpu_ref.crop_model_from_features(feat.float(), wk, b, K, J, ocfg)
+        truth = cpu_ref.crop_model_from_features_fp64(feat.float(), wk, b, K, J, ocfg)
     packed = kernels.head_pack_weights(w.cuda(), b.cuda(), J, 8, dtype)
     c2d, c3d = kernels.head_fused(feat.cuda(), packed, C, J, cfg)
     ours = kernels.reconstruct_absolute(c2d, c3d, K.cuda(), cfg).cpu()

@@ -21,16 +21,7 @@ def mcfg(cfg):
     return MetrabsConfig.from_any(cfg.as_dict())
 
 
-def kernel_weights(w, dtype):
-    """The weights as the GEMM sees them: 16-bit features go through the f16 / bf16 MFMA kernel with
-    the weights rounded to the feature dtype (what autocast does to conv_final in the reference's
-    GPU path), unless C % 8 != 0 or a switch forces the f32 cores (f32 weights, features widened
-    in staging)."""
-    import os
-    forced_f32 = os.environ.get('MTR_HEAD_H16') == '0' or os.environ.get('MTR_HEAD_CORE') == '16'
-    if dtype == torch.float32 or forced_f32 or w.shape[1] % 8:  # (16-byte channel vectors: C % 8 == 0)
-        return w
-    return w.to(dtype).float()
+kernel_weights = cases.head_weights_as_consumed
 
 
 def run_fused(feat, w, b, J, cfg):
