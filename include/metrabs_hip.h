@@ -95,11 +95,15 @@ int mtr_softargmax_decode(const void* logits, int dtype, int layout, int B, int 
  * tiled layout the kernel streams; `packed` must hold
  * mtr_head_packed_bytes(...) bytes.  features: [B, C, H, W] (MTR_NCHW) or [B, H, W, C] (MTR_NHWC,
  * C % 4 == 0); H*W must be a multiple of 4 and <= 256, 1+D <= 64 (else: 1x1-conv GEMM +
- * mtr_softargmax_decode).  Arithmetic: f32-input MFMA with f32 weights (v_mfma_f32_32x32x2_f32 for
- * maps of 33..128 positions, v_mfma_f32_16x16x4_f32 otherwise; the packed blob holds the weights in
- * both tile layouts); for f32 features the f32 chains are 16 channels long and carried into f64
- * accumulators (parity with the fp32 CPU reference), for f16/bf16 features one f32 chain runs over
- * all of C.
+ * mtr_softargmax_decode).  Arithmetic, f32 features: f32-input MFMA with f32 weights
+ * (v_mfma_f32_32x32x2_f32 for maps of 33..128 positions, v_mfma_f32_16x16x4_f32 otherwise; the
+ * packed blob holds the weights in both tile layouts), f32 chains of 16 channels carried into f64
+ * accumulators (parity with the fp32 CPU reference).  f16 / bf16 features with C % 8 == 0:
+ * v_mfma_f32_32x32x16_{f16,bf16} on the features and on the weights ROUNDED TO THE FEATURE DTYPE
+ * (what autocast does to conv_final in the reference's GPU path), f32 accumulation, f32 logits; the
+ * rounded weights are a third section of the blob, so `packed` is specific to the feat_dtype it was
+ * packed for: pass the same feat_dtype to mtr_head_packed_bytes, mtr_head_pack_weights and
+ * mtr_head_fused.  (C % 8 != 0: the 16-bit features are widened in staging and run on the f32 path.)
  */
 size_t mtr_head_packed_bytes(int C, int J, int D, int feat_dtype);
 int mtr_head_pack_weights(const float* weight /*[J*(1+D), C] f32*/, const float* bias /*[J*(1+D)]*/,

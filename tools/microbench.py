@@ -77,11 +77,13 @@ def bench_head():
         o = (torch.empty(B, J, 2, device='cuda'), torch.empty(B, J, 3, device='cuda'))
         t = timeit(lambda: kernels.head_fused(feat, packed, C, J, cfg, out=o))
         flops = 2.0 * C * J * 9 * H * H * B
-        peak = 157.3e12  # f32-input MFMA (both precision classes use v_mfma_f32_16x16x4_f32)
+        # f32 features: f32-input MFMA (157.3 TFLOP/s dense); 16-bit: f16 / bf16 MFMA (2.5 PFLOP/s
+        # dense, MI355X_MICROARCH.md) -- there the kernel is staging / HBM bound, see frac_hbm
+        peak = 157.3e12 if dt == torch.float32 else 2.5e15
         nbytes = feat.numel() * feat.element_size()
         out.append(dict(kernel='head_fused', core=core, case=name, us=round(t * 1e6, 1),
                         TFLOPs=round(flops / t / 1e12, 2), frac_mfma=round(flops / t / peak, 3),
-                        GBps=round(nbytes / t / 1e9, 1)))
+                        GBps=round(nbytes / t / 1e9, 1), frac_hbm=round(nbytes / t / HBM, 3)))
     return out
 
 
