@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12          # B/s spec (MI355X_MICROARCH.md); 6.29e12 measured float4 copy
 HBM_COPY_MEASURED = 6.29e12
 MFMA_F32_PEAK = 157.3e12   # FLOP/s, f32-in MFMA
+MFMA_F16_PEAK = 2.5e15     # FLOP/s, dense f16 / bf16 MFMA (MI355X_MICROARCH.md)
 MFMA_F64_PEAK = 78.6e12    # FLOP/s, f64 MFMA / vector
 
 JOINT_NAMES = ['nose', 'leye', 'reye', 'lear', 'rear', 'lsho', 'rsho', 'lelb', 'relb', 'lwri', 'rwri',
@@ -152,8 +153,10 @@ def depth72_variant(args, dev, im_h, im_w, n_box):
                      '(every shipped configuration of the reference)')
 
 
-def head_kernel_name(hw, n_crops, J, D):
+def head_kernel_name(hw, n_crops, J, D, precision='f32', C=1280):
     """Which GEMM kernel mtr_head_fused dispatches to (metrabs_amd/csrc/head_fused.hip:dispatch_head)."""
+    if precision != 'f32' and C % 8 == 0:
+        return 'head_fused16_kernel'  # f16 / bf16 MFMA, a staging loop: bounded by feature bytes
     if not 32 < hw <= 128:
         return 'head_fused_kernel'
     jg_max = 64 // (1 + D)
@@ -428,12 +431,16 @@ def main():
                                    (im_h // 4) * (im_w // 4) * 4)
     src_bytes = source_footprint_bytes(extras['wp'], args.res, im_h, im_w)
     head_flops = 2.0 * C * J * (1 + D) * hw * n_crops
-    mfma_peak = MFMA_F32_PEAK  # f32-input MFMA in both precision classes (f64 carry on the VALU)
+    head_kernel = head_kernel_name(hw, n_crops, J, D, args.precision, C)
+    # f32 features: f32-input MFMA (f64 carry on the VALU), matrix-bound.  16-bit features: f16 / bf16
+    # MFMA at 16x that rate -- the kernel is bounded by the feature bytes it stages
+    h16 = head_kernel == 'head_fused16_kernel'
+    mfma_peak = MFMA_F16_PEAK if h16 else MFMA_F32_PEAK
     alg = {
         'pyramid': dict(kernel='build_pyramid_u8_wide_kernel', bound='hbm', bytes=pyr_bytes),
         'warp': dict(kernel='warp_crops_kernel', bound='hbm',
                      bytes=n_crops * 3 * args.res ** 2 * out_bytes + src_bytes),
-        'head_fused': dict(kernel=head_kernel_name(hw, n_crops, J, D), bound='mfma', flops=head_flops,
+        'head_fused': dict(kernel=head_kernel, bound='hbm' if h16 else 'mfma', flops=head_flops,
                            bytes=n_crops * (C * hw * feat_bytes + 20 * J)),
     }
     ours = {k: stages[k] for k in ('pyramid', 'geometry', 'warp', 'head_fused', 'reconstruct',
