@@ -52,7 +52,13 @@ class MetrabsHeads(torch.nn.Module):
                 c_in, self.n_points, self.config.depth, h, w, kernels._is_channels_last(inp)):
             return kernels.head_fused(inp, self._packed_weights(inp.dtype), c_in, self.n_points,
                                       self.config)
-        logits = self.conv_final(inp)  # 1x1 conv as a library GEMM (rocBLAS / MIOpen)
+        # 1x1 conv as a library GEMM (rocBLAS / MIOpen).  16-bit features (the autocast backbone's
+        # output) meet f32 parameters here: run the conv as autocast would (multiperson_model.py:241)
+        if inp.dtype != self.conv_final.weight.dtype and inp.dtype in (torch.float16, torch.bfloat16):
+            with torch.autocast(device_type=inp.device.type, dtype=inp.dtype):
+                logits = self.conv_final(inp)
+        else:
+            logits = self.conv_final(inp)
         return kernels.softargmax_decode(logits, self.n_points, self.config)
 
 

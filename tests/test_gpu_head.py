@@ -170,6 +170,25 @@ def test_depth72_goes_through_gemm_plus_decode(hip_lib):
     assert float((c2d.cpu() - o2d).abs().max()) <= 4e-4
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_depth72_16bit_features_f32_parameters(dtype, hip_lib):
+    """The autocast backbone hands 16-bit features to heads whose parameters are f32; a shape the
+    fused kernel does not take (73 rows per joint) must then run the library conv the way autocast
+    would, and decode its 16-bit logits.  Bound: the logits are rounded to 16 bits (as in the
+    reference's GPU path), so this is a sanity bound, not the 1e-3 mm gate."""
+    from metrabs_amd.config import MetrabsConfig
+    from metrabs_amd.models.metrabs import MetrabsHeads
+    heads = MetrabsHeads(17, MetrabsConfig(depth=72), in_channels=64, fused=True).cuda()
+    g = cases.gen(73)
+    feat = torch.randn(3, 64, 8, 8, generator=g)
+    with torch.inference_mode():
+        c2d, c3d = heads(feat.to(dtype).cuda())
+        r2d, r3d = heads(feat.cuda())
+    assert c3d.dtype == torch.float32 and torch.isfinite(c3d).all()
+    tol = 2.0 if dtype == torch.float16 else 16.0  # mm; 2200 mm box, logits to 11 / 8 bits
+    assert float((c3d - r3d).abs().max()) <= tol
+
+
 def test_fused_head_full_size_properties(hip_lib):
     """BASELINE config 2 (B=64, C=1280, 8x8, J=17): permutation equivariance over crops (each crop
     is computed independently and deterministically) + sampled crops equal the oracle."""
