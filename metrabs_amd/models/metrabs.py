@@ -25,7 +25,12 @@ class MetrabsHeads(torch.nn.Module):
             self.conv_final = torch.nn.LazyConv2d(out_channels=sum(self.n_outs), kernel_size=1)
         else:
             self.conv_final = torch.nn.Conv2d(in_channels, sum(self.n_outs), kernel_size=1)
+        # True: hand-written GEMM + decode in one kernel.  False: library 1x1 conv + the HIP decode
+        # kernel on the materialised logits.  'auto': time both once per (shape, dtype, layout) on
+        # the first eager call and keep the faster (DESIGN.md has the measured table: the library
+        # path wins for f32 features, the fused kernel for f16 / bf16 at J <= 24).
         self.fused = fused
+        self._auto_choice = {}
         self._packed = None
         self._packed_key = None
 
@@ -48,10 +53,38 @@ class MetrabsHeads(torch.nn.Module):
                 self.conv_final.has_uninitialized_params():
             self.conv_final(inp[:1])  # materialise the lazy conv exactly like the reference would
         _, c_in, h, w = inp.shape
-        if self.fused and kernels.head_fused_supported(
-                c_in, self.n_points, self.config.depth, h, w, kernels._is_channels_last(inp)):
-            return kernels.head_fused(inp, self._packed_weights(inp.dtype), c_in, self.n_points,
-                                      self.config)
+        use_fused = bool(self.fused) and kernels.head_fused_supported(
+            c_in, self.n_points, self.config.depth, h, w, kernels._is_channels_last(inp))
+        if use_fused and self.fused == 'auto':
+            use_fused = self._auto_pick(inp)
+        if use_fused:
+            return self._forward_fused(inp)
+        return self._forward_unfused(inp)
+
+    def _forward_fused(self, inp):
+        return kernels.head_fused(inp, self._packed_weights(inp.dtype), inp.shape[1], self.n_points,
+                                  self.config)
+
+    def _auto_pick(self, inp):
+        key = (tuple(inp.shape), inp.dtype, kernels._is_channels_last(inp))
+        if key not in self._auto_choice:
+            if torch.cuda.is_current_stream_capturing():
+                return True  # nothing can be timed inside a capture; decided on an eager call
+            times = []
+            for fn in (self._forward_fused, self._forward_unfused):
+                for _ in range(3):
+                    fn(inp)
+                start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                start.record()
+                for _ in range(10):
+                    fn(inp)
+                stop.record()
+                stop.synchronize()
+                times.append(start.elapsed_time(stop))
+            self._auto_choice[key] = times[0] <= times[1]
+        return self._auto_choice[key]
+
+    def _forward_unfused(self, inp):
         # 1x1 conv as a library GEMM (rocBLAS / MIOpen).  16-bit features (the autocast backbone's
         # output) meet f32 parameters here: run the conv as autocast would (multiperson_model.py:241)
         if inp.dtype != self.conv_final.weight.dtype and inp.dtype in (torch.float16, torch.bfloat16):

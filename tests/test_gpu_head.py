@@ -146,6 +146,28 @@ def test_fused_equals_unfused_and_module(hip_lib):
     assert set(sd) == {'conv_final.weight', 'conv_final.bias'} and sd['conv_final.weight'].shape == (153, 128, 1, 1)
 
 
+def test_auto_head_path_is_timed_once_and_equivalent(hip_lib):
+    """MetrabsHeads(fused='auto'): both paths are timed on the first eager call of a (shape, dtype,
+    layout) and the faster one is kept; whichever wins, the result stays within the parity bound
+    of the fused path."""
+    from metrabs_amd.config import MetrabsConfig
+    from metrabs_amd.models.metrabs import MetrabsHeads
+    torch.manual_seed(1)
+    heads = MetrabsHeads(17, MetrabsConfig(), in_channels=256, fused='auto').cuda()
+    feat = torch.randn(16, 256, 8, 8, device='cuda')
+    with torch.inference_mode():
+        a2d, a3d = heads(feat)
+        assert list(heads._auto_choice) == [((16, 256, 8, 8), torch.float32, False)]
+        choice = dict(heads._auto_choice)
+        b2d, b3d = heads(feat)
+        assert heads._auto_choice == choice and torch.equal(a3d, b3d)
+        heads(feat.half())
+        assert len(heads._auto_choice) == 2
+        heads.fused = True
+        f2d, f3d = heads(feat)
+    assert float((a3d - f3d).abs().max()) <= 2e-3 and float((a2d - f2d).abs().max()) <= 4e-4
+
+
 def test_depth72_goes_through_gemm_plus_decode(hip_lib):
     """72 depth bins (the metric string of BASELINE.json): a joint's 73 rows do not fit the fused
     head's 64-row tile, so MetrabsHeads runs the 1x1 conv as a library GEMM and the HIP decode
