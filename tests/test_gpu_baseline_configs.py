@@ -105,3 +105,32 @@ def test_end_to_end_every_backbone_family(backbone, res, num_aug, hip_lib):
         assert p2.shape == (len(b), 17, 2)
     # (no bitwise repeatability check here: MIOpen / rocBLAS may change algorithm between calls;
     #  the hand-written kernels' determinism is asserted bitwise in the permutation tests)
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_autocast_crop_model_tracks_the_fp32_one(dtype, hip_lib):
+    """The reference's GPU mode (crop model under torch.autocast, multiperson_model.py:241): 16-bit
+    backbone output straight into the f16 / bf16 MFMA head.  Same weights, same crops as the fp32
+    model: the poses must stay finite and within the noise of a 16-bit backbone (sanity bound; the
+    1e-3 mm gate is the fp32 path's)."""
+    from metrabs_amd.backbones import build_backbone, calibrate_batchnorm
+    from metrabs_amd.config import MetrabsConfig
+    from metrabs_amd.joint_info import JointInfo
+    from metrabs_amd.models.metrabs import Metrabs
+    torch.manual_seed(4)
+    net = calibrate_batchnorm(build_backbone('resnet18').cuda(), 256, 'cuda', batch_size=4)
+    ji = JointInfo(cases.COCO17, cases.COCO17_EDGES)
+    m32 = Metrabs(net, ji, MetrabsConfig(), in_channels=net.out_channels).cuda().eval()
+    m16 = Metrabs(net, ji, MetrabsConfig(), in_channels=net.out_channels, autocast_dtype=dtype).cuda().eval()
+    m16.heatmap_heads.load_state_dict(m32.heatmap_heads.state_dict())
+    g = torch.Generator(device='cuda').manual_seed(5)
+    crops = torch.rand(6, 3, 256, 256, device='cuda', generator=g)
+    K = cases.intrinsics_for(256, 256, 55.0, 1)[None].repeat(6, 1, 1).cuda()
+    with torch.inference_mode():
+        p32 = m32((crops, K))
+        p16 = m16((crops, K))
+    assert p16.dtype == torch.float32 and p16.shape == p32.shape == (6, 17, 3)
+    assert torch.isfinite(p16).all()
+    d = (p16 - p32).norm(dim=-1)
+    print(f'[parity] autocast {dtype} crop model vs fp32: mean {float(d.mean()):.3f} mm, max {float(d.max()):.3f} mm')
+    assert float(d.mean()) <= (5.0 if dtype == torch.float16 else 40.0)
