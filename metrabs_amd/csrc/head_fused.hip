@@ -1392,6 +1392,154 @@ __global__ __launch_bounds__(256, MTR_H16_MINWAVES) void head_fused16_kernel(
   }
 }
 
+// ---- the same kernel with the staging done by the memory pipeline: global_load_lds_dwordx4
+// (gfx950) writes 16 bytes per lane straight into LDS at M0 + lane * 16 -- no staging registers,
+// no ds_write pass, no VALU between the global load and the tile.  A wave-wide load fills 8 tile
+// rows (1 KiB); the XOR swizzle moves to the SOURCE side: the lane that owns LDS slot s' of row r
+// fetches channel slot s' ^ swz(r), which stays inside the row's 128-byte line.  NHWC features
+// with C % 64 == 0 only (a partial last stage would read the next position's channels; with
+// registers in between they are zeroed, here they cannot be).  Positions >= HW: those lanes are
+// masked off and the rows keep their zero fill.
+// One barrier per stage: the loads of stage s + 1 are issued right after the fragment reads of
+// stage s and land under its MFMAs; the compiler waits for them (vmcnt) in front of the barrier.
+template <typename FeatT, int CT, int GPW>
+__device__ __forceinline__ void issue_stage16dma(const FeatT* const (&a_src)[2 * GPW],
+                                                 const FeatT* const (&b_src)[CT],
+                                                 const bool (&b_on)[CT], char* Ab, char* Bb,
+                                                 int stage, int wid) {
+#pragma unroll
+  for (int i = 0; i < 2 * GPW; ++i)
+    __builtin_amdgcn_global_load_lds(a_src[i] + (size_t)stage * (kRows * kKH),
+                                     Ab + (i * 4 + wid) * 1024, 16, 0, 0);
+#pragma unroll
+  for (int i = 0; i < CT; ++i)
+    if (b_on[i])
+      __builtin_amdgcn_global_load_lds(b_src[i] + (size_t)stage * kKH, Bb + (i * 4 + wid) * 1024, 16,
+                                       0, 0);
+}
+
+template <typename FeatT, int CT, int GPW>
+__global__ __launch_bounds__(256) void head_fused16dma_kernel(
+    const FeatT* __restrict__ feat, const float* __restrict__ packed, int B, int C, int H, int W,
+    int J, int D, HeadGeom g, HeadScale hs, float* __restrict__ coords2d,
+    float* __restrict__ coords3d_rel) {
+  constexpr int TPW = (CT + 1) / 2;
+  constexpr int HWP = hw_pad32<CT>();
+  constexpr int A_STAGE = GPW * kRows * 128;  // bytes
+  constexpr int B_STAGE = CT * 32 * 128;      // bytes
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* As = reinterpret_cast<char*>(smem);   // [2][GPW*64][128 B]
+  char* Bs = As + 2 * A_STAGE;                // [2][CT*32][128 B]
+  float* Ls = smem;                           // epilogue alias: [64][HWP], one group at a time
+
+  const int HW = H * W;
+  const int wg_per_crop = (g.n_groups + GPW - 1) / GPW;
+  const int chunk = 8 * wg_per_crop;
+  const int id = blockIdx.x;
+  const int crop = (id / chunk) * 8 + (id % 8);
+  const int grp0 = ((id % chunk) / 8) * GPW;
+  if (crop >= B) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int n_st = C / kKH;
+  const size_t n_w = (size_t)g.n_groups * g.c_pad * kRows;
+  const float* bias = packed + n_w;
+  const FeatT* w16 = reinterpret_cast<const FeatT*>(packed + 2 * n_w + (size_t)g.n_groups * kRows);
+  const FeatT* fcrop = feat + (size_t)crop * C * HW;
+
+  for (int v = tid; v < 2 * B_STAGE / 16; v += 256)
+    reinterpret_cast<v4u*>(Bs)[v] = v4u{0u, 0u, 0u, 0u};
+
+  // per-lane sources of this wave's loads, stage 0.  Load i of the weights covers tile rows
+  // (i * 4 + wid) * 8 .. + 7, load i of the features positions (i * 4 + wid) * 8 .. + 7; lane L is
+  // (row + (L >> 3), LDS slot L & 7).
+  const int lr = lane >> 3, ls = lane & 7;
+  const FeatT* a_src[2 * GPW];
+#pragma unroll
+  for (int i = 0; i < 2 * GPW; ++i) {
+    const int row = (i * 4 + wid) * 8 + lr;            // 0 .. 64 * GPW - 1
+    const int grp = min(grp0 + (row >> 6), g.n_groups - 1);
+    a_src[i] = w16 + (size_t)grp * n_st * (kRows * kKH) + (row & 63) * kKH + ((ls ^ swz(row)) << 3);
+  }
+  const FeatT* b_src[CT];
+  bool b_on[CT];
+#pragma unroll
+  for (int i = 0; i < CT; ++i) {
+    const int pos = (i * 4 + wid) * 8 + lr;
+    b_on[i] = pos < HW;
+    b_src[i] = fcrop + (size_t)(b_on[i] ? pos : 0) * C + ((ls ^ swz(pos)) << 3);
+  }
+  const int rp = wid & 1, cp = wid >> 1;
+  const int fi = lane & 31, fg = lane >> 5;
+  int a_off[GPW], b_off[TPW];
+  bool on[TPW];
+#pragma unroll
+  for (int k = 0; k < GPW; ++k) {
+    const int row = (2 * k + rp) * 32 + fi;
+    a_off[k] = row * 128 + ((fg ^ swz(row)) << 4);
+  }
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    on[t] = cp + 2 * t < CT;
+    const int pos = (on[t] ? cp + 2 * t : 0) * 32 + fi;
+    b_off[t] = pos * 128 + ((fg ^ swz(pos)) << 4);
+  }
+
+  f32x16 acc[GPW][TPW];
+#pragma unroll
+  for (int k = 0; k < GPW; ++k)
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[k][t] = f32x16{0};
+
+  __syncthreads();  // zero fill done
+  issue_stage16dma<FeatT, CT, GPW>(a_src, b_src, b_on, As, Bs, 0, wid);
+  for (int st = 0; st < n_st; ++st) {
+    __syncthreads();  // stage st has landed; every wave finished reading the other buffer
+    const int cur = st & 1;
+    const char* Ab = As + cur * A_STAGE;
+    const char* Bb = Bs + cur * B_STAGE;
+    v4u af[GPW][4], bf[TPW][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int q = 0; q < GPW; ++q)
+        af[q][u] = *reinterpret_cast<const v4u*>(Ab + (a_off[q] ^ (u << 5)));
+#pragma unroll
+      for (int t = 0; t < TPW; ++t)
+        bf[t][u] = *reinterpret_cast<const v4u*>(Bb + (b_off[t] ^ (u << 5)));
+    }
+    // (behind the last stage: a repeat into the idle buffer)
+    issue_stage16dma<FeatT, CT, GPW>(a_src, b_src, b_on, As + (cur ^ 1) * A_STAGE, Bs + (cur ^ 1) * B_STAGE,
+                                     min(st + 1, n_st - 1), wid);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int q = 0; q < GPW; ++q)
+          acc[q][t] = Mfma16<FeatT>::run(af[q][u], bf[t][u], acc[q][t]);
+  }
+
+#pragma unroll
+  for (int q = 0; q < GPW; ++q) {
+    __syncthreads();
+    if (grp0 + q >= g.n_groups) break;
+    const float* bgrp = bias + (size_t)(grp0 + q) * kRows;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      if (!on[t]) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rp * 32 + 8 * (r >> 2) + 4 * fg + (r & 3);
+        Ls[row * HWP + (cp + 2 * t) * 32 + fi] = acc[q][t][r] + bgrp[row];
+      }
+    }
+    __syncthreads();
+    decode_group_from_lds<false, (CT > 2 ? 4 : 2)>(Ls, HWP, grp0 + q, g, crop, J, D, H, W, hs,
+                                                   coords2d, coords3d_rel, wid, lane);
+  }
+}
+
 template <int CT, int GPW>
 constexpr size_t head16_lds_bytes() {
   constexpr size_t stage = 2 * ((size_t)GPW * kRows * 128 + (size_t)CT * 32 * 128) + 256 * 16;
@@ -1472,6 +1620,16 @@ static int launch_head32w8(const void* feat, const float* packed, int B, int C, 
   return MTR_OK;
 }
 
+// MTR_HEAD_DMA=0: NHWC 16-bit features staged through registers like NCHW ones (default: staged by
+// global_load_lds when C % 64 == 0; measured 5 - 15 % faster at every launch size)
+static bool use_dma16() {
+  static const bool v = [] {
+    const char* e = getenv("MTR_HEAD_DMA");
+    return !(e && e[0] == '0');
+  }();
+  return v;
+}
+
 template <typename FeatT, int CT, int GPW, bool NHWC>
 static int launch_head16(const void* feat, const float* packed, int B, int C, int H, int W, int J,
                          int D, const HeadGeom& g, const HeadScale& hs, float* c2d, float* c3d,
@@ -1480,15 +1638,30 @@ static int launch_head16(const void* feat, const float* packed, int B, int C, in
     return MTR_E_DTYPE;
   } else {
     constexpr size_t lds = head16_lds_bytes<CT, GPW>();
+    const int chunk = 8 * ((g.n_groups + GPW - 1) / GPW);
+    const long long blocks = (long long)((B + 7) / 8) * chunk;
+    if (blocks > 0x7fffffffLL) return MTR_E_SHAPE;
+    if constexpr (NHWC) {
+      if (use_dma16() && C % kKH == 0) {
+        auto dma = head_fused16dma_kernel<FeatT, CT, GPW>;
+        if (lds > 64 * 1024) {
+          hipError_t e = hipFuncSetAttribute((const void*)dma,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          if (e != hipSuccess) return (int)e;
+        }
+        MTR_CLEAR_STALE();
+        hipLaunchKernelGGL(dma, dim3((unsigned)blocks), dim3(256), lds, stream, (const FeatT*)feat,
+                           packed, B, C, H, W, J, D, g, hs, c2d, c3d);
+        MTR_CHECK_LAUNCH();
+        return MTR_OK;
+      }
+    }
     auto kern = head_fused16_kernel<FeatT, CT, GPW, NHWC>;
     if (lds > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute((const void*)kern,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return (int)e;
     }
-    const int chunk = 8 * ((g.n_groups + GPW - 1) / GPW);
-    const long long blocks = (long long)((B + 7) / 8) * chunk;
-    if (blocks > 0x7fffffffLL) return MTR_E_SHAPE;
     MTR_CLEAR_STALE();
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, (const FeatT*)feat,
                        packed, B, C, H, W, J, D, g, hs, c2d, c3d);

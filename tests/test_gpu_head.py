@@ -256,8 +256,8 @@ def test_fused_head_channels_last_features(shape, dtype, hip_lib):
 
 
 @pytest.mark.parametrize('env', [{'MTR_HEAD_CORE': '16'}, {'MTR_HEAD_W8': '0'}, {'MTR_HEAD_W8': '1'},
-                                 {'MTR_HEAD_H16': '0'}],
-                         ids=['core16', 'w4', 'w8', 'f32core_on_16bit'])
+                                 {'MTR_HEAD_H16': '0'}, {'MTR_HEAD_DMA': '0'}],
+                         ids=['core16', 'w4', 'w8', 'f32core_on_16bit', 'nhwc16_through_registers'])
 def test_every_gemm_variant_on_all_shapes_subprocess(env, hip_lib):
     """Three GEMM kernels sit behind mtr_head_fused: the 16x16x4 core, the 4-wave 32x32x2 kernel and
     its 8-wave K-split variant for small launches.  The dispatch picks by map size and launch size;
@@ -266,7 +266,7 @@ def test_every_gemm_variant_on_all_shapes_subprocess(env, hip_lib):
     import os
     import subprocess
     import sys
-    if os.environ.get('MTR_HEAD_CORE') or os.environ.get('MTR_HEAD_W8') or os.environ.get('MTR_HEAD_H16'):
+    if any(os.environ.get(k) for k in ('MTR_HEAD_CORE', 'MTR_HEAD_W8', 'MTR_HEAD_H16', 'MTR_HEAD_DMA')):
         pytest.skip('already inside a forced-variant run')
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-m', 'gpu',
                         '-k', 'golden or odd_shapes or 16bit or channels_last or full_size'],
