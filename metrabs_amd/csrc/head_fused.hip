@@ -1402,23 +1402,32 @@ __global__ __launch_bounds__(256, MTR_H16_MINWAVES) void head_fused16_kernel(
 // masked off and the rows keep their zero fill.
 // One barrier per stage: the loads of stage s + 1 are issued right after the fragment reads of
 // stage s and land under its MFMAs; the compiler waits for them (vmcnt) in front of the barrier.
-template <typename FeatT, int CT, int GPW>
-__device__ __forceinline__ void issue_stage16dma(const FeatT* const (&a_src)[2 * GPW],
-                                                 const FeatT* const (&b_src)[CT],
-                                                 const bool (&b_on)[CT], char* Ab, char* Bb,
-                                                 int stage, int wid) {
-#pragma unroll
-  for (int i = 0; i < 2 * GPW; ++i)
-    __builtin_amdgcn_global_load_lds(a_src[i] + (size_t)stage * (kRows * kKH),
-                                     Ab + (i * 4 + wid) * 1024, 16, 0, 0);
-#pragma unroll
-  for (int i = 0; i < CT; ++i)
-    if (b_on[i])
-      __builtin_amdgcn_global_load_lds(b_src[i] + (size_t)stage * kKH, Bb + (i * 4 + wid) * 1024, 16,
-                                       0, 0);
+// The builtin has to sit in a __device__ function: used directly in the kernel template (or in a
+// lambda there) it compiles for the device but the host pass drops the kernel's handle, and the
+// library then fails to load with an undefined symbol.
+__device__ __forceinline__ void dma16_to_lds(const void* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(src, lds_wave_base, 16, 0, 0);  // lane L -> base + 16 L
 }
 
-template <typename FeatT, int CT, int GPW>
+// two transposing 8-byte LDS reads = one 8-channel MFMA operand (semantics: see the kernel)
+__device__ __forceinline__ v4u lds_read_tr16_pair(const char* p0, const char* p1) {
+  using trv = __attribute__((ext_vector_type(4))) short;
+  using lds_trv = __attribute__((address_space(3))) trv;
+  struct Two { trv a, b; };
+  return __builtin_bit_cast(v4u, Two{__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_trv*)p0),
+                                     __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_trv*)p1)});
+}
+
+#define HEAD16_DMA_ISSUE(STAGE, AB, BB)                                                           \
+  {                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 2 * GPW; ++i)                                           \
+      dma16_to_lds(a_src[i] + (size_t)(STAGE) * (kRows * kKH), (AB) + (i * 4 + wid) * 1024);      \
+    _Pragma("unroll") for (int i = 0; i < CT; ++i)                                                \
+      if (b_on[i])                                                                                \
+        dma16_to_lds(b_src[i] + (size_t)(STAGE) * b_stage_elems, (BB) + (i * 4 + wid) * 1024);    \
+  }
+
+template <typename FeatT, int CT, int GPW, bool NHWC>
 __global__ __launch_bounds__(256) void head_fused16dma_kernel(
     const FeatT* __restrict__ feat, const float* __restrict__ packed, int B, int C, int H, int W,
     int J, int D, HeadGeom g, HeadScale hs, float* __restrict__ coords2d,
@@ -1463,11 +1472,26 @@ __global__ __launch_bounds__(256) void head_fused16dma_kernel(
   }
   const FeatT* b_src[CT];
   bool b_on[CT];
+  // NCHW: the tile keeps the memory layout, [channel][position] rows of HW * 2 bytes, and the
+  // transpose happens in the LDS read (ds_read_b64_tr_b16).  16-byte chunk j (8 positions) of
+  // channel row k sits at chunk (j + rot(k)) % n_chunks of the row, rot(k) = 4 * ((k >> 1) & 1):
+  // the four channels a 16-lane group reads together then cover all 64 banks.
+  const int n_chunks = HW >> 3;
+  const size_t b_stage_elems = NHWC ? (size_t)kKH : (size_t)kKH * HW;
 #pragma unroll
   for (int i = 0; i < CT; ++i) {
-    const int pos = (i * 4 + wid) * 8 + lr;
-    b_on[i] = pos < HW;
-    b_src[i] = fcrop + (size_t)(b_on[i] ? pos : 0) * C + ((ls ^ swz(pos)) << 3);
+    if constexpr (NHWC) {
+      const int pos = (i * 4 + wid) * 8 + lr;
+      b_on[i] = pos < HW;
+      b_src[i] = fcrop + (size_t)(b_on[i] ? pos : 0) * C + ((ls ^ swz(pos)) << 3);
+    } else {
+      const int cid = (i * 4 + wid) * 64 + lane;  // linear 16-byte chunk of the stage in LDS
+      b_on[i] = cid < kKH * n_chunks;
+      const int k = b_on[i] ? cid / n_chunks : 0, jl = b_on[i] ? cid - k * n_chunks : 0;
+      const int rot = ((k >> 1) & 1) << 2;
+      const int j = jl >= rot ? jl - rot : jl - rot + n_chunks;  // source chunk of LDS chunk jl
+      b_src[i] = fcrop + (size_t)k * HW + j * 8;
+    }
   }
   const int rp = wid & 1, cp = wid >> 1;
   const int fi = lane & 31, fg = lane >> 5;
@@ -1482,8 +1506,23 @@ __global__ __launch_bounds__(256) void head_fused16dma_kernel(
   for (int t = 0; t < TPW; ++t) {
     on[t] = cp + 2 * t < CT;
     const int pos = (on[t] ? cp + 2 * t : 0) * 32 + fi;
-    b_off[t] = pos * 128 + ((fg ^ swz(pos)) << 4);
+    if constexpr (NHWC) {
+      b_off[t] = pos * 128 + ((fg ^ swz(pos)) << 4);
+    } else {
+      // ds_read_b64_tr_b16 (probed, tools/experiments/tr_probe.hip): within a 16-lane group, lane
+      // j receives element (j % 4) of the 8 bytes addressed by lanes (j / 4) + 4 i, i = 0..3.
+      // So reader lane r = q + 4 i of group G addresses channel i (+ 4 per second read, + 8 g,
+      // + 16 u) at positions P .. P + 3, P = tile + 16 (G & 1) + 4 q, and lane (n = tile + l % 32,
+      // g = l / 32) ends up with channels 16 u + 8 g + 0..7 of position n: the MFMA operand.
+      const int G = lane >> 4, r = lane & 15, q = r & 3, ci = r >> 2;
+      const int P = (on[t] ? cp + 2 * t : 0) * 32 + 16 * (G & 1) + 4 * q;
+      const int Pc = P < HW ? P : 0;  // (padding columns of the last tile: any valid data)
+      int jl = (Pc >> 3) + (((ci >> 1) & 1) << 2);
+      jl = jl >= n_chunks ? jl - n_chunks : jl;
+      b_off[t] = (8 * fg + ci) * (HW * 2) + jl * 16 + (Pc & 7) * 2;
+    }
   }
+  const int tr_pitch4 = 4 * HW * 2;  // bytes between the two transposing reads of a fragment
 
   f32x16 acc[GPW][TPW];
 #pragma unroll
@@ -1492,7 +1531,7 @@ __global__ __launch_bounds__(256) void head_fused16dma_kernel(
     for (int t = 0; t < TPW; ++t) acc[k][t] = f32x16{0};
 
   __syncthreads();  // zero fill done
-  issue_stage16dma<FeatT, CT, GPW>(a_src, b_src, b_on, As, Bs, 0, wid);
+  HEAD16_DMA_ISSUE(0, As, Bs)
   for (int st = 0; st < n_st; ++st) {
     __syncthreads();  // stage st has landed; every wave finished reading the other buffer
     const int cur = st & 1;
@@ -1505,12 +1544,17 @@ __global__ __launch_bounds__(256) void head_fused16dma_kernel(
       for (int q = 0; q < GPW; ++q)
         af[q][u] = *reinterpret_cast<const v4u*>(Ab + (a_off[q] ^ (u << 5)));
 #pragma unroll
-      for (int t = 0; t < TPW; ++t)
-        bf[t][u] = *reinterpret_cast<const v4u*>(Bb + (b_off[t] ^ (u << 5)));
+      for (int t = 0; t < TPW; ++t) {
+        if constexpr (NHWC) {
+          bf[t][u] = *reinterpret_cast<const v4u*>(Bb + (b_off[t] ^ (u << 5)));
+        } else {
+          const char* p = Bb + b_off[t] + u * (4 * tr_pitch4);
+          bf[t][u] = lds_read_tr16_pair(p, p + tr_pitch4);
+        }
+      }
     }
     // (behind the last stage: a repeat into the idle buffer)
-    issue_stage16dma<FeatT, CT, GPW>(a_src, b_src, b_on, As + (cur ^ 1) * A_STAGE, Bs + (cur ^ 1) * B_STAGE,
-                                     min(st + 1, n_st - 1), wid);
+    HEAD16_DMA_ISSUE(min(st + 1, n_st - 1), As + (cur ^ 1) * A_STAGE, Bs + (cur ^ 1) * B_STAGE)
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -1641,9 +1685,11 @@ static int launch_head16(const void* feat, const float* packed, int B, int C, in
     const int chunk = 8 * ((g.n_groups + GPW - 1) / GPW);
     const long long blocks = (long long)((B + 7) / 8) * chunk;
     if (blocks > 0x7fffffffLL) return MTR_E_SHAPE;
-    if constexpr (NHWC) {
-      if (use_dma16() && C % kKH == 0) {
-        auto dma = head_fused16dma_kernel<FeatT, CT, GPW>;
+    {
+      // NHWC: any map; NCHW: whole 16-byte chunks per channel row (H*W % 8 == 0, at least the 8
+      // chunks the bank rotation assumes)
+      if (use_dma16() && C % kKH == 0 && (NHWC || ((H * W) % 8 == 0 && H * W >= 64))) {
+        auto dma = head_fused16dma_kernel<FeatT, CT, GPW, NHWC>;
         if (lds > 64 * 1024) {
           hipError_t e = hipFuncSetAttribute((const void*)dma,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
