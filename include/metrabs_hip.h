@@ -103,7 +103,9 @@ int mtr_softargmax_decode(const void* logits, int dtype, int layout, int B, int 
  * (what autocast does to conv_final in the reference's GPU path), f32 accumulation, f32 logits; the
  * rounded weights are a third section of the blob, so `packed` is specific to the feat_dtype it was
  * packed for: pass the same feat_dtype to mtr_head_packed_bytes, mtr_head_pack_weights and
- * mtr_head_fused.  (C % 8 != 0: the 16-bit features are widened in staging and run on the f32 path.)
+ * mtr_head_fused.  (C % 8 != 0: the 16-bit features are widened in staging and run on the f32 path.
+ * C % 64 == 0, and for NCHW also H*W % 8 == 0 and H*W >= 64: the tiles are staged by
+ * global_load_lds instead of through registers -- same arithmetic, same results.)
  */
 size_t mtr_head_packed_bytes(int C, int J, int D, int feat_dtype);
 int mtr_head_pack_weights(const float* weight /*[J*(1+D), C] f32*/, const float* bias /*[J*(1+D)]*/,

@@ -17,7 +17,7 @@ def run(seed0, n, gpw):
         if (H * W) % 4 or H * W > 256:
             continue
         D = rnd.choice([1, 2, 4, 8, 8, 8, 15, 31, 63]); J = rnd.choice([1, 2, 5, 7, 17, 24, 33, 122])
-        C = 8 * rnd.randint(1, 40); B = rnd.choice([1, 2, 3, 8, 9, 17, 40])
+        C = rnd.choice([8 * rnd.randint(1, 40), 64 * rnd.randint(1, 6)]); B = rnd.choice([1, 2, 3, 8, 9, 17, 40])
         dt = rnd.choice([torch.float16, torch.bfloat16]); nhwc = rnd.random() < 0.5
         if J * (1 + D) * H * W * B > 3e7:
             continue
