@@ -100,11 +100,16 @@ def test_fused_head_16bit_features(dtype, hip_lib):
                                    (1, 64, 3, 8, 16, 16), (2, 96, 30, 4, 10, 10), (9, 32, 1, 8, 8, 8),
                                    (2, 100, 7, 8, 2, 8), (3, 72, 17, 8, 6, 6), (2, 33, 9, 8, 8, 12),
                                    (2, 65, 17, 8, 8, 16), (10, 31, 17, 8, 8, 8), (2, 200, 4, 8, 14, 14),
-                                   (3, 128, 11, 8, 10, 16), (2, 1280, 122, 8, 12, 12)])
+                                   (3, 128, 11, 8, 10, 16), (2, 1280, 122, 8, 12, 12),
+                                   (3, 64, 17, 8, 8, 8), (2, 192, 9, 8, 6, 12), (9, 128, 17, 8, 8, 12),
+                                   (2, 256, 5, 8, 8, 16), (2, 320, 24, 4, 16, 16)])
 def test_fused_head_16bit_odd_shapes(shape, dtype, hip_lib):
     """The 16-bit MFMA kernel on every column-tile count (1 .. 8 tiles of 32 positions), C not a
     multiple of its 64-channel stage (fewer stages than the prefetch depth included), ragged joint
-    groups, both layouts; C % 8 != 0 takes the f32 cores."""
+    groups, both layouts; C % 8 != 0 takes the f32 cores.  C % 64 == 0 is staged by global_load_lds
+    (NCHW additionally needs whole 16-byte chunks per channel row, H*W % 8 == 0 and >= 64, and is
+    transposed by ds_read_b64_tr_b16): one-stage K loops, 9 / 12 / 16 / 20 / 32 chunks per row.
+    The register-staged twin of every such shape runs in the MTR_HEAD_DMA=0 variant below."""
     from metrabs_amd import kernels
     B, C, J, D, H, W = shape
     cfg = cpu_ref.HeadConfig(depth=D, proc_side=max(H, W) * 8, stride_test=8, stride_train=8)
