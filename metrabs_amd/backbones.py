@@ -16,13 +16,34 @@ import torch
 from torch import nn
 
 
+class DepthwiseConv2d(nn.Conv2d):
+    """A depthwise convolution that runs on PyTorch's own HIP depthwise kernel instead of MIOpen.
+    MIOpen serves f32 / f16 NCHW depthwise 3x3 with its naive direct kernel on this stack; with
+    MIOpen switched off for these layers the EfficientNetV2-S forward at the bench shape takes
+    13.13 instead of 14.02 ms in f32 (10.87 vs 11.71 ms under f16 autocast), features equal to
+    5e-6 relative (tools/experiments/depthwise_backend_probe.py).  Same parameters, same
+    state_dict keys; still PyTorch-ROCm, only the backend choice of these layers changes."""
+
+    use_miopen = False  # class-wide switch (tools/experiments/depthwise_backend_probe.py flips it)
+
+    def forward(self, x):
+        if x.is_cuda and not DepthwiseConv2d.use_miopen and torch.backends.cudnn.enabled:
+            torch.backends.cudnn.enabled = False
+            try:
+                return super().forward(x)
+            finally:
+                torch.backends.cudnn.enabled = True
+        return super().forward(x)
+
+
 class ConvBNAct(nn.Sequential):
     """conv '0' + batch norm '1' (+ activation '2'): the parameter names of torchvision's
     Conv2dNormActivation, which the reference's checkpoints use."""
 
     def __init__(self, cin, cout, k=3, s=1, groups=1, act=nn.SiLU, eps=1e-3, padding=None):
-        layers = [nn.Conv2d(cin, cout, k, s, k // 2 if padding is None else padding, groups=groups,
-                            bias=False),
+        conv = DepthwiseConv2d if groups == cin == cout and groups > 1 else nn.Conv2d
+        layers = [conv(cin, cout, k, s, k // 2 if padding is None else padding, groups=groups,
+                       bias=False),
                   nn.BatchNorm2d(cout, eps=eps)]
         if act is not None:
             layers.append(act())
