@@ -60,6 +60,9 @@ def parse_args():
                     help='depth bins of the volumetric heatmap (8 = every shipped config of the reference)')
     ap.add_argument('--no-depth72', action='store_true',
                     help="skip the extra timed run at the metric string's 72 depth bins")
+    ap.add_argument('--no-fold-bn', action='store_true',
+                    help='keep the backbone\'s batch norms as separate kernels (default: folded into '
+                         'the convolutions, the usual inference-time transformation)')
     ap.add_argument('--precision', default='f32', choices=['f32', 'f16', 'bf16'],
                     help='backbone arithmetic: f32 = the reference CPU path; f16 = its autocast GPU path')
     ap.add_argument('--no-graph', action='store_true')
@@ -85,15 +88,18 @@ def synth_inputs(pipe, frames, im_h, im_w, n_box, seed):
 
 
 def build_model(args, dev):
-    from metrabs_amd.backbones import build_backbone, calibrate_batchnorm
+    from metrabs_amd.backbones import build_backbone, calibrate_batchnorm, fold_batchnorm
     from metrabs_amd.config import MetrabsConfig
     from metrabs_amd.joint_info import JointInfo
     from metrabs_amd.models.metrabs import Metrabs
     from metrabs_amd.multiperson.multiperson_model import Pose3dEstimator
-    # MIOpen's immediate mode (PyTorch's default) falls back to its naive direct convolution for
-    # the depthwise layers on this stack (44 % of the step's GPU time in profiles/r01d_kernel_trace).
-    # Benchmark mode (MIOpen times its applicable solvers per layer shape) was tried: 2 minutes of
-    # search on a fresh box and the same 14.1 ms step, so it stays off (MTR_BENCH_MIOPEN_FIND=1).
+    # The backbone is PyTorch-ROCm (out of the hand-written scope); three backend choices were
+    # measured for it (tools/experiments/*_probe.py).  (1) MIOpen's immediate mode falls back to its
+    # naive direct convolution for the depthwise layers: those run on PyTorch's own depthwise
+    # kernel instead (backbones.DepthwiseConv2d; 14.0 -> 13.1 ms).  (2) Inference-time batch norm is
+    # folded into the preceding convolution (backbones.fold_batchnorm; 13.3 -> 11.8 ms; the same
+    # function up to rounding, --no-fold-bn keeps the separate BN kernels).  (3) MIOpen benchmark
+    # mode: 2 minutes of search on a fresh box for the same step time, off (MTR_BENCH_MIOPEN_FIND=1).
     if os.environ.get('MTR_BENCH_MIOPEN_FIND', '0') == '1':
         torch.backends.cudnn.benchmark = True
     torch.manual_seed(1234)
@@ -108,6 +114,8 @@ def build_model(args, dev):
     model = model.to(dev)
     calibrate_batchnorm(model.backbone, args.res, dev)
     model = model.eval()
+    if not args.no_fold_bn:
+        model.backbone = fold_batchnorm(model.backbone)
     # (channels_last measured slower than NCHW on this MIOpen for both dtypes: 19.1 vs 14.0 ms in f32,
     #  15.0 vs 11.4 ms under f16 autocast -- tools/experiments/backbone_f16_probe.py)
     channels_last = os.environ.get('MTR_BENCH_CHANNELS_LAST') == '1'
@@ -490,7 +498,10 @@ def main():
                                f'J={J}, D={D}, random weights',
                    'global_batch': crops_per_step, 'parallelism': f'dp{world} (crops sharded, one '
                    f'all-gather of poses)' if world > 1 else 'single GPU',
-                   'hip_graph': not args.no_graph},
+                   'hip_graph': not args.no_graph,
+                   'backbone': 'PyTorch-ROCm (rocBLAS / MIOpen; depthwise layers on PyTorch\'s own '
+                               'kernel' + ('' if args.no_fold_bn else ', inference batch norm folded into '
+                               'the convolutions') + ')'},
         'roofline': roofline,
         'stage_us': kernels_us,
         'hand_written_kernels': per_kernel,

@@ -236,6 +236,27 @@ def build_backbone(name):
     raise ValueError(f'unknown backbone {name}')
 
 
+def fold_batchnorm(backbone):
+    """Inference-time copy of `backbone` with every batch norm folded into the convolution in front
+    of it (w' = w * gamma / sqrt(var + eps), b' = beta - mean * gamma / sqrt(var + eps)): the same
+    function up to rounding (features equal to ~1e-5 relative in f32), one elementwise pass over
+    every activation less.  EfficientNetV2-S forward at the bench shape: 13.3 -> 11.8 ms in f32,
+    11.6 -> 10.2 ms under f16 autocast (tools/experiments/bn_backend_probe.py).  The original keeps
+    its checkpoint-compatible parameters; the copy has conv biases and no BatchNorm2d."""
+    import copy
+    from torch.nn.utils.fusion import fuse_conv_bn_eval
+    if backbone.training:
+        raise ValueError('fold_batchnorm needs the running statistics of an eval-mode network')
+    folded = copy.deepcopy(backbone)
+    for m in folded.modules():
+        if isinstance(m, ConvBNAct) and isinstance(m[1], nn.BatchNorm2d):
+            m[0] = fuse_conv_bn_eval(m[0], m[1])
+            m[1] = nn.Identity()
+    if any(isinstance(m, nn.BatchNorm2d) for m in folded.modules()):
+        raise ValueError('a BatchNorm2d outside a ConvBNAct block cannot be folded here')
+    return folded
+
+
 def calibrate_batchnorm(backbone, res, dev, batches=2, batch_size=16, seed=7):
     """Random-weight networks with untouched BatchNorm statistics (mean 0 / var 1) let activations
     grow layer by layer until they overflow.  A few forward passes in training mode on synthetic

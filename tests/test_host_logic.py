@@ -127,3 +127,28 @@ def test_detector_geometry_matches_the_reference_arithmetic():
         assert g.out_h % 32 == 0 and g.out_w % 32 == 0
     with pytest.raises(RuntimeError):
         kernels.detector_geometry(5000, 3)  # target width 0
+
+
+def test_fold_batchnorm_is_the_same_function():
+    """backbones.fold_batchnorm: every conv + BN pair of every backbone family becomes one conv with
+    a bias; same features up to rounding; the original (checkpoint-compatible) network is untouched."""
+    import torch
+    from metrabs_amd import backbones
+    for name, res in [('resnet18', 64), ('mobilenetv3', 64), ('effnetv2-s', 128)]:
+        torch.manual_seed(0)
+        # (enough samples per channel for sane running statistics: a random 40-layer network with
+        #  degenerate statistics amplifies rounding differences chaotically)
+        net = backbones.calibrate_batchnorm(backbones.build_backbone(name), res, 'cpu', batches=2, batch_size=4)
+        keys = set(net.state_dict())
+        folded = backbones.fold_batchnorm(net)
+        assert set(net.state_dict()) == keys and net.out_channels == folded.out_channels
+        assert not any(isinstance(m, torch.nn.BatchNorm2d) for m in folded.modules())
+        assert any(isinstance(m, backbones.DepthwiseConv2d) for m in folded.modules()) == (name != 'resnet18')
+        x = torch.rand(2, 3, res, res, generator=torch.Generator().manual_seed(1))
+        with torch.inference_mode():
+            a, b = net(x), folded(x)
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= 2e-4 * float(a.abs().max()), name
+    import pytest
+    with pytest.raises(ValueError):
+        backbones.fold_batchnorm(backbones.build_backbone('resnet18').train())
