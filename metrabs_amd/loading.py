@@ -54,8 +54,11 @@ def load_joint_info(model_dir):
     return JointInfo(ji['joint_names'], ji['joint_edges'])
 
 
-def load_crop_model(model_dir, map_location='cpu'):
-    """demo_image.py:59-74 -> Metrabs in eval mode with the checkpoint loaded (strict)."""
+def load_crop_model(model_dir, map_location='cpu', fold_batchnorm=False):
+    """demo_image.py:59-74 -> Metrabs in eval mode with the checkpoint loaded (strict).
+    fold_batchnorm=True then replaces the backbone by its inference copy with every batch norm
+    folded into the convolution in front of it (backbones.fold_batchnorm: the same function up to
+    rounding, ~12 % less backbone time); the default keeps the checkpoint's own arithmetic."""
     cfg, raw = load_config(model_dir)
     backbone = backbone_from_config(raw)
     # (the reference materialises its LazyConv2d head with a dummy forward, demo_image.py:69-72;
@@ -63,12 +66,16 @@ def load_crop_model(model_dir, map_location='cpu'):
     model = Metrabs(backbone, load_joint_info(model_dir), cfg, in_channels=backbone.out_channels)
     state = torch.load(os.path.join(model_dir, 'ckpt.pt'), map_location=map_location)
     model.load_state_dict(state, strict=True)
-    return model.eval()
+    model = model.eval()
+    if fold_batchnorm:
+        from .backbones import fold_batchnorm as fold
+        model.backbone = fold(model.backbone)
+    return model
 
 
-def load_multiperson_model(model_dir, device='cuda', detector=None):
+def load_multiperson_model(model_dir, device='cuda', detector=None, fold_batchnorm=False):
     """demo_image.py:49-56 -> Pose3dEstimator on `device`."""
-    model = load_crop_model(model_dir)
+    model = load_crop_model(model_dir, fold_batchnorm=fold_batchnorm)
     with open(os.path.join(model_dir, 'skeleton_infos.pkl'), 'rb') as f:
         skeleton_infos = pickle.load(f)
     joint_transform_matrix = np.load(os.path.join(model_dir, 'joint_transform_matrix.npy'))

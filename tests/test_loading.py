@@ -91,6 +91,10 @@ def test_model_directory_round_trip(tmp_path):
         assert k1 == k2 and torch.equal(v1, v2)
     cfg, raw2 = loading.load_config(d)
     assert cfg.proc_side == 256 and cfg.depth == 8 and raw2['efficientnet_size'] == 's'
+    # the inference copy with folded batch norms: no BatchNorm2d left, same head parameters
+    folded = loading.load_crop_model(d, fold_batchnorm=True)
+    assert not any(isinstance(m, torch.nn.BatchNorm2d) for m in folded.backbone.modules())
+    assert torch.equal(folded.heatmap_heads.conv_final.weight, loaded.heatmap_heads.conv_final.weight)
     with open(os.path.join(d, 'skeleton_infos.pkl'), 'rb') as f:
         assert pickle.load(f)['upper']['indices'] == [0, 5, 6, 7, 8]
     # a checkpoint with a missing or renamed key must not load silently
