@@ -75,3 +75,24 @@ def test_missing_library_fails_loudly(tmp_path):
     from metrabs_amd import _lib
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         _lib.load(str(tmp_path / 'nope.so'))
+
+
+def test_every_entry_point_rejects_null_pointers_on_the_host(lib):
+    """All pointer arguments NULL, integers 1, floats 1.0: every int-returning entry point answers
+    MTR_E_NULL before it touches a device (no GPU here), none dereferences first."""
+    from metrabs_amd import _lib
+    checked = 0
+    for name, (res, args) in sorted(_lib.SIGNATURES.items()):
+        if res is not ctypes.c_int or name == 'mtr_version':
+            continue
+        vals = []
+        for a in args:
+            if a in (ctypes.c_int, ctypes.c_uint, ctypes.c_size_t, ctypes.c_longlong):
+                vals.append(1)
+            elif a in (ctypes.c_float, ctypes.c_double):
+                vals.append(1.0)
+            else:
+                vals.append(None)  # data pointers, parameter structs, the stream
+        assert getattr(lib, name)(*vals) == -1, name
+        checked += 1
+    assert checked >= 16
