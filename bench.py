@@ -161,6 +161,34 @@ def depth72_variant(args, dev, im_h, im_w, n_box):
                      '(every shipped configuration of the reference)')
 
 
+def unfolded_bn_variant(args, dev, im_h, im_w, n_box):
+    """`value` runs the backbone's inference copy with batch norm folded into the convolutions (the
+    same function up to rounding).  For transparency: the SAME step with the batch norms left as
+    separate kernels, reported beside `value`."""
+    import copy
+    from metrabs_amd.pipeline import GraphedCropPipeline
+    a = copy.copy(args)
+    a.no_fold_bn = True
+    est, _ = build_model(a, dev)
+    pipe = GraphedCropPipeline(est, args.frames, im_h, im_w, n_box, num_aug=args.num_aug,
+                               use_graph=not args.no_graph)
+    synth_inputs(pipe, args.frames, im_h, im_w, n_box, seed=100)
+    pipe.capture()
+    for _ in range(3):
+        pipe.run()
+    torch.cuda.synchronize()
+    n = max(5, args.steps // 2)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        pipe.run()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    assert torch.isfinite(pipe.poses).all()
+    return dict(crops_per_s_per_gpu=n_box * args.num_aug / ms * 1e3, ms_per_step=ms, steps=n,
+                note='same step as `value` with the backbone\'s batch norms as separate kernels '
+                     '(--no-fold-bn)')
+
+
 def head_kernel_name(hw, n_crops, J, D, precision='f32', C=1280):
     """Which GEMM kernel mtr_head_fused dispatches to (metrabs_amd/csrc/head_fused.hip:dispatch_head)."""
     if precision != 'f32' and C % 8 == 0:
@@ -550,6 +578,8 @@ def main():
     out['parity'] = parity_probe(est, extras, cfg)
     if world == 1 and args.depth != 72 and not args.no_depth72:
         out['depth72'] = depth72_variant(args, dev, im_h, im_w, n_box)
+        if not args.no_fold_bn:
+            out['bn_not_folded'] = unfolded_bn_variant(args, dev, im_h, im_w, n_box)
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(est, pipe, args, cfg, args.cpu_seconds)
     else:
