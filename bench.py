@@ -63,6 +63,9 @@ def parse_args():
     ap.add_argument('--no-fold-bn', action='store_true',
                     help='keep the backbone\'s batch norms as separate kernels (default: folded into '
                          'the convolutions, the usual inference-time transformation)')
+    ap.add_argument('--no-fused-epilogue', action='store_true',
+                    help='behind the folded convolutions, leave "+ bias" and the activation to PyTorch\'s '
+                         'two elementwise kernels instead of the one in-place HIP pass (K10)')
     ap.add_argument('--precision', default='f32', choices=['f32', 'f16', 'bf16'],
                     help='backbone arithmetic: f32 = the reference CPU path; f16 = its autocast GPU path')
     ap.add_argument('--no-graph', action='store_true')
@@ -98,8 +101,11 @@ def build_model(args, dev):
     # naive direct convolution for the depthwise layers: those run on PyTorch's own depthwise
     # kernel instead (backbones.DepthwiseConv2d; 14.0 -> 13.1 ms).  (2) Inference-time batch norm is
     # folded into the preceding convolution (backbones.fold_batchnorm; 13.3 -> 11.8 ms; the same
-    # function up to rounding, --no-fold-bn keeps the separate BN kernels).  (3) MIOpen benchmark
-    # mode: 2 minutes of search on a fresh box for the same step time, off (MTR_BENCH_MIOPEN_FIND=1).
+    # function up to rounding, --no-fold-bn keeps the separate BN kernels), and "+ bias, activation"
+    # behind each folded convolution is one in-place HIP pass (K10, csrc/bias_act.hip) instead of
+    # PyTorch-ROCm's two elementwise kernels (11.7 -> 10.6 ms; --no-fused-epilogue).  (3) MIOpen
+    # benchmark mode: 2 minutes of search on a fresh box for the same step time, off
+    # (MTR_BENCH_MIOPEN_FIND=1).
     if os.environ.get('MTR_BENCH_MIOPEN_FIND', '0') == '1':
         torch.backends.cudnn.benchmark = True
     torch.manual_seed(1234)
@@ -115,7 +121,7 @@ def build_model(args, dev):
     calibrate_batchnorm(model.backbone, args.res, dev)
     model = model.eval()
     if not args.no_fold_bn:
-        model.backbone = fold_batchnorm(model.backbone)
+        model.backbone = fold_batchnorm(model.backbone, fused_epilogue=not args.no_fused_epilogue)
     # (channels_last measured slower than NCHW on this MIOpen for both dtypes: 19.1 vs 14.0 ms in f32,
     #  15.0 vs 11.4 ms under f16 autocast -- tools/experiments/backbone_f16_probe.py)
     channels_last = os.environ.get('MTR_BENCH_CHANNELS_LAST') == '1'
@@ -555,7 +561,8 @@ def main():
                    'hip_graph': not args.no_graph,
                    'backbone': 'PyTorch-ROCm (rocBLAS / MIOpen; depthwise layers on PyTorch\'s own '
                                'kernel' + ('' if args.no_fold_bn else ', inference batch norm folded into '
-                               'the convolutions') + ')'},
+                               'the convolutions' + ('' if args.no_fused_epilogue else ', bias + activation '
+                               'behind them as one in-place HIP pass (K10)')) + ')'},
         'roofline': roofline,
         'stage_us': kernels_us,
         'hand_written_kernels': per_kernel,

@@ -274,6 +274,18 @@ int mtr_filter_poses(const float* poses3d, const float* poses2d, const float* bo
                      int max_per_image, uint8_t* valid, int32_t* keep_idx, int32_t* keep_count,
                      mtr_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * K10 (outside the reference's hot path): fused epilogue for the PyTorch-ROCm
+ * backbone's inference copy, metrabs_amd/backbones.py:fold_batchnorm(fused_epilogue=True).  With
+ * batch norm folded into a convolution, what follows it is "+ bias[c]" and an activation -- two
+ * elementwise kernels in PyTorch-ROCm (torchvision Conv2dNormActivation: ops/misc.py; the
+ * reference's backbones/efficientnet.py:11-18 builds on it).  In place on y [B, C, HW] (NCHW,
+ * 16-byte aligned, HW % (16 / sizeof(dtype)) == 0): y = act(y + bias[c]) computed in f32.
+ * act: 0 none, 1 ReLU, 2 SiLU, 3 Hardswish.
+ */
+int mtr_bias_act_nchw(void* y, int dtype, const float* bias /*[C] f32*/, int act, long long B, int C,
+                      int HW, mtr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -236,13 +236,39 @@ def build_backbone(name):
     raise ValueError(f'unknown backbone {name}')
 
 
-def fold_batchnorm(backbone):
+_ACT_NAMES = {nn.SiLU: 'silu', nn.ReLU: 'relu', nn.Hardswish: 'hardswish'}
+
+
+class ConvBiasAct(nn.Module):
+    """A folded conv + BN (+ activation): the convolution without its bias (MIOpen / rocBLAS), then
+    "+ bias[c]" and the activation as ONE in-place pass (kernels.bias_act_, K10) instead of the two
+    elementwise kernels PyTorch-ROCm would launch.  CPU tensors take the plain torch ops."""
+
+    def __init__(self, conv, bias, act):
+        super().__init__()
+        self.conv = conv
+        self.register_buffer('bias', bias.detach().float().contiguous())
+        self.act = act
+        self.act_name = None if act is None else _ACT_NAMES[type(act)]
+
+    def forward(self, x):
+        y = self.conv(x)
+        if y.is_cuda and y.is_contiguous():
+            from . import kernels
+            return kernels.bias_act_(y, self.bias, self.act_name)
+        y = y + self.bias.view(1, -1, 1, 1).to(y.dtype)
+        return y if self.act is None else self.act(y)
+
+
+def fold_batchnorm(backbone, fused_epilogue=False):
     """Inference-time copy of `backbone` with every batch norm folded into the convolution in front
     of it (w' = w * gamma / sqrt(var + eps), b' = beta - mean * gamma / sqrt(var + eps)): the same
     function up to rounding (features equal to ~1e-5 relative in f32), one elementwise pass over
     every activation less.  EfficientNetV2-S forward at the bench shape: 13.3 -> 11.8 ms in f32,
     11.6 -> 10.2 ms under f16 autocast (tools/experiments/bn_backend_probe.py).  The original keeps
-    its checkpoint-compatible parameters; the copy has conv biases and no BatchNorm2d."""
+    its checkpoint-compatible parameters; the copy has conv biases and no BatchNorm2d.
+    fused_epilogue=True additionally runs "+ bias, activation" behind each folded convolution as one
+    in-place HIP pass (ConvBiasAct) instead of PyTorch-ROCm's two elementwise kernels."""
     import copy
     from torch.nn.utils.fusion import fuse_conv_bn_eval
     if backbone.training:
@@ -250,7 +276,15 @@ def fold_batchnorm(backbone):
     folded = copy.deepcopy(backbone)
     for m in folded.modules():
         if isinstance(m, ConvBNAct) and isinstance(m[1], nn.BatchNorm2d):
-            m[0] = fuse_conv_bn_eval(m[0], m[1])
+            conv = fuse_conv_bn_eval(m[0], m[1])
+            act = m[2] if len(m) > 2 else None
+            if fused_epilogue and (act is None or type(act) in _ACT_NAMES):
+                bias, conv.bias = conv.bias, None
+                m[0] = ConvBiasAct(conv, bias, act)
+                if act is not None:
+                    m[2] = nn.Identity()
+            else:
+                m[0] = conv
             m[1] = nn.Identity()
     if any(isinstance(m, nn.BatchNorm2d) for m in folded.modules()):
         raise ValueError('a BatchNorm2d outside a ConvBNAct block cannot be folded here')

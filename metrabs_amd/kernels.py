@@ -373,3 +373,23 @@ def filter_poses(poses3d, poses2d, boxes, n_per_image, edges, mean_bones, n_join
                                _ptr(valid), _ptr(keep_idx), _ptr(keep_count),
                                current_stream_ptr(dev)), 'mtr_filter_poses')
     return keep_idx, keep_count, valid.bool()
+
+
+# ------------------------------------------------------------------------------------------------
+# K10: bias + activation epilogue for the backbone's inference copy (backbones.fold_batchnorm)
+
+ACT_CODES = {None: 0, 'none': 0, 'relu': 1, 'silu': 2, 'hardswish': 3}
+
+
+def bias_act_(y, bias, act):
+    """In place: y[b, c, ...] = act(y[b, c, ...] + bias[c]) on an NCHW-contiguous activation
+    (f32 / f16 / bf16), one HBM pass instead of PyTorch-ROCm's bias-add and activation kernels."""
+    require_cuda(y, bias)
+    if not y.is_contiguous():
+        raise ValueError('bias_act_ needs an NCHW-contiguous tensor')
+    B, C = y.shape[0], y.shape[1]
+    hw = y.numel() // max(B * C, 1)
+    check(_lib.load().mtr_bias_act_nchw(_ptr(y), dtype_code(y.dtype), _ptr(bias.contiguous().float()),
+                                        ACT_CODES[act], B, C, hw, current_stream_ptr(y.device)),
+          'mtr_bias_act_nchw')
+    return y

@@ -1,0 +1,52 @@
+"""GPU: K10, the in-place bias + activation epilogue of the backbone's inference copy, against the
+torch ops it replaces; and the folded + fused backbone against the original network."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+ACTS = {None: lambda t: t, 'relu': F.relu, 'silu': F.silu, 'hardswish': F.hardswish}
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(3, 5, 8, 8), (2, 1536, 8, 8), (64, 24, 128, 128), (1, 7, 2, 4), (5, 960, 16, 16)])
+@pytest.mark.parametrize('act', [None, 'relu', 'silu', 'hardswish'])
+def test_bias_act_vs_torch(shape, act, dtype, hip_lib):
+    from metrabs_amd import kernels
+    g = torch.Generator(device='cuda').manual_seed(sum(shape))
+    y = (torch.randn(shape, device='cuda', generator=g) * 3).to(dtype)
+    b = torch.randn(shape[1], device='cuda', generator=g)
+    want = ACTS[act](y.float() + b.view(1, -1, 1, 1))
+    got = kernels.bias_act_(y.clone(), b, act)
+    assert got.dtype == dtype and got.shape == y.shape
+    tol = {torch.float32: 2e-6, torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype]
+    err = float(((got.float() - want).abs() / (1 + want.abs())).max())
+    assert err <= tol, err
+    # in place, and the f32 path is the same arithmetic as the torch ops up to the exp
+    y2 = y.clone()
+    assert kernels.bias_act_(y2, b, act).data_ptr() == y2.data_ptr()
+
+
+def test_bias_act_rejects_what_it_cannot_vectorise(hip_lib):
+    from metrabs_amd import kernels
+    y = torch.zeros(2, 3, 3, 3, device='cuda')  # H*W = 9: a 16-byte vector would straddle channels
+    with pytest.raises(RuntimeError):
+        kernels.bias_act_(y, torch.zeros(3, device='cuda'), 'silu')
+    with pytest.raises(ValueError):
+        kernels.bias_act_(torch.zeros(2, 4, 4, 4, device='cuda').permute(0, 2, 3, 1), torch.zeros(4, device='cuda'), None)
+
+
+@pytest.mark.parametrize('name,res', [('effnetv2-s', 256), ('mobilenetv3', 256), ('resnet18', 256)])
+def test_folded_fused_backbone_is_the_same_function(name, res, hip_lib):
+    from metrabs_amd import backbones
+    torch.manual_seed(0)
+    net = backbones.calibrate_batchnorm(backbones.build_backbone(name).cuda(), res, 'cuda', batch_size=4)
+    fused = backbones.fold_batchnorm(net, fused_epilogue=True)
+    x = torch.rand(4, 3, res, res, device='cuda')
+    with torch.inference_mode():
+        a, b = net(x), fused(x)
+        with torch.autocast('cuda', dtype=torch.float16):
+            c = fused(x)
+    assert float((a - b).abs().max()) <= 1e-3 * float(a.abs().max())
+    assert c.dtype == torch.float16 and float((a - c.float()).abs().max()) <= 0.1 * float(a.abs().max())

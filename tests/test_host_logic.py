@@ -145,10 +145,13 @@ def test_fold_batchnorm_is_the_same_function():
         assert not any(isinstance(m, torch.nn.BatchNorm2d) for m in folded.modules())
         assert any(isinstance(m, backbones.DepthwiseConv2d) for m in folded.modules()) == (name != 'resnet18')
         x = torch.rand(2, 3, res, res, generator=torch.Generator().manual_seed(1))
+        fused = backbones.fold_batchnorm(net, fused_epilogue=True)  # (CPU: its torch-op branch)
+        assert any(isinstance(m, backbones.ConvBiasAct) for m in fused.modules())
         with torch.inference_mode():
-            a, b = net(x), folded(x)
-        assert a.shape == b.shape
+            a, b, c = net(x), folded(x), fused(x)
+        assert a.shape == b.shape == c.shape
         assert float((a - b).abs().max()) <= 2e-4 * float(a.abs().max()), name
+        assert float((a - c).abs().max()) <= 2e-4 * float(a.abs().max()), name
     import pytest
     with pytest.raises(ValueError):
         backbones.fold_batchnorm(backbones.build_backbone('resnet18').train())

@@ -55,7 +55,11 @@ for m in folded.modules():
         n_fold += 1
 left = sum(isinstance(m, torch.nn.BatchNorm2d) for m in folded.modules())
 print(f'folded {n_fold} conv+BN pairs, {left} BatchNorm2d left')
+from metrabs_amd.backbones import fold_batchnorm
+fused = fold_batchnorm(net, fused_epilogue=True)
 for dtype in (None, torch.float16):
+    t3, y3 = run(fused, dtype)
+    print(f'{dtype}: folded + K10 bias/activation epilogue {t3:.2f} ms', flush=True)
     t0, y0 = run(net, dtype)
     t1, y1 = run(native, dtype)
     t2, y2 = run(folded, dtype)

@@ -175,8 +175,29 @@ def bench_filter():
     return out
 
 
+def bench_bias_act():
+    """K10: in-place bias + activation on an activation tensor (read + write = the algorithmic bytes),
+    beside the two torch kernels it replaces."""
+    import torch.nn.functional as F
+    out = []
+    g = torch.Generator(device='cuda').manual_seed(0)
+    for name, shape, dt in [('B=64 96ch 64x64 f32 silu', (64, 96, 64, 64), torch.float32),
+                            ('B=64 24ch 128x128 f32 silu', (64, 24, 128, 128), torch.float32),
+                            ('B=64 1536ch 8x8 f32 silu', (64, 1536, 8, 8), torch.float32),
+                            ('B=64 96ch 64x64 f16 silu', (64, 96, 64, 64), torch.float16)]:
+        y = torch.randn(shape, device='cuda', generator=g).to(dt)
+        b = torch.randn(shape[1], device='cuda', generator=g)
+        t = timeit(lambda: kernels.bias_act_(y, b, 'silu'))
+        bb = b.view(1, -1, 1, 1).to(dt)
+        tt = timeit(lambda: F.silu(y + bb))
+        nbytes = 2 * y.numel() * y.element_size()
+        out.append(dict(kernel='bias_act', case=name, us=round(t * 1e6, 1), torch_two_kernels_us=round(tt * 1e6, 1),
+                        GBps=round(nbytes / t / 1e9, 1), frac_hbm=round(nbytes / t / HBM, 3)))
+    return out
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['decode', 'head', 'warp', 'recon', 'detector', 'filter']
+    which = sys.argv[1:] or ['decode', 'head', 'warp', 'recon', 'detector', 'filter', 'bias_act']
     res = []
     if 'decode' in which:
         res += bench_decode()
@@ -190,5 +211,7 @@ if __name__ == '__main__':
         res += bench_detector_pre()
     if 'filter' in which:
         res += bench_filter()
+    if 'bias_act' in which:
+        res += bench_bias_act()
     for r in res:
         print(json.dumps(r))
