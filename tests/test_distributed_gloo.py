@@ -30,7 +30,9 @@ def _worker(rank, world, port, n_boxes, per_batch, q):
     full = distributed.gather_poses(local, ranges, n_boxes, per_batch, world)
     moments = torch.tensor([1.0 + rank, 10.0 * (rank + 1), float(len(local))], dtype=torch.float64)
     moments = distributed.allreduce_moments(moments)
-    q.put((rank, full, moments))
+    # by value (numpy pickles into the pipe): a torch tensor would travel as a shared-memory handle
+    # that disappears if this process exits before the parent has opened it
+    q.put((rank, full.numpy(), moments.numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -61,6 +63,7 @@ def test_round_robin_shards_and_single_gather(n_boxes, per_batch):
     expected = torch.arange(n_boxes, dtype=torch.float32).reshape(-1, 1, 1, 1).repeat(1, 2, 17, 3) \
         + 0.001 * (torch.arange(n_boxes) // per_batch).float().reshape(-1, 1, 1, 1)
     for rank, full, moments in results:
+        full, moments = torch.from_numpy(full), torch.from_numpy(moments)
         assert full.shape == (n_boxes, 2, 17, 3)
         assert torch.equal(full, expected), f'rank {rank} gathered a wrong / mis-ordered result'
         assert moments[:2].tolist() == [3.0, 30.0] and moments[2] == n_boxes
