@@ -280,11 +280,12 @@ int mtr_filter_poses(const float* poses3d, const float* poses2d, const float* bo
  * batch norm folded into a convolution, what follows it is "+ bias[c]" and an activation -- two
  * elementwise kernels in PyTorch-ROCm (torchvision Conv2dNormActivation: ops/misc.py; the
  * reference's backbones/efficientnet.py:11-18 builds on it).  In place on y [B, C, HW] (NCHW,
- * 16-byte aligned, HW % (16 / sizeof(dtype)) == 0): y = act(y + bias[c]) computed in f32.
+ * 16-byte aligned, HW % (16 / sizeof(dtype)) == 0): y = act(y + bias[c]) (+ residual, the skip
+ * connection of an (Fused)MBConv block, same shape and dtype as y, may be NULL), computed in f32.
  * act: 0 none, 1 ReLU, 2 SiLU, 3 Hardswish.
  */
-int mtr_bias_act_nchw(void* y, int dtype, const float* bias /*[C] f32*/, int act, long long B, int C,
-                      int HW, mtr_stream_t stream);
+int mtr_bias_act_nchw(void* y, int dtype, const float* bias /*[C] f32*/, const void* residual, int act,
+                      long long B, int C, int HW, mtr_stream_t stream);
 
 #ifdef __cplusplus
 }

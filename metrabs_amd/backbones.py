@@ -96,8 +96,7 @@ class FusedMBConv(nn.Module):
         self.block = nn.Sequential(layers)
 
     def forward(self, x):
-        y = self.block(x)
-        return x + y if self.residual else y
+        return _block_plus_skip(self.block, x) if self.residual else self.block(x)
 
 
 class MBConv(nn.Module):
@@ -118,8 +117,7 @@ class MBConv(nn.Module):
         self.block = nn.Sequential(layers)
 
     def forward(self, x):
-        y = self.block(x)
-        return x + y if self.residual else y
+        return _block_plus_skip(self.block, x) if self.residual else self.block(x)
 
 
 class Preproc(nn.Module):
@@ -203,8 +201,7 @@ class MBv3Block(nn.Module):
         self.block = nn.Sequential(*layers)
 
     def forward(self, x):
-        y = self.block(x)
-        return x + y if self.residual else y
+        return _block_plus_skip(self.block, x) if self.residual else self.block(x)
 
 
 def mobilenet_v3_large():
@@ -251,13 +248,30 @@ class ConvBiasAct(nn.Module):
         self.act = act
         self.act_name = None if act is None else _ACT_NAMES[type(act)]
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
         y = self.conv(x)
-        if y.is_cuda and y.is_contiguous():
+        if y.is_cuda and y.is_contiguous() and (
+                residual is None or (residual.dtype == y.dtype and residual.is_contiguous())):
             from . import kernels
-            return kernels.bias_act_(y, self.bias, self.act_name)
+            return kernels.bias_act_(y, self.bias, self.act_name, residual)
         y = y + self.bias.view(1, -1, 1, 1).to(y.dtype)
-        return y if self.act is None else self.act(y)
+        y = y if self.act is None else self.act(y)
+        return y if residual is None else residual + y
+
+
+def _block_plus_skip(block, x):
+    """x + block(x) of an (Fused)MBConv; when the block ends in a folded convolution (ConvBiasAct)
+    the skip connection rides on its epilogue instead of being a kernel of its own."""
+    last = block[-1]
+    tail = last[0] if isinstance(last, ConvBNAct) else None
+    if isinstance(tail, ConvBiasAct):
+        y = x
+        for m in list(block)[:-1]:
+            y = m(y)
+        for m in list(last)[1:]:
+            assert isinstance(m, nn.Identity)
+        return tail(y, residual=x)
+    return x + block(x)
 
 
 def fold_batchnorm(backbone, fused_epilogue=False):

@@ -381,15 +381,20 @@ def filter_poses(poses3d, poses2d, boxes, n_per_image, edges, mean_bones, n_join
 ACT_CODES = {None: 0, 'none': 0, 'relu': 1, 'silu': 2, 'hardswish': 3}
 
 
-def bias_act_(y, bias, act):
-    """In place: y[b, c, ...] = act(y[b, c, ...] + bias[c]) on an NCHW-contiguous activation
-    (f32 / f16 / bf16), one HBM pass instead of PyTorch-ROCm's bias-add and activation kernels."""
+def bias_act_(y, bias, act, residual=None):
+    """In place: y[b, c, ...] = act(y[b, c, ...] + bias[c]) (+ residual) on an NCHW-contiguous
+    activation (f32 / f16 / bf16), one HBM pass instead of PyTorch-ROCm's bias-add, activation and
+    skip-connection kernels."""
     require_cuda(y, bias)
     if not y.is_contiguous():
         raise ValueError('bias_act_ needs an NCHW-contiguous tensor')
+    if residual is not None:
+        if residual.shape != y.shape or residual.dtype != y.dtype or not residual.is_contiguous():
+            raise ValueError('residual must match y in shape, dtype and layout')
     B, C = y.shape[0], y.shape[1]
     hw = y.numel() // max(B * C, 1)
     check(_lib.load().mtr_bias_act_nchw(_ptr(y), dtype_code(y.dtype), _ptr(bias.contiguous().float()),
-                                        ACT_CODES[act], B, C, hw, current_stream_ptr(y.device)),
+                                        None if residual is None else _ptr(residual), ACT_CODES[act],
+                                        B, C, hw, current_stream_ptr(y.device)),
           'mtr_bias_act_nchw')
     return y

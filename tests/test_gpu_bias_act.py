@@ -23,9 +23,15 @@ def test_bias_act_vs_torch(shape, act, dtype, hip_lib):
     tol = {torch.float32: 2e-6, torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype]
     err = float(((got.float() - want).abs() / (1 + want.abs())).max())
     assert err <= tol, err
-    # in place, and the f32 path is the same arithmetic as the torch ops up to the exp
+    # in place
     y2 = y.clone()
     assert kernels.bias_act_(y2, b, act).data_ptr() == y2.data_ptr()
+    # with the skip connection riding on the same pass: act(y + b) + r
+    r = (torch.randn(shape, device='cuda', generator=g) * 2).to(dtype)
+    got_r = kernels.bias_act_(y.clone(), b, act, residual=r)
+    want_r = want + r.float()
+    err_r = float(((got_r.float() - want_r).abs() / (1 + want_r.abs())).max())
+    assert err_r <= tol, err_r
 
 
 def test_bias_act_rejects_what_it_cannot_vectorise(hip_lib):
