@@ -103,7 +103,8 @@ def build_model(args, dev):
     # folded into the preceding convolution (backbones.fold_batchnorm; 13.3 -> 11.8 ms; the same
     # function up to rounding, --no-fold-bn keeps the separate BN kernels), and "+ bias, activation"
     # behind each folded convolution is one in-place HIP pass (K10, csrc/bias_act.hip) instead of
-    # PyTorch-ROCm's two elementwise kernels (11.7 -> 10.6 ms; --no-fused-epilogue).  (3) MIOpen
+    # PyTorch-ROCm's two elementwise kernels, with the blocks' skip connection and the squeeze-excite
+    # mean riding on the same pass (11.7 -> 9.8 ms; --no-fused-epilogue).  (3) MIOpen
     # benchmark mode: 2 minutes of search on a fresh box for the same step time, off
     # (MTR_BENCH_MIOPEN_FIND=1).
     if os.environ.get('MTR_BENCH_MIOPEN_FIND', '0') == '1':

@@ -287,6 +287,13 @@ int mtr_filter_poses(const float* poses3d, const float* poses2d, const float* bo
 int mtr_bias_act_nchw(void* y, int dtype, const float* bias /*[C] f32*/, const void* residual, int act,
                       long long B, int C, int HW, mtr_stream_t stream);
 
+/* Same pass without a residual, additionally row_mean[b * C + c] = mean over H*W of the stored result:
+ * the input of the squeeze-excite block behind a depthwise convolution (x.mean((2, 3)), the first
+ * statement of torchvision's SqueezeExcitation that efficientnet.py:110-173 uses), otherwise a
+ * reduction kernel of its own. */
+int mtr_bias_act_rowmean_nchw(void* y, int dtype, const float* bias /*[C] f32*/, int act, long long B,
+                              int C, int HW, float* row_mean /*[B*C] f32*/, mtr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

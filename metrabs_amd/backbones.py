@@ -57,8 +57,16 @@ class SqueezeExcite(nn.Module):
         self.fc2 = nn.Conv2d(squeeze, channels, 1)
         self.act, self.gate = act(), gate()
 
+    # set by fold_batchnorm(fused_epilogue=True): the ConvBiasAct in front of this block, whose
+    # epilogue pass also produced the per-channel mean of the tensor it handed over
+    mean_from = ()
+
     def forward(self, x):
-        s = x.mean((2, 3), keepdim=True)
+        s = None
+        for src in self.mean_from:
+            s = src.take_mean(x)
+        if s is None:
+            s = x.mean((2, 3), keepdim=True)
         return x * self.gate(self.fc2(self.act(self.fc1(s))))
 
 
@@ -247,12 +255,26 @@ class ConvBiasAct(nn.Module):
         self.register_buffer('bias', bias.detach().float().contiguous())
         self.act = act
         self.act_name = None if act is None else _ACT_NAMES[type(act)]
+        self.emit_mean = False  # a squeeze-excite block follows: give it its x.mean((2, 3)) for free
+        self._mean = None
+
+    def take_mean(self, x):
+        """The [B, C, 1, 1] mean of `x` if `x` is the very tensor this module returned last."""
+        held, self._mean = self._mean, None
+        if held is not None and held[0] is x:
+            return held[1].to(x.dtype).view(x.shape[0], x.shape[1], 1, 1)
+        return None
 
     def forward(self, x, residual=None):
         y = self.conv(x)
         if y.is_cuda and y.is_contiguous() and (
                 residual is None or (residual.dtype == y.dtype and residual.is_contiguous())):
             from . import kernels
+            hw_vec_ok = (y.shape[2] * y.shape[3]) % (16 // y.element_size()) == 0
+            if self.emit_mean and residual is None and hw_vec_ok:
+                y, mean = kernels.bias_act_rowmean_(y, self.bias, self.act_name)
+                self._mean = (y, mean)
+                return y
             return kernels.bias_act_(y, self.bias, self.act_name, residual)
         y = y + self.bias.view(1, -1, 1, 1).to(y.dtype)
         y = y if self.act is None else self.act(y)
@@ -302,6 +324,17 @@ def fold_batchnorm(backbone, fused_epilogue=False):
             m[1] = nn.Identity()
     if any(isinstance(m, nn.BatchNorm2d) for m in folded.modules()):
         raise ValueError('a BatchNorm2d outside a ConvBNAct block cannot be folded here')
+    if fused_epilogue:  # conv -> squeeze-excite: the epilogue pass also emits the channel means
+        for seq in folded.modules():
+            if not isinstance(seq, nn.Sequential) or isinstance(seq, ConvBNAct):
+                continue
+            kids = list(seq)
+            for prev, nxt in zip(kids, kids[1:]):
+                if isinstance(nxt, SqueezeExcite) and isinstance(prev, ConvBNAct) and \
+                        isinstance(prev[0], ConvBiasAct) and \
+                        all(isinstance(m, nn.Identity) for m in list(prev)[1:]):
+                    prev[0].emit_mean = True
+                    nxt.mean_from = (prev[0],)
     return folded
 
 

@@ -398,3 +398,19 @@ def bias_act_(y, bias, act, residual=None):
                                         B, C, hw, current_stream_ptr(y.device)),
           'mtr_bias_act_nchw')
     return y
+
+
+def bias_act_rowmean_(y, bias, act):
+    """bias_act_ + the mean over H*W of every (b, c) row of the result, [B, C] f32, from the same pass
+    (what a squeeze-excite block behind the convolution starts with)."""
+    require_cuda(y, bias)
+    if not y.is_contiguous():
+        raise ValueError('bias_act_rowmean_ needs an NCHW-contiguous tensor')
+    B, C = y.shape[0], y.shape[1]
+    hw = y.numel() // max(B * C, 1)
+    mean = torch.empty(B, C, device=y.device, dtype=torch.float32)
+    check(_lib.load().mtr_bias_act_rowmean_nchw(_ptr(y), dtype_code(y.dtype), _ptr(bias.contiguous().float()),
+                                                ACT_CODES[act], B, C, hw, _ptr(mean),
+                                                current_stream_ptr(y.device)),
+          'mtr_bias_act_rowmean_nchw')
+    return y, mean

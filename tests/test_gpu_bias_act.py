@@ -34,6 +34,22 @@ def test_bias_act_vs_torch(shape, act, dtype, hip_lib):
     assert err_r <= tol, err_r
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+@pytest.mark.parametrize('shape', [(3, 5, 8, 8), (2, 1536, 8, 8), (64, 960, 16, 16), (1, 7, 2, 4), (2, 9, 28, 28),
+                                   (130, 3, 4, 4)])
+def test_bias_act_rowmean_vs_torch(shape, dtype, hip_lib):
+    """The row-mean variant: same result tensor as bias_act_, and the mean over H*W of that result."""
+    from metrabs_amd import kernels
+    g = torch.Generator(device='cuda').manual_seed(sum(shape) + 1)
+    y = (torch.randn(shape, device='cuda', generator=g) * 3).to(dtype)
+    b = torch.randn(shape[1], device='cuda', generator=g)
+    plain = kernels.bias_act_(y.clone(), b, 'silu')
+    got, mean = kernels.bias_act_rowmean_(y.clone(), b, 'silu')
+    assert torch.equal(got, plain) and mean.shape == shape[:2] and mean.dtype == torch.float32
+    want = plain.float().mean((2, 3))
+    assert float((mean - want).abs().max()) <= 1e-5 * (1 + float(want.abs().max()))
+
+
 def test_bias_act_rejects_what_it_cannot_vectorise(hip_lib):
     from metrabs_amd import kernels
     y = torch.zeros(2, 3, 3, 3, device='cuda')  # H*W = 9: a 16-byte vector would straddle channels
@@ -49,6 +65,8 @@ def test_folded_fused_backbone_is_the_same_function(name, res, hip_lib):
     torch.manual_seed(0)
     net = backbones.calibrate_batchnorm(backbones.build_backbone(name).cuda(), res, 'cuda', batch_size=4)
     fused = backbones.fold_batchnorm(net, fused_epilogue=True)
+    n_se = sum(isinstance(m, backbones.SqueezeExcite) for m in fused.modules())
+    assert sum(bool(m.mean_from) for m in fused.modules() if isinstance(m, backbones.SqueezeExcite)) == n_se
     x = torch.rand(4, 3, res, res, device='cuda')
     with torch.inference_mode():
         a, b = net(x), fused(x)
