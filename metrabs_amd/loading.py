@@ -54,11 +54,13 @@ def load_joint_info(model_dir):
     return JointInfo(ji['joint_names'], ji['joint_edges'])
 
 
-def load_crop_model(model_dir, map_location='cpu', fold_batchnorm=False):
+def load_crop_model(model_dir, map_location='cpu', fold_batchnorm=False, fused_epilogue=False):
     """demo_image.py:59-74 -> Metrabs in eval mode with the checkpoint loaded (strict).
     fold_batchnorm=True then replaces the backbone by its inference copy with every batch norm
     folded into the convolution in front of it (backbones.fold_batchnorm: the same function up to
-    rounding, ~12 % less backbone time); the default keeps the checkpoint's own arithmetic."""
+    rounding, ~12 % less backbone time; fused_epilogue=True also runs bias + activation behind the
+    folded convolutions as one in-place HIP pass, K10); the default keeps the checkpoint's own
+    arithmetic."""
     cfg, raw = load_config(model_dir)
     backbone = backbone_from_config(raw)
     # (the reference materialises its LazyConv2d head with a dummy forward, demo_image.py:69-72;
@@ -69,13 +71,14 @@ def load_crop_model(model_dir, map_location='cpu', fold_batchnorm=False):
     model = model.eval()
     if fold_batchnorm:
         from .backbones import fold_batchnorm as fold
-        model.backbone = fold(model.backbone)
+        model.backbone = fold(model.backbone, fused_epilogue=fused_epilogue)
     return model
 
 
-def load_multiperson_model(model_dir, device='cuda', detector=None, fold_batchnorm=False):
+def load_multiperson_model(model_dir, device='cuda', detector=None, fold_batchnorm=False,
+                           fused_epilogue=False):
     """demo_image.py:49-56 -> Pose3dEstimator on `device`."""
-    model = load_crop_model(model_dir, fold_batchnorm=fold_batchnorm)
+    model = load_crop_model(model_dir, fold_batchnorm=fold_batchnorm, fused_epilogue=fused_epilogue)
     with open(os.path.join(model_dir, 'skeleton_infos.pkl'), 'rb') as f:
         skeleton_infos = pickle.load(f)
     joint_transform_matrix = np.load(os.path.join(model_dir, 'joint_transform_matrix.npy'))
