@@ -294,6 +294,17 @@ int mtr_bias_act_nchw(void* y, int dtype, const float* bias /*[C] f32*/, const v
 int mtr_bias_act_rowmean_nchw(void* y, int dtype, const float* bias /*[C] f32*/, int act, long long B,
                               int C, int HW, float* row_mean /*[B*C] f32*/, mtr_stream_t stream);
 
+/* K11 (outside the reference's hot path, like K10): depthwise 3x3 convolution of the backbone's
+ * inference copy with the K10 epilogue in the same pass.  x [B, C, H, W] -> y [B, C, OH, OW] (NCHW,
+ * same dtype; OH = (H + 2 pad - 3) / stride + 1, OW likewise and a multiple of 4), cross-correlation
+ * with weight [C, 3, 3] f32 (torch Conv2d(groups=C).weight with the batch norm folded in), zero
+ * padding `pad` in {0, 1} on every side, stride in {1, 2}; y = act(conv + bias[c]) in f32 arithmetic;
+ * row_mean (may be NULL): [B*C] f32 mean of the stored result per (b, c) plane, the input of the
+ * squeeze-excite block behind the layer (efficientnet.py:110-173). */
+int mtr_depthwise3x3_bias_act(const void* x, int dtype, const float* weight, const float* bias, int act,
+                              long long B, int C, int H, int W, int stride, int pad, void* y,
+                              float* row_mean, mtr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,7 @@ fixed padding, efficientnet.py:1127-1161; irrelevant for throughput).
 import collections
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 
@@ -281,6 +282,48 @@ class ConvBiasAct(nn.Module):
         return y if residual is None else residual + y
 
 
+class DepthwiseBiasAct(nn.Module):
+    """A folded depthwise 3x3 conv + BN + activation as ONE HIP pass over the plane (K11): the
+    convolution, "+ bias", the activation and -- in front of a squeeze-excite block -- the
+    per-channel mean, instead of PyTorch's depthwise kernel followed by K10.  Other tensors (CPU,
+    non-contiguous, widths that are not a multiple of 4) take the torch ops."""
+
+    def __init__(self, conv, bias, act):
+        super().__init__()
+        self.weight = nn.Parameter(conv.weight.detach().float().contiguous(), requires_grad=False)
+        self.register_buffer('bias', bias.detach().float().contiguous())
+        self.stride, self.pad = conv.stride[0], conv.padding[0]
+        self.act = act
+        self.act_name = None if act is None else _ACT_NAMES[type(act)]
+        self.emit_mean = False
+        self._mean = None
+
+    @staticmethod
+    def applies_to(conv):
+        return (isinstance(conv, nn.Conv2d) and conv.groups == conv.in_channels == conv.out_channels
+                and conv.groups > 1 and conv.kernel_size == (3, 3) and conv.dilation == (1, 1)
+                and conv.stride in ((1, 1), (2, 2)) and conv.padding in ((0, 0), (1, 1))
+                and conv.padding_mode == 'zeros')
+
+    take_mean = ConvBiasAct.take_mean
+
+    def forward(self, x):
+        ow = (x.shape[3] + 2 * self.pad - 3) // self.stride + 1
+        if x.is_cuda and x.is_contiguous() and ow % 4 == 0 and \
+                x.dtype in (torch.float32, torch.float16, torch.bfloat16):
+            from . import kernels
+            if self.emit_mean:
+                y, mean = kernels.depthwise3x3_bias_act(x, self.weight, self.bias, self.act_name,
+                                                        self.stride, self.pad, want_mean=True)
+                self._mean = (y, mean)
+                return y
+            return kernels.depthwise3x3_bias_act(x, self.weight, self.bias, self.act_name,
+                                                 self.stride, self.pad)
+        y = F.conv2d(x, self.weight.to(x.dtype), self.bias.to(x.dtype), self.stride, self.pad,
+                     groups=self.weight.shape[0])
+        return y if self.act is None else self.act(y)
+
+
 def _block_plus_skip(block, x):
     """x + block(x) of an (Fused)MBConv; when the block ends in a folded convolution (ConvBiasAct)
     the skip connection rides on its epilogue instead of being a kernel of its own."""
@@ -316,7 +359,8 @@ def fold_batchnorm(backbone, fused_epilogue=False):
             act = m[2] if len(m) > 2 else None
             if fused_epilogue and (act is None or type(act) in _ACT_NAMES):
                 bias, conv.bias = conv.bias, None
-                m[0] = ConvBiasAct(conv, bias, act)
+                m[0] = (DepthwiseBiasAct if DepthwiseBiasAct.applies_to(conv) else ConvBiasAct)(
+                    conv, bias, act)
                 if act is not None:
                     m[2] = nn.Identity()
             else:
@@ -331,7 +375,7 @@ def fold_batchnorm(backbone, fused_epilogue=False):
             kids = list(seq)
             for prev, nxt in zip(kids, kids[1:]):
                 if isinstance(nxt, SqueezeExcite) and isinstance(prev, ConvBNAct) and \
-                        isinstance(prev[0], ConvBiasAct) and \
+                        isinstance(prev[0], (ConvBiasAct, DepthwiseBiasAct)) and \
                         all(isinstance(m, nn.Identity) for m in list(prev)[1:]):
                     prev[0].emit_mean = True
                     nxt.mean_from = (prev[0],)

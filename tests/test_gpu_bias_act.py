@@ -50,6 +50,31 @@ def test_bias_act_rowmean_vs_torch(shape, dtype, hip_lib):
     assert float((mean - want).abs().max()) <= 1e-5 * (1 + float(want.abs().max()))
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+@pytest.mark.parametrize('cfg', [(2, 960, 16, 16, 1, 1), (3, 256, 32, 32, 2, 1), (2, 96, 18, 18, 2, 0),
+                                 (5, 1536, 8, 8, 1, 1), (1, 7, 4, 8, 1, 1), (2, 5, 9, 9, 2, 0), (70, 3, 16, 16, 1, 1)])
+def test_depthwise3x3_bias_act_vs_torch(cfg, dtype, hip_lib):
+    """K11 vs F.conv2d(groups=C) + bias + SiLU and the mean of that: every (stride, pad) the backbones
+    use, planes of 2 .. 64 output vectors, plane counts that do not fill the last wave."""
+    from metrabs_amd import kernels
+    B, C, H, W, stride, pad = cfg
+    g = torch.Generator(device='cuda').manual_seed(sum(cfg))
+    x = torch.randn(B, C, H, W, device='cuda', generator=g).to(dtype)
+    w = torch.randn(C, 1, 3, 3, device='cuda', generator=g) * 0.4
+    b = torch.randn(C, device='cuda', generator=g)
+    want = F.silu(F.conv2d(x.float(), w, b, stride, pad, groups=C))
+    got, mean = kernels.depthwise3x3_bias_act(x, w, b, 'silu', stride, pad, want_mean=True)
+    assert got.shape == want.shape and got.dtype == dtype
+    tol = 3e-6 if dtype == torch.float32 else 2e-3
+    assert float(((got.float() - want).abs() / (1 + want.abs())).max()) <= tol
+    assert float((mean - got.float().mean((2, 3))).abs().max()) <= 1e-5 * (1 + float(want.abs().max()))
+    plain = kernels.depthwise3x3_bias_act(x, w, b, 'silu', stride, pad)
+    assert torch.equal(plain, got)
+    none = kernels.depthwise3x3_bias_act(x, w, b, None, stride, pad)
+    want_none = F.conv2d(x.float(), w, b, stride, pad, groups=C)
+    assert float(((none.float() - want_none).abs() / (1 + want_none.abs())).max()) <= tol
+
+
 def test_bias_act_rejects_what_it_cannot_vectorise(hip_lib):
     from metrabs_amd import kernels
     y = torch.zeros(2, 3, 3, 3, device='cuda')  # H*W = 9: a 16-byte vector would straddle channels
@@ -65,6 +90,7 @@ def test_folded_fused_backbone_is_the_same_function(name, res, hip_lib):
     torch.manual_seed(0)
     net = backbones.calibrate_batchnorm(backbones.build_backbone(name).cuda(), res, 'cuda', batch_size=4)
     fused = backbones.fold_batchnorm(net, fused_epilogue=True)
+    assert any(isinstance(m, backbones.DepthwiseBiasAct) for m in fused.modules()) == (name != 'resnet18')
     n_se = sum(isinstance(m, backbones.SqueezeExcite) for m in fused.modules())
     assert sum(bool(m.mean_from) for m in fused.modules() if isinstance(m, backbones.SqueezeExcite)) == n_se
     x = torch.rand(4, 3, res, res, device='cuda')
