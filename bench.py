@@ -104,7 +104,8 @@ def build_model(args, dev):
     # function up to rounding, --no-fold-bn keeps the separate BN kernels), and "+ bias, activation"
     # behind each folded convolution is one in-place HIP pass (K10, csrc/bias_act.hip) instead of
     # PyTorch-ROCm's two elementwise kernels, with the blocks' skip connection and the squeeze-excite
-    # mean riding on the same pass (11.7 -> 9.8 ms; --no-fused-epilogue).  (3) MIOpen
+    # mean riding on the same pass, and the depthwise 3x3 layers run with that epilogue as one HIP
+    # pass over the plane (K11, csrc/depthwise.hip) (11.7 -> 8.8 ms; --no-fused-epilogue).  (3) MIOpen
     # benchmark mode: 2 minutes of search on a fresh box for the same step time, off
     # (MTR_BENCH_MIOPEN_FIND=1).
     if os.environ.get('MTR_BENCH_MIOPEN_FIND', '0') == '1':
@@ -560,10 +561,13 @@ def main():
                    'global_batch': crops_per_step, 'parallelism': f'dp{world} (crops sharded, one '
                    f'all-gather of poses)' if world > 1 else 'single GPU',
                    'hip_graph': not args.no_graph,
-                   'backbone': 'PyTorch-ROCm (rocBLAS / MIOpen; depthwise layers on PyTorch\'s own '
-                               'kernel' + ('' if args.no_fold_bn else ', inference batch norm folded into '
-                               'the convolutions' + ('' if args.no_fused_epilogue else ', bias + activation '
-                               'behind them as one in-place HIP pass (K10)')) + ')'},
+                   'backbone': 'PyTorch-ROCm (dense convolutions on rocBLAS / MIOpen' + (
+                       '; depthwise layers on PyTorch\'s own kernel' if args.no_fold_bn else
+                       '; inference batch norm folded into the convolutions' + (
+                           '; depthwise layers on PyTorch\'s own kernel' if args.no_fused_epilogue else
+                           '; bias + activation (+ skip connection, + squeeze-excite mean) behind them as '
+                           'one in-place HIP pass (K10); depthwise 3x3 layers with that epilogue in one '
+                           'HIP pass (K11)')) + ')'},
         'roofline': roofline,
         'stage_us': kernels_us,
         'hand_written_kernels': per_kernel,

@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(
   const T* xp = x + p * (long long)H * W;
   T* yp = y + p * (long long)OH * OW;
   const int ow4 = OW >> 2, nvec = OH * ow4;
+  const bool vec_rows = STRIDE == 1 && pad == 1 && (W & 3) == 0;  // (wave-uniform)
   float sum = 0.0f;
   for (int v = sub; v < nvec; v += lpp) {
     const int oy = v / ow4, ox0 = (v - oy * ow4) << 2;
@@ -52,11 +53,23 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(
       const bool row_ok = iy >= 0 && iy < H;
       const T* row = xp + (row_ok ? iy : 0) * W;
       float in[NIN];
+      if (STRIDE == 1 && vec_rows) {
+        // stride 1, pad 1, W % 4 == 0: the four centre taps are one aligned vector, the two outer
+        // ones single elements (zero at the plane's edge)
+        struct alignas(4 * sizeof(T)) In4 { T v[4]; };
+        const In4 mid = *reinterpret_cast<const In4*>(row + ox0);
+        const T lft = row[ox0 > 0 ? ox0 - 1 : 0], rgt = row[ox0 + 4 < W ? ox0 + 4 : 0];
+        in[0] = (row_ok && ox0 > 0) ? to_f32(lft) : 0.0f;
 #pragma unroll
-      for (int j = 0; j < NIN; ++j) {
-        const int ix = ox0 * STRIDE - pad + j;
-        const bool ok = row_ok && ix >= 0 && ix < W;
-        in[j] = ok ? to_f32(row[ok ? ix : 0]) : 0.0f;
+        for (int j = 0; j < 4; ++j) in[1 + j] = row_ok ? to_f32(mid.v[j]) : 0.0f;
+        in[5] = (row_ok && ox0 + 4 < W) ? to_f32(rgt) : 0.0f;
+      } else {
+#pragma unroll
+        for (int j = 0; j < NIN; ++j) {
+          const int ix = ox0 * STRIDE - pad + j;
+          const bool ok = row_ok && ix >= 0 && ix < W;
+          in[j] = ok ? to_f32(row[ok ? ix : 0]) : 0.0f;
+        }
       }
 #pragma unroll
       for (int o = 0; o < 4; ++o)

@@ -196,8 +196,40 @@ def bench_bias_act():
     return out
 
 
+def bench_depthwise():
+    """K11: depthwise 3x3 + bias + SiLU (+ plane mean) in one pass (read x + write y = the
+    algorithmic bytes), beside PyTorch's depthwise kernel + the elementwise ops."""
+    import torch.nn.functional as F
+    out = []
+    g = torch.Generator(device='cuda').manual_seed(0)
+    for name, (B, C, H), stride, dt in [('B=64 960ch 16x16 s1 f32', (64, 960, 16), 1, torch.float32),
+                                        ('B=64 1536ch 8x8 s1 f32', (64, 1536, 8), 1, torch.float32),
+                                        ('B=64 256ch 32x32 s2 f32', (64, 256, 32), 2, torch.float32),
+                                        ('B=64 960ch 16x16 s1 f16', (64, 960, 16), 1, torch.float16)]:
+        x = torch.randn(B, C, H, H, device='cuda', generator=g).to(dt)
+        w = torch.randn(C, 1, 3, 3, device='cuda', generator=g) * 0.3
+        b = torch.randn(C, device='cuda', generator=g)
+        t = timeit(lambda: kernels.depthwise3x3_bias_act(x, w, b, 'silu', stride, 1, want_mean=True))
+        wd, bd = w.to(dt), b.to(dt)
+
+        def torch_path():
+            prev = torch.backends.cudnn.enabled
+            torch.backends.cudnn.enabled = False
+            try:
+                y = F.silu(F.conv2d(x, wd, bd, stride, 1, groups=C))
+            finally:
+                torch.backends.cudnn.enabled = prev
+            return y, y.mean((2, 3))
+        tt = timeit(torch_path)
+        oh = (H + 2 - 3) // stride + 1
+        nbytes = (x.numel() + B * C * oh * oh) * x.element_size()
+        out.append(dict(kernel='depthwise3x3', case=name, us=round(t * 1e6, 1), torch_ops_us=round(tt * 1e6, 1),
+                        GBps=round(nbytes / t / 1e9, 1), frac_hbm=round(nbytes / t / HBM, 3)))
+    return out
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['decode', 'head', 'warp', 'recon', 'detector', 'filter', 'bias_act']
+    which = sys.argv[1:] or ['decode', 'head', 'warp', 'recon', 'detector', 'filter', 'bias_act', 'depthwise']
     res = []
     if 'decode' in which:
         res += bench_decode()
@@ -213,5 +245,7 @@ if __name__ == '__main__':
         res += bench_filter()
     if 'bias_act' in which:
         res += bench_bias_act()
+    if 'depthwise' in which:
+        res += bench_depthwise()
     for r in res:
         print(json.dumps(r))
