@@ -169,14 +169,15 @@ def depth72_variant(args, dev, im_h, im_w, n_box):
                      '(every shipped configuration of the reference)')
 
 
-def unfolded_bn_variant(args, dev, im_h, im_w, n_box):
-    """`value` runs the backbone's inference copy with batch norm folded into the convolutions (the
-    same function up to rounding).  For transparency: the SAME step with the batch norms left as
-    separate kernels, reported beside `value`."""
+def backbone_variant(args, dev, im_h, im_w, n_box, fold_bn, fused_epilogue, note):
+    """`value` runs the backbone's inference copy with batch norm folded into the convolutions and
+    the K10 / K11 epilogue kernels (the same function up to rounding).  For transparency: the SAME
+    step with less of that, reported beside `value`."""
     import copy
     from metrabs_amd.pipeline import GraphedCropPipeline
     a = copy.copy(args)
-    a.no_fold_bn = True
+    a.no_fold_bn = not fold_bn
+    a.no_fused_epilogue = not fused_epilogue
     est, _ = build_model(a, dev)
     pipe = GraphedCropPipeline(est, args.frames, im_h, im_w, n_box, num_aug=args.num_aug,
                                use_graph=not args.no_graph)
@@ -192,9 +193,7 @@ def unfolded_bn_variant(args, dev, im_h, im_w, n_box):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / n * 1e3
     assert torch.isfinite(pipe.poses).all()
-    return dict(crops_per_s_per_gpu=n_box * args.num_aug / ms * 1e3, ms_per_step=ms, steps=n,
-                note='same step as `value` with the backbone\'s batch norms as separate kernels '
-                     '(--no-fold-bn)')
+    return dict(crops_per_s_per_gpu=n_box * args.num_aug / ms * 1e3, ms_per_step=ms, steps=n, note=note)
 
 
 def head_kernel_name(hw, n_crops, J, D, precision='f32', C=1280):
@@ -591,7 +590,15 @@ def main():
     if world == 1 and args.depth != 72 and not args.no_depth72:
         out['depth72'] = depth72_variant(args, dev, im_h, im_w, n_box)
         if not args.no_fold_bn:
-            out['bn_not_folded'] = unfolded_bn_variant(args, dev, im_h, im_w, n_box)
+            out['bn_not_folded'] = backbone_variant(
+                args, dev, im_h, im_w, n_box, False, False,
+                'same step as `value` with the backbone\'s batch norms as separate kernels and no '
+                'K10 / K11 (--no-fold-bn): every backbone kernel is PyTorch-ROCm\'s own')
+            if not args.no_fused_epilogue:
+                out['bn_folded_torch_ops'] = backbone_variant(
+                    args, dev, im_h, im_w, n_box, True, False,
+                    'same step as `value` with the batch norms folded but bias / activation / skip / '
+                    'mean and the depthwise layers left to PyTorch-ROCm\'s kernels (--no-fused-epilogue)')
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(est, pipe, args, cfg, args.cpu_seconds)
     else:
