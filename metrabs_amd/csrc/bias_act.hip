@@ -12,16 +12,6 @@
 
 namespace mtr {
 
-enum Act { kActNone = 0, kActRelu = 1, kActSilu = 2, kActHardswish = 3 };
-
-template <int ACT>
-__device__ __forceinline__ float activate(float x) {
-  if constexpr (ACT == kActRelu) return fmaxf(x, 0.0f);
-  if constexpr (ACT == kActSilu) return x / (1.0f + __expf(-x));  // at::silu: x / (1 + exp(-x))
-  if constexpr (ACT == kActHardswish) return x * fminf(fmaxf(x + 3.0f, 0.0f), 6.0f) * (1.0f / 6.0f);
-  return x;
-}
-
 template <typename T> struct Vec16 { static constexpr int n = 16 / sizeof(T); };
 
 template <typename T, int ACT, bool RES>

@@ -20,6 +20,18 @@ constexpr int kWave = 64;
     if (e_ != hipSuccess) return (int)e_;        \
   } while (0)
 
+// activations of the backbone epilogues (K10 bias_act.hip, K11 depthwise.hip); codes = the `act`
+// argument of their entry points
+enum Act { kActNone = 0, kActRelu = 1, kActSilu = 2, kActHardswish = 3 };
+
+template <int ACT>
+__device__ __forceinline__ float activate(float x) {
+  if constexpr (ACT == kActRelu) return fmaxf(x, 0.0f);
+  if constexpr (ACT == kActSilu) return x / (1.0f + __expf(-x));  // at::silu: x / (1 + exp(-x))
+  if constexpr (ACT == kActHardswish) return x * fminf(fmaxf(x + 3.0f, 0.0f), 6.0f) * (1.0f / 6.0f);
+  return x;
+}
+
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(__half v) { return __half2float(v); }
 __device__ __forceinline__ float to_f32(__hip_bfloat16 v) { return __bfloat162float(v); }

@@ -12,16 +12,6 @@
 
 namespace mtr {
 
-enum DwAct { kDwNone = 0, kDwRelu = 1, kDwSilu = 2, kDwHardswish = 3 };
-
-template <int ACT>
-__device__ __forceinline__ float dw_activate(float x) {
-  if constexpr (ACT == kDwRelu) return fmaxf(x, 0.0f);
-  if constexpr (ACT == kDwSilu) return x / (1.0f + __expf(-x));
-  if constexpr (ACT == kDwHardswish) return x * fminf(fmaxf(x + 3.0f, 0.0f), 6.0f) * (1.0f / 6.0f);
-  return x;
-}
-
 template <typename T, int ACT, int STRIDE>
 __global__ __launch_bounds__(256) void depthwise3x3_kernel(
     const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
@@ -79,7 +69,7 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(
     Out4 out;
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
-      const float r = dw_activate<ACT>(acc[o] + b);
+      const float r = activate<ACT>(acc[o] + b);
       if constexpr (sizeof(T) == 4) out.v[o] = r; else out.v[o] = T(r);
       sum += to_f32(out.v[o]);
     }
@@ -108,10 +98,10 @@ static int launch_depthwise(const void* x, const float* w, const float* bias, in
   hipLaunchKernelGGL((depthwise3x3_kernel<T, A, STRIDE>), grid, block, 0, stream, (const T*)x, w,  \
                      bias, (T*)y, row_mean, n_planes, C, H, W, OH, OW, pad, lpp, inv)
   switch (act) {
-    case kDwNone: MTR_DW_LAUNCH(kDwNone); break;
-    case kDwRelu: MTR_DW_LAUNCH(kDwRelu); break;
-    case kDwSilu: MTR_DW_LAUNCH(kDwSilu); break;
-    case kDwHardswish: MTR_DW_LAUNCH(kDwHardswish); break;
+    case kActNone: MTR_DW_LAUNCH(kActNone); break;
+    case kActRelu: MTR_DW_LAUNCH(kActRelu); break;
+    case kActSilu: MTR_DW_LAUNCH(kActSilu); break;
+    case kActHardswish: MTR_DW_LAUNCH(kActHardswish); break;
     default: return MTR_E_PARAM;
   }
 #undef MTR_DW_LAUNCH
