@@ -155,3 +155,23 @@ def test_fold_batchnorm_is_the_same_function():
     import pytest
     with pytest.raises(ValueError):
         backbones.fold_batchnorm(backbones.build_backbone('resnet18').train())
+
+
+def test_bench_cli_contract_and_kernel_naming(monkeypatch):
+    """bench.py: the driver's flags parse (--gpus N --steps K --warmup W, defaults N=1), and the
+    roofline entry names the GEMM kernel mtr_head_fused dispatches to for the shape and precision."""
+    import importlib
+    import sys
+    bench = importlib.import_module('bench')
+    monkeypatch.setattr(sys, 'argv', ['bench.py'])
+    a = bench.parse_args()
+    assert (a.gpus, a.precision, a.no_fold_bn, a.no_fused_epilogue) == (1, 'f32', False, False)
+    assert a.steps > 0 and a.warmup >= 0
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '8', '--steps', '7', '--warmup', '2'])
+    a = bench.parse_args()
+    assert (a.gpus, a.steps, a.warmup) == (8, 7, 2)
+    assert bench.head_kernel_name(64, 64, 17, 8) == 'head_fused32w8_kernel'          # config 2
+    assert bench.head_kernel_name(64, 1024, 17, 8) == 'head_fused32_kernel'          # large launch
+    assert bench.head_kernel_name(144, 32, 17, 8) == 'head_fused_kernel'             # 12x12 maps, f32
+    assert bench.head_kernel_name(64, 64, 17, 8, 'f16', 1280) == 'head_fused16_kernel'
+    assert bench.head_kernel_name(64, 64, 17, 8, 'f16', 1283) == 'head_fused32w8_kernel'  # C % 8 != 0
