@@ -122,6 +122,7 @@ def build_model(args, dev):
     model = model.to(dev)
     calibrate_batchnorm(model.backbone, args.res, dev)
     model = model.eval()
+    reference_backbone = model.backbone  # the unfolded network: what the CPU baseline runs
     if not args.no_fold_bn:
         model.backbone = fold_batchnorm(model.backbone, fused_epilogue=not args.no_fused_epilogue)
     # (channels_last measured slower than NCHW on this MIOpen for both dtypes: 19.1 vs 14.0 ms in f32,
@@ -131,6 +132,7 @@ def build_model(args, dev):
         model = model.to(memory_format=torch.channels_last)
     skel = {'': dict(indices=list(range(args.joints)), names=names, edges=edges)}
     est = Pose3dEstimator(model, skel, None)
+    object.__setattr__(est, 'reference_backbone', reference_backbone)  # (not a submodule of est)
     if autocast is not None:
         est.crop_dtype = autocast
     if channels_last:
@@ -311,7 +313,9 @@ def cpu_baseline(est, pipe, args, cfg, seconds):
     from oracle import cpu_ref
     ocfg = cpu_ref.HeadConfig(proc_side=cfg.proc_side)
     model = est.crop_model
-    backbone = copy.deepcopy(model.backbone).to('cpu', torch.float32).eval()
+    # the network as the reference runs it (batch norms as their own ops, torch kernels only), not
+    # the folded inference copy the GPU step uses
+    backbone = copy.deepcopy(getattr(est, 'reference_backbone', model.backbone)).to('cpu', torch.float32).eval()
     w = model.heatmap_heads.conv_final.weight.detach().cpu().float()
     b = model.heatmap_heads.conv_final.bias.detach().cpu().float()
     J = model.joint_info.n_joints
