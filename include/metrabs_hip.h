@@ -107,6 +107,13 @@ int mtr_softargmax_decode(const void* logits, int dtype, int layout, int B, int 
  * C % 64 == 0, and for NCHW also H*W % 8 == 0 and H*W >= 64: the tiles are staged by
  * global_load_lds instead of through registers -- same arithmetic, same results.)
  */
+/* host-only, no GPU work: the row order of the f32 row-tile kernel.  conv_final's J*(1+D) channels
+ * are re-ordered into n_tiles 16-row MFMA tiles so that the rows of one softmax (a joint's 2D row;
+ * a joint's D depth slices) never straddle a workgroup's block of tiles; atoms of tiles_per_atom
+ * consecutive tiles are the unit a block is made of.  row_channel (may be NULL; `capacity` ints,
+ * >= n_tiles*16) receives for every packed row the conv_final channel it holds, -1 for padding. */
+int mtr_head_row_plan(int J, int D, int32_t* n_tiles, int32_t* tiles_per_atom, int32_t* row_channel,
+                      int capacity);
 size_t mtr_head_packed_bytes(int C, int J, int D, int feat_dtype);
 int mtr_head_pack_weights(const float* weight /*[J*(1+D), C] f32*/, const float* bias /*[J*(1+D)]*/,
                           int C, int J, int D, int feat_dtype, void* packed, mtr_stream_t stream);

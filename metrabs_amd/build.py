@@ -17,6 +17,10 @@ LIB_PATH = os.path.join(CSRC, 'libmetrabs_hip.so')
 BUILD_DIR = os.path.join(CSRC, 'build')
 ARCH = 'gfx950'
 FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function']
+# per-source extras.  head_rt.hip: MFMA accumulators in VGPRs (gfx950's register file is unified):
+# its f32 chains are carried into f64 on the VALU every stage, and from AGPRs every element costs a
+# v_accvgpr_read first.
+EXTRA_FLAGS = {'head_rt.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1']}
 
 
 def sources():
@@ -32,7 +36,7 @@ def _hipcc():
 
 def _digest(path):
     h = hashlib.sha256()
-    h.update(' '.join(FLAGS).encode())
+    h.update(' '.join(FLAGS + EXTRA_FLAGS.get(os.path.basename(path), [])).encode())
     for dep in [path] + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith('.h')] \
             + [os.path.join(os.path.dirname(os.path.dirname(CSRC)), 'include', 'metrabs_hip.h')]:
         with open(dep, 'rb') as f:
@@ -47,7 +51,7 @@ def _compile(src, force):
     digest = _digest(path)
     if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == digest:
         return obj, False
-    cmd = [_hipcc(), *FLAGS, '-c', path, '-o', obj]
+    cmd = [_hipcc(), *FLAGS, *EXTRA_FLAGS.get(src, []), '-c', path, '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'hipcc failed for {src}:\n{r.stdout}\n{r.stderr}')

@@ -45,6 +45,7 @@
 #include <utility>
 
 #include "common.h"
+#include "head_rt.h"
 
 namespace mtr {
 
@@ -1825,15 +1826,60 @@ static int check_head_dims(int C, int J, int D) {
   return MTR_OK;
 }
 
-}  // namespace mtr
-
-extern "C" size_t mtr_head_packed_bytes(int C, int J, int D, int feat_dtype) {
-  if (mtr::check_head_dims(C, J, D)) return 0;
-  const mtr::HeadGeom g = mtr::head_geom(C, J, D);
-  size_t n = (2 * (size_t)g.n_groups * g.c_pad * mtr::kRows + (size_t)g.n_groups * mtr::kRows) * sizeof(float);
+// bytes of the joint-group sections (64-row cores and the 16-bit kernel); 0 when 1 + D > 64
+static size_t group_sections_bytes(int C, int J, int D, int feat_dtype) {
+  if (check_head_dims(C, J, D)) return 0;
+  const HeadGeom g = head_geom(C, J, D);
+  size_t n = (2 * (size_t)g.n_groups * g.c_pad * kRows + (size_t)g.n_groups * kRows) * sizeof(float);
   // 16-bit feature dtypes: + the weights rounded to that dtype, for the f16 / bf16 MFMA kernel
   if (feat_dtype == MTR_F16 || feat_dtype == MTR_BF16)
-    n += (size_t)g.n_groups * ((C + mtr::kKH - 1) / mtr::kKH) * mtr::kRows * mtr::kKH * 2;
+    n += (size_t)g.n_groups * ((C + kKH - 1) / kKH) * kRows * kKH * 2;
+  return n;
+}
+
+// MTR_HEAD_F32=groups: f32 features through the 64-row joint-group cores instead of the row-tile
+// core (A/B measurements)
+static bool force_group_cores() {
+  static const bool v = [] {
+    const char* e = getenv("MTR_HEAD_F32");
+    return e && e[0] == 'g';
+  }();
+  return v;
+}
+static int rt_tiles_hint() {
+  static const int v = [] {
+    const char* e = getenv("MTR_HEAD_RTG");
+    return e && e[0] >= '1' && e[0] <= '5' ? e[0] - '0' : 0;
+  }();
+  return v;
+}
+
+}  // namespace mtr
+
+// host-only: the row plan of the row-tile core (which conv_final channel each packed row holds)
+extern "C" int mtr_head_row_plan(int J, int D, int32_t* n_tiles, int32_t* tiles_per_atom,
+                                 int32_t* row_channel, int capacity) {
+  if (!n_tiles || !tiles_per_atom) return MTR_E_NULL;
+  if (!mtr::rt_shape_ok(1, J, D)) return MTR_E_SHAPE;
+  const mtr::RtGeom g = mtr::rt_geom(J, D);
+  *n_tiles = g.n_tiles;
+  *tiles_per_atom = g.a;
+  if (row_channel) {
+    if (capacity < g.n_tiles * 16) return MTR_E_WORKSPACE;
+    for (int r = 0; r < g.n_tiles * 16; ++r) {
+      const mtr::RtRow rr = mtr::rt_row(g, J, D, r);
+      row_channel[r] = rr.kind == 0 ? -1 : (rr.kind == 1 ? rr.joint : J + rr.d * J + rr.joint);
+    }
+  }
+  return MTR_OK;
+}
+
+// packed = [joint-group sections (f32 16x16 layout, bias, f32 32x32 layout, 16-bit weights)]
+//          [row-tile section (f32 features only)]
+extern "C" size_t mtr_head_packed_bytes(int C, int J, int D, int feat_dtype) {
+  if (C <= 0 || J <= 0 || D <= 0) return 0;
+  size_t n = mtr::group_sections_bytes(C, J, D, feat_dtype);
+  if (feat_dtype == MTR_F32) n += mtr::rt_section_bytes(C, J, D);
   return n;
 }
 
@@ -1841,9 +1887,14 @@ extern "C" int mtr_head_pack_weights(const float* weight, const float* bias, int
                                      int feat_dtype, void* packed, mtr_stream_t stream) {
   if (!weight || !bias || !packed) return MTR_E_NULL;
   if (feat_dtype != MTR_F32 && feat_dtype != MTR_F16 && feat_dtype != MTR_BF16) return MTR_E_DTYPE;
-  int rc = mtr::check_head_dims(C, J, D);
-  if (rc) return rc;
+  if (mtr_head_packed_bytes(C, J, D, feat_dtype) == 0) return MTR_E_SHAPE;
   if ((uintptr_t)packed % 16) return MTR_E_ALIGN;
+  const size_t group_bytes = mtr::group_sections_bytes(C, J, D, feat_dtype);
+  if (feat_dtype == MTR_F32 && mtr::rt_shape_ok(C, J, D)) {
+    int rc = mtr::rt_pack(weight, bias, C, J, D, (char*)packed + group_bytes, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  if (group_bytes == 0) return MTR_OK;
   const mtr::HeadGeom g = mtr::head_geom(C, J, D);
   const size_t total = 2 * (size_t)g.n_groups * g.c_pad * mtr::kRows + (size_t)g.n_groups * mtr::kRows;
   size_t blocks = (total + 255) / 256;
@@ -1873,18 +1924,27 @@ extern "C" int mtr_head_fused(const void* features, int feat_dtype, int layout, 
                               int W, const void* packed, int J, int D, const mtr_head_params* p,
                               float* coords2d, float* coords3d_rel, mtr_stream_t stream) {
   if (!features || !packed || !p || !coords2d || !coords3d_rel) return MTR_E_NULL;
-  if (B < 0 || H <= 0 || W <= 0) return MTR_E_SHAPE;
-  int rc = mtr::check_head_dims(C, J, D);
-  if (rc) return rc;
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || J <= 0 || D <= 0) return MTR_E_SHAPE;
   if (layout != MTR_NCHW && layout != MTR_NHWC) return MTR_E_DTYPE;
-  if ((H * W) % 4 != 0 || H * W > 256) return MTR_E_SHAPE;  // wider maps: GEMM + mtr_softargmax_decode
+  if (feat_dtype != MTR_F32 && feat_dtype != MTR_F16 && feat_dtype != MTR_BF16) return MTR_E_DTYPE;
+  if ((H * W) % 4 != 0) return MTR_E_SHAPE;                  // 16-byte position vectors
   if (layout == MTR_NHWC && C % 4 != 0) return MTR_E_SHAPE;  // 16-byte channel vectors
   if (p->proc_side <= 0 || p->stride_test <= 0) return MTR_E_PARAM;
   if (((uintptr_t)features % 16) || ((uintptr_t)packed % 16)) return MTR_E_ALIGN;
-  if (B == 0) return MTR_OK;
-  const mtr::HeadGeom g = mtr::head_geom(C, J, D);
   const mtr::HeadScale hs = mtr::make_head_scale(*p);
   hipStream_t s = (hipStream_t)stream;
+  const size_t group_bytes = mtr::group_sections_bytes(C, J, D, feat_dtype);
+  // f32 features: the row-tile core (any map size, D <= 80)
+  if (feat_dtype == MTR_F32 && mtr::rt_shape_ok(C, J, D) &&
+      !(mtr::force_group_cores() && group_bytes && H * W <= 256)) {
+    if (B == 0) return MTR_OK;
+    return mtr::rt_launch((const float*)features, layout, (const char*)packed + group_bytes, B, C, H,
+                          W, J, D, hs, coords2d, coords3d_rel, mtr::rt_tiles_hint(), s);
+  }
+  // joint-group kernels: a joint's 1 + D rows inside one 64-row tile, maps of <= 256 positions
+  if (group_bytes == 0 || H * W > 256) return MTR_E_SHAPE;  // -> 1x1-conv GEMM + mtr_softargmax_decode
+  if (B == 0) return MTR_OK;
+  const mtr::HeadGeom g = mtr::head_geom(C, J, D);
   const float* pk = (const float*)packed;
   switch (feat_dtype) {
     case MTR_F32: return mtr::dispatch_head_layout<float>(layout, features, pk, B, C, H, W, J, D, g, hs, coords2d, coords3d_rel, s);

@@ -202,10 +202,17 @@ def warp_crops(pyramid, warp_params, res, antialias=1, out_dtype=torch.float32,
     return out
 
 
-def head_fused_supported(C, J, D, H, W, channels_last=False):
-    """Shapes the fused projection+decode kernel covers; everything else goes through a library
-    GEMM for the 1x1 conv followed by the HIP decode kernel (same results, logits via HBM)."""
-    return (H * W) % 4 == 0 and H * W <= 256 and (1 + D) <= 64 and (not channels_last or C % 4 == 0)
+def head_fused_supported(C, J, D, H, W, channels_last=False, dtype=torch.float32):
+    """Shapes the fused projection+decode kernels cover; everything else goes through a library
+    GEMM for the 1x1 conv followed by the HIP decode kernel (same results, logits via HBM).
+    f32 features run the row-tile kernel: any map size, up to 80 depth bins.  f16 / bf16 features
+    run the joint-group MFMA kernel: a joint's 1 + D rows inside a 64-row tile, maps of <= 256
+    positions."""
+    if (H * W) % 4 != 0 or (channels_last and C % 4 != 0):
+        return False
+    if dtype == torch.float32:
+        return D <= 80
+    return H * W <= 256 and (1 + D) <= 64
 
 
 def _is_channels_last(t):

@@ -54,7 +54,7 @@ class MetrabsHeads(torch.nn.Module):
             self.conv_final(inp[:1])  # materialise the lazy conv exactly like the reference would
         _, c_in, h, w = inp.shape
         use_fused = bool(self.fused) and kernels.head_fused_supported(
-            c_in, self.n_points, self.config.depth, h, w, kernels._is_channels_last(inp))
+            c_in, self.n_points, self.config.depth, h, w, kernels._is_channels_last(inp), inp.dtype)
         if use_fused and self.fused == 'auto':
             use_fused = self._auto_pick(inp)
         if use_fused:

@@ -61,7 +61,11 @@ def test_fused_head_vs_golden(name, hip_lib):
 @pytest.mark.parametrize('shape', [(3, 40, 17, 8, 8, 8), (2, 24, 5, 8, 4, 4), (2, 33, 17, 8, 12, 12),
                                    (1, 64, 3, 8, 16, 16), (2, 96, 30, 4, 10, 10), (9, 32, 1, 8, 8, 8),
                                    (2, 100, 7, 8, 2, 8), (3, 70, 17, 8, 6, 6), (2, 33, 9, 8, 8, 12),
-                                   (2, 65, 17, 8, 8, 16), (10, 31, 17, 8, 8, 8)])
+                                   (2, 65, 17, 8, 8, 16), (10, 31, 17, 8, 8, 8),
+                                   (2, 48, 17, 8, 24, 24), (1, 40, 5, 8, 20, 36), (2, 64, 3, 20, 8, 8),
+                                   (2, 36, 4, 40, 6, 6), (3, 96, 17, 72, 8, 8), (2, 32, 122, 8, 12, 12),
+                                   (2, 64, 9, 5, 8, 8), (2, 40, 6, 16, 10, 10), (1, 32, 2, 80, 4, 4),
+                                   (2, 64, 3, 72, 12, 12), (1, 1280, 17, 8, 8, 8)])
 def test_fused_head_odd_shapes_vs_oracle(shape, hip_lib):
     """C not a multiple of the 32-channel stage (odd and even stage counts), J not filling the joint
     groups, every tile count of both GEMM cores (16x16: HW <= 32 and > 128; 32x32: 2, 3 and 4
@@ -79,6 +83,12 @@ def test_fused_head_odd_shapes_vs_oracle(shape, hip_lib):
     print(f'[parity] fused head odd {shape}: max {float((c3d - o3d).abs().max()):.2e} mm')
     assert float((c3d - o3d).abs().max()) <= 2e-3 and cpu_ref.mpjpe(c3d, o3d) <= 1e-3
     assert float((c2d - o2d).abs().max()) <= 4e-4
+    if C % 4 == 0:  # NHWC memory: same MFMA k-order, so the same bits
+        from metrabs_amd import kernels
+        packed = kernels.head_pack_weights(w.cuda(), b.cuda(), J, D)
+        l2d, l3d = kernels.head_fused(feat.cuda().contiguous(memory_format=torch.channels_last),
+                                      packed, C, J, mcfg(cfg))
+        assert torch.equal(l3d.cpu(), c3d) and torch.equal(l2d.cpu(), c2d)
 
 
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
@@ -173,15 +183,16 @@ def test_auto_head_path_is_timed_once_and_equivalent(hip_lib):
     assert float((a3d - f3d).abs().max()) <= 2e-3 and float((a2d - f2d).abs().max()) <= 4e-4
 
 
-def test_depth72_goes_through_gemm_plus_decode(hip_lib):
-    """72 depth bins (the metric string of BASELINE.json): a joint's 73 rows do not fit the fused
-    head's 64-row tile, so MetrabsHeads runs the 1x1 conv as a library GEMM and the HIP decode
-    kernel on the logits -- still no CPU, and the oracle's bounds hold."""
+def test_depth72_runs_in_the_fused_kernel(hip_lib):
+    """72 depth bins (the metric string of BASELINE.json): a joint's 72 depth slices are one softmax
+    unit of the row-tile kernel (an atom of 5 tiles, head_rt.h), so f32 features stay on the fused
+    path; the library GEMM + decode pair gives the same coordinates to rounding."""
     from metrabs_amd import kernels
     from metrabs_amd.config import MetrabsConfig
     from metrabs_amd.models.metrabs import MetrabsHeads
     cfg = MetrabsConfig(depth=72)
-    assert not kernels.head_fused_supported(256, 17, 72, 8, 8)
+    assert kernels.head_fused_supported(256, 17, 72, 8, 8)
+    assert not kernels.head_fused_supported(256, 17, 72, 8, 8, dtype=torch.float16)
     heads = MetrabsHeads(17, cfg, in_channels=256, fused=True).cuda()
     g = cases.gen(72)
     w, b = cases.default_conv_init(17 * 73, 256, g)
@@ -191,10 +202,13 @@ def test_depth72_goes_through_gemm_plus_decode(hip_lib):
     feat = torch.randn(5, 256, 8, 8, generator=g)
     with torch.inference_mode():
         c2d, c3d = heads(feat.cuda())
+        heads.fused = False
+        u2d, u3d = heads(feat.cuda())
         o2d, o3d = cpu_ref.heads_forward(feat, w * 3, b * 3, 17, cpu_ref.HeadConfig(depth=72))
     assert c3d.shape == (5, 17, 3)
     assert float((c3d.cpu() - o3d).abs().max()) <= 2e-3 and cpu_ref.mpjpe(c3d.cpu(), o3d) <= 1e-3
     assert float((c2d.cpu() - o2d).abs().max()) <= 4e-4
+    assert float((u3d.cpu() - o3d).abs().max()) <= 2e-3 and float((u2d.cpu() - o2d).abs().max()) <= 4e-4
 
 
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
@@ -260,9 +274,13 @@ def test_fused_head_channels_last_features(shape, dtype, hip_lib):
     assert float((c3d.cpu() - o3d).abs().max()) <= 2e-3
 
 
-@pytest.mark.parametrize('env', [{'MTR_HEAD_CORE': '16'}, {'MTR_HEAD_W8': '0'}, {'MTR_HEAD_W8': '1'},
-                                 {'MTR_HEAD_H16': '0'}, {'MTR_HEAD_DMA': '0'}],
-                         ids=['core16', 'w4', 'w8', 'f32core_on_16bit', 'nhwc16_through_registers'])
+@pytest.mark.parametrize('env', [{'MTR_HEAD_F32': 'groups', 'MTR_HEAD_CORE': '16'},
+                                 {'MTR_HEAD_F32': 'groups', 'MTR_HEAD_W8': '0'},
+                                 {'MTR_HEAD_F32': 'groups', 'MTR_HEAD_W8': '1'},
+                                 {'MTR_HEAD_H16': '0'}, {'MTR_HEAD_DMA': '0'},
+                                 {'MTR_HEAD_RTG': '1'}, {'MTR_HEAD_RTG': '2'}, {'MTR_HEAD_RTG': '5'}],
+                         ids=['core16', 'w4', 'w8', 'f32core_on_16bit', 'nhwc16_through_registers',
+                              'rowtile_1', 'rowtile_2', 'rowtile_5'])
 def test_every_gemm_variant_on_all_shapes_subprocess(env, hip_lib):
     """Three GEMM kernels sit behind mtr_head_fused: the 16x16x4 core, the 4-wave 32x32x2 kernel and
     its 8-wave K-split variant for small launches.  The dispatch picks by map size and launch size;
@@ -271,7 +289,8 @@ def test_every_gemm_variant_on_all_shapes_subprocess(env, hip_lib):
     import os
     import subprocess
     import sys
-    if any(os.environ.get(k) for k in ('MTR_HEAD_CORE', 'MTR_HEAD_W8', 'MTR_HEAD_H16', 'MTR_HEAD_DMA')):
+    if any(os.environ.get(k) for k in ('MTR_HEAD_CORE', 'MTR_HEAD_W8', 'MTR_HEAD_H16', 'MTR_HEAD_DMA',
+                                       'MTR_HEAD_F32', 'MTR_HEAD_RTG')):
         pytest.skip('already inside a forced-variant run')
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-m', 'gpu',
                         '-k', 'golden or odd_shapes or 16bit or channels_last or full_size'],
