@@ -32,7 +32,22 @@ namespace mtr {
 
 using v4f = __attribute__((ext_vector_type(4))) float;
 
-constexpr int kRtNbuf = 4;        // LDS ring: 3 stages in flight behind the one being consumed
+// developer-only timing ablations (tools/experiments/ablate_rt.py); 0 in the product:
+// 1 = no decode epilogue, 2 = no MFMA, 4 = no copies inside the K loop, 8 = no f64 carry (one f32
+// chain per tile over all of K), 16 = no fragment reads
+#ifndef MTR_RT_ABLATE
+#define MTR_RT_ABLATE 0
+#endif
+#ifndef MTR_RT_NBUF
+#define MTR_RT_NBUF 0       // 0: by block size (rt_nbuf)
+#endif
+
+// LDS ring: NBUF - 1 stages in flight behind the one being consumed.  Blocks of <= 3 tiles (the
+// small-launch configuration: one workgroup per CU, nothing else to hide the first HBM misses) keep
+// 3 stages in flight; 4- and 5-tile blocks run with one stage in flight and two workgroups per CU
+// (the other workgroup covers the latency; measured equal to the deep ring at every launch size,
+// tools/experiments/ablate_rt.py) so that 5 tiles' accumulators and their LDS fit twice.
+__host__ __device__ constexpr int rt_nbuf(int rtmax) { return MTR_RT_NBUF ? MTR_RT_NBUF : (rtmax <= 3 ? 4 : 2); }
 constexpr int kRtLP = 68;         // logits row pitch in LDS (floats)
 constexpr int kRtChunkNCHW = 1088;  // 4 channel rows of 64 positions + 64 B: the two channel groups
                                     // a 32-lane ds_read_b32 group touches land 16 banks apart
@@ -41,8 +56,9 @@ __host__ __device__ constexpr int rt_stage_bytes(int rt, bool nhwc) {
   return rt * 2048 + (nhwc ? 8192 : 8 * kRtChunkNCHW);
 }
 __host__ __device__ constexpr int rt_lds_bytes(int rtmax, bool nhwc) {
-  // ring + logits [R][68] + per row: max, unit max, bias (f32), label (i32), 3 f64 sums
-  return kRtNbuf * rt_stage_bytes(rtmax, nhwc) + rtmax * 16 * (kRtLP * 4 + 16 + 24);
+  // ring + logits [R][68] + per row: max, unit max, bias (f32), label (i32), 3 f64 sums, and the
+  // unit's running (max, 4 sums) across column blocks (5 f64)
+  return rt_nbuf(rtmax) * rt_stage_bytes(rtmax, nhwc) + rtmax * 16 * (kRtLP * 4 + 16 + 24 + 40);
 }
 
 __global__ void head_rt_pack_kernel(const float* __restrict__ w, const float* __restrict__ bias, int C,
@@ -99,20 +115,30 @@ struct RtArgs {
   int B, C, H, W, J, D;
   int n_tiles, rtg, n_blocks, n_stages;
   HeadScale hs;
+  AxisInv inv;           // 1 / (W - 1), 1 / (H - 1), 1 / (D - 1)
   float* c2d;
   float* c3d;
 };
 
+constexpr int kRtCarry = 8;  // stages (of 32 channels) summed in f32 before the sum goes into f64
+
 template <int RT>
 struct RtRegs {
-  double acc[RT][4];
-  v4f part[2][2][RT];  // [stage parity][16-channel chain of the stage][tile]
-  v4f ya[RT], yb;      // fragments of the previous stage's second chain (consumed one barrier late)
+  double acc[RT][4];   // f64 totals
+  v4f run[RT];         // f32 sum of the finished chains of up to kRtCarry stages
+  v4f part[2][RT];     // the 32-channel MFMA chain of a stage, by stage parity
+  v4f ya[RT], yb;      // fragments of the previous stage's second half (consumed one barrier late)
 };
 
 template <int RT, bool NHWC>
 __device__ __forceinline__ void rt_read_frags(const char* buf, int a_addr, int b_addr, v4f (&fa)[RT],
                                               v4f& fb) {
+  if (MTR_RT_ABLATE & 16) {
+#pragma unroll
+    for (int t = 0; t < RT; ++t) fa[t] = v4f{(float)a_addr, 1.f, 2.f, (float)t};
+    fb = v4f{(float)b_addr, 1.f, 2.f, 3.f};
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < RT; ++t) fa[t] = *reinterpret_cast<const v4f*>(buf + t * 2048 + a_addr);
   if constexpr (NHWC) {
@@ -123,23 +149,44 @@ __device__ __forceinline__ void rt_read_frags(const char* buf, int a_addr, int b
   }
 }
 
-// One MFMA slot: slot n of a 16-channel chain group is tile n % RT, k-step n / RT (tile-major inside
-// a k-step, so consecutive MFMAs never share an accumulator).
+// One MFMA slot: slot n of a half stage is tile n % RT, k-step n / RT (tile-major inside a k-step,
+// so consecutive MFMAs never share an accumulator).  A stage's chain starts from zero in the first
+// k-step of its first half.
 template <int RT>
-__device__ __forceinline__ void rt_mfma_slot(v4f (&chain)[RT], const v4f (&fa)[RT], const v4f& fb, int n) {
+__device__ __forceinline__ void rt_mfma_slot(v4f (&chain)[RT], const v4f (&fa)[RT], const v4f& fb, int n,
+                                             bool first_half) {
   const int t = n % RT, k = n / RT;
-  chain[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[t][k], fb[k], k == 0 ? v4f{0.f, 0.f, 0.f, 0.f} : chain[t],
-                                                  0, 0, 0);
+  if (MTR_RT_ABLATE & 2) {
+    chain[t][0] += fa[t][k] * fb[k];
+    return;
+  }
+  chain[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+      fa[t][k], fb[k], (first_half && k == 0 && !(MTR_RT_ABLATE & 8)) ? v4f{0.f, 0.f, 0.f, 0.f} : chain[t],
+      0, 0, 0);
 }
-// carry element e of a finished stage: its two chains added in f32, then into f64
+// element pair e2 (two adjacent registers of tile e2 / 2) of a finished chain into the f32 running sum
 template <int RT>
-__device__ __forceinline__ void rt_carry(double (&acc)[RT][4], const v4f (&done)[2][RT], int e) {
-  acc[e >> 2][e & 3] += (double)(done[0][e >> 2][e & 3] + done[1][e >> 2][e & 3]);
+__device__ __forceinline__ void rt_run_add(v4f (&run)[RT], const v4f (&done)[RT], int e2) {
+  if (MTR_RT_ABLATE & 8) return;
+  const int t = e2 >> 1, r = (e2 & 1) * 2;
+  run[t][r] += done[t][r];
+  run[t][r + 1] += done[t][r + 1];
+}
+// the running sums into f64, and restart them
+template <int RT>
+__device__ __forceinline__ void rt_flush(double (&acc)[RT][4], v4f (&run)[RT]) {
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[t][r] += (double)run[t][r];
+    run[t] = v4f{0.f, 0.f, 0.f, 0.f};
+  }
 }
 
 template <int RT, int RTMAX, bool NHWC>
 __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, int t0) {
   constexpr int STAGE = rt_stage_bytes(RT, NHWC);
+  constexpr int kRtNbuf = rt_nbuf(RTMAX);
   constexpr int JOBS = 2 * RT + 8;       // 1 KiB copies per stage: 2 per weight tile, 8 of features
   constexpr int JPW = (JOBS + 3) / 4;    // per wave (upper bound)
   constexpr int R = RT * 16;
@@ -149,6 +196,7 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
   float* bias_s = unitmax + RTMAX * 16;
   int* info_s = reinterpret_cast<int*>(bias_s + RTMAX * 16);
   double* rowsum = reinterpret_cast<double*>(info_s + RTMAX * 16);  // [R][3]
+  double* runstat = rowsum + RTMAX * 16 * 3;                        // [R][5], maps of > 64 positions
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -177,57 +225,67 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
     b_q1 = b_off + 4 * kRtChunkNCHW;
   }
 
-  // running (max, sums) of the unit that starts at row tid, across column blocks
-  double run_s = 0, run_x = 0, run_y = 0, run_z = 0;
-  float run_m = -INFINITY;
-
   const int n_cb = (HW + 63) >> 6;
   for (int cb = 0; cb < n_cb; ++cb) {
-    // ---- this wave's copies: job j = wid + 4 i (0 .. 2RT-1: weight tiles, then 8 feature chunks)
-    const char* gptr[JPW];
-    unsigned gstride[JPW], voff[JPW], voff_tail[JPW], ldso[JPW];
+    // ---- this wave's copies: job j = wid + 4 i (0 .. 2RT-1: weight tiles, then 8 feature chunks).
+    // Every wave issues JPW copies per stage so that one counted s_waitcnt serves all of them;
+    // a wave whose last index falls behind the list repeats its previous copy (same bytes to the
+    // same place, served by the L1 it just filled).
+    const char* gbase[JPW];
+    unsigned gstride[JPW], voff[JPW], ldso[JPW];
 #pragma unroll
     for (int i = 0; i < JPW; ++i) {
-      const int j = min(wid + 4 * i, JOBS - 1);
+      const int j = wid + 4 * i < JOBS ? wid + 4 * i : wid + 4 * (i - 1);
       if (j < 2 * RT) {
-        gptr[i] = a.wt + (size_t)t0 * 2048 + j * 1024;
+        gbase[i] = a.wt + (size_t)t0 * 2048 + j * 1024;
         gstride[i] = (unsigned)a.n_tiles * 2048u;
-        voff[i] = voff_tail[i] = lane * 16;
+        voff[i] = lane * 16;
         ldso[i] = j * 1024;
       } else {
         const int jb = j - 2 * RT;
-        gptr[i] = fcrop;
+        gbase[i] = fcrop;
         if constexpr (NHWC) {
           const int pos = jb * 8 + (lane >> 3), slot = (lane & 7) ^ ((pos >> 1) & 7);
           const int P = cb * 64 + pos;
-          const unsigned prow = (unsigned)(P < HW ? P : 0) * (unsigned)a.C * 4u;
           gstride[i] = 128;
-          voff[i] = prow + slot * 16;
-          voff_tail[i] = prow + (c0_last + slot * 4 < a.C ? slot * 16 : 0);
+          voff[i] = (unsigned)(P < HW ? P : 0) * (unsigned)a.C * 4u + slot * 16;
           ldso[i] = RT * 2048 + jb * 1024;
         } else {
           const int ch = jb * 4 + (lane >> 4);
           const int p = cb * 64 + (lane & 15) * 4;
-          const unsigned pbytes = (unsigned)(p < HW ? p : 0) * 4u;
           gstride[i] = 32u * (unsigned)HW * 4u;
-          voff[i] = (unsigned)ch * (unsigned)HW * 4u + pbytes;
-          voff_tail[i] = (unsigned)(c0_last + ch < a.C ? ch : 0) * (unsigned)HW * 4u + pbytes;
+          voff[i] = (unsigned)ch * (unsigned)HW * 4u + (unsigned)(p < HW ? p : 0) * 4u;
           ldso[i] = RT * 2048 + jb * kRtChunkNCHW;
         }
       }
+      gbase[i] = uniform_ptr(gbase[i]);
     }
-    // (waves whose last job index falls behind the list issue one copy fewer; their vmcnt differs)
-    const bool short_wave = wid + 4 * (JPW - 1) >= JOBS;
-    auto issue_job = [&](int i, int stage) {
-      const unsigned buf = lds0 + (unsigned)(stage & (kRtNbuf - 1)) * STAGE;
-      const bool tail = c_tail && stage == n_stages - 1;
-      if (i == JPW - 1 && short_wave) return;
-      rt_dma16(uniform_ptr(gptr[i]), tail ? voff_tail[i] : voff[i], buf + ldso[i]);
-      gptr[i] += gstride[i];
+    // copy i of the next stage into ring slot `slot` (stages are issued in order: the per-lane
+    // offset walks along K; the last stage of a C that is not a multiple of 32 redirects the lanes
+    // whose channels do not exist to ones that do -- their products meet zero weights)
+    int issued = 0;
+    auto issue_job = [&](int i, int slot) {
+      rt_dma16(gbase[i], voff[i], lds0 + (unsigned)slot * STAGE + ldso[i]);
+      voff[i] += gstride[i];
     };
-    auto issue = [&](int stage) {
+    auto redirect_tail = [&]() {  // (rare path: recomputed here rather than held in registers)
 #pragma unroll
-      for (int i = 0; i < JPW; ++i) issue_job(i, stage);
+      for (int i = 0; i < JPW; ++i) {
+        const int j = wid + 4 * i < JOBS ? wid + 4 * i : wid + 4 * (i - 1);
+        if (j < 2 * RT) continue;
+        const int jb = j - 2 * RT;
+        if constexpr (NHWC) {
+          const int pos = jb * 8 + (lane >> 3), slot = (lane & 7) ^ ((pos >> 1) & 7);
+          if (c0_last + slot * 4 >= a.C) voff[i] -= (unsigned)(slot * 16);  // -> channel slot 0
+        } else {
+          const int ch = jb * 4 + (lane >> 4);
+          if (c0_last + ch >= a.C) voff[i] -= (unsigned)ch * (unsigned)HW * 4u;  // -> channel row 0
+        }
+      }
+    };
+    auto stage_issued = [&]() {
+      ++issued;
+      if (c_tail && issued == n_stages - 1) redirect_tail();
     };
 
     RtRegs<RT> rg;
@@ -235,106 +293,148 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
     for (int t = 0; t < RT; ++t) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) rg.acc[t][r] = 0.0;
-#pragma unroll
-      for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) rg.part[p][q][t] = v4f{0.f, 0.f, 0.f, 0.f};
-      rg.ya[t] = v4f{0.f, 0.f, 0.f, 0.f};
+      rg.part[0][t] = rg.part[1][t] = rg.run[t] = rg.ya[t] = v4f{0.f, 0.f, 0.f, 0.f};
     }
     rg.yb = v4f{0.f, 0.f, 0.f, 0.f};
 
     // prologue: stages 0 .. NBUF-2 in flight
+    if (c_tail && n_stages == 1) redirect_tail();
 #pragma unroll
     for (int p = 0; p < kRtNbuf - 1; ++p)
-      if (p < n_stages) issue(p);
+      if (p < n_stages) {
+#pragma unroll
+        for (int i = 0; i < JPW; ++i) issue_job(i, p);
+        stage_issued();
+      }
 
-    // Iteration of stage s with parity P = s & 1 (a literal: the partial sets are registers):
+    // Iteration of stage s with parity P = s & 1 and ring slot BUF = s % NBUF (literals: the chains
+    // are registers, the LDS addresses immediates):
     //   wait for this wave's copies of stage s (those of s+1 .. s+NBUF-2 stay in flight), barrier
-    //   (all copies of s visible; everyone finished reading the buffer of s-1); read the first
-    //   chain's fragments of s; SECOND chain of s-1 from the fragments read before the barrier
-    //   (covers the LDS latency), with the copies of stage s+NBUF-1 into the buffer of s-1 and the
-    //   second half of stage s-2's carry in the MFMAs' shadow; read the second chain's fragments;
-    //   first chain of s with the first half of stage s-1's carry.
-    // Every MFMA is followed by at most one carry element (3 VALU) or one copy, and a scheduling
-    // fence: a single wave per SIMD issues in order, so work placed between two MFMAs runs in the
-    // first one's 32-cycle shadow, while a block of VALU behind a block of MFMAs does not.
-#define RT_ITER(S, P)                                                                             \
+    //   (all copies of s visible; everyone finished reading the slot of s-1); read the first
+    //   half's fragments of s; SECOND half of stage s-1's chain from the fragments read before the
+    //   barrier (covers the LDS latency), with the copies of stage s+NBUF-1 into the slot of s-1
+    //   in the MFMAs' shadow; read the second half's fragments; first half of stage s's chain with
+    //   the finished chain of s-1 added to the f32 running sums underneath.  Every kRtCarry stages
+    //   the running sums go into f64.
+    // The wave issues in order: whatever sits between two MFMAs runs in the first one's 32-cycle
+    // shadow (about 5 instructions), a longer run of scalar or vector work idles the matrix pipe --
+    // so the loop is unrolled over the ring (no index arithmetic), MORE is a literal in the main
+    // loop (no branches around the copies), and an MFMA is followed by at most one copy or one
+    // packed add, pinned by a scheduling fence.
+#define RT_ITER(S, P, BUF, MORE)                                                                  \
   {                                                                                               \
     const int s_ = (S);                                                                           \
-    const bool more = s_ + kRtNbuf - 1 < n_stages;                                                \
-    if (more) {                                                                                   \
-      if (short_wave) rt_wait_vmcnt<(kRtNbuf - 2) * (JPW - 1)>();                                 \
-      else rt_wait_vmcnt<(kRtNbuf - 2) * JPW>();                                                  \
-    } else {                                                                                      \
-      rt_wait_vmcnt<0>();                                                                         \
-    }                                                                                             \
+    const bool more = (MORE);                                                                     \
+    if (more) rt_wait_vmcnt<(kRtNbuf - 2) * JPW>(); else rt_wait_vmcnt<0>();                      \
     __syncthreads();                                                                              \
-    const char* buf = smem + (s_ & (kRtNbuf - 1)) * STAGE;                                        \
+    const char* buf = smem + (BUF) * STAGE;                                                       \
     v4f xa[RT], xb;                                                                               \
     rt_read_frags<RT, NHWC>(buf, a_off, b_off, xa, xb);                                           \
     __builtin_amdgcn_sched_barrier(0);                                                            \
     _Pragma("unroll") for (int n = 0; n < 4 * RT; ++n) {                                          \
-      rt_mfma_slot<RT>(rg.part[(P) ^ 1][1], rg.ya, rg.yb, n);                                     \
-      if (n < JPW) {                                                                              \
-        if (more) issue_job(n, s_ + kRtNbuf - 1);                                                 \
-      } else if ((n - JPW) % 2 == 0 && (n - JPW) / 2 < 2 * RT) {                                  \
-        rt_carry<RT>(rg.acc, rg.part[P], 2 * RT + (n - JPW) / 2);                                 \
-      }                                                                                           \
+      rt_mfma_slot<RT>(rg.part[(P) ^ 1], rg.ya, rg.yb, n, false);                                 \
+      if (n < JPW && more && !(MTR_RT_ABLATE & 4)) issue_job(n, ((BUF) + kRtNbuf - 1) % kRtNbuf); \
+      if (n == JPW && more) stage_issued();                                                       \
       __builtin_amdgcn_sched_barrier(0);                                                          \
     }                                                                                             \
-    /* (carry elements that found no slot above: JPW + 4RT - 1 > 4RT only for RT = 1) */          \
-    _Pragma("unroll") for (int e = (4 * RT - JPW + 1) / 2; e < 2 * RT; ++e)                       \
-        rt_carry<RT>(rg.acc, rg.part[P], 2 * RT + e);                                             \
     rt_read_frags<RT, NHWC>(buf, a_off ^ 64, b_q1, rg.ya, rg.yb);                                 \
     __builtin_amdgcn_sched_barrier(0);                                                            \
     _Pragma("unroll") for (int n = 0; n < 4 * RT; ++n) {                                          \
-      rt_mfma_slot<RT>(rg.part[P][0], xa, xb, n);                                                 \
-      if (n % 2 == 1) rt_carry<RT>(rg.acc, rg.part[(P) ^ 1], n / 2);                              \
+      rt_mfma_slot<RT>(rg.part[P], xa, xb, n, true);                                              \
+      if (n % 2 == 1) rt_run_add<RT>(rg.run, rg.part[(P) ^ 1], n / 2);                            \
       __builtin_amdgcn_sched_barrier(0);                                                          \
     }                                                                                             \
   }
-    for (int s = 0; s < n_stages; s += 2) {
-      RT_ITER(s, 0)
-      if (s + 1 < n_stages) RT_ITER(s + 1, 1)
+    static_assert(kRtNbuf == 4 || kRtNbuf == 2, "the main loop is unrolled over a ring of 4 or 2 slots");
+    static_assert(JPW < 4 * RT, "the copies fit the first half stage");
+    int s = 0;
+    // main loop: every iteration issues a stage.  run holds the stages up to s - 2 at the top of
+    // iteration s; it is emptied into f64 every kRtCarry stages (any point between two iterations
+    // is a valid one).
+    if constexpr (kRtNbuf == 4) {
+      for (; s + kRtNbuf - 1 + 3 < n_stages; s += 4) {
+        RT_ITER(s, 0, 0, true)
+        if (s >= kRtCarry && s % kRtCarry == 0) rt_flush<RT>(rg.acc, rg.run);
+        RT_ITER(s + 1, 1, 1, true)
+        RT_ITER(s + 2, 0, 2, true)
+        RT_ITER(s + 3, 1, 3, true)
+      }
+    } else {
+      for (; s + kRtNbuf - 1 + 1 < n_stages; s += 2) {
+        RT_ITER(s, 0, 0, true)
+        if (s >= kRtCarry && s % kRtCarry == 0) rt_flush<RT>(rg.acc, rg.run);
+        RT_ITER(s + 1, 1, 1, true)
+      }
+    }
+    // remainder (the last issuing iterations + the NBUF - 1 that only consume)
+    for (; s < n_stages; ++s) {
+      if (s >= 2 && (s - 1) % kRtCarry == 0) rt_flush<RT>(rg.acc, rg.run);
+      const bool more_rt = s + kRtNbuf - 1 < n_stages;
+      if constexpr (kRtNbuf == 4) {
+        switch (s & 3) {
+          case 0: RT_ITER(s, 0, 0, more_rt) break;
+          case 1: RT_ITER(s, 1, 1, more_rt) break;
+          case 2: RT_ITER(s, 0, 2, more_rt) break;
+          default: RT_ITER(s, 1, 3, more_rt) break;
+        }
+      } else {
+        if (s & 1) RT_ITER(s, 1, 1, more_rt) else RT_ITER(s, 0, 0, more_rt)
+      }
     }
 #undef RT_ITER
-    // drain: second chain of the last stage (parity PL) + what is left of the carries
+    // drain: second half of the last stage's chain (parity PL), then the sums
 #define RT_DRAIN(PL)                                                                              \
   {                                                                                               \
     _Pragma("unroll") for (int n = 0; n < 4 * RT; ++n) {                                          \
-      rt_mfma_slot<RT>(rg.part[PL][1], rg.ya, rg.yb, n);                                          \
-      if (n % 2 == 1) rt_carry<RT>(rg.acc, rg.part[(PL) ^ 1], 2 * RT + n / 2);                    \
+      rt_mfma_slot<RT>(rg.part[PL], rg.ya, rg.yb, n, false);                                      \
       __builtin_amdgcn_sched_barrier(0);                                                          \
     }                                                                                             \
-    _Pragma("unroll") for (int e = 0; e < 4 * RT; ++e) rt_carry<RT>(rg.acc, rg.part[PL], e);      \
+    _Pragma("unroll") for (int e2 = 0; e2 < 2 * RT; ++e2) rt_run_add<RT>(rg.run, rg.part[PL], e2); \
+    if (MTR_RT_ABLATE & 8) {                                                                      \
+      _Pragma("unroll") for (int t = 0; t < RT; ++t) rg.run[t] = rg.part[0][t] + rg.part[1][t];   \
+    }                                                                                             \
+    rt_flush<RT>(rg.acc, rg.run);                                                                 \
   }
     if ((n_stages - 1) & 1) RT_DRAIN(1) else RT_DRAIN(0)
 #undef RT_DRAIN
 
     // ---- logits (+bias) -> LDS.  C/D layout of 16x16x4: col = l & 15, row = 4 (l >> 4) + reg
+    {
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));  // (as below: addresses computed here, not held through the K loop)
+      const int col = wid * 16 + (lane_e & 15), row0 = (lane_e >> 4) * 4;
 #pragma unroll
-    for (int t = 0; t < RT; ++t)
+      for (int t = 0; t < RT; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = t * 16 + g4 * 4 + r;
-        Ls[row * kRtLP + wid * 16 + i16] = (float)(rg.acc[t][r] + (double)bias_s[row]);
-      }
+        for (int r = 0; r < 4; ++r) {
+          const int row = t * 16 + row0 + r;
+          Ls[row * kRtLP + col] = (float)(rg.acc[t][r] + (double)bias_s[row]);
+        }
+    }
     __syncthreads();
 
+    if (MTR_RT_ABLATE & 1) {  // no decode: one store per workgroup keeps the GEMM alive
+      if (tid == 0 && cb == n_cb - 1) a.c2d[(size_t)crop * a.J * 2] = Ls[0];
+      continue;
+    }
     // ---- decode, a 16-lane group per row (RT rounds of 16 rows)
-    const int grp = tid >> 4;
-    const int pbase = cb * 64 + i16 * 4;  // this lane's 4 positions
+    // (the addresses below do not depend on the column block; the empty asm keeps the compiler from
+    //  computing them once in front of the K loop and holding them in registers through it)
+    int tid_d = tid;
+    asm volatile("" : "+v"(tid_d));
+    const int grp = tid_d >> 4, l16 = tid_d & 15;
+    const int pbase = cb * 64 + l16 * 4;  // this lane's 4 positions
     v4f x[RT];
 #pragma unroll
     for (int k = 0; k < RT; ++k) {
       const int row = k * 16 + grp;
-      x[k] = *reinterpret_cast<const v4f*>(Ls + row * kRtLP + i16 * 4);
+      x[k] = *reinterpret_cast<const v4f*>(Ls + row * kRtLP + l16 * 4);
       float m = -INFINITY;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if (pbase + q < HW) m = fmaxf(m, x[k][q]);
       m = group_max<16>(m);
-      if (i16 == 0) rowmax[row] = m;
+      if (l16 == 0) rowmax[row] = m;
     }
     __syncthreads();
 #pragma unroll
@@ -344,7 +444,7 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
       const int kind = inf & 3, d = (inf >> 2) & 0x3fff;
       const int first = kind == 2 ? row - d : row, n = kind == 2 ? a.D : 1;
       float m = -INFINITY;
-      for (int kk = i16; kk < n; kk += 16) m = fmaxf(m, rowmax[first + kk]);
+      for (int kk = l16; kk < n; kk += 16) m = fmaxf(m, rowmax[first + kk]);
       m = group_max<16>(m);
       double s = 0, sx = 0, sy = 0;
 #pragma unroll
@@ -361,7 +461,7 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
       s = group_sum<16>(s);
       sx = group_sum<16>(sx);
       sy = group_sum<16>(sy);
-      if (i16 == 0) {
+      if (l16 == 0) {
         rowsum[row * 3 + 0] = s;
         rowsum[row * 3 + 1] = sx;
         rowsum[row * 3 + 2] = sy;
@@ -369,40 +469,51 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
       }
     }
     __syncthreads();
-    if (tid < R) {
-      const unsigned inf = (unsigned)info_s[tid];
+    int tid_c = tid;
+    asm volatile("" : "+v"(tid_c));
+    if (tid_c < R) {
+      const unsigned inf = (unsigned)info_s[tid_c];
       const int kind = inf & 3, d = (inf >> 2) & 0x3fff, j = (int)(inf >> 16);
       if (kind == 1 || (kind == 2 && d == 0)) {
         const int n = kind == 2 ? a.D : 1;
         double S = 0, SX = 0, SY = 0, SZ = 0;
         for (int k = 0; k < n; ++k) {
-          const double s = rowsum[(tid + k) * 3];
+          const double s = rowsum[(tid_c + k) * 3];
           S += s;
-          SX += rowsum[(tid + k) * 3 + 1];
-          SY += rowsum[(tid + k) * 3 + 2];
+          SX += rowsum[(tid_c + k) * 3 + 1];
+          SY += rowsum[(tid_c + k) * 3 + 2];
           SZ += s * (double)k;
         }
-        const float mu = unitmax[tid];
-        if (cb == 0) {
-          run_m = mu; run_s = S; run_x = SX; run_y = SY; run_z = SZ;
-        } else {
-          const float mn = fmaxf(run_m, mu);
-          const double f1 = exp_neg64((double)run_m - (double)mn), f2 = exp_neg64((double)mu - (double)mn);
-          run_s = run_s * f1 + S * f2;
-          run_x = run_x * f1 + SX * f2;
-          run_y = run_y * f1 + SY * f2;
-          run_z = run_z * f1 + SZ * f2;
+        // (max, sums) of the unit across column blocks live in LDS, not in registers that would
+        // stay allocated through the K loop
+        double run_m = (double)unitmax[tid_c], run_s = S, run_x = SX, run_y = SY, run_z = SZ;
+        if (cb > 0) {
+          const double pm = runstat[tid_c * 5];
+          const double mn = fmax(pm, run_m);
+          const double f1 = exp_neg64(pm - mn), f2 = exp_neg64(run_m - mn);
+          run_s = runstat[tid_c * 5 + 1] * f1 + S * f2;
+          run_x = runstat[tid_c * 5 + 2] * f1 + SX * f2;
+          run_y = runstat[tid_c * 5 + 3] * f1 + SY * f2;
+          run_z = runstat[tid_c * 5 + 4] * f1 + SZ * f2;
           run_m = mn;
+        }
+        if (cb < n_cb - 1) {
+          runstat[tid_c * 5] = run_m;
+          runstat[tid_c * 5 + 1] = run_s;
+          runstat[tid_c * 5 + 2] = run_x;
+          runstat[tid_c * 5 + 3] = run_y;
+          runstat[tid_c * 5 + 4] = run_z;
         }
         if (cb == n_cb - 1) {
           const size_t o = (size_t)crop * a.J + j;
+          const double inv_s = fast_rcp64(run_s);
           if (kind == 1) {
-            a.c2d[o * 2 + 0] = heatmap_to_px(axis_coord(run_x, run_s, a.W), a.hs);
-            a.c2d[o * 2 + 1] = heatmap_to_px(axis_coord(run_y, run_s, a.H), a.hs);
+            a.c2d[o * 2 + 0] = heatmap_to_px(axis_coord_rcp(run_x, inv_s, a.inv.w), a.hs);
+            a.c2d[o * 2 + 1] = heatmap_to_px(axis_coord_rcp(run_y, inv_s, a.inv.h), a.hs);
           } else {
-            a.c3d[o * 3 + 0] = heatmap_to_mm_xy(axis_coord(run_x, run_s, a.W), a.hs);
-            a.c3d[o * 3 + 1] = heatmap_to_mm_xy(axis_coord(run_y, run_s, a.H), a.hs);
-            a.c3d[o * 3 + 2] = heatmap_to_mm_z(axis_coord(run_z, run_s, a.D), a.hs);
+            a.c3d[o * 3 + 0] = heatmap_to_mm_xy(axis_coord_rcp(run_x, inv_s, a.inv.w), a.hs);
+            a.c3d[o * 3 + 1] = heatmap_to_mm_xy(axis_coord_rcp(run_y, inv_s, a.inv.h), a.hs);
+            a.c3d[o * 3 + 2] = heatmap_to_mm_z(axis_coord_rcp(run_z, inv_s, a.inv.d), a.hs);
           }
         }
       }
@@ -413,7 +524,7 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
 }
 
 template <int RTMAX, bool NHWC>
-__global__ __launch_bounds__(256) void head_rt_kernel(RtArgs a) {
+__global__ __launch_bounds__(256, RTMAX <= 3 ? 1 : 2) void head_rt_kernel(RtArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // XCD-aware remap (block id b runs on XCD b % 8): the blocks of a crop share an XCD, so its
   // features come from HBM once and are re-read from that XCD's L2
@@ -476,15 +587,28 @@ int rt_launch(const float* feat, int layout, const void* section, int B, int C, 
   a.B = B; a.C = C; a.H = H; a.W = W; a.J = J; a.D = D;
   a.n_tiles = g.n_tiles;
   if (g.a == 1 && rtg_hint == 0) {
-    // one-tile atoms: 3 tiles per workgroup while that still gives every CU a workgroup; narrower
-    // blocks for launches that would otherwise leave CUs idle (few crops, large maps)
+    // one-tile atoms: how many tiles a workgroup takes.
     const long long crops8 = (long long)((B + 7) / 8) * 8;
-    rtg_hint = 3;
-    while (rtg_hint > 1 && crops8 * ((g.n_tiles + rtg_hint - 1) / rtg_hint) < 256) --rtg_hint;
+    if (crops8 * ((g.n_tiles + 2) / 3) <= 512) {
+      // small launches (one round of at most 2 workgroups per CU): 3 tiles per workgroup, fewer
+      // when that would leave CUs without one (few crops, large maps)
+      rtg_hint = 3;
+      while (rtg_hint > 1 && crops8 * ((g.n_tiles + rtg_hint - 1) / rtg_hint) < 256) --rtg_hint;
+    } else {
+      // several rounds of workgroups: equal blocks first (a crop's 10 tiles as 5 + 5 measured 270 us
+      // at B = 1024 against 315 us as 3 + 3 + 3 + 1), then the larger block (fewer barriers, LDS
+      // reads and feature copies per MFMA)
+      int best_pad = 1 << 30;
+      for (int cand = 5; cand >= 2; --cand) {
+        const int pad = (g.n_tiles + cand - 1) / cand * cand - g.n_tiles;
+        if (pad < best_pad) { best_pad = pad; rtg_hint = cand; }
+      }
+    }
   }
   a.rtg = rt_block_tiles(g, rtg_hint);
   a.n_blocks = (g.n_tiles + a.rtg - 1) / a.rtg;
   a.hs = hs;
+  a.inv = make_axis_inv(W, H, D);
   a.c2d = coords2d;
   a.c3d = coords3d_rel;
   const bool nhwc = layout == MTR_NHWC;

@@ -1,0 +1,104 @@
+"""Timing ablations of head_rt_kernel (developer tool, not part of the library).
+
+    python tools/experiments/ablate_rt.py build      # here (hipcc cross-compiles): one .so per variant
+    python tools/experiments/ablate_rt.py run        # on the GPU box: times every variant
+
+MTR_RT_ABLATE bits (metrabs_amd/csrc/head_rt.hip): 1 = no decode epilogue, 2 = no MFMA, 4 = no copies
+inside the K loop, 8 = no f64 carry, 16 = no fragment reads.  MTR_RT_NBUF = ring depth.
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+OUT = os.path.join(ROOT, 'tools', 'experiments', '_build')
+VARIANTS = {'full': [], 'nodecode': ['-DMTR_RT_ABLATE=1'], 'nomfma': ['-DMTR_RT_ABLATE=2'],
+            'nodma': ['-DMTR_RT_ABLATE=4'], 'nocarry': ['-DMTR_RT_ABLATE=8'],
+            'nodma_nocarry': ['-DMTR_RT_ABLATE=12'], 'nofrag': ['-DMTR_RT_ABLATE=16'],
+            'mfma_only': ['-DMTR_RT_ABLATE=29'], 'nbuf2': ['-DMTR_RT_NBUF=2'], 'nbuf4': ['-DMTR_RT_NBUF=4']}
+if os.environ.get('RT_VARIANTS'):
+    VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ['RT_VARIANTS'].split(',')}
+
+
+def build():
+    os.makedirs(OUT, exist_ok=True)
+    csrc = os.path.join(ROOT, 'metrabs_amd', 'csrc')
+    procs = []
+    for name, flags in VARIANTS.items():
+        # only the two head sources + capi: the other kernels are not called here
+        srcs = [os.path.join(csrc, f) for f in ('head_rt.hip', 'head_fused.hip', 'capi.hip', 'decode.hip')]
+        cmd = ['hipcc', '-O3', '-std=c++17', '-fPIC', '-shared', '--offload-arch=gfx950',
+               '-mllvm', '-amdgpu-mfma-vgpr-form=1', *flags, '-I', os.path.join(ROOT, 'include'), *srcs,
+               '-o', os.path.join(OUT, f'libmtr_rt_{name}.so')]
+        procs.append((name, subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)))
+    for name, p in procs:
+        _, err = p.communicate()
+        if p.returncode:
+            sys.exit(name + '\n' + err.decode())
+
+
+def run_one(name):
+    sys.path.insert(0, ROOT)
+    import ctypes
+    import torch
+    from metrabs_amd import _lib
+    lib = ctypes.CDLL(os.path.join(OUT, f'libmtr_rt_{name}.so'))
+    hp = _lib.HeadParams(256, 32, 1, 0, 2200.0)
+    g = torch.Generator(device='cuda').manual_seed(0)
+    res = {'variant': name}
+    lib.mtr_head_packed_bytes.restype = ctypes.c_size_t
+    for label, B, H, nhwc in [('B64', 64, 8, False), ('B64 nhwc', 64, 8, True), ('B1024', 1024, 8, False),
+                              ('B32 12x12', 32, 12, False), ('B256 12x12', 256, 12, False)]:
+        C, J, D = 1280, 17, 8
+        feat = torch.randn(B, C, H, H, device='cuda', generator=g)
+        if nhwc:
+            feat = feat.contiguous(memory_format=torch.channels_last)
+        w = torch.randn(153, C, device='cuda', generator=g) * 0.03
+        bias = torch.zeros(153, device='cuda')
+        nb = lib.mtr_head_packed_bytes(C, J, D, 0)
+        packed = torch.empty(nb // 4, device='cuda')
+        vp = ctypes.c_void_p
+        s = vp(torch.cuda.current_stream().cuda_stream)
+        assert lib.mtr_head_pack_weights(vp(w.data_ptr()), vp(bias.data_ptr()), C, J, D, 0,
+                                         vp(packed.data_ptr()), s) == 0
+        c2 = torch.empty(B, J, 2, device='cuda'); c3 = torch.empty(B, J, 3, device='cuda')
+
+        def call(stream):
+            rc = lib.mtr_head_fused(vp(feat.data_ptr()), 0, 1 if nhwc else 0, B, C, H, H,
+                                    vp(packed.data_ptr()), J, D, ctypes.byref(hp), vp(c2.data_ptr()),
+                                    vp(c3.data_ptr()), vp(stream))
+            assert rc == 0, rc
+        for _ in range(5):
+            call(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        n = 20
+        st = torch.cuda.Stream()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(st):
+            call(st.cuda_stream)
+            st.synchronize()
+            with torch.cuda.graph(graph, stream=st):
+                for _ in range(n):
+                    call(st.cuda_stream)
+        graph.replay()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        a.record()
+        for _ in range(reps):
+            graph.replay()
+        b.record()
+        torch.cuda.synchronize()
+        res[label] = round(a.elapsed_time(b) / (n * reps) * 1e3, 1)
+    print(json.dumps(res), flush=True)
+
+
+if __name__ == '__main__':
+    if sys.argv[1] == 'build':
+        build()
+    elif sys.argv[1] == 'run':
+        for name in VARIANTS:
+            subprocess.run([sys.executable, os.path.abspath(__file__), 'one', name], check=False)
+    else:
+        run_one(sys.argv[2])

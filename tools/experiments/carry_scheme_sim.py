@@ -47,6 +47,25 @@ def combine(ch, group, mode):
     return tot
 
 
+def combine_running(ch, per_stage, stages, pair_first):
+    """Two-level f32: the chains of a stage (per_stage of them) are added pairwise first (pair_first)
+    or one by one into an f32 running sum that spans `stages` stages; that sum is carried into f64."""
+    n = ch.shape[0]
+    tot = np.zeros(ch.shape[1:], np.float64)
+    run = np.zeros(ch.shape[1:], np.float32)
+    for i0 in range(0, n, per_stage):
+        blk = ch[i0:i0 + per_stage]
+        if pair_first:
+            run = run + tree32(blk)
+        else:
+            for c in blk:
+                run = run + c
+        if ((i0 // per_stage) + 1) % stages == 0:
+            tot = tot + run.astype(np.float64)
+            run = np.zeros_like(run)
+    return tot + run.astype(np.float64)
+
+
 def main():
     for name in ('s256_c1280', 's256_c1280_peaked', 'l384_c1280'):
         feat, w, b, J, cfg = cases.headconv_case(name)
@@ -66,11 +85,16 @@ def main():
             ch = chains(Wn, F, L)
             for group, mode in ((1, 'f64'), (2, 'f64'), (4, 'f64'), (8, 'f64'), (len(ch), 'f64'), (1, 'f32'), (8, 'f32')):
                 rows.append((f'chain {L}, tree of {group} in f32, then {mode}', combine(ch, group, mode).astype(np.float64)))
+        ch16, ch32 = chains(Wn, F, 16), chains(Wn, F, 32)
+        for stages in (2, 4, 8, 40):
+            rows.append((f'chain 16 x2 paired, f32 running over {stages} stages, then f64', combine_running(ch16, 2, stages, True)))
+            rows.append((f'chain 16 x2 one by one, f32 running over {stages} stages, then f64', combine_running(ch16, 2, stages, False)))
+            rows.append((f'chain 32, f32 running over {stages} stages, then f64', combine_running(ch32, 1, stages, False)))
         for label, lg in rows:
             lg = torch.from_numpy(lg) + b.double()[None, :, None]
             lg = lg.float().double()  # one rounding to f32, as the kernel writes logits
             c2d, c3d = cpu_ref.heads_from_logits(lg.reshape(B, -1, H, Wd), J, cfg)
-            print(f'   {label:45s} max {float((c3d - t3d).abs().max()):.2e}  mean {float((c3d - t3d).abs().mean()):.2e} mm')
+            print(f'   {label:68s} max {float((c3d - t3d).abs().max()):.2e}  mean {float((c3d - t3d).abs().mean()):.2e} mm')
 
 
 if __name__ == '__main__':
