@@ -56,7 +56,7 @@ def reconstruct(coords2d, coords3d_rel, K, cfg):
     c = _cfg(cfg)
     rc = lib().orc_reconstruct(_p(c2d), _p(rel), _p(K), B, J, ctypes.byref(c), _p(out))
     if rc != 0:
-        raise NotImplementedError('weak perspective is not restated in C (unpinned branch)')
+        raise RuntimeError(f'orc_reconstruct returned {rc}')
     return out
 
 

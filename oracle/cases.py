@@ -165,6 +165,53 @@ def recon_case(name):
 
 # ------------------------------------------------------------------------------------ images / warp
 
+def weak_perspective_kat():
+    """Hand-derived known answer for reconstruct_absolute(weak_perspective=True) (ptu3d.py:9-49,
+    ptu.py:4-34) at the default config (FOV bounds [24, 232] px, mix 0.5), K = [[500,0,128],
+    [0,500,128],[0,0,1]].
+
+    Crop 0: four in-FOV joints on a rectangle + one joint outside the FOV (masked out of every
+    mean).  Normalised 2D: x in {-0.04, 0.08}, y in {-0.12, 0.04} -> mean (0.02, -0.04), deviations
+    (+-0.06, +-0.08): stdev2d = sqrt(4 (0.0036 + 0.0064) / 4) = 0.1.  Relative 3D: x in {-120, 180},
+    y in {-220, 180} -> mean (30, -20), deviations (+-150, +-200): stdev3d = sqrt(4 (22500 + 40000) / 4)
+    = 250; z mean 50.  Reference depth = 250 / 0.1 = 2500, ref = (0.02, -0.04, 1) 2500 - (30, -20, 50)
+    = (20, -80, 2450).  In-FOV joints: 0.5 (rel + ref) + 0.5 (x_n, y_n, 1) (rel_z + 2450); the masked
+    joint: rel + ref.
+    Crop 1: no joint in the FOV -> masked means are nan_to_num(0 / 0) = 0, both stdevs
+    max(sqrt(0 + 1e-10), 1e-5) -> depth 1, ref = (0, 0, 1); every joint: rel + (0, 0, 1).
+    -> (coords2d [2,5,2], coords3d_rel [2,5,3], K [2,3,3], expected poses3d [2,5,3])"""
+    K = torch.tensor([[500.0, 0, 128], [0, 500.0, 128], [0, 0, 1]]).repeat(2, 1, 1)
+    c2d = torch.tensor([[[108.0, 68.0], [168.0, 68.0], [108.0, 148.0], [168.0, 148.0], [10.0, 128.0]],
+                        [[5.0, 5.0], [250.0, 5.0], [5.0, 250.0], [250.0, 250.0], [128.0, 240.0]]])
+    rel = torch.tensor([[[-120.0, -220.0, -100.0], [180.0, -220.0, 50.0], [-120.0, 180.0, 150.0],
+                         [180.0, 180.0, 100.0], [999.0, -999.0, 999.0]],
+                        [[10.0, 20.0, 30.0], [-40.0, 50.0, -60.0], [70.0, -80.0, 90.0],
+                         [0.0, 0.0, 0.0], [-1.0, 2.0, -3.0]]])
+    want = torch.tensor([[[-97.0, -291.0, 2350.0], [200.0, -300.0, 2500.0], [-102.0, 102.0, 2600.0],
+                          [202.0, 101.0, 2550.0], [1019.0, -1079.0, 3449.0]],
+                         [[10.0, 20.0, 31.0], [-40.0, 50.0, -59.0], [70.0, -80.0, 91.0],
+                          [0.0, 0.0, 1.0], [-1.0, 2.0, -2.0]]])
+    return c2d, rel, K, want
+
+
+def box_consistency_kat():
+    """Hand-derived known answers for is_pose_consistent_with_box (TF plausibility_check.py:66-84;
+    PyTorch port :86-107): the pose's 2D bounding box is (10,10)-(50,90).
+    -> (pose2d [6,3,2], boxes [6,5], expected bool [6])"""
+    pose = torch.tensor([[10.0, 90.0], [50.0, 10.0], [30.0, 40.0]])
+    rows = [
+        ([0.0, 0.0, 60.0, 100.0, 1.0], True),     # intersection 40 x 80 = 3200 > 3000
+        ([0.0, 0.0, 100.0, 100.0, 1.0], False),   # 3200 < 5000
+        ([200.0, 0.0, 50.0, 50.0, 1.0], False),   # disjoint: relu -> 0
+        ([10.0, 10.0, 80.0, 80.0, 0.3], False),   # 40 x 80 = 3200 > 3200 is false (strict >)
+        ([30.0, 50.0, 40.0, 80.0, 0.9], False),   # x 30..50, y 50..90: 800 < 1600
+        ([20.0, 20.0, 20.0, 60.0, 0.9], True),    # box inside the pose box: 1200 > 600
+    ]
+    boxes = torch.tensor([r[0] for r in rows])
+    want = torch.tensor([r[1] for r in rows])
+    return pose[None].repeat(len(rows), 1, 1), boxes, want
+
+
 def synth_images(n, h, w, seed):
     """uint8 [n,3,h,w]: even images are uniform noise (worst case for bilinear rounding), odd
     images are smooth gradients + mild noise."""

@@ -8,6 +8,7 @@ The reference modules are imported unmodified through oracle/ref_harness.py; inp
 oracle/cases.py (seeded).  Each file stores the reference outputs plus a sha256 of the inputs they
 were computed from.  Nothing here is used by the product.
 """
+import contextlib
 import os
 import platform
 import sys
@@ -88,25 +89,27 @@ def gen_headconv(ref):
              input_sha256=np.array(cases.sha256_of(feat, w, b)))
 
 
-def gen_recon(ref):
+def gen_recon(ref, only=None):
     for name in cases.RECON_CASES:
-        c2d, rel, K, cfg = cases.recon_case(name)
-        if cfg.weak_perspective:
-            # reconstruct_ref_weakpersp cannot run in the reference on torch 2.10
-            # (ptu.py:30 'torch.Size + list' TypeError) -> that branch is PARITY-UNPINNED; the
-            # oracle restates it from the code (and the TF twin tfu3d.py:145-162) only.
-            print(f'recon_{name}: skipped (reference branch not executable)')
+        if only and name != only:
             continue
-        with rh.config(**cfg_kwargs(cfg)), torch.inference_mode():
-            out = ref.ptu3d.reconstruct_absolute(
-                c2d, rel, K, mix_3d_inside_fov=cfg.mix_3d_inside_fov)
+        c2d, rel, K, cfg = cases.recon_case(name)
+        # weak perspective: ptu.reduce_mean_masked adds a list to a torch.Size (ptu.py:30), a TypeError
+        # on torch 2.x; rh.weak_perspective_runnable hands the reference a mask whose .shape adds to
+        # lists -- the reference code itself runs unmodified
+        ctx = rh.weak_perspective_runnable(ref) if cfg.weak_perspective else contextlib.nullcontext()
+        with rh.config(**cfg_kwargs(cfg)), torch.inference_mode(), ctx:
+            out = rh.plain(ref.ptu3d.reconstruct_absolute(
+                c2d, rel, K, mix_3d_inside_fov=cfg.mix_3d_inside_fov,
+                weak_perspective=cfg.weak_perspective))
             # the reference point itself (pre-mix), useful for debugging the solver
             inv_k = torch.linalg.inv(K)
             norm2d = (ref.ptu3d.to_homogeneous(c2d) @ inv_k.transpose(1, 2))[..., :2]
             in_fov = ref.ptu3d.is_within_fov(c2d)
             fn = (ref.ptu3d.reconstruct_ref_weakpersp if cfg.weak_perspective
                   else ref.ptu3d.reconstruct_ref_fullpersp)
-            refpoint = fn(norm2d, rel, in_fov)
+            refpoint = rh.plain(fn(norm2d, rel, in_fov))
+            in_fov = rh.plain(in_fov)
         save(f'recon_{name}', poses3d=out, ref_point=refpoint, in_fov=in_fov,
              input_sha256=np.array(cases.sha256_of(c2d, rel, K)))
 
@@ -147,8 +150,9 @@ def gen_detpre(ref):
 def gen_filter(ref):
     """Plausibility filter + pose NMS (row f.2).  The PyTorch reference never calls these functions
     (multiperson_model.py:158-163 is commented out) and is_pose_consistent_with_box does not run as
-    written, so the vectors hold the outputs of the reference functions that DO run, on the case
-    inputs: is_pose_plausible, are_augmentation_results_consistent (torch.var: unbiased),
+    written (it runs given an argument for which torch.min(dim=) yields values, rh.minmax_values),
+    so the vectors hold the outputs of the reference functions on the case inputs: is_pose_plausible,
+    is_pose_consistent_with_box, are_augmentation_results_consistent (torch.var: unbiased),
     compute_pose_similarity, and pose_non_max_suppression given the oracle's validity mask."""
     import simplepyutils
     from oracle import cpu_ref
@@ -168,6 +172,12 @@ def gen_filter(ref):
                 if p3.shape[1] > 1:
                     out[f'aug_consistent_unbiased_{i}'] = pc.are_augmentation_results_consistent(p3)
                 out[f'similarity_{i}'] = pc.compute_pose_similarity(m3)
+                # (the PyTorch port passes torch.min's (values, indices) pair on and raises;
+                #  rh.minmax_values makes torch.min / max return the values, as the TF twin's
+                #  reduce_min / reduce_max do -- the rest of the function runs as written)
+                m2 = c['poses2d'][i].mean(dim=-3)
+                out[f'box_consistent_{i}'] = rh.plain(
+                    pc.is_pose_consistent_with_box(rh.minmax_values(m2), b))
                 out[f'valid_mask_{i}'] = mask
                 out[f'keep_{i}'] = pc.pose_non_max_suppression(m3, b[:, 4], mask)
         save(f'filter_{name}', n_images=np.array(len(c['boxes'])),
@@ -278,13 +288,17 @@ def gen_e2e(ref):
 
 
 def main():
-    """python oracle/gen_golden.py [group ...]   (default: every group)"""
+    """python oracle/gen_golden.py [group | recon:case ...]   (default: every group)"""
     torch.manual_seed(0)
     ref = rh.load()
     groups = dict(heads=gen_heads, headconv=gen_headconv, recon=gen_recon, warp=gen_warp,
                   tta=gen_tta, e2e=gen_e2e, detpre=gen_detpre, filter=gen_filter, backbone=gen_backbone)
     for name in (sys.argv[1:] or groups):
-        groups[name](ref)
+        if ':' in name:  # one case of a group (recon only: its lstsq goldens carry run-to-run jitter)
+            group, only = name.split(':', 1)
+            groups[group](ref, only=only)
+        else:
+            groups[name](ref)
 
 
 if __name__ == '__main__':

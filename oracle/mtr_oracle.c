@@ -126,10 +126,42 @@ static int in_fov(float x, float y, const orc_config* f) {
   return x >= lo && x <= hi && y >= lo && y <= hi;
 }
 
-/* ptu3d.reconstruct_absolute with reconstruct_ref_fullpersp, ptu3d.py:9-33,56-105 */
+/* ptu3d.reconstruct_ref_weakpersp, ptu3d.py:36-49 with ptu.mean_stdev_masked / reduce_mean_masked,
+   ptu.py:4-34: masked means over the in-FOV joints, stdev over joints AND the two coordinates,
+   depth of the reference point = stdev3d / stdev2d (both floored at 1e-5; no valid joint: the
+   means are nan_to_num(0/0) = 0 and both stdevs sqrt(1e-10)) */
+static void ref_weakpersp(const double* n2, const float* rel, const int* valid, int J, float* ref) {
+  double nv = 0, m3[3] = {0, 0, 0}, m2[2] = {0, 0};
+  for (int j = 0; j < J; ++j)
+    if (valid[j]) {
+      nv += 1;
+      for (int k = 0; k < 3; ++k) m3[k] += rel[j * 3 + k];
+      m2[0] += n2[j * 2]; m2[1] += n2[j * 2 + 1];
+    }
+  if (nv > 0) {
+    for (int k = 0; k < 3; ++k) m3[k] /= nv;
+    m2[0] /= nv; m2[1] /= nv;
+  }
+  double q3 = 0, q2 = 0;
+  for (int j = 0; j < J; ++j)
+    if (valid[j])
+      for (int k = 0; k < 2; ++k) {
+        double d3 = rel[j * 3 + k] - m3[k], d2 = n2[j * 2 + k] - m2[k];
+        q3 += d3 * d3; q2 += d2 * d2;
+      }
+  double s3 = sqrt((nv > 0 ? q3 / nv : 0.0) + 1e-10), s2 = sqrt((nv > 0 ? q2 / nv : 0.0) + 1e-10);
+  if (s3 < 1e-5) s3 = 1e-5;
+  if (s2 < 1e-5) s2 = 1e-5;
+  double z = s3 / s2;
+  ref[0] = (float)(m2[0] * z - m3[0]);
+  ref[1] = (float)(m2[1] * z - m3[1]);
+  ref[2] = (float)(z - m3[2]);
+}
+
+/* ptu3d.reconstruct_absolute, ptu3d.py:9-33, with reconstruct_ref_fullpersp (:56-105) or
+   reconstruct_ref_weakpersp (:36-49) */
 int orc_reconstruct(const float* coords2d, const float* rel, const float* K, int B, int J,
                     const orc_config* f, float* out) {
-  if (f->weak_perspective) return -1; /* unpinned branch: see oracle/cpu_ref.py */
   double* n2 = (double*)malloc(sizeof(double) * (size_t)B * J * 2);
   double s2d = 0.0, srb = 0.0;
   for (int b = 0; b < B; ++b) {
@@ -166,6 +198,13 @@ int orc_reconstruct(const float* coords2d, const float* rel, const float* K, int
     double r0 = Mi[0] * v0 + Mi[1] * v1 + Mi[2] * v2, r1 = Mi[3] * v0 + Mi[4] * v1 + Mi[5] * v2,
            r2 = Mi[6] * v0 + Mi[7] * v1 + Mi[8] * v2;
     float ref[3] = {(float)(r0 * scale_rb), (float)(r1 * scale_rb), (float)(r2 * (scale_rb / scale2d))};
+    if (f->weak_perspective) {
+      int* valid = (int*)malloc(sizeof(int) * (size_t)J);
+      for (int j = 0; j < J; ++j)
+        valid[j] = in_fov(coords2d[((size_t)b * J + j) * 2], coords2d[((size_t)b * J + j) * 2 + 1], f);
+      ref_weakpersp(n2 + (size_t)b * J * 2, rel + (size_t)b * J * 3, valid, J, ref);
+      free(valid);
+    }
     for (int j = 0; j < J; ++j) {
       size_t o = (size_t)b * J + j;
       float a3[3] = {rel[o * 3] + ref[0], rel[o * 3 + 1] + ref[1], rel[o * 3 + 2] + ref[2]};

@@ -278,6 +278,71 @@ def _install_stubs():
         torch.split = split_compat
 
 
+class _FlexShape(list):
+    """A shape that adds to tuples AND lists.  ptu.reduce_mean_masked / reduce_sum_masked
+    (ptu.py:30,41) compute ``is_valid.shape + [1] * n`` -- torch.Size + list is a TypeError on
+    torch >= 2.x -- while ptu.mean_stdev_masked (ptu.py:12) adds a tuple."""
+
+    def __add__(self, other):
+        return _FlexShape(list(self) + list(other))
+
+    def __radd__(self, other):
+        return _FlexShape(list(other) + list(self))
+
+
+def flex_mask(mask):
+    """The same boolean tensor as a subclass whose ``.shape`` is a _FlexShape: the only thing the
+    reference's masked reductions need to run on this torch.  The reference code itself executes
+    unmodified, every arithmetic op is torch's own."""
+    import torch
+
+    class FlexShapeMask(torch.Tensor):
+        @property
+        def shape(self):
+            return _FlexShape(super().shape)
+
+    return mask.as_subclass(FlexShapeMask)
+
+
+@contextlib.contextmanager
+def weak_perspective_runnable(ref):
+    """Inside this context ptu3d.is_within_fov returns a flex_mask, so that
+    ptu3d.reconstruct_absolute(weak_perspective=True) (ptu3d.py:9-33 -> :36-49 -> ptu.py:4-34) runs
+    end to end.  Results come back as FlexShapeMask-typed tensors: call plain() on them."""
+    orig = ref.ptu3d.is_within_fov
+    ref.ptu3d.is_within_fov = lambda *a, **k: flex_mask(orig(*a, **k))
+    try:
+        yield
+    finally:
+        ref.ptu3d.is_within_fov = orig
+
+
+def plain(t):
+    import torch
+    return t.as_subclass(torch.Tensor)
+
+
+def minmax_values(t):
+    """The same tensor as a subclass for which ``torch.min(t, dim=...)`` / ``torch.max(t, dim=...)``
+    return the values alone, the way tf.reduce_min / reduce_max do in the TF twin
+    (metrabs_tf/multiperson/plausibility_check.py:75-76).  The PyTorch port of
+    is_pose_consistent_with_box (metrabs_pytorch/multiperson/plausibility_check.py:86-107) feeds the
+    (values, indices) pair of torch.min straight into torch.maximum and raises; with this argument
+    type the rest of the function -- the reference's own arithmetic -- runs unmodified."""
+    import torch
+
+    class ValuesOnlyMinMax(torch.Tensor):
+        @classmethod
+        def __torch_function__(cls, func, types, args=(), kwargs=None):
+            kwargs = kwargs or {}
+            out = super().__torch_function__(func, types, args, kwargs)
+            if func in (torch.min, torch.max) and ('dim' in kwargs or len(args) > 1):
+                return out.values
+            return out
+
+    return t.as_subclass(ValuesOnlyMinMax)
+
+
 def load():
     """Returns a namespace with the reference modules (ptu, ptu3d, model_util, metrabs_model,
     warping, multiperson_model, person_detector)."""

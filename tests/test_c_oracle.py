@@ -20,7 +20,7 @@ def test_c_decode_vs_golden(name):
     assert np.abs(c2d - g['coords2d']).max() <= 2e-4
 
 
-@pytest.mark.parametrize('name', ['b64_j17', 'b5_j122_384', 'b1_j17', 'b8_legacy', 'b6_nomix', 'b4_outfov'])
+@pytest.mark.parametrize('name', ['b64_j17', 'b5_j122_384', 'b1_j17', 'b8_legacy', 'b6_nomix', 'b4_outfov', 'b8_weak'])
 def test_c_reconstruct_vs_golden(name):
     g = load_golden(f'recon_{name}')
     c2d, rel, K, cfg = cases.recon_case(name)

@@ -131,14 +131,24 @@ def test_reconstruct_vs_golden_and_oracle(name, hip_lib):
         oracle = cpu_ref.reconstruct_absolute(c2d, rel, K, cfg)
     out = kernels.reconstruct_absolute(c2d.cuda(), rel.cuda(), K.cuda(), mcfg(cfg)).cpu()
     report(f'recon {name} vs oracle [mm]', out, oracle)
-    if name != 'b8_weak':  # weak perspective has no golden: the reference branch cannot run
-        g = load_golden(f'recon_{name}')
-        golden = torch.from_numpy(g['poses3d'])
-        report(f'recon {name} vs golden [mm]', out, golden)
-        assert cpu_ref.mpjpe(out, golden) <= 1e-3
-        assert float((out - golden).abs().max()) <= 4e-3
+    g = load_golden(f'recon_{name}')  # (b8_weak: minted through ref_harness.weak_perspective_runnable)
+    golden = torch.from_numpy(g['poses3d'])
+    report(f'recon {name} vs golden [mm]', out, golden)
+    assert cpu_ref.mpjpe(out, golden) <= 1e-3
+    assert float((out - golden).abs().max()) <= 4e-3
     assert cpu_ref.mpjpe(out, oracle) <= 1e-3
     assert float((out - oracle).abs().max()) <= 4e-3
+
+
+def test_weak_perspective_known_answer(hip_lib):
+    """ptu3d.reconstruct_ref_weakpersp (ptu3d.py:36-49): the hand-derived case (a masked joint, a
+    crop with no joint in the FOV)."""
+    from metrabs_amd import kernels
+    from metrabs_amd.config import MetrabsConfig
+    c2d, rel, K, want = cases.weak_perspective_kat()
+    out = kernels.reconstruct_absolute(c2d.cuda(), rel.cuda(), K.cuda(),
+                                       MetrabsConfig(weak_perspective=True)).cpu()
+    assert float((out - want).abs().max()) <= 2e-3, out
 
 
 def test_reconstruct_batch_coupling_and_split(hip_lib):

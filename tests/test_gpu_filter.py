@@ -77,6 +77,22 @@ def test_ragged_and_degenerate_cases(hip_lib):
     assert keep_count.tolist() == [1] and keep_idx.tolist() == [1, -1]
 
 
+def test_box_consistency_known_answer(hip_lib):
+    """is_pose_consistent_with_box (TF plausibility_check.py:66-84): the hand-derived cases of
+    cases.box_consistency_kat through K8 (no bone table, one augmentation: the box test alone
+    decides `valid`), incl. the strict '>' at exactly half the box area."""
+    from metrabs_amd import kernels
+    pose2d, boxes, want = cases.box_consistency_kat()
+    n = len(boxes)
+    p2 = pose2d[:, None]                                            # [n, A=1, J=3, 2]
+    p3 = torch.cat([p2, torch.full_like(p2[..., :1], 3000.0)], dim=-1) + \
+        torch.arange(n).reshape(n, 1, 1, 1) * 5000.0                # far apart: the NMS keeps all
+    keep_idx, keep_count, valid = kernels.filter_poses(p3.cuda(), p2.contiguous().cuda(), boxes.cuda(),
+                                                       [n], None, None)
+    assert valid.cpu().tolist() == want.tolist()
+    assert keep_count.tolist() == [int(want.sum())]
+
+
 def test_detect_poses_applies_the_filter_when_bone_lengths_are_set(hip_lib):
     """Pose3dEstimator.detect_poses_batched(suppress_implausible_poses=True): ignored without bone
     lengths (the PyTorch reference's behaviour), K8 with them -- same poses, a subset of the rows."""

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from conftest import load_golden, same_cpu_as_golden
-from oracle import cases, cpu_ref
+from oracle import c_oracle, cases, cpu_ref
 from oracle import ref_harness as rh
 
 
@@ -51,7 +51,7 @@ def test_headconv_vs_golden(name):
     check(c3d, g['coords3d_rel'], g, atol=1e-2)
 
 
-@pytest.mark.parametrize('name', [n for n in cases.RECON_CASES if n != 'b8_weak'])
+@pytest.mark.parametrize('name', list(cases.RECON_CASES))
 def test_recon_vs_golden(name):
     g = load_golden(f'recon_{name}')
     c2d, rel, K, cfg = cases.recon_case(name)
@@ -153,6 +153,8 @@ def test_pose_filter_vs_golden(name):
             assert np.array_equal(cpu_ref.are_augmentation_results_consistent(p3, unbiased=True).numpy(),
                                   g[f'aug_consistent_unbiased_{i}'])
         check(cpu_ref.compute_pose_similarity(m3), g[f'similarity_{i}'], g, atol=1e-6)
+        assert np.array_equal(cpu_ref.is_pose_consistent_with_box(c['poses2d'][i].mean(dim=-3), b).numpy(),
+                              g[f'box_consistent_{i}'])
         assert np.array_equal(masks[i].numpy(), g[f'valid_mask_{i}'])
         assert np.array_equal(keep[i].numpy(), g[f'keep_{i}'])
 
@@ -225,6 +227,34 @@ class TestAgainstLiveReference:
             one = cpu_ref.reconstruct_absolute(c2d[:1], rel[:1], K[:1], cfg)
         assert float((full - full_ref).abs().max()) < 2e-3 and float((one - one_ref).abs().max()) < 2e-3
         assert float((full[:1] - one).abs().max()) > 1e-4  # the coupling is real
+
+    def test_weak_perspective_branch(self):
+        """The reference's own reconstruct_absolute(weak_perspective=True), made runnable on this
+        torch by a mask whose .shape adds to lists (ref_harness.flex_mask): bit-equal reference
+        point, poses equal to the oracle's, and the hand-derived known answer."""
+        ref = rh.load()
+        for c2d, rel, K, cfg in (cases.recon_case('b8_weak'),
+                                 cases.weak_perspective_kat()[:3] + (cpu_ref.HeadConfig(weak_perspective=True),)):
+            with rh.config(**cfg.as_dict()), torch.inference_mode(), rh.weak_perspective_runnable(ref):
+                out = rh.plain(ref.ptu3d.reconstruct_absolute(c2d, rel, K, mix_3d_inside_fov=0.5,
+                                                              weak_perspective=True))
+            assert torch.equal(out, cpu_ref.reconstruct_absolute(c2d, rel, K, cfg))
+        assert float((out - cases.weak_perspective_kat()[3]).abs().max()) <= 2e-3
+
+    def test_box_consistency(self):
+        """metrabs_pytorch/multiperson/plausibility_check.py:86-107 with torch.min / max returning
+        values (ref_harness.minmax_values): the hand-derived cases and random ones, bit-equal."""
+        ref = rh.load()
+        pose2d, boxes, want = cases.box_consistency_kat()
+        got = rh.plain(ref.plausibility_check.is_pose_consistent_with_box(rh.minmax_values(pose2d), boxes))
+        assert torch.equal(got, want)
+        g = cases.gen(55)
+        p = torch.rand(200, 17, 2, generator=g) * 300
+        b = torch.cat([torch.rand(200, 2, generator=g) * 200, 50 + torch.rand(200, 2, generator=g) * 250,
+                       torch.ones(200, 1)], dim=1)
+        got = rh.plain(ref.plausibility_check.is_pose_consistent_with_box(rh.minmax_values(p), b))
+        mine = cpu_ref.is_pose_consistent_with_box(p, b)
+        assert torch.equal(got, mine) and 20 < int(mine.sum()) < 180
 
     def test_geometry_helpers(self):
         ref = rh.load()
@@ -322,9 +352,19 @@ def test_kat_consistent_pose_reconstruction():
     assert float((out - abs3d).abs().max()) < 5.0  # mm; the ridge term biases the ref depth
 
 
-def test_weak_perspective_unpinned_but_runs():
-    """reconstruct_ref_weakpersp is parity-unpinned (the reference branch does not run on torch
-    2.10); it must at least run and give finite, roughly right depths."""
-    c2d, rel, K, cfg = cases.recon_case('b8_weak')
+def test_weak_perspective_known_answer():
+    """reconstruct_ref_weakpersp (ptu3d.py:36-49): the hand-derived case of
+    cases.weak_perspective_kat (masked joint, rectangle of known spread, a crop with no joint in the
+    FOV).  The golden recon_b8_weak (minted by the reference's own code through
+    ref_harness.weak_perspective_runnable) is checked in test_recon_vs_golden."""
+    c2d, rel, K, want = cases.weak_perspective_kat()
+    cfg = cpu_ref.HeadConfig(weak_perspective=True)
     out = cpu_ref.reconstruct_absolute(c2d, rel, K, cfg)
-    assert torch.isfinite(out).all() and float(out[..., 2].median()) > 500
+    assert float((out - want).abs().max()) <= 2e-3, out
+    c_out = c_oracle.reconstruct(c2d.numpy(), rel.numpy(), K.numpy(), cfg)
+    assert float(np.abs(c_out - want.numpy()).max()) <= 2e-3, c_out
+
+
+def test_box_consistency_known_answer():
+    pose2d, boxes, want = cases.box_consistency_kat()
+    assert torch.equal(cpu_ref.is_pose_consistent_with_box(pose2d, boxes), want)
