@@ -11,6 +11,7 @@ metrabs_tf/backbones/resnet.py:746-754 (ResNet-18) and metrabs_tf/backbones/mobi
 fixed padding, efficientnet.py:1127-1161; irrelevant for throughput).
 """
 import collections
+import threading
 
 import torch
 import torch.nn.functional as F
@@ -26,14 +27,14 @@ class DepthwiseConv2d(nn.Conv2d):
     state_dict keys; still PyTorch-ROCm, only the backend choice of these layers changes."""
 
     use_miopen = False  # class-wide switch (tools/experiments/depthwise_backend_probe.py flips it)
+    _backend_lock = threading.Lock()  # the MIOpen switch is process-global state in torch
 
     def forward(self, x):
         if x.is_cuda and not DepthwiseConv2d.use_miopen and torch.backends.cudnn.enabled:
-            torch.backends.cudnn.enabled = False
-            try:
+            # scoped, and serialised: another inference thread must neither see MIOpen switched off
+            # for its own convolutions nor switch it back on underneath this call
+            with DepthwiseConv2d._backend_lock, torch.backends.cudnn.flags(enabled=False):
                 return super().forward(x)
-            finally:
-                torch.backends.cudnn.enabled = True
         return super().forward(x)
 
 
@@ -268,11 +269,14 @@ class ConvBiasAct(nn.Module):
 
     def forward(self, x, residual=None):
         y = self.conv(x)
-        if y.is_cuda and y.is_contiguous() and (
-                residual is None or (residual.dtype == y.dtype and residual.is_contiguous())):
+        # K10 moves 16 bytes per lane: planes of a multiple of the vector width (7x7 maps at 224 px,
+        # 5x5 at 160 px are not), 16-byte aligned storage; everything else takes the torch ops
+        hw_vec_ok = (y.shape[2] * y.shape[3]) % (16 // y.element_size()) == 0
+        if y.is_cuda and y.is_contiguous() and hw_vec_ok and y.data_ptr() % 16 == 0 and (
+                residual is None or (residual.dtype == y.dtype and residual.is_contiguous()
+                                     and residual.data_ptr() % 16 == 0)):
             from . import kernels
-            hw_vec_ok = (y.shape[2] * y.shape[3]) % (16 // y.element_size()) == 0
-            if self.emit_mean and residual is None and hw_vec_ok:
+            if self.emit_mean and residual is None:
                 y, mean = kernels.bias_act_rowmean_(y, self.bias, self.act_name)
                 self._mean = (y, mean)
                 return y

@@ -116,6 +116,50 @@ def headconv_case(name):
     return feat, w * c['gain'], b * c['gain'], c['J'], cfg
 
 
+def consistent_head_case(B, C, J, hw, proc_side, D, amp, seed, spread=0.18):
+    """Features + head parameters whose logits describe a PLAUSIBLE pose (a person filling most of
+    the crop, 2.5 - 4.5 m from the camera), for the features -> poses3d parity gates.
+
+    Why not random features x random weights: their heatmaps are nearly uniform, every joint decodes
+    to the crop centre, the 2D and 3D spreads both vanish and the reference-point depth (their
+    ratio, ptu3d.py:56-105) is ill-conditioned -- the median depth of such a batch is ~0 mm and even
+    exactly rounded logits land 2e-3 mm from an fp64 evaluation.  No detector crop looks like that.
+
+    Construction: conv_final keeps torch's default initialisation (W [N, C], bias); the target
+    logits L* are Gaussian bumps of height `amp` (4: |logit| <= 5, 'low'; 25: 'peaked') around each
+    joint's 2D / 3D heatmap position; the features of every position are the minimum-norm solution
+    of W f = L* - bias plus a random N(0,1) vector projected onto W's null space, computed in
+    float64 and rounded to float32 once.  So the features look like noise of unit scale (the
+    K = C accumulation sees realistic magnitudes), the logits equal L* to rounding, and the poses
+    are well conditioned.  -> (features [B,C,hw,hw] f32, weight [N,C], bias [N], K [B,3,3])"""
+    g = gen(seed)
+    w, b = default_conv_init(J * (1 + D), C, g)
+    w, b = w.double(), b.double()
+    f = (450 + 100 * torch.rand(B, generator=g)) * proc_side / 256
+    K = torch.zeros(B, 3, 3)
+    K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2], K[:, 2, 2] = f, f, proc_side / 2, proc_side / 2, 1
+    rel = (torch.randn(B, J, 3, generator=g, dtype=torch.float64) *
+           torch.tensor([0.13, 0.17, 0.12], dtype=torch.float64)).clamp(-0.3, 0.3)
+    u3 = 0.5 + rel                                   # (x, y, z) in heatmap units
+    u2 = 0.5 + rel[..., :2] / (1.0 + 0.5 * rel[..., 2:])  # nearer joints project farther out
+    gx = torch.linspace(0, 1, hw, dtype=torch.float64)
+    gz = torch.linspace(0, 1, D, dtype=torch.float64)
+    d2 = ((gx[None, None, None, :] - u2[..., 0, None, None]) ** 2 +
+          (gx[None, None, :, None] - u2[..., 1, None, None]) ** 2)
+    l2 = amp * torch.exp(-d2 / (2 * spread * spread))                                 # [B,J,h,w]
+    d3 = ((gx[None, None, None, None, :] - u3[..., 0, None, None, None]) ** 2 +
+          (gx[None, None, None, :, None] - u3[..., 1, None, None, None]) ** 2 +
+          (gz[None, None, :, None, None] - u3[..., 2, None, None, None]) ** 2)
+    l3 = amp * torch.exp(-d3 / (2 * spread * spread))                                 # [B,J,D,h,w]
+    # conv_final's channel order: J 2D rows, then slice d of joint j at J + d*J + j
+    target = torch.cat([l2, l3.permute(0, 2, 1, 3, 4).reshape(B, D * J, hw, hw)], dim=1)
+    target = (target - b[None, :, None, None]).reshape(B, J * (1 + D), hw * hw)
+    w_pinv = w.T @ torch.linalg.inv(w @ w.T)         # [C, N]
+    noise = torch.randn(B, C, hw * hw, generator=g, dtype=torch.float64)
+    feat = w_pinv @ target + noise - w_pinv @ (w @ noise)
+    return feat.reshape(B, C, hw, hw).float(), w.float(), b.float(), K
+
+
 # ------------------------------------------------------------------------------------ reconstruct
 
 RECON_CASES = {

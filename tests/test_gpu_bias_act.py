@@ -84,8 +84,11 @@ def test_bias_act_rejects_what_it_cannot_vectorise(hip_lib):
         kernels.bias_act_(torch.zeros(2, 4, 4, 4, device='cuda').permute(0, 2, 3, 1), torch.zeros(4, device='cuda'), None)
 
 
-@pytest.mark.parametrize('name,res', [('effnetv2-s', 256), ('mobilenetv3', 256), ('resnet18', 256)])
+@pytest.mark.parametrize('name,res', [('effnetv2-s', 256), ('mobilenetv3', 256), ('resnet18', 256),
+                                      ('effnetv2-s', 224), ('effnetv2-s', 160), ('mobilenetv3', 224)])
 def test_folded_fused_backbone_is_the_same_function(name, res, hip_lib):
+    """(224 / 160 px: 7x7 = 49 and 5x5 = 25-position maps are not a multiple of K10's 16-byte vectors:
+    those layers must take the torch ops, not raise.)"""
     from metrabs_amd import backbones
     torch.manual_seed(0)
     net = backbones.calibrate_batchnorm(backbones.build_backbone(name).cuda(), res, 'cuda', batch_size=4)

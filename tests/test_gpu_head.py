@@ -1,16 +1,19 @@
 """GPU parity of the fused head (K1+K2-K4, MFMA projection + decode epilogue) through the C-ABI.
 
 Identical features + weights -> coords.  The reference's CPU conv (oneDNN) and our exact-fp32 MFMA
-accumulate the K=C products in different orders; the golden files carry the reference's own
-fp32-vs-fp64 logit error for each case.  Bounds: MPJPE-style mean error <= 1e-3 mm on coords3d_rel
-for default-init heads; peaked heads (logit magnitude 20-50x) are bounded by 2x the reference's own
-distance to the fp64 truth, which the test computes."""
+accumulate the K=C products in different orders.  Bounds on the golden cases are FIXED numbers per
+case (GOLDEN_BOUNDS, ~2x the values measured when they were set, profiles/r02_parity_report.jsonl):
+mean error <= 1e-3 mm on coords3d_rel everywhere; the max-abs bound of the peaked case (logits
++-52) is above 1e-3 mm because the reference's own conv is 2.7e-3 mm from fp64 there."""
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import load_golden
+from conftest import ROOT, load_golden
 from oracle import cases, cpu_ref
 
 pytestmark = pytest.mark.gpu
@@ -22,6 +25,17 @@ def mcfg(cfg):
 
 
 kernel_weights = cases.head_weights_as_consumed
+
+# golden headconv cases, coords3d_rel in mm / coords2d in px:
+# (MPJPE ours-vs-reference, max-abs ours-vs-reference, max-abs ours-vs-fp64, max-abs 2D ours-vs-reference)
+GOLDEN_BOUNDS = {
+    's256_c64': (1e-3, 1e-3, 1e-3, 2e-4),
+    's256_c1280': (1e-3, 1e-3, 1e-3, 2e-4),
+    's256_c1280_peaked': (1e-3, 6e-3, 2e-3, 6e-4),
+    'l384_c1280': (1e-3, 2e-3, 1e-3, 3e-4),
+    'r18_c512': (1e-3, 2e-3, 1e-3, 3e-4),
+    'l384_j122_c96': (1e-3, 2e-3, 1e-3, 3e-4),
+}
 
 
 def run_fused(feat, w, b, J, cfg):
@@ -52,10 +66,19 @@ def test_fused_head_vs_golden(name, hip_lib):
     print(f'[parity] fused head {name}: |ours-ref| max {float(ours_vs_ref.max()):.2e} '
           f'mean {float(ours_vs_ref.mean()):.2e} mm; |ours-fp64| max {float(ours_vs_truth.max()):.2e}; '
           f'|ref-fp64| max {float(ref_vs_truth.max()):.2e} (logits absmax {float(g["logits_absmax"]):.1f})')
-    assert cpu_ref.mpjpe(c3d, g3d) <= 1e-3 or cpu_ref.mpjpe(c3d, g3d) <= 2 * cpu_ref.mpjpe(g3d, t3d.float())
-    assert float(ours_vs_ref.max()) <= max(1e-3, 2 * float(ref_vs_truth.max()) + float(ours_vs_truth.max()))
-    assert float(ours_vs_truth.max()) <= max(1e-3, 2 * float(ref_vs_truth.max()))
-    assert float((c2d - g2d).abs().max()) <= max(2e-4, 2 * float((g2d.double() - t2d).abs().max()))
+    r = dict(case=f'headconv_{name}', regime='golden', logits_absmax=round(float(g['logits_absmax']), 2),
+             mpjpe3d_ours_vs_ref=cpu_ref.mpjpe(c3d, g3d), max3d_ours_vs_ref=float(ours_vs_ref.max()),
+             max3d_ours_vs_fp64=float(ours_vs_truth.max()), max3d_ref_vs_fp64=float(ref_vs_truth.max()),
+             max2d_ours_vs_ref=float((c2d - g2d).abs().max()))
+    out_dir = os.path.join(ROOT, 'gpurun_out')
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, 'parity_report.jsonl'), 'a') as fh:
+            fh.write(json.dumps(r) + '\n')
+    b_mpjpe, b_max_ref, b_max_64, b_2d = GOLDEN_BOUNDS[name]
+    assert r['mpjpe3d_ours_vs_ref'] <= b_mpjpe, r
+    assert r['max3d_ours_vs_ref'] <= b_max_ref, r
+    assert r['max3d_ours_vs_fp64'] <= b_max_64, r
+    assert r['max2d_ours_vs_ref'] <= b_2d, r
 
 
 @pytest.mark.parametrize('shape', [(3, 40, 17, 8, 8, 8), (2, 24, 5, 8, 4, 4), (2, 33, 17, 8, 12, 12),

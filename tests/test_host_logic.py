@@ -170,8 +170,8 @@ def test_bench_cli_contract_and_kernel_naming(monkeypatch):
     monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '8', '--steps', '7', '--warmup', '2'])
     a = bench.parse_args()
     assert (a.gpus, a.steps, a.warmup) == (8, 7, 2)
-    assert bench.head_kernel_name(64, 64, 17, 8) == 'head_fused32w8_kernel'          # config 2
-    assert bench.head_kernel_name(64, 1024, 17, 8) == 'head_fused32_kernel'          # large launch
-    assert bench.head_kernel_name(144, 32, 17, 8) == 'head_fused_kernel'             # 12x12 maps, f32
-    assert bench.head_kernel_name(64, 64, 17, 8, 'f16', 1280) == 'head_fused16_kernel'
-    assert bench.head_kernel_name(64, 64, 17, 8, 'f16', 1283) == 'head_fused32w8_kernel'  # C % 8 != 0
+    assert bench.head_kernel_name(64, 64, 17, 8) == 'head_rt_kernel'                 # config 2, f32
+    assert bench.head_kernel_name(144, 32, 17, 72) == 'head_rt_kernel'               # any map, D <= 80
+    assert bench.head_kernel_name(64, 64, 17, 8, 'f16', 1280) == 'head_fused16dma_kernel'
+    assert bench.head_kernel_name(36, 64, 17, 8, 'f16', 1280) == 'head_fused16_kernel'   # 6x6: registers
+    assert bench.head_kernel_name(64, 64, 17, 8, 'f16', 1283) == 'head_fused32_kernel'   # C % 8 != 0
