@@ -91,22 +91,34 @@ int mtr_softargmax_decode(const void* logits, int dtype, int layout, int B, int 
  * never reach HBM.  Replaces MetrabsHeads.forward as a whole (models/metrabs.py:75-85; the conv is
  * torch.nn.LazyConv2d(kernel_size=1), models/metrabs.py:73).
  *
- * mtr_head_pack_weights re-orders conv_final.weight [J*(1+D), C] (+bias) ONCE into the joint-major
- * tiled layout the kernel streams; `packed` must hold
- * mtr_head_packed_bytes(...) bytes.  features: [B, C, H, W] (MTR_NCHW) or [B, H, W, C] (MTR_NHWC,
- * C % 4 == 0); H*W must be a multiple of 4 and <= 256, 1+D <= 64 (else: 1x1-conv GEMM +
- * mtr_softargmax_decode).  Arithmetic, f32 features: f32-input MFMA with f32 weights
- * (v_mfma_f32_32x32x2_f32 for maps of 33..128 positions, v_mfma_f32_16x16x4_f32 otherwise; the
- * packed blob holds the weights in both tile layouts), f32 chains of 16 channels carried into f64
- * accumulators (parity with the fp32 CPU reference).  f16 / bf16 features with C % 8 == 0:
- * v_mfma_f32_32x32x16_{f16,bf16} on the features and on the weights ROUNDED TO THE FEATURE DTYPE
- * (what autocast does to conv_final in the reference's GPU path), f32 accumulation, f32 logits; the
- * rounded weights are a third section of the blob, so `packed` is specific to the feat_dtype it was
- * packed for: pass the same feat_dtype to mtr_head_packed_bytes, mtr_head_pack_weights and
- * mtr_head_fused.  (C % 8 != 0: the 16-bit features are widened in staging and run on the f32 path.
- * C % 64 == 0, and for NCHW also H*W % 8 == 0 and H*W >= 64: the tiles are staged by
- * global_load_lds instead of through registers -- same arithmetic, same results.)
+ * mtr_head_pack_weights re-orders conv_final.weight [J*(1+D), C] (+bias) ONCE into the tiled
+ * layout the kernel streams; `packed` must hold mtr_head_packed_bytes(...) bytes
+ * (0 = no fused kernel for this (C, J, D, dtype): run the 1x1 conv as a GEMM and
+ * mtr_softargmax_decode on its logits).  The blob is specific to the feat_dtype it was packed for:
+ * pass the same feat_dtype to mtr_head_packed_bytes, mtr_head_pack_weights and mtr_head_fused.
+ * features: [B, C, H, W] (MTR_NCHW) or [B, H, W, C] (MTR_NHWC, C % 4 == 0); H*W a multiple of 4.
+ *
+ * f32 features (the reference's CPU arithmetic) -- row-tile kernel, any map size, D <= 80:
+ *   v_mfma_f32_16x16x4_f32 on f32 weights, chains of 32 channels summed in f32 over 8 stages and
+ *   carried into f64 accumulators; 16-row tiles of whole softmax units (mtr_head_row_plan), a
+ *   workgroup = (crop, block of <= 5 tiles), tiles staged by global_load_lds.
+ * f16 / bf16 features (the reference's autocast GPU arithmetic) -- joint-group kernels, C % 8 == 0,
+ *   1 + D <= 64, H*W <= 256: v_mfma_f32_32x32x16_{f16,bf16} on the features and on the weights
+ *   ROUNDED TO THE FEATURE DTYPE (what autocast does to conv_final), f32 accumulation, f32 logits.
+ *   (C % 64 == 0, and for NCHW also H*W % 8 == 0 and H*W >= 64: tiles staged by global_load_lds
+ *   instead of through registers -- same arithmetic, same results.)
+ *
+ * mtr_head_fused_opts: the same launch with explicit dispatch choices (A/B measurements, tests of
+ * every kernel variant); options == NULL or all-zero fields = the library's own choice.  There are
+ * no environment switches and no other global state behind these entry points.
  */
+typedef struct mtr_head_options {
+  int32_t rt_tiles_per_workgroup;  /* f32: row tiles per workgroup for one-tile atoms, 1..5; 0 = by launch size */
+  int32_t groups_per_workgroup;    /* 16-bit: joint groups per workgroup, 1..3; 0 = by launch size        */
+  int32_t dma_staging;             /* 16-bit: 1 = global_load_lds where possible, 0 = through registers,
+                                      -1 = library's choice (NB: a zeroed struct selects registers)    */
+} mtr_head_options;
+
 /* host-only, no GPU work: the row order of the f32 row-tile kernel.  conv_final's J*(1+D) channels
  * are re-ordered into n_tiles 16-row MFMA tiles so that the rows of one softmax (a joint's 2D row;
  * a joint's D depth slices) never straddle a workgroup's block of tiles; atoms of tiles_per_atom
@@ -120,6 +132,10 @@ int mtr_head_pack_weights(const float* weight /*[J*(1+D), C] f32*/, const float*
 int mtr_head_fused(const void* features, int feat_dtype, int layout, int B, int C, int H, int W,
                    const void* packed, int J, int D, const mtr_head_params* p, float* coords2d,
                    float* coords3d_rel, mtr_stream_t stream);
+int mtr_head_fused_opts(const void* features, int feat_dtype, int layout, int B, int C, int H, int W,
+                        const void* packed, int J, int D, const mtr_head_params* p,
+                        const mtr_head_options* options, float* coords2d, float* coords3d_rel,
+                        mtr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K5: absolute (camera-space) reconstruction.  Replaces

@@ -20,6 +20,12 @@ class HeadParams(ctypes.Structure):
                 ('legacy_centered_stride_bug', c_int32), ('box_size_mm', c_float)]
 
 
+class HeadOptions(ctypes.Structure):
+    """mtr_head_options (include/metrabs_hip.h): explicit dispatch choices of mtr_head_fused_opts."""
+    _fields_ = [('rt_tiles_per_workgroup', c_int32), ('groups_per_workgroup', c_int32),
+                ('dma_staging', c_int32)]
+
+
 class ReconParams(ctypes.Structure):
     """mtr_recon_params (include/metrabs_hip.h)."""
     _fields_ = [('proc_side', c_int32), ('stride_train', c_int32), ('centered_stride', c_int32),
@@ -56,6 +62,9 @@ SIGNATURES = {
                                       c_void_p]),
     'mtr_head_fused': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                c_int, POINTER(HeadParams), c_void_p, c_void_p, c_void_p]),
+    'mtr_head_fused_opts': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                                    c_int, POINTER(HeadParams), POINTER(HeadOptions), c_void_p, c_void_p,
+                                    c_void_p]),
     'mtr_reconstruct_workspace_bytes': (c_size_t, [c_int, c_int]),
     'mtr_reconstruct_absolute': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int,
                                          POINTER(ReconParams), c_void_p, c_void_p, c_size_t,

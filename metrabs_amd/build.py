@@ -81,5 +81,34 @@ def build_library(force=False, verbose=True):
     return LIB_PATH
 
 
+def kernel_resources(src):
+    """Register / scratch / LDS footprint of every kernel of one source file, read from the code
+    object metadata the compiler emits (hipcc -S --cuda-device-only, same flags as the build).
+    -> list of dicts: name (mangled), vgpr_count, agpr_count, vgpr_spill_count, sgpr_spill_count,
+    private_segment_fixed_size (scratch bytes per lane), group_segment_fixed_size (static LDS)."""
+    import re
+    import tempfile
+    path = os.path.join(CSRC, src)
+    with tempfile.TemporaryDirectory() as tmp:
+        asm = os.path.join(tmp, src + '.s')
+        cmd = [_hipcc(), *[f for f in FLAGS if f != '-fPIC'], *EXTRA_FLAGS.get(src, []), '-S',
+               '--cuda-device-only', path, '-o', asm]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'hipcc -S failed for {src}:\n{r.stderr}')
+        text = open(asm).read()
+    out = []
+    meta = text[text.index('amdhsa.kernels:'):] if 'amdhsa.kernels:' in text else ''
+    for blk in re.split(r'\n  - ', meta)[1:]:
+        if '.vgpr_count:' not in blk:
+            continue  # (amdhsa.version's list items)
+        get = lambda k: int(re.search(rf'\.{k}:\s+(\d+)', blk).group(1))
+        out.append(dict(name=re.search(r'\.name:\s+(\S+)', blk).group(1),
+                        **{k: get(k) for k in ('vgpr_count', 'agpr_count', 'vgpr_spill_count',
+                                               'sgpr_spill_count', 'private_segment_fixed_size',
+                                               'group_segment_fixed_size')}))
+    return out
+
+
 if __name__ == '__main__':
     build_library(force='--force' in sys.argv)

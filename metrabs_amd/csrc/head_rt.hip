@@ -323,7 +323,6 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
     // packed add, pinned by a scheduling fence.
 #define RT_ITER(S, P, BUF, MORE)                                                                  \
   {                                                                                               \
-    const int s_ = (S);                                                                           \
     const bool more = (MORE);                                                                     \
     if (more) rt_wait_vmcnt<(kRtNbuf - 2) * JPW>(); else rt_wait_vmcnt<0>();                      \
     __syncthreads();                                                                              \

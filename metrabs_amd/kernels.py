@@ -212,7 +212,7 @@ def head_fused_supported(C, J, D, H, W, channels_last=False, dtype=torch.float32
         return False
     if dtype == torch.float32:
         return D <= 80
-    return H * W <= 256 and (1 + D) <= 64
+    return H * W <= 256 and (1 + D) <= 64 and C % 8 == 0
 
 
 def _is_channels_last(t):
@@ -239,9 +239,11 @@ def head_pack_weights(weight2d, bias, n_points, depth, feat_dtype=torch.float32)
     return packed
 
 
-def head_fused(features, packed, C, n_points, cfg, out=None):
+def head_fused(features, packed, C, n_points, cfg, out=None, rt_tiles=0, groups_per_workgroup=0,
+               dma_staging=-1):
     """features [B,C,H,W] (f32/f16/bf16; NCHW-contiguous or torch channels_last = NHWC memory, which
-    is consumed in place) -> (coords2d, coords3d_rel)."""
+    is consumed in place) -> (coords2d, coords3d_rel).  rt_tiles / groups_per_workgroup /
+    dma_staging: explicit dispatch choices (mtr_head_options; defaults = the library's own)."""
     require_cuda(features, packed)
     lib = _lib.load()
     nhwc = _is_channels_last(features)
@@ -257,11 +259,18 @@ def head_fused(features, packed, C, n_points, cfg, out=None):
     else:
         c2d, c3d = out
     hp = cfg.head_params()
-    check(lib.mtr_head_fused(
-        _ptr(features), dtype_code(features.dtype), _lib.MTR_NHWC if nhwc else _lib.MTR_NCHW, B, C,
-        H, W, _ptr(packed), J, D,
-        ctypes.byref(hp), _ptr(c2d), _ptr(c3d), current_stream_ptr(features.device)),
-        'mtr_head_fused')
+    layout = _lib.MTR_NHWC if nhwc else _lib.MTR_NCHW
+    if rt_tiles or groups_per_workgroup or dma_staging != -1:
+        opts = _lib.HeadOptions(int(rt_tiles), int(groups_per_workgroup), int(dma_staging))
+        check(lib.mtr_head_fused_opts(
+            _ptr(features), dtype_code(features.dtype), layout, B, C, H, W, _ptr(packed), J, D,
+            ctypes.byref(hp), ctypes.byref(opts), _ptr(c2d), _ptr(c3d),
+            current_stream_ptr(features.device)), 'mtr_head_fused_opts')
+    else:
+        check(lib.mtr_head_fused(
+            _ptr(features), dtype_code(features.dtype), layout, B, C, H, W, _ptr(packed), J, D,
+            ctypes.byref(hp), _ptr(c2d), _ptr(c3d), current_stream_ptr(features.device)),
+            'mtr_head_fused')
     return c2d, c3d
 
 

@@ -576,12 +576,10 @@ def backbone_probe_input():
 
 
 def head_weights_as_consumed(w, feat_dtype):
-    """The conv_final weights as the fused head's GEMM consumes them, for building the expected
-    value on the CPU: 16-bit features go through the f16 / bf16 MFMA kernel with the weights
-    rounded to the feature dtype (what autocast does to conv_final in the reference's GPU path,
-    SURVEY.md section 0), unless C % 8 != 0 or a developer switch forces the f32 cores."""
-    import os
-    forced_f32 = os.environ.get('MTR_HEAD_H16') == '0' or os.environ.get('MTR_HEAD_CORE') == '16'
-    if feat_dtype == torch.float32 or forced_f32 or w.shape[1] % 8:
+    """The conv_final weights as the head's GEMM consumes them, for building the expected value on
+    the CPU: with 16-bit features the weights are rounded to the feature dtype (what autocast does
+    to conv_final in the reference's GPU path; the f16 / bf16 MFMA kernel and
+    the library-GEMM path both do that)."""
+    if feat_dtype == torch.float32:
         return w
     return w.to(feat_dtype).float()

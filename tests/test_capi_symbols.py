@@ -55,15 +55,15 @@ def test_version_strerror_and_host_side_argument_checks(lib):
     assert lib.mtr_softargmax_decode(None, 0, 0, 1, 17, 8, 8, 8, ctypes.byref(hp), None, None, None) == -1
     assert lib.mtr_reconstruct_absolute(None, None, None, 1, 17, None, None, None, 0, None) == -1
     assert lib.mtr_warp_crops(None, None, None, 1, 8, 8, None, 1, 8, 1, 0, 0, None, None) == -1
-    # joint-group sections: 3 groups x 1280 channels x 64 rows in both tile layouts (16x16 and 32x32
-    # core) + bias; row-tile section (f32 features): 40 stages x 10 tiles x 2 KiB + 160 rows x
-    # (bias f32 + label i32)
-    groups = (2 * 3 * 1280 * 64 + 3 * 64) * 4
-    assert lib.mtr_head_packed_bytes(1280, 17, 8, 0) == groups + 40 * 10 * 2048 + 160 * 8
-    # 72 depth bins (the metric string's shape): no joint-group sections (a joint's 73 rows exceed the
-    # 64-row tile), 17 atoms of 5 row tiles for the row-tile core
+    # f32 features: the row-tile blob = 40 stages x 10 tiles x 2 KiB + 160 rows x (bias f32 + label i32)
+    assert lib.mtr_head_packed_bytes(1280, 17, 8, 0) == 40 * 10 * 2048 + 160 * 8
+    # 72 depth bins (the metric string's shape): 17 atoms of 5 row tiles
     assert lib.mtr_head_packed_bytes(1280, 17, 72, 0) == 40 * 85 * 2048 + 85 * 16 * 8
     assert lib.mtr_head_packed_bytes(1280, 17, 81, 0) == 0  # > 80 depth bins: library GEMM + decode
+    # f16 features: 3 joint groups x 64 rows of bias (f32) + 3 x 20 stages x 64 rows x 64 channels x 2 B
+    assert lib.mtr_head_packed_bytes(1280, 17, 8, 1) == 3 * 64 * 4 + 3 * 20 * 64 * 64 * 2
+    assert lib.mtr_head_packed_bytes(1283, 17, 8, 1) == 0   # C % 8 != 0: no 16-byte operands
+    assert lib.mtr_head_packed_bytes(1280, 17, 72, 2) == 0  # a joint's 73 rows exceed the 64-row group
     assert lib.mtr_reconstruct_workspace_bytes(64, 17) == (4 + 2 * 16) * 8
 
 

@@ -38,10 +38,10 @@ GOLDEN_BOUNDS = {
 }
 
 
-def run_fused(feat, w, b, J, cfg):
+def run_fused(feat, w, b, J, cfg, **options):
     from metrabs_amd import kernels
     packed = kernels.head_pack_weights(w.cuda(), b.cuda(), J, cfg.depth, feat.dtype)
-    c2d, c3d = kernels.head_fused(feat.cuda(), packed, w.shape[1], J, mcfg(cfg))
+    c2d, c3d = kernels.head_fused(feat.cuda(), packed, w.shape[1], J, mcfg(cfg), **options)
     return c2d.cpu(), c3d.cpu()
 
 
@@ -90,10 +90,10 @@ def test_fused_head_vs_golden(name, hip_lib):
                                    (2, 64, 9, 5, 8, 8), (2, 40, 6, 16, 10, 10), (1, 32, 2, 80, 4, 4),
                                    (2, 64, 3, 72, 12, 12), (1, 1280, 17, 8, 8, 8)])
 def test_fused_head_odd_shapes_vs_oracle(shape, hip_lib):
-    """C not a multiple of the 32-channel stage (odd and even stage counts), J not filling the joint
-    groups, every tile count of both GEMM cores (16x16: HW <= 32 and > 128; 32x32: 2, 3 and 4
-    column tiles), non-square maps, D != 8, B not a multiple of the 8-crop XCD chunk: vs the
-    oracle's conv+decode on the same seeded inputs."""
+    """C not a multiple of the 32-channel stage (odd and even stage counts), J not filling a row
+    tile, maps of less than one / exactly one / several 64-position column blocks, non-square maps,
+    D = 4 .. 80 (one-tile atoms with 1 - 4 joints per tile, multi-tile atoms), B not a multiple of
+    the 8-crop XCD chunk: vs the oracle's conv+decode on the same seeded inputs."""
     B, C, J, D, H, W = shape
     cfg = cpu_ref.HeadConfig(depth=D, proc_side=max(H, W) * 8, stride_test=8, stride_train=8)
     g = cases.gen(8000 + sum(shape))
@@ -139,12 +139,16 @@ def test_fused_head_16bit_features(dtype, hip_lib):
 def test_fused_head_16bit_odd_shapes(shape, dtype, hip_lib):
     """The 16-bit MFMA kernel on every column-tile count (1 .. 8 tiles of 32 positions), C not a
     multiple of its 64-channel stage (fewer stages than the prefetch depth included), ragged joint
-    groups, both layouts; C % 8 != 0 takes the f32 cores.  C % 64 == 0 is staged by global_load_lds
-    (NCHW additionally needs whole 16-byte chunks per channel row, H*W % 8 == 0 and >= 64, and is
-    transposed by ds_read_b64_tr_b16): one-stage K loops, 9 / 12 / 16 / 20 / 32 chunks per row.
-    The register-staged twin of every such shape runs in the MTR_HEAD_DMA=0 variant below."""
+    groups, both layouts; C % 8 != 0 has no fused kernel (library GEMM + decode, checked through
+    MetrabsHeads).  C % 64 == 0 is staged by global_load_lds (NCHW additionally needs whole 16-byte
+    chunks per channel row, H*W % 8 == 0 and >= 64, and is transposed by ds_read_b64_tr_b16):
+    one-stage K loops, 9 / 12 / 16 / 20 / 32 chunks per row.  Every explicit dispatch choice
+    (register staging, 1 / 2 / 3 joint groups per workgroup) must give the SAME bits: the k-order of
+    every MFMA chain is identical, only staging and work split differ."""
     from metrabs_amd import kernels
     B, C, J, D, H, W = shape
+    if C % 8:
+        return _check_unfused_16bit(shape, dtype)
     cfg = cpu_ref.HeadConfig(depth=D, proc_side=max(H, W) * 8, stride_test=8, stride_train=8)
     g = cases.gen(8300 + sum(shape))
     feat = torch.randn(B, C, H, W, generator=g).to(dtype)
@@ -156,11 +160,36 @@ def test_fused_head_16bit_odd_shapes(shape, dtype, hip_lib):
     print(f'[parity] fused head 16-bit {shape} {dtype}: max {float((c3d - o3d).abs().max()):.2e} mm')
     assert float((c3d - o3d).abs().max()) <= 2e-3 and cpu_ref.mpjpe(c3d, o3d) <= 1e-3
     assert float((c2d - o2d).abs().max()) <= 4e-4
+    for options in (dict(dma_staging=0), dict(groups_per_workgroup=1), dict(groups_per_workgroup=2),
+                    dict(groups_per_workgroup=3), dict(groups_per_workgroup=2, dma_staging=0)):
+        v2d, v3d = run_fused(feat, w, b, J, cfg, **options)
+        assert torch.equal(v3d, c3d) and torch.equal(v2d, c2d), options
     if C % 4 == 0:
         packed = kernels.head_pack_weights(w.cuda(), b.cuda(), J, D, dtype)
         l2d, l3d = kernels.head_fused(feat.cuda().contiguous(memory_format=torch.channels_last),
                                       packed, C, J, mcfg(cfg))
         assert float((l3d.cpu() - o3d).abs().max()) <= 2e-3 and float((l2d.cpu() - o2d).abs().max()) <= 4e-4
+
+
+def _check_unfused_16bit(shape, dtype):
+    """16-bit features, C % 8 != 0: mtr_head_packed_bytes answers 0 and MetrabsHeads runs the 1x1 conv
+    as a library GEMM (16-bit logits, as under autocast) + mtr_softargmax_decode.  Sanity bound: the
+    logits are rounded to 11 / 8 bits."""
+    from metrabs_amd import _lib, kernels
+    from metrabs_amd.config import MetrabsConfig
+    from metrabs_amd.models.metrabs import MetrabsHeads
+    B, C, J, D, H, W = shape
+    assert _lib.load().mtr_head_packed_bytes(C, J, D, kernels.dtype_code(dtype)) == 0
+    assert not kernels.head_fused_supported(C, J, D, H, W, dtype=dtype)
+    cfg = MetrabsConfig(depth=D, proc_side=max(H, W) * 8, stride_test=8, stride_train=8)
+    heads = MetrabsHeads(J, cfg, in_channels=C, fused=True).cuda()
+    g = cases.gen(8300 + sum(shape))
+    feat = torch.randn(B, C, H, W, generator=g)
+    with torch.inference_mode():
+        c2d, c3d = heads(feat.to(dtype).cuda())
+        r2d, r3d = heads(feat.cuda())
+    assert c3d.dtype == torch.float32 and torch.isfinite(c3d).all()
+    assert float((c3d - r3d).abs().max()) <= (0.5 if dtype == torch.float16 else 4.0) * cfg.box_size_mm / 2200
 
 
 def test_fused_equals_unfused_and_module(hip_lib):
@@ -297,26 +326,41 @@ def test_fused_head_channels_last_features(shape, dtype, hip_lib):
     assert float((c3d.cpu() - o3d).abs().max()) <= 2e-3
 
 
-@pytest.mark.parametrize('env', [{'MTR_HEAD_F32': 'groups', 'MTR_HEAD_CORE': '16'},
-                                 {'MTR_HEAD_F32': 'groups', 'MTR_HEAD_W8': '0'},
-                                 {'MTR_HEAD_F32': 'groups', 'MTR_HEAD_W8': '1'},
-                                 {'MTR_HEAD_H16': '0'}, {'MTR_HEAD_DMA': '0'},
-                                 {'MTR_HEAD_RTG': '1'}, {'MTR_HEAD_RTG': '2'}, {'MTR_HEAD_RTG': '5'}],
-                         ids=['core16', 'w4', 'w8', 'f32core_on_16bit', 'nhwc16_through_registers',
-                              'rowtile_1', 'rowtile_2', 'rowtile_5'])
-def test_every_gemm_variant_on_all_shapes_subprocess(env, hip_lib):
-    """Three GEMM kernels sit behind mtr_head_fused: the 16x16x4 core, the 4-wave 32x32x2 kernel and
-    its 8-wave K-split variant for small launches.  The dispatch picks by map size and launch size;
-    the MTR_HEAD_CORE / MTR_HEAD_W8 switches (read once per process) force one of them.  Re-run this
-    file's parity tests under each, so every kernel is held to the same bounds on every shape."""
-    import os
-    import subprocess
-    import sys
-    if any(os.environ.get(k) for k in ('MTR_HEAD_CORE', 'MTR_HEAD_W8', 'MTR_HEAD_H16', 'MTR_HEAD_DMA',
-                                       'MTR_HEAD_F32', 'MTR_HEAD_RTG')):
-        pytest.skip('already inside a forced-variant run')
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-m', 'gpu',
-                        '-k', 'golden or odd_shapes or 16bit or channels_last or full_size'],
-                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=900,
-                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+@pytest.mark.parametrize('rt_tiles', [1, 2, 3, 4, 5])
+def test_every_row_tile_block_size_gives_the_same_bits(rt_tiles, hip_lib):
+    """The row-tile core picks the tiles per workgroup from the launch size (3 for small launches,
+    equal blocks of <= 5 otherwise); mtr_head_options.rt_tiles_per_workgroup forces one.  Every
+    choice runs the same MFMA chains on the same rows, so the results must be bit-identical -- on
+    the golden cases and on the odd shapes (ragged last blocks, multi-column-block maps, NHWC)."""
+    from metrabs_amd import kernels
+    for name in cases.HEADCONV_CASES:
+        feat, w, b, J, cfg = cases.headconv_case(name)
+        a2d, a3d = run_fused(feat, w, b, J, cfg)
+        v2d, v3d = run_fused(feat, w, b, J, cfg, rt_tiles=rt_tiles)
+        assert torch.equal(v3d, a3d) and torch.equal(v2d, a2d), name
+    for shape in [(3, 40, 17, 8, 8, 8), (2, 33, 17, 8, 12, 12), (1, 64, 3, 8, 16, 16), (10, 31, 17, 8, 8, 8),
+                  (2, 48, 17, 8, 24, 24), (2, 64, 9, 5, 8, 8), (2, 40, 6, 16, 10, 10), (2, 32, 122, 8, 12, 12)]:
+        B, C, J, D, H, W = shape
+        cfg = cpu_ref.HeadConfig(depth=D, proc_side=max(H, W) * 8, stride_test=8, stride_train=8)
+        g = cases.gen(8000 + sum(shape))
+        feat = torch.randn(B, C, H, W, generator=g)
+        w, b = cases.default_conv_init(J * (1 + D), C, g)
+        a2d, a3d = run_fused(feat, w * 3, b * 3, J, cfg)
+        v2d, v3d = run_fused(feat, w * 3, b * 3, J, cfg, rt_tiles=rt_tiles)
+        assert torch.equal(v3d, a3d) and torch.equal(v2d, a2d), shape
+        if C % 4 == 0:
+            packed = kernels.head_pack_weights((w * 3).cuda(), (b * 3).cuda(), J, D)
+            l2d, l3d = kernels.head_fused(feat.cuda().contiguous(memory_format=torch.channels_last),
+                                          packed, C, J, mcfg(cfg), rt_tiles=rt_tiles)
+            assert torch.equal(l3d.cpu(), a3d) and torch.equal(l2d.cpu(), a2d), shape
+
+
+def test_head_options_are_validated(hip_lib):
+    from metrabs_amd import kernels
+    from metrabs_amd.config import MetrabsConfig
+    w, b = cases.default_conv_init(153, 64, cases.gen(1))
+    packed = kernels.head_pack_weights(w.cuda(), b.cuda(), 17, 8)
+    feat = torch.randn(2, 64, 8, 8, device='cuda')
+    for bad in (dict(rt_tiles=6), dict(groups_per_workgroup=4), dict(dma_staging=2)):
+        with pytest.raises(RuntimeError):
+            kernels.head_fused(feat, packed, 64, 17, MetrabsConfig(), **bad)

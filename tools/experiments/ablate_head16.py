@@ -51,7 +51,7 @@ def run_one(name):
     var.mtr_head_fused.restype = ctypes.c_int
     var.mtr_head_fused.argtypes = base.mtr_head_fused.argtypes
     g = torch.Generator(device='cuda').manual_seed(0)
-    res = {'variant': name, 'gpw': os.environ.get('MTR_HEAD_GPW', '0')}
+    res = {'variant': name, 'gpw': os.environ.get('HEAD_GPW', '0')}
     for cname, B, J, side, nhwc in CASES:
         feat = torch.randn(B, 1280, side, side, device='cuda', generator=g).half()
         if nhwc:
@@ -91,6 +91,6 @@ if __name__ == '__main__':
         for name in VARIANTS:
             for gpw in GPWS:
                 subprocess.run([sys.executable, os.path.abspath(__file__), 'one', name], check=False,
-                               env=dict(os.environ, MTR_HEAD_GPW=gpw))
+                               env=dict(os.environ, HEAD_GPW=gpw))
     else:
         run_one(sys.argv[2])

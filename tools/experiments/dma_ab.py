@@ -1,5 +1,5 @@
-"""NHWC 16-bit fused head, graph-replayed timing under the current environment (MTR_HEAD_DMA,
-MTR_HEAD_GPW): developer A/B probe."""
+"""NHWC 16-bit fused head, graph-replayed timing for explicit dispatch choices (HEAD_DMA = 0 / 1,
+HEAD_GPW = 1..3 in the environment of THIS tool -> mtr_head_options): developer A/B probe."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from metrabs_amd import kernels
@@ -35,5 +35,5 @@ for name, B, C, J, side in [('B64', 64, 1280, 17, 8), ('B256', 256, 1280, 17, 8)
     packed = kernels.head_pack_weights(w, torch.zeros(J * 9, device='cuda'), J, 8, torch.float16)
     cfg = MetrabsConfig(proc_side=side * 32)
     o = (torch.empty(B, J, 2, device='cuda'), torch.empty(B, J, 3, device='cuda'))
-    res[name] = round(timed(lambda: kernels.head_fused(feat, packed, C, J, cfg, out=o)), 1)
-print(f"DMA={os.environ.get('MTR_HEAD_DMA', '0')} GPW={os.environ.get('MTR_HEAD_GPW', 'auto')}: {res}", flush=True)
+    res[name] = round(timed(lambda: kernels.head_fused(feat, packed, C, J, cfg, out=o, dma_staging=int(os.environ.get('HEAD_DMA', '-1')), groups_per_workgroup=int(os.environ.get('HEAD_GPW', '0')))), 1)
+print(f"DMA={os.environ.get('HEAD_DMA', 'auto')} GPW={os.environ.get('HEAD_GPW', 'auto')}: {res}", flush=True)

@@ -1,6 +1,5 @@
 """f32 fused head: row-tile core vs the library pair (1x1 conv + HIP decode), graph-replayed, with
-the distance of each to the fp64 evaluation.  MTR_HEAD_F32=groups / MTR_HEAD_RTG=n in the environment
-select the old joint-group cores / the tiles per workgroup (read once per process).
+the distance of each to an fp64 evaluation (restated inline: tools never import oracle/).
 
     python tools/experiments/head_rt_ab.py [tag]
 """
@@ -9,7 +8,22 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from metrabs_amd.config import MetrabsConfig
 from metrabs_amd.models.metrabs import MetrabsHeads
-from oracle import cpu_ref
+
+
+def coords3d_fp64(logits, J, D, box_mm=2200.0):
+    """models/metrabs.py:78-83 in float64: joint softmax over (d, h, w), expectation per axis,
+    heatmap_to_metric (models/util.py:20-33) at stride 32, centered stride."""
+    B, _, H, W = logits.shape
+    x = logits[:, J:].reshape(B, D, J, H, W).double()
+    p = torch.softmax(x.permute(0, 2, 1, 3, 4).reshape(B, J, -1), dim=-1).reshape(B, J, D, H, W)
+    lin = lambda n: torch.linspace(0, 1, n, dtype=torch.float64) if n > 1 else torch.full((1,), 0.5, dtype=torch.float64)
+    cx = (p.sum((2, 3)) * lin(W)).sum(-1)
+    cy = (p.sum((2, 4)) * lin(H)).sum(-1)
+    cz = (p.sum((3, 4)) * lin(D)).sum(-1)
+    P = H * 32
+    px = lambda c: c * (P - 1 - ((P - 1) % 32)) + 16
+    return torch.stack([px(cx) * box_mm / P, px(cy) * box_mm / P, cz * box_mm], dim=-1)
+
 
 
 def timed(fn, n=20, reps=10):
@@ -51,7 +65,7 @@ for (B, C, J, D, H, nhwc) in SHAPES:
     with torch.inference_mode():
         sub = feat[:4].double().cpu().contiguous()
         logits = torch.einsum('nc,bchw->bnhw', w, sub) + b[None, :, None, None]
-        t2, t3 = cpu_ref.heads_from_logits(logits, J, cpu_ref.HeadConfig(depth=D, proc_side=H * 32))
+        t3 = coords3d_fp64(logits, J, D)
         for fused in ((True,) if only_fused else (True, False)):
             heads.fused = fused
             key = 'fused' if fused else 'library'

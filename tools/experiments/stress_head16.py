@@ -32,7 +32,7 @@ def run(seed0, n, gpw):
         f = feat.cuda()
         if nhwc:
             f = f.contiguous(memory_format=torch.channels_last)
-        c2, c3 = kernels.head_fused(f, packed, C, J, MetrabsConfig.from_any(cfg.as_dict()))
+        c2, c3 = kernels.head_fused(f, packed, C, J, MetrabsConfig.from_any(cfg.as_dict()), groups_per_workgroup=int(os.environ.get('HEAD_GPW', '0')))
         e3, e2 = float((c3.cpu() - o3).abs().max()), float((c2.cpu() - o2).abs().max())
         worst = max(worst, e3)
         if not (e3 <= 2e-3 and e2 <= 4e-4) or not torch.isfinite(c3).all():
@@ -42,8 +42,8 @@ def run(seed0, n, gpw):
 
 if __name__ == '__main__':
     if len(sys.argv) > 1:
-        run(int(sys.argv[1]), int(sys.argv[2]), os.environ.get('MTR_HEAD_GPW', '0'))
+        run(int(sys.argv[1]), int(sys.argv[2]), os.environ.get('HEAD_GPW', '0'))
     else:
         for gpw in ('0', '1', '2', '3'):
             subprocess.run([sys.executable, os.path.abspath(__file__), str(11 + int(gpw)), '150'],
-                           env=dict(os.environ, MTR_HEAD_GPW=gpw))
+                           env=dict(os.environ, HEAD_GPW=gpw))

@@ -52,7 +52,7 @@ def bench_decode():
 def bench_head():
     out = []
     g = torch.Generator(device='cuda').manual_seed(0)
-    core = os.environ.get('MTR_HEAD_CORE', 'auto')
+    core = 'row-tile (f32) / joint-group MFMA (16-bit)'
     for name, B, C, J, H, dt, nhwc in [('cfg2 B=64 f32', 64, 1280, 17, 8, torch.float32, False),
                                        ('cfg2 B=64 f32 nhwc', 64, 1280, 17, 8, torch.float32, True),
                                        ('cfg2 B=64 f16', 64, 1280, 17, 8, torch.float16, False),
