@@ -4,14 +4,15 @@ metrabs_pytorch CPU path -- as HARD gates at every BASELINE.json config shape, i
 * 'consistent_low' / 'consistent_peaked': features + default-initialised conv_final whose logits
   describe a plausible pose (cases.consistent_head_case: Gaussian bumps of height 4, |logit| <= 5,
   or height 25 around each joint; the person fills the crop 2.5 - 4.5 m from the camera).
-  Gate: MPJPE(ours, oracle) <= 1e-3 mm and MPJPE(ours, fp64) <= 1e-3 mm.  No escape clause.
+  Gate: MPJPE(ours, oracle) <= 1e-3 mm and MPJPE(ours, fp64) <= 5e-4 mm as fixed numbers (two
+  documented exceptions where the oracle itself is > 1e-3 mm from fp64: CONSISTENT_BOUND).
 * 'random_head': N(0,1) features x default-initialised conv_final x 8 (logits +-25), the kind of
   input bench.py's random network produces.  Its heatmaps are nearly uniform, all joints decode to
   the crop centre and the reference-point depth -- the ratio of two vanishing spreads -- is
   ill-conditioned (median depth ~0 mm): the reference's own fp32 result is 1e-3 ... 4e-3 mm from an
   fp64 evaluation of the same formulas, so no implementation can sit within 1e-3 mm of it.  Gates
   there: FIXED numbers per case (~2x the values measured when they were set,
-  profiles/r02_parity_report.jsonl) on ours-vs-fp64 and on ours-vs-oracle, so that a head that
+  profiles/r02b_parity_report.jsonl) on ours-vs-fp64 and on ours-vs-oracle, so that a head that
   gets noisier fails whatever the oracle's own floor does.
 
 f16 features (configs[4]): the oracle evaluates the f32 conv on the same rounded features and
@@ -40,19 +41,28 @@ SHAPES = {
     'metric string: 72 depth bins, 256 px, B=64': (64, 1280, 17, 8, 256, 72, torch.float32),
 }
 
-# mm: (MPJPE ours-vs-fp64, MPJPE ours-vs-oracle, max-abs ours-vs-oracle)
+# mm: (MPJPE ours-vs-fp64, MPJPE ours-vs-oracle, max-abs ours-vs-oracle); measured r02b (profiles/
+# r02b_parity_report.jsonl): ours-vs-fp64 2.7e-4 .. 6.6e-4, ours-vs-oracle 7.3e-4 .. 1.5e-3 (= the
+# oracle's own 6.7e-4 .. 1.3e-3 from fp64), max 2.9e-3 .. 5.9e-3
 RANDOM_HEAD_BOUNDS = {
-    'configs[0] ResNet-18 256 B=1': (2e-3, 1e-2, 5e-2),
-    'configs[1] EffNetV2-S 256 B=64': (2e-3, 1e-2, 5e-2),
-    'configs[2] EffNetV2-L 384 B=32/GPU': (2e-3, 1e-2, 5e-2),
-    'configs[2] EffNetV2-L 384 B=256 on one GPU': (2e-3, 1e-2, 5e-2),
-    'configs[3] MobileNetV3 256, 8 boxes x 5 aug': (2e-3, 1e-2, 5e-2),
-    'configs[4] EffNetV2-L 384 f16 J=122 B=32/GPU': (2e-3, 1e-2, 5e-2),
-    'metric string: 72 depth bins, 256 px, B=64': (2e-3, 1e-2, 5e-2),
+    'configs[0] ResNet-18 256 B=1': (6e-4, 3e-3, 6e-3),
+    'configs[1] EffNetV2-S 256 B=64': (7e-4, 2e-3, 1e-2),
+    'configs[2] EffNetV2-L 384 B=32/GPU': (7e-4, 1.5e-3, 6e-3),
+    'configs[2] EffNetV2-L 384 B=256 on one GPU': (7e-4, 1.5e-3, 7e-3),
+    'configs[3] MobileNetV3 256, 8 boxes x 5 aug': (7e-4, 2e-3, 8e-3),
+    'configs[4] EffNetV2-L 384 f16 J=122 B=32/GPU': (1.3e-3, 2e-3, 1.2e-2),
+    'metric string: 72 depth bins, 256 px, B=64': (7e-4, 2.2e-3, 1.2e-2),
 }
-# consistent heads: 1e-3 mm everywhere except where the ORACLE's own fp32 conv is farther than that
-# from fp64 (72 depth bins, peaked: 1,241 output rows on K = 1280 -> features of std 35)
-CONSISTENT_BOUND = {('metric string: 72 depth bins, 256 px, B=64', 'consistent_peaked'): 2.5e-3}
+# consistent heads, MPJPE ours-vs-oracle: 1e-3 mm everywhere (measured 4.4e-4 .. 9.0e-4) except the
+# two cases where the ORACLE's own fp32 result is farther than that from fp64:
+#  * configs[0] is ONE crop: MPJPE over its 17 joints is the error of one reference point, and the
+#    oracle's fp32 lstsq lands 1.9e-3 mm from fp64 on this crop (ours: 2.2e-4);
+#  * 72 depth bins, peaked: 1,241 output rows on K = 1280 make the minimum-norm features large
+#    (std 40): the oracle's conv is 1.5e-3 mm from fp64 (ours: 5.3e-4).
+CONSISTENT_BOUND = {('configs[0] ResNet-18 256 B=1', 'consistent_low'): 3e-3,
+                    ('metric string: 72 depth bins, 256 px, B=64', 'consistent_peaked'): 2.5e-3}
+# ... and MPJPE ours-vs-fp64: 5e-4 mm everywhere (measured 1.2e-4 .. 3.3e-4), 1e-3 for the second one
+CONSISTENT_FP64_BOUND = {('metric string: 72 depth bins, 256 px, B=64', 'consistent_peaked'): 1e-3}
 
 
 def make_inputs(name, regime):
@@ -114,7 +124,7 @@ def test_plausible_poses_are_within_1e3_mm_of_the_reference(name, regime, hip_li
     assert r['median_depth_mm'] > 1500  # a person in front of the camera, not a degenerate solve
     assert (r['logits_absmax'] <= 5.5) if regime == 'consistent_low' else (r['logits_absmax'] >= 20)
     assert r['mpjpe_ours_vs_ref'] <= bound, r
-    assert r['mpjpe_ours_vs_fp64'] <= bound, r
+    assert r['mpjpe_ours_vs_fp64'] <= CONSISTENT_FP64_BOUND.get((name, regime), 5e-4), r
 
 
 @pytest.mark.parametrize('name', list(SHAPES))
