@@ -6,78 +6,185 @@
 // runs these layers with its naive direct kernel and PyTorch's own depthwise kernel takes ~61 us
 // per layer at the bench shape, followed by the bias / activation / mean passes; here a (b, c)
 // plane is read once and written once: HBM-bound, the taps re-read the plane out of L1.
-// Mapping: LPP lanes share a plane (its groups of four horizontally adjacent outputs strided over
-// them), 64 / LPP planes per wave; each lane keeps the channel's nine weights in registers.
 #include "common.h"
 
 namespace mtr {
 
-template <typename T, int ACT, int STRIDE>
+// Work item of a wave = 64 groups of four horizontally adjacent outputs: one 16x16 plane, four
+// 8x8 planes, a quarter of a 32x32 plane.  A (b, c) plane is 0.25 - 4 KB, so a wave that handles
+// one item and exits spends its life in two dependent latencies (weights, then taps): the first
+// version ran at 38 % of the HBM spec.  Here the grid is persistent (a few waves per SIMD) and
+// every wave walks its items with the raw taps AND weights of the next two items already in
+// flight (a ring of three register sets, the loop unrolled over it); zeroing of out-of-plane taps
+// happens when an item is finished, not when it is loaded, so that nothing waits on a load that
+// was just issued.  Rows with pad 1 and W % 4 == 0 (every layer of the backbones at the shipped
+// resolutions) are read as aligned vectors: stride 1 = one vector + two edge elements per row,
+// stride 2 = two vectors + the left edge element.
+struct DwGeom {
+  int n_planes;
+  int C, H, W, OH, OW, pad;
+  int lpp;        // lanes per plane inside an item (power of two <= 64)
+  int chunks;     // items per plane group (> 1: planes of more than 64 groups)
+  int groups;     // groups of four outputs per plane = OH * OW / 4
+  int n_pg;       // plane groups = ceil(n_planes / (64 / lpp))
+  float inv_hw;
+};
+
+template <typename T, int STRIDE>
+struct DwRaw {
+  static constexpr int NV = STRIDE;  // aligned 4-element vectors per row
+  struct alignas(4 * sizeof(T)) V4 { T v[4]; };
+  V4 mid[3][NV];
+  T edge[3][2];          // [left, right]; stride 2 uses the left one only
+  T tap[3][3 * STRIDE + 3];  // scalar path (pad 0 or unaligned rows)
+  float w[9], b;
+};
+
+template <typename T, int STRIDE, bool VEC>
+__device__ __forceinline__ void dw_issue(const T* __restrict__ x, const float* __restrict__ w,
+                                         const float* __restrict__ bias, const DwGeom& g, int p,
+                                         int v, DwRaw<T, STRIDE>& r) {
+  using Raw = DwRaw<T, STRIDE>;
+  constexpr int NIN = 3 * STRIDE + 3;
+  const int c = (int)((unsigned)p % (unsigned)g.C);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) r.w[k] = w[c * 9 + k];
+  r.b = bias[c];
+  const int ow4 = g.OW >> 2;
+  const int oy = v / ow4, ox0 = (v - oy * ow4) << 2;
+  const T* xp = x + (size_t)p * (size_t)(g.H * g.W);
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    int iy = oy * STRIDE - g.pad + ky;
+    iy = iy < 0 ? 0 : (iy >= g.H ? g.H - 1 : iy);  // clamped: masked when the item is finished
+    const T* row = xp + iy * g.W;
+    if constexpr (VEC) {
+      const int ix0 = ox0 * STRIDE;  // first centre column (pad 1: column ix0 - 1 is the left edge)
+#pragma unroll
+      for (int n = 0; n < Raw::NV; ++n)
+        r.mid[ky][n] = *reinterpret_cast<const typename Raw::V4*>(row + ix0 + 4 * n);
+      r.edge[ky][0] = row[ix0 > 0 ? ix0 - 1 : 0];
+      if constexpr (STRIDE == 1) r.edge[ky][1] = row[ix0 + 4 < g.W ? ix0 + 4 : 0];
+    } else {
+#pragma unroll
+      for (int j = 0; j < NIN; ++j) {
+        int ix = ox0 * STRIDE - g.pad + j;
+        ix = ix < 0 ? 0 : (ix >= g.W ? g.W - 1 : ix);
+        r.tap[ky][j] = row[ix];
+      }
+    }
+  }
+}
+
+template <typename T, int ACT, int STRIDE, bool VEC>
+__device__ __forceinline__ float dw_finish(T* __restrict__ y, const DwGeom& g, int p, int v,
+                                           bool live, const DwRaw<T, STRIDE>& r) {
+  constexpr int NIN = 3 * STRIDE + 3;
+  struct alignas(4 * sizeof(T)) Out4 { T v[4]; };
+  const int ow4 = g.OW >> 2;
+  const int oy = v / ow4, ox0 = (v - oy * ow4) << 2;
+  float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy * STRIDE - g.pad + ky;
+    const bool row_ok = iy >= 0 && iy < g.H;
+    float in[NIN];
+    if constexpr (VEC) {
+      const int ix0 = ox0 * STRIDE;
+      in[0] = (row_ok && ix0 > 0) ? to_f32(r.edge[ky][0]) : 0.0f;
+#pragma unroll
+      for (int n = 0; n < STRIDE; ++n)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) in[1 + 4 * n + j] = row_ok ? to_f32(r.mid[ky][n].v[j]) : 0.0f;
+      if constexpr (STRIDE == 1) in[5] = (row_ok && ix0 + 4 < g.W) ? to_f32(r.edge[ky][1]) : 0.0f;
+    } else {
+#pragma unroll
+      for (int j = 0; j < NIN; ++j) {
+        const int ix = ox0 * STRIDE - g.pad + j;
+        in[j] = (row_ok && ix >= 0 && ix < g.W) ? to_f32(r.tap[ky][j]) : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) acc[o] = fmaf(in[o * STRIDE + kx], r.w[ky * 3 + kx], acc[o]);
+  }
+  Out4 out;
+  float sum = 0.0f;
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    const float a = activate<ACT>(acc[o] + r.b);
+    if constexpr (sizeof(T) == 4) out.v[o] = a; else out.v[o] = T(a);
+    sum += to_f32(out.v[o]);
+  }
+  if (live) *reinterpret_cast<Out4*>(y + (size_t)p * (size_t)(g.OH * g.OW) + oy * g.OW + ox0) = out;
+  return live ? sum : 0.0f;
+}
+
+template <typename T, int ACT, int STRIDE, bool VEC>
 __global__ __launch_bounds__(256) void depthwise3x3_kernel(
     const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-    T* __restrict__ y, float* __restrict__ row_mean, long long n_planes, int C, int H, int W, int OH,
-    int OW, int pad, int lpp, float inv_hw) {
-  constexpr int NIN = 3 * STRIDE + 3;  // input columns feeding four adjacent outputs
-  struct alignas(4 * sizeof(T)) Out4 { T v[4]; };
-  const int lane = threadIdx.x & 63, sub = lane & (lpp - 1);
-  const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const long long plane = wave * (64 / lpp) + lane / lpp;
-  const bool live = plane < n_planes;
-  const long long p = live ? plane : n_planes - 1;  // idle lanes recompute the last plane, no store
-  const int c = (int)(p % C);
-  float wk[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) wk[k] = w[c * 9 + k];
-  const float b = bias[c];
-  const T* xp = x + p * (long long)H * W;
-  T* yp = y + p * (long long)OH * OW;
-  const int ow4 = OW >> 2, nvec = OH * ow4;
-  const bool vec_rows = STRIDE == 1 && pad == 1 && (W & 3) == 0;  // (wave-uniform)
+    T* __restrict__ y, float* __restrict__ row_mean, DwGeom g) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & (g.lpp - 1), pl = lane / g.lpp, ppi = 64 / g.lpp;
+  const int n_waves = (int)gridDim.x * (int)(blockDim.x >> 6);
+  const int wave = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+  // items of this wave, in order: plane groups wave, wave + n_waves, ...; inside a group its chunks
+  int pg_i[3];
+  int ch_i[3];
+  auto item_plane = [&](int pg, int& p, bool& live) {
+    const int plane = pg * ppi + pl;
+    live = pg < g.n_pg && plane < g.n_planes;
+    p = live ? plane : g.n_planes - 1;  // dead lanes / items recompute the last plane, no store
+  };
+  auto item_group = [&](int ch, bool& live) {
+    const int v = ch * 64 + sub;  // (lpp < 64: one chunk, v = sub)
+    if (v >= g.groups) live = false;
+    return v < g.groups ? v : g.groups - 1;
+  };
+  auto advance = [&](int& pg, int& ch) {
+    if (++ch == g.chunks) { ch = 0; pg += n_waves; }
+  };
+  DwRaw<T, STRIDE> r0, r1, r2;
+  int pg = wave;
+  int ch = 0;
+  auto issue = [&](DwRaw<T, STRIDE>& r, int slot) {
+    pg_i[slot] = pg; ch_i[slot] = ch;
+    int p; bool live;
+    item_plane(pg, p, live);
+    const int v = item_group(ch, live);
+    dw_issue<T, STRIDE, VEC>(x, w, bias, g, p, v, r);
+    advance(pg, ch);
+  };
   float sum = 0.0f;
-  for (int v = sub; v < nvec; v += lpp) {
-    const int oy = v / ow4, ox0 = (v - oy * ow4) << 2;
-    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int iy = oy * STRIDE - pad + ky;
-      const bool row_ok = iy >= 0 && iy < H;
-      const T* row = xp + (row_ok ? iy : 0) * W;
-      float in[NIN];
-      if (STRIDE == 1 && vec_rows) {
-        // stride 1, pad 1, W % 4 == 0: the four centre taps are one aligned vector, the two outer
-        // ones single elements (zero at the plane's edge)
-        struct alignas(4 * sizeof(T)) In4 { T v[4]; };
-        const In4 mid = *reinterpret_cast<const In4*>(row + ox0);
-        const T lft = row[ox0 > 0 ? ox0 - 1 : 0], rgt = row[ox0 + 4 < W ? ox0 + 4 : 0];
-        in[0] = (row_ok && ox0 > 0) ? to_f32(lft) : 0.0f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) in[1 + j] = row_ok ? to_f32(mid.v[j]) : 0.0f;
-        in[5] = (row_ok && ox0 + 4 < W) ? to_f32(rgt) : 0.0f;
-      } else {
-#pragma unroll
-        for (int j = 0; j < NIN; ++j) {
-          const int ix = ox0 * STRIDE - pad + j;
-          const bool ok = row_ok && ix >= 0 && ix < W;
-          in[j] = ok ? to_f32(row[ok ? ix : 0]) : 0.0f;
-        }
-      }
-#pragma unroll
-      for (int o = 0; o < 4; ++o)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) acc[o] = fmaf(in[o * STRIDE + kx], wk[ky * 3 + kx], acc[o]);
+  auto finish = [&](const DwRaw<T, STRIDE>& r, int slot) {
+    int p; bool live;
+    item_plane(pg_i[slot], p, live);
+    const int v = item_group(ch_i[slot], live);
+    sum += dw_finish<T, ACT, STRIDE, VEC>(y, g, p, v, live, r);
+    if (row_mean && ch_i[slot] == g.chunks - 1) {  // (wave-uniform) the plane group is complete
+      float s = sum;
+      for (int m = g.lpp >> 1; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+      bool alive; int pp;
+      item_plane(pg_i[slot], pp, alive);
+      if (alive && sub == 0) row_mean[pp] = s * g.inv_hw;
+      sum = 0.0f;
     }
-    Out4 out;
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      const float r = activate<ACT>(acc[o] + b);
-      if constexpr (sizeof(T) == 4) out.v[o] = r; else out.v[o] = T(r);
-      sum += to_f32(out.v[o]);
-    }
-    if (live) *reinterpret_cast<Out4*>(yp + oy * OW + ox0) = out;
-  }
-  if (row_mean) {
-    for (int m = lpp >> 1; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
-    if (live && sub == 0) row_mean[plane] = sum * inv_hw;
+  };
+  if (wave >= g.n_pg) return;  // (whole wave)
+  issue(r0, 0);
+  issue(r1, 1);
+  // items of this wave: ceil((n_pg - wave) / n_waves) * chunks
+  const int n_items = ((g.n_pg - wave + n_waves - 1) / n_waves) * g.chunks;
+  for (int i = 0; i < n_items; i += 3) {
+    issue(r2, 2);
+    finish(r0, 0);
+    if (i + 1 >= n_items) break;
+    issue(r0, 0);
+    finish(r1, 1);
+    if (i + 2 >= n_items) break;
+    issue(r1, 1);
+    finish(r2, 2);
   }
 }
 
@@ -85,18 +192,28 @@ template <typename T, int STRIDE>
 static int launch_depthwise(const void* x, const float* w, const float* bias, int act, void* y,
                             float* row_mean, long long n_planes, int C, int H, int W, int OH, int OW,
                             int pad, hipStream_t stream) {
-  const int nvec = OH * (OW / 4);
-  int lpp = 1;
-  while (lpp < 64 && lpp < nvec) lpp <<= 1;
-  const long long waves = (n_planes + 64 / lpp - 1) / (64 / lpp);
-  const long long blocks = (waves + 3) / 4;
-  if (blocks > 0x7fffffffLL) return MTR_E_SHAPE;
+  if (n_planes >= (1LL << 30)) return MTR_E_SHAPE;
+  DwGeom g;
+  g.n_planes = (int)n_planes; g.C = C; g.H = H; g.W = W; g.OH = OH; g.OW = OW; g.pad = pad;
+  g.groups = OH * (OW / 4);
+  g.lpp = 1;
+  while (g.lpp < 64 && g.lpp < g.groups) g.lpp <<= 1;
+  g.chunks = (g.groups + 63) / 64;
+  g.n_pg = (int)((n_planes + 64 / g.lpp - 1) / (64 / g.lpp));
+  g.inv_hw = 1.0f / (float)(OH * OW);
+  // persistent grid: 256 CUs x 4 SIMDs x 4 waves (three register sets of taps + weights per wave)
+  int blocks = (g.n_pg + 3) / 4;
+  if (blocks > 256 * 4) blocks = 256 * 4;
   const dim3 grid((unsigned)blocks), block(256);
-  const float inv = 1.0f / (float)(OH * OW);
+  const bool vec = pad == 1 && (W & 3) == 0 && ((uintptr_t)x % 16) == 0 && (STRIDE == 1 || OW * 2 == W);
   MTR_CLEAR_STALE();
-#define MTR_DW_LAUNCH(A)                                                                          \
-  hipLaunchKernelGGL((depthwise3x3_kernel<T, A, STRIDE>), grid, block, 0, stream, (const T*)x, w,  \
-                     bias, (T*)y, row_mean, n_planes, C, H, W, OH, OW, pad, lpp, inv)
+#define MTR_DW_LAUNCH(A)                                                                            \
+  if (vec)                                                                                          \
+    hipLaunchKernelGGL((depthwise3x3_kernel<T, A, STRIDE, true>), grid, block, 0, stream, (const T*)x, \
+                       w, bias, (T*)y, row_mean, g);                                                \
+  else                                                                                              \
+    hipLaunchKernelGGL((depthwise3x3_kernel<T, A, STRIDE, false>), grid, block, 0, stream,          \
+                       (const T*)x, w, bias, (T*)y, row_mean, g)
   switch (act) {
     case kActNone: MTR_DW_LAUNCH(kActNone); break;
     case kActRelu: MTR_DW_LAUNCH(kActRelu); break;

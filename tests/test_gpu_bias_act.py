@@ -52,10 +52,14 @@ def test_bias_act_rowmean_vs_torch(shape, dtype, hip_lib):
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
 @pytest.mark.parametrize('cfg', [(2, 960, 16, 16, 1, 1), (3, 256, 32, 32, 2, 1), (2, 96, 18, 18, 2, 0),
-                                 (5, 1536, 8, 8, 1, 1), (1, 7, 4, 8, 1, 1), (2, 5, 9, 9, 2, 0), (70, 3, 16, 16, 1, 1)])
+                                 (5, 1536, 8, 8, 1, 1), (1, 7, 4, 8, 1, 1), (2, 5, 9, 9, 2, 0), (70, 3, 16, 16, 1, 1),
+                                 (3, 4, 32, 32, 1, 1), (2, 5, 64, 64, 2, 1), (2, 6, 10, 18, 1, 0),
+                                 (64, 960, 16, 16, 1, 1), (33, 130, 8, 8, 1, 1), (2, 3, 24, 40, 1, 1)])
 def test_depthwise3x3_bias_act_vs_torch(cfg, dtype, hip_lib):
     """K11 vs F.conv2d(groups=C) + bias + SiLU and the mean of that: every (stride, pad) the backbones
-    use, planes of 2 .. 64 output vectors, plane counts that do not fill the last wave."""
+    use, planes of 2 .. 256 output vectors (several 64-group items per plane: the mean spans them),
+    plane counts that do not fill the last wave, launches of one item per wave and of many (the
+    persistent grid's three-deep prefetch ring and its tails), aligned-vector and scalar rows."""
     from metrabs_amd import kernels
     B, C, H, W, stride, pad = cfg
     g = torch.Generator(device='cuda').manual_seed(sum(cfg))
