@@ -27,7 +27,9 @@ enum Act { kActNone = 0, kActRelu = 1, kActSilu = 2, kActHardswish = 3 };
 template <int ACT>
 __device__ __forceinline__ float activate(float x) {
   if constexpr (ACT == kActRelu) return fmaxf(x, 0.0f);
-  if constexpr (ACT == kActSilu) return x / (1.0f + __expf(-x));  // at::silu: x / (1 + exp(-x))
+  // at::silu: x / (1 + exp(-x)); the quotient as x * v_rcp_f32 (1 ulp) instead of the ten-instruction
+  // IEEE division sequence -- K11 is VALU-bound and 2e-7 relative is far inside the backbone's own noise
+  if constexpr (ACT == kActSilu) return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
   if constexpr (ACT == kActHardswish) return x * fminf(fmaxf(x + 3.0f, 0.0f), 6.0f) * (1.0f / 6.0f);
   return x;
 }

@@ -188,11 +188,129 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(
   }
 }
 
+// ---- stride 1, pad 1, whole 4x4 output blocks (the 27 stride-1 layers of EfficientNetV2-S at 256 px:
+// 16x16 and 8x8 planes).  The generic kernel above spends ~800 VALU instructions per lane and item
+// (index arithmetic, 18 selects, per-group set-up) and is VALU-bound at 30 - 38 % of the HBM spec.
+// Here a lane owns a 4 x 4 block of outputs: six aligned row vectors are all it loads; the columns
+// left and right of them come from the neighbouring lanes through DPP row shifts (a plane row's
+// lanes are adjacent and never straddle a 16-lane DPP row); rows above / below the plane and the
+// plane's left / right edge are zeroed with 12 + 12 selects for 16 outputs; the lanes of a plane
+// (1 .. 64, a power of two) reduce the squeeze-excite mean with xor shuffles.
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_shift(float v) {
+  // row_shr:1 (0x111): lane i gets lane i - 1; row_shl:1 (0x101): lane i gets lane i + 1;
+  // bound_ctrl: lanes without a source inside the 16-lane row get 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void depthwise3x3_s1_block_kernel(
+    const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    T* __restrict__ y, float* __restrict__ row_mean, int n_planes, int C, int H, int W, int lp_log2,
+    int tw_log2, float inv_hw) {
+  struct alignas(4 * sizeof(T)) V4 { T v[4]; };
+  const int gid = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  const int plane = gid >> lp_log2, local = gid & ((1 << lp_log2) - 1);
+  const int ty = local >> tw_log2, tx = local & ((1 << tw_log2) - 1);
+  const bool live = plane < n_planes;
+  const int p = live ? plane : n_planes - 1;  // dead lanes recompute the last plane, no store
+  const int c = (int)((unsigned)p % (unsigned)C);
+  const int oy0 = ty << 2, ox0 = tx << 2;
+  const T* xp = x + (size_t)p * (size_t)(H * W) + ox0;
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  V4 raw[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    int iy = oy0 - 1 + r;
+    iy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
+    if constexpr (sizeof(T) == 4) {  // (a native vector type: one global_load_dwordx4)
+      const f32x4 t = *reinterpret_cast<const f32x4*>(xp + iy * W);
+      raw[r].v[0] = t[0]; raw[r].v[1] = t[1]; raw[r].v[2] = t[2]; raw[r].v[3] = t[3];
+    } else {
+      raw[r] = *reinterpret_cast<const V4*>(xp + iy * W);
+    }
+  }
+  float wk[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) wk[k] = w[c * 9 + k];
+  const float b = bias[c];
+  const bool has_left = tx > 0, has_right = tx + 1 < (1 << tw_log2);
+  float in[6][6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    const bool row_ok = (r != 0 || oy0 > 0) && (r != 5 || oy0 + 4 < H);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) in[r][1 + j] = row_ok ? to_f32(raw[r].v[j]) : 0.0f;
+    const float l = dpp_row_shift<0x111>(in[r][4]), rgt = dpp_row_shift<0x101>(in[r][1]);
+    in[r][0] = has_left ? l : 0.0f;
+    in[r][5] = has_right ? rgt : 0.0f;
+  }
+  float sum = 0.0f;
+  T* yp = y + (size_t)p * (size_t)(H * W) + oy0 * W + ox0;
+#pragma unroll
+  for (int orow = 0; orow < 4; ++orow) {
+    float acc[4] = {b, b, b, b};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[o] = fmaf(in[orow + ky][o + kx], wk[ky * 3 + kx], acc[o]);
+    V4 out;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const float a = activate<ACT>(acc[o]);
+      if constexpr (sizeof(T) == 4) out.v[o] = a; else out.v[o] = T(a);
+      sum += to_f32(out.v[o]);
+    }
+    if (live) {
+      if constexpr (sizeof(T) == 4)
+        *reinterpret_cast<f32x4*>(yp + orow * W) = f32x4{out.v[0], out.v[1], out.v[2], out.v[3]};
+      else
+        *reinterpret_cast<V4*>(yp + orow * W) = out;
+    }
+  }
+  if (row_mean) {
+    for (int m = (1 << lp_log2) >> 1; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
+    if (live && local == 0) row_mean[plane] = sum * inv_hw;
+  }
+}
+
+static int ilog2_exact(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return (1 << l) == v ? l : -1;
+}
+
 template <typename T, int STRIDE>
 static int launch_depthwise(const void* x, const float* w, const float* bias, int act, void* y,
                             float* row_mean, long long n_planes, int C, int H, int W, int OH, int OW,
                             int pad, hipStream_t stream) {
   if (n_planes >= (1LL << 30)) return MTR_E_SHAPE;
+  if constexpr (STRIDE == 1) {
+    const int tw = ilog2_exact(W / 4), th = ilog2_exact(H / 4);
+    if (pad == 1 && (W & 3) == 0 && (H & 3) == 0 && tw >= 0 && tw <= 4 && th >= 0 && tw + th <= 6 &&
+        ((uintptr_t)x % 16) == 0 && n_planes < (1LL << 24)) {
+      const int lp_log2 = tw + th;
+      const long long lanes = n_planes << lp_log2;
+      const dim3 grid((unsigned)((lanes + 255) / 256)), block(256);
+      const float inv = 1.0f / (float)(H * W);
+      MTR_CLEAR_STALE();
+#define MTR_DW_BLOCK(A)                                                                            \
+  hipLaunchKernelGGL((depthwise3x3_s1_block_kernel<T, A>), grid, block, 0, stream, (const T*)x, w, \
+                     bias, (T*)y, row_mean, (int)n_planes, C, H, W, lp_log2, tw, inv)
+      switch (act) {
+        case kActNone: MTR_DW_BLOCK(kActNone); break;
+        case kActRelu: MTR_DW_BLOCK(kActRelu); break;
+        case kActSilu: MTR_DW_BLOCK(kActSilu); break;
+        case kActHardswish: MTR_DW_BLOCK(kActHardswish); break;
+        default: return MTR_E_PARAM;
+      }
+#undef MTR_DW_BLOCK
+      MTR_CHECK_LAUNCH();
+      return MTR_OK;
+    }
+  }
   DwGeom g;
   g.n_planes = (int)n_planes; g.C = C; g.H = H; g.W = W; g.OH = OH; g.OW = OW; g.pad = pad;
   g.groups = OH * (OW / 4);

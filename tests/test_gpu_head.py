@@ -303,7 +303,7 @@ def test_fused_head_full_size_properties(hip_lib):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
-@pytest.mark.parametrize('shape', [(5, 1280, 17, 8, 8), (3, 100, 9, 12, 12), (2, 40, 17, 4, 4),
+@pytest.mark.parametrize('shape', [(5, 1280, 17, 8, 8), (3, 104, 9, 12, 12), (2, 40, 17, 4, 4),
                                    (2, 64, 5, 16, 16)])
 def test_fused_head_channels_last_features(shape, dtype, hip_lib):
     """NHWC memory (torch channels_last; the TF twin's layout, tf models/metrabs.py:100-101) is
