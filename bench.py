@@ -221,17 +221,35 @@ def head_kernel_name(hw, n_crops, J, D, precision='f32', C=1280):
     return 'head_fused32_kernel' if 32 < hw <= 128 else 'head_fused_kernel'
 
 
+def graph_time(calls, replays):
+    """Average duration of one call: the list of zero-argument `calls` is captured ONCE into a HIP
+    graph (so that no Python / ctypes / allocator time sits between the launches) and the graph is
+    replayed `replays` times between two HIP events on the capture stream."""
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st), torch.inference_mode():
+        for c in calls:  # lazy initialisation outside the capture
+            c()
+        st.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            for c in calls:
+                c()
+        g.replay()
+        st.synchronize()
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record(st)
+        for _ in range(replays):
+            g.replay()
+        stop.record(st)
+        st.synchronize()
+    torch.cuda.current_stream().wait_stream(st)
+    return start.elapsed_time(stop) * 1e-3 / (replays * len(calls))
+
+
 def time_stage(fn, iters, warm=3):
-    for _ in range(warm):
-        fn()
-    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    start.record()
-    for _ in range(iters):
-        fn()
-    stop.record()
-    torch.cuda.synchronize()
-    return start.elapsed_time(stop) * 1e-3 / iters
+    """One stage on its own, cache-hot inputs: `iters` launches inside one graph, 3 replays."""
+    return graph_time([fn] * max(1, iters), 3)
 
 
 def stage_breakdown(pipe, est, args, iters):
@@ -280,19 +298,10 @@ ROTATE_BYTES = 640 << 20   # > 2x the 256 MiB Infinity Cache: what a kernel read
 
 
 def time_rotating(make_call, n_sets, iters, warm=None):
-    """Average launch duration (HIP events on the launch stream) of make_call(i % n_sets): every
-    launch works on another input set, n_sets of them spanning more than ROTATE_BYTES."""
-    warm = n_sets if warm is None else warm
-    for i in range(warm):
-        make_call(i % n_sets)
-    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    start.record()
-    for i in range(iters):
-        make_call(i % n_sets)
-    stop.record()
-    torch.cuda.synchronize()
-    return start.elapsed_time(stop) * 1e-3 / iters
+    """Average launch duration of make_call(i): every launch of the captured graph works on another
+    input set, n_sets of them spanning more than ROTATE_BYTES (nothing it reads is still on die)."""
+    calls = [(lambda i=i: make_call(i)) for i in range(n_sets)]
+    return graph_time(calls, max(2, -(-iters // n_sets)))
 
 
 def rotating_sampler_times(pipe, est, args, wp, iters):

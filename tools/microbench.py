@@ -17,17 +17,41 @@ from metrabs_amd.config import MetrabsConfig  # noqa: E402
 HBM = 8.0e12
 
 
-def timeit(fn, iters=50, warm=10):
-    for _ in range(warm):
-        fn()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    a.record()
-    for _ in range(iters):
-        fn()
-    b.record()
-    torch.cuda.synchronize()
-    return a.elapsed_time(b) * 1e-3 / iters
+def timeit(fn, iters=50, warm=10, graph=True):
+    """Average duration of one launch: `iters` launches captured in ONE HIP graph (no Python /
+    ctypes / allocator time between them), replayed 3 times between two HIP events.  graph=False
+    (wrappers that copy host lists to the device): an eager loop between two events."""
+    if not graph:
+        for _ in range(warm):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) * 1e-3 / iters
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st), torch.inference_mode():
+        for _ in range(min(warm, 3)):
+            fn()
+        st.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            for _ in range(iters):
+                fn()
+        g.replay()
+        st.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(st)
+        for _ in range(3):
+            g.replay()
+        b.record(st)
+        st.synchronize()
+    torch.cuda.current_stream().wait_stream(st)
+    return a.elapsed_time(b) * 1e-3 / (3 * iters)
 
 
 def bench_decode():
@@ -110,7 +134,8 @@ def bench_warp_pyramid():
         K = torch.tensor([[1844.0, 0, 960], [0, 1844.0, 540], [0, 0, 1]]).repeat(n, 1, 1).cuda()
         up = torch.tensor([0.0, -1, 0]).repeat(n, 1).cuda()
         ids = (torch.arange(n) % 8).int().cuda()
-        geo = lambda: kernels.crop_geometry(boxes, K, torch.zeros(n, 12).cuda(), up, ids,
+        dist = torch.zeros(n, 12).cuda()
+        geo = lambda: kernels.crop_geometry(boxes, K, dist, up, ids,
                                             tta['rotflipmat'], tta['scales'], tta['gammas'], 256, aa)
         tg = timeit(geo)
         _, _, wp = geo()
@@ -165,7 +190,7 @@ def bench_filter():
         boxes, p3, p2 = c['boxes'] * reps, c['poses3d'] * reps, c['poses2d'] * reps
         counts = [len(b) for b in boxes]
         P3, P2, BX = torch.cat(p3).cuda(), torch.cat(p2).cuda(), torch.cat(boxes).cuda()
-        t = timeit(lambda: kernels.filter_poses(P3, P2, BX, counts, c['edges'], c['mean_bones']))
+        t = timeit(lambda: kernels.filter_poses(P3, P2, BX, counts, c['edges'], c['mean_bones']), graph=False)
         t0 = time.perf_counter()
         for _ in range(3):
             cpu_ref.filter_poses(boxes, p3, p2, c['edges'], c['mean_bones'])
@@ -230,22 +255,10 @@ def bench_depthwise():
 
 if __name__ == '__main__':
     which = sys.argv[1:] or ['decode', 'head', 'warp', 'recon', 'detector', 'filter', 'bias_act', 'depthwise']
-    res = []
-    if 'decode' in which:
-        res += bench_decode()
-    if 'head' in which:
-        res += bench_head()
-    if 'warp' in which or 'pyramid' in which:
-        res += bench_warp_pyramid()
-    if 'recon' in which:
-        res += bench_recon()
-    if 'detector' in which:
-        res += bench_detector_pre()
-    if 'filter' in which:
-        res += bench_filter()
-    if 'bias_act' in which:
-        res += bench_bias_act()
-    if 'depthwise' in which:
-        res += bench_depthwise()
-    for r in res:
-        print(json.dumps(r))
+    benches = [('decode', bench_decode), ('head', bench_head), ('warp', bench_warp_pyramid),
+               ('recon', bench_recon), ('detector', bench_detector_pre), ('filter', bench_filter),
+               ('bias_act', bench_bias_act), ('depthwise', bench_depthwise)]
+    for name, fn in benches:
+        if name in which or (name == 'warp' and 'pyramid' in which):
+            for r in fn():
+                print(json.dumps(r), flush=True)
