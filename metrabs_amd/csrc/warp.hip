@@ -609,11 +609,14 @@ static int warp_entry(const void* level0, const float* lut, const float* level1,
   if (!level0 || (!level1 && !l1_empty) || (!level2 && !l2_empty) || !warp_params || !out ||
       (L0U8 && !lut))
     return MTR_E_NULL;
-  if ((long long)N * 3 * Hi * Wi > 0xffffffffLL) return MTR_E_SHAPE;
-  // Range of the uint8 descriptor, rounded up so that the dword PAIR covering the last byte is in
-  // range (a dword straddling num_records reads as zero).  The <= 8 bytes past the tensor belong to
-  // the same allocation granule (torch: 512 B) and only ever meet zero tap weights.
-  const unsigned u8_bytes = (unsigned)((((long long)N * 3 * Hi * Wi + 3) & ~3LL) + 4);
+  if ((long long)N * 3 * Hi * Wi >= 0x7fffffffLL) return MTR_E_SHAPE;  // (32-bit byte offsets in the kernel)
+  // Range of the uint8 descriptor: the tensor's bytes rounded up to a whole dword (a dword
+  // straddling num_records reads as zero, and the byte pair of the last texels may sit in the
+  // dword that holds the tensor's last byte).  The <= 3 bytes past the tensor are in the SAME
+  // aligned 4-byte word as its last byte -- same page, same allocation granule, whoever allocated
+  // it -- and only ever meet zero tap weights; the second dword of a pair beyond that is out of
+  // range and returns zero without touching memory.
+  const unsigned u8_bytes = (unsigned)(((long long)N * 3 * Hi * Wi + 3) & ~3LL);
   if (out_layout != MTR_NCHW && out_layout != MTR_NHWC) return MTR_E_DTYPE;
   if (n_crops == 0) return MTR_OK;
   if ((uintptr_t)out % 16) return MTR_E_ALIGN;

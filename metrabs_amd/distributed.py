@@ -44,35 +44,75 @@ def shard_internal_batches(n_boxes, boxes_per_batch, rank, world_size):
             for i in range(n_batches) if i % world_size == rank]
 
 
-def gather_poses(local_poses, ranges_of_rank, n_boxes, boxes_per_batch, world_size, group=None):
-    """One all-gather of the per-rank results, then un-shuffling into global box order.
-
-    local_poses: [n_local, ...] results of this rank's internal batches, concatenated in the order
-    of ``shard_internal_batches``.  Every rank returns the full [n_boxes, ...] tensor."""
-    if world_size == 1:
-        return local_poses
+def split_internal_batches(n_boxes, boxes_per_batch, world_size):
+    """exact-monolithic mode: EVERY internal batch is cut into world_size contiguous slices (sizes
+    differing by at most one box; a slice may be empty), so that the batch-global RMS of
+    reconstruct_ref_fullpersp (ptu3d.py:71-74) still spans the reference's internal batch: the
+    ranks all-reduce its three moment sums between mtr_reconstruct_moments and
+    mtr_reconstruct_solve.  -> per rank, the list of (start, stop) slices in batch order (one entry
+    per internal batch, empty slices included: every rank takes part in every all-reduce)."""
     if boxes_per_batch <= 0:
         boxes_per_batch = max(n_boxes, 1)
-    n_batches = (n_boxes + boxes_per_batch - 1) // boxes_per_batch
-    max_batches = (n_batches + world_size - 1) // world_size
-    cap = max_batches * boxes_per_batch  # equal-sized padded shard
-    tail = local_poses.shape[1:]
-    padded = local_poses.new_zeros((cap,) + tuple(tail))
-    padded[:local_poses.shape[0]] = local_poses
-    gathered = local_poses.new_empty((world_size * cap,) + tuple(tail))
+    out = [[] for _ in range(world_size)]
+    for b0 in range(0, n_boxes, boxes_per_batch):
+        n = min(boxes_per_batch, n_boxes - b0)
+        base, extra = divmod(n, world_size)
+        start = b0
+        for r in range(world_size):
+            size = base + (1 if r < extra else 0)
+            out[r].append((start, start + size))
+            start += size
+    return out
+
+
+def _collective_device(t):
+    """gloo (CPU tests; two ranks sharing one GPU in the -m gpu shard test) moves CUDA tensors
+    through the host; RCCL works on them in place."""
+    return 'cpu' if (t.is_cuda and dist.get_backend() == 'gloo') else t.device
+
+
+def gather_ranges(local, ranges_by_rank, n_boxes, group=None):
+    """One all-gather of the per-rank results, then un-shuffling into global box order.
+
+    local: [n_local, ...] results of THIS rank's ranges, concatenated in order;
+    ranges_by_rank: for every rank its list of (start, stop) box ranges (host-side knowledge, the
+    same on all ranks).  Every rank returns the full [n_boxes, ...] tensor."""
+    world_size = len(ranges_by_rank)
+    if world_size == 1:
+        return local
+    cap = max(sum(b - a for a, b in rr) for rr in ranges_by_rank)  # equal-sized padded shards
+    tail = tuple(local.shape[1:])
+    dev = _collective_device(local)
+    padded = torch.zeros((cap,) + tail, dtype=local.dtype, device=dev)
+    padded[:local.shape[0]] = local.to(dev)
+    gathered = torch.empty((world_size * cap,) + tail, dtype=local.dtype, device=dev)
     dist.all_gather_into_tensor(gathered, padded, group=group)
-    gathered = gathered.reshape((world_size, cap) + tuple(tail))
-    out = local_poses.new_empty((n_boxes,) + tuple(tail))
-    for r in range(world_size):
+    gathered = gathered.reshape((world_size, cap) + tail).to(local.device)
+    out = local.new_empty((n_boxes,) + tail)
+    for r, rr in enumerate(ranges_by_rank):
         offset = 0
-        for start, stop in shard_internal_batches(n_boxes, boxes_per_batch, r, world_size):
+        for start, stop in rr:
             out[start:stop] = gathered[r, offset:offset + (stop - start)]
             offset += stop - start
     return out
 
 
+def gather_poses(local_poses, ranges_of_rank, n_boxes, boxes_per_batch, world_size, group=None):
+    """Round-robin sharding (shard_internal_batches): one all-gather of the per-rank results."""
+    if world_size == 1:
+        return local_poses
+    return gather_ranges(local_poses, [shard_internal_batches(n_boxes, boxes_per_batch, r, world_size)
+                                       for r in range(world_size)], n_boxes, group)
+
+
 def allreduce_moments(moments, group=None):
     """exact-monolithic mode: sum the (sum2d, sumrb, count) f64 triple over ranks."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(moments, op=dist.ReduceOp.SUM, group=group)
+        dev = _collective_device(moments)
+        if dev == 'cpu':
+            host = moments.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            moments.copy_(host)
+        else:
+            dist.all_reduce(moments, op=dist.ReduceOp.SUM, group=group)
     return moments

@@ -115,6 +115,8 @@ class Metrabs(torch.nn.Module):
         self.heatmap_heads = MetrabsHeads(
             n_points=joint_info.n_joints, config=self.config, in_channels=in_channels,
             fused=fused_head)
+        # set by Pose3dEstimator(shard_across_ranks='exact_monolithic') around its calls
+        self.exact_monolithic = False
 
     def forward(self, inp):
         image, intrinsics = inp
@@ -124,4 +126,12 @@ class Metrabs(torch.nn.Module):
         else:
             features = self.backbone(image)
         coords2d, coords3d = self.heatmap_heads(features)
+        if self.exact_monolithic and torch.distributed.is_initialized() and \
+                torch.distributed.get_world_size() > 1 and not self.config.weak_perspective:
+            # this call holds one rank's slice of a reference internal batch: the batch-global RMS
+            # scalars of reconstruct_ref_fullpersp (ptu3d.py:71-74) come from the summed moments
+            from metrabs_amd import distributed
+            moments = kernels.reconstruct_moments(coords2d, coords3d, intrinsics)
+            distributed.allreduce_moments(moments)
+            return kernels.reconstruct_solve(coords2d, coords3d, intrinsics, moments, self.config)
         return kernels.reconstruct_absolute(coords2d, coords3d, intrinsics, self.config)

@@ -116,6 +116,8 @@ class Pose3dEstimator(torch.nn.Module):
             extrinsic_matrix=(DEFAULT_EXTRINSIC_MATRIX,), world_up_vector=DEFAULT_WORLD_UP,
             default_fov_degrees=55, internal_batch_size=64, antialias_factor=1, num_aug=5,
             average_aug=True, skeleton=''):
+        boxes = [torch.as_tensor(b, dtype=torch.float32) for b in boxes]
+        boxes = [b.reshape(-1, 4) if b.numel() == 0 else b for b in boxes]  # (an empty (0,) list of boxes)
         boxes = [torch.cat([b[..., :4], torch.ones_like(b[..., :1])], dim=-1) for b in boxes]
         pred = self._estimate_poses_batched(
             images, boxes, intrinsic_matrix, distortion_coeffs, extrinsic_matrix, world_up_vector,
@@ -197,8 +199,7 @@ class Pose3dEstimator(torch.nn.Module):
             raise RuntimeError('metrabs_amd.Pose3dEstimator needs the crop model on a GPU')
         images = torch.as_tensor(images).to(dev)
         n_images = len(images)
-        intrinsic_matrix = torch.as_tensor(np.asarray(intrinsic_matrix) if not torch.is_tensor(
-            intrinsic_matrix) else intrinsic_matrix, dtype=torch.float32)
+        intrinsic_matrix = _as_f32(intrinsic_matrix)  # (camera set-up happens on the host)
         distortion_coeffs = _as_f32(distortion_coeffs)
         extrinsic_matrix = _as_f32(extrinsic_matrix)
         world_up_vector = _as_f32(world_up_vector)
@@ -223,9 +224,10 @@ class Pose3dEstimator(torch.nn.Module):
         camspace_up_b = per_box(camspace_up)
         inv_extrinsics_b = per_box(inv_extrinsics)
         image_id_per_box = per_box(torch.arange(n_images))
+        image_id_host = np.repeat(np.arange(n_images), counts)
         boxes_out = boxes
-        boxes_flat = torch.cat([torch.as_tensor(b, dtype=torch.float32).reshape(-1, b.shape[-1])
-                                for b in boxes], dim=0).to(dev) if sum(counts) else \
+        boxes_flat = torch.cat([torch.as_tensor(b, dtype=torch.float32).reshape(-1, 5)
+                                for b in boxes if len(b)], dim=0).to(dev) if sum(counts) else \
             torch.zeros(0, 5, device=dev)
 
         tta = self._tta(num_aug, dev)
@@ -244,7 +246,8 @@ class Pose3dEstimator(torch.nn.Module):
                             joint_transform=self._joint_transform_on(dev))
                 packed = self._predict_in_batches(
                     images, intrinsic_matrix_b, distortion_b, camspace_up_b, boxes_flat,
-                    image_id_per_box, internal_batch_size, tta, antialias_factor, post=post)
+                    image_id_per_box, internal_batch_size, tta, antialias_factor, post=post,
+                    image_id_host=image_id_host)
                 poses3d_flat, poses2d_flat = packed[..., :3], packed[..., 3:]
         else:
             if sum(counts) == 0:
@@ -252,7 +255,8 @@ class Pose3dEstimator(torch.nn.Module):
             else:
                 poses3d_flat = self._predict_in_batches(
                     images, intrinsic_matrix_b, distortion_b, camspace_up_b, boxes_flat,
-                    image_id_per_box, internal_batch_size, tta, antialias_factor)
+                    image_id_per_box, internal_batch_size, tta, antialias_factor,
+                    image_id_host=image_id_host)
             # post-processing as torch ops (multiperson_model.py:143-178)
             if self.joint_transform_matrix is not None:
                 poses3d_flat = torch.einsum(
@@ -288,11 +292,15 @@ class Pose3dEstimator(torch.nn.Module):
         return dict(boxes=boxes_out, poses3d=poses3d, poses2d=poses2d)
 
     def _predict_in_batches(self, images, intrinsic_matrix, distortion12, camspace_up, boxes_flat,
-                            image_id_per_box, internal_batch_size, tta, antialias_factor, post=None):
+                            image_id_per_box, internal_batch_size, tta, antialias_factor, post=None,
+                            image_id_host=None):
         """multiperson_model.py:184-225.  The whole-image gamma decode (:196) is fused with the
         pyramid build: one launch for all images of the call.  With ``shard_across_ranks`` the
         internal batches are dealt round-robin to the ranks of the default process group and the
-        results are all-gathered once at the end (metrabs_amd/distributed.py).
+        results are all-gathered once at the end (metrabs_amd/distributed.py);
+        ``shard_across_ranks = 'exact_monolithic'`` instead cuts EVERY internal batch into one slice
+        per rank and all-reduces the three reconstruction moments, i.e. the numbers of the
+        un-sharded call.  Either way a rank builds the pyramid of the frames its own boxes reference.
 
         post=None  -> poses [n, A, J, 3] in the original camera frame (torch-op post-processing);
         post=dict  -> K7 runs per internal batch; returns [n, (A,) S, 5] = poses3d | poses2d."""
@@ -304,22 +312,49 @@ class Pose3dEstimator(torch.nn.Module):
         rank, world = 0, 1
         if self.shard_across_ranks and torch.distributed.is_initialized():
             rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
-        ranges = distributed.shard_internal_batches(n_total, boxes_per_batch, rank, world)
-        pyramid = kernels.build_pyramid(images)
+        exact = self.shard_across_ranks == 'exact_monolithic' and world > 1
+        if exact:
+            ranges_by_rank = distributed.split_internal_batches(n_total, boxes_per_batch, world)
+        else:
+            ranges_by_rank = [distributed.shard_internal_batches(n_total, boxes_per_batch, r, world)
+                              for r in range(world)]
+        ranges = ranges_by_rank[rank]
+        # the pyramid of the frames THIS rank's boxes reference (all of them on one rank)
+        if world > 1 and image_id_host is not None:
+            needed = sorted({int(i) for a, b in ranges for i in image_id_host[a:b]})
+            if len(needed) < len(images):
+                remap = torch.full((len(images),), -1, dtype=image_id_per_box.dtype)
+                remap[needed] = torch.arange(len(needed), dtype=image_id_per_box.dtype)
+                image_id_per_box = remap.to(image_id_per_box.device)[image_id_per_box.long()]
+                images = images[torch.tensor(needed, device=images.device)] if needed else images[:0]
+        pyramid = kernels.build_pyramid(images) if len(images) else None
+        if exact:
+            if not hasattr(self.crop_model, 'exact_monolithic'):
+                raise RuntimeError("shard_across_ranks='exact_monolithic' needs metrabs_amd's Metrabs "
+                                   "crop model (the moments are all-reduced inside its forward)")
+            self.crop_model.exact_monolithic = True
         out = []
-        for start, stop in ranges:
-            s = slice(start, stop)
-            res = self._predict_single_batch(
-                pyramid, intrinsic_matrix[s], distortion12[s], camspace_up[s], boxes_flat[s],
-                image_id_per_box[s], tta, antialias_factor, raw=post is not None)
-            if post is not None:
-                poses_flat, rot = res
-                p3, p2 = kernels.postprocess_poses(
-                    poses_flat, rot, tta['should_flip_u8'], tta['mirror_i32'], intrinsic_matrix[s],
-                    distortion12[s], post['inv_extrinsics'][s], post['joint_transform'],
-                    post['skeleton'], post['average_aug'])
-                res = torch.cat([p3, p2], dim=-1)
-            out.append(res)
+        try:
+            for start, stop in ranges:
+                if start == stop:  # (exact mode) an empty slice still joins the batch's all-reduce
+                    distributed.allreduce_moments(torch.zeros(3, dtype=torch.float64,
+                                                              device=boxes_flat.device))
+                    continue
+                s = slice(start, stop)
+                res = self._predict_single_batch(
+                    pyramid, intrinsic_matrix[s], distortion12[s], camspace_up[s], boxes_flat[s],
+                    image_id_per_box[s], tta, antialias_factor, raw=post is not None)
+                if post is not None:
+                    poses_flat, rot = res
+                    p3, p2 = kernels.postprocess_poses(
+                        poses_flat, rot, tta['should_flip_u8'], tta['mirror_i32'], intrinsic_matrix[s],
+                        distortion12[s], post['inv_extrinsics'][s], post['joint_transform'],
+                        post['skeleton'], post['average_aug'])
+                    res = torch.cat([p3, p2], dim=-1)
+                out.append(res)
+        finally:
+            if exact:
+                self.crop_model.exact_monolithic = False
         if out:
             local = torch.cat(out, dim=0)
         elif post is not None:
@@ -328,7 +363,7 @@ class Pose3dEstimator(torch.nn.Module):
             local = torch.zeros(*shape, device=boxes_flat.device)
         else:
             local = torch.zeros(0, num_aug, self.joint_info.n_joints, 3, device=boxes_flat.device)
-        return distributed.gather_poses(local, ranges, n_total, boxes_per_batch, world)
+        return distributed.gather_ranges(local, ranges_by_rank, n_total)
 
     def _get_crops(self, pyramid, intrinsic_matrix, distortion12, camspace_up, boxes, image_ids, tta,
                    antialias_factor):
