@@ -50,6 +50,11 @@ def parse_args():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--config', type=int, default=1, choices=[1, 2],
+                    help='BASELINE.json configs[N]: 1 = EffNetV2-S 256 px, 64 crops per GPU and step (weak '
+                         'scaling, the metric\'s line); 2 = EffNetV2-L 384 px, 256 crops per step in internal '
+                         'batches of 32 dealt round-robin to the ranks (strong scaling)')
+    ap.add_argument('--total-crops', type=int, default=256, help='--config 2: crops per step, whole job')
     ap.add_argument('--backbone', default='effnetv2-s')
     ap.add_argument('--res', type=int, default=256)
     ap.add_argument('--batch', type=int, default=64, help='crops per GPU per step')
@@ -72,7 +77,15 @@ def parse_args():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-decode-roofline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.config == 2:  # (explicit --backbone / --res / --batch still win when given)
+        if args.backbone == 'effnetv2-s':
+            args.backbone = 'effnetv2-l'
+        if args.res == 256:
+            args.res = 384
+        if args.batch == 64:
+            args.batch = 32
+    return args
 
 
 def synth_inputs(pipe, frames, im_h, im_w, n_box, seed):
@@ -484,44 +497,54 @@ def cpu_baseline(est, pipe, args, cfg, seconds):
                 torch.eye(4)[None], torch.tensor([0.0, -1.0, 0.0]), 55, args.batch * args.num_aug,
                 1, args.num_aug, True)
 
-    run(min(8, args.batch))  # warm-up (thread pools, oneDNN primitive cache)
-    t0 = time.time()
-    reps = 0
-    while True:
-        run(args.batch)
-        reps += 1
-        if time.time() - t0 >= seconds * 0.5 or reps >= 3:
-            break
-    dt = (time.time() - t0) / reps
-    crops = args.batch * args.num_aug
-    cores = torch.get_num_threads()
-    # the reference pins OMP_NUM_THREADS=1 (metrabs_pytorch/init.py:3): the same path on ONE thread,
-    # on a smaller sample (2 boxes of frame 0; the frame's gamma decode alone is ~0.5 s)
-    one = None
-    try:
-        torch.set_num_threads(1)
+    def run_frame0(n_box):
+        with torch.inference_mode():
+            return cpu_ref.estimate_poses_batched(
+                crop_model, mirror, J, args.res, images[:1], [boxes_all[ids == 0][:n_box]], K,
+                torch.zeros(1, 5), torch.eye(4)[None], torch.tensor([0.0, -1.0, 0.0]), 55,
+                args.batch * args.num_aug, 1, args.num_aug, True)
 
-        def run1(n_box):
-            with torch.inference_mode():
-                return cpu_ref.estimate_poses_batched(
-                    crop_model, mirror, J, args.res, images[:1], [boxes_all[ids == 0][:n_box]], K,
-                    torch.zeros(1, 5), torch.eye(4)[None], torch.tensor([0.0, -1.0, 0.0]), 55,
-                    args.batch * args.num_aug, 1, args.num_aug, True)
-        n1 = max(1, min(2, int((ids == 0).sum())))
-        run1(1)
-        t1 = time.time()
-        run1(n1)
-        dt1 = time.time() - t1
-        one = dict(value=n1 * args.num_aug / dt1, unit='crops/s', cores=1,
-                   sample=f'{n1 * args.num_aug} crops of one 1080p frame, torch.set_num_threads(1)',
-                   seconds=dt1)
+    # Thread count: torch's default (all hardware threads) is NOT the fastest setting of this path
+    # on a many-core host (per-crop Python loops + small ops oversubscribe), and the reference
+    # itself pins OMP_NUM_THREADS=1 (metrabs_pytorch/init.py:3).  A short sample (the boxes of frame
+    # 0: the workload's 8 crops per frame) is timed at 1 thread and at a few larger counts; `value`
+    # is the whole batch at the best of them, `one_thread` the reference's own setting.
+    all_threads = torch.get_num_threads()
+    n0 = max(1, int((ids == 0).sum()))
+    by_threads = {}
+    try:
+        for t in sorted({1, 8, 32, all_threads}):
+            if t > all_threads:
+                continue
+            torch.set_num_threads(t)
+            run_frame0(1)
+            t0 = time.time()
+            run_frame0(n0)
+            by_threads[t] = n0 * args.num_aug / (time.time() - t0)
+        best = max(by_threads, key=by_threads.get)
+        torch.set_num_threads(best)
+        run(min(8, args.batch))  # warm-up at the chosen setting
+        t0 = time.time()
+        reps = 0
+        while True:
+            run(args.batch)
+            reps += 1
+            if time.time() - t0 >= seconds * 0.5 or reps >= 3:
+                break
+        dt = (time.time() - t0) / reps
     finally:
-        torch.set_num_threads(cores)
-    return dict(value=crops / dt, unit='crops/s', cores=cores, kind='port',
+        torch.set_num_threads(all_threads)
+    crops = args.batch * args.num_aug
+    return dict(value=crops / dt, unit='crops/s', cores=best, kind='port',
                 sample=f'{reps} x {crops} crops ({args.frames} 1080p frames), same step as the GPU '
                        f'(gamma decode + pyramid + sampler + {args.backbone} fp32 + head + '
-                       f'reconstruction), oracle/cpu_ref.py on torch CPU',
-                seconds_per_batch=dt, one_thread=one)
+                       f'reconstruction), oracle/cpu_ref.py on torch CPU with {best} of the host\'s '
+                       f'{all_threads} hardware threads (the fastest of the sampled settings)',
+                seconds_per_batch=dt, host_threads=all_threads,
+                crops_per_s_by_threads={str(k): round(v, 2) for k, v in by_threads.items()},
+                one_thread=dict(value=by_threads.get(1), unit='crops/s', cores=1,
+                                sample=f'{n0 * args.num_aug} crops of one 1080p frame, '
+                                       f'torch.set_num_threads(1) (the reference pins OMP_NUM_THREADS=1)'))
 
 
 def _parity_numbers(ours, ref, truth):
@@ -614,12 +637,29 @@ def main():
     pipe.capture()
 
     J = est.joint_info.n_joints
-    gathered = torch.empty(world * n_box, J, 3, device=dev) if world > 1 else None
+    # config 1 (weak scaling): one internal batch per rank and step.  config 2 (strong scaling): the
+    # step's total crops form internal batches of args.batch crops, dealt round-robin to the ranks
+    # (metrabs_amd.distributed.shard_internal_batches -- the unit of multiperson_model.py:189-220);
+    # a rank replays its graph once per batch it owns, then the poses of the step are all-gathered.
+    strong = args.config == 2
+    if strong:
+        total_boxes = args.total_crops // args.num_aug
+        my_batches = len(distributed.shard_internal_batches(total_boxes, n_box, rank, world))
+        max_batches = len(distributed.shard_internal_batches(total_boxes, n_box, 0, world))
+    else:
+        my_batches = max_batches = 1
+    gathered = torch.empty(world * max_batches * n_box, J, 3, device=dev) if world > 1 else None
+    shard_out = torch.zeros(max_batches * n_box, J, 3, device=dev) if strong else None
 
     use_base_gather = world > 1 and torch.distributed.get_backend() == 'nccl'
 
     def step():
-        poses = pipe.run()
+        if strong:
+            for b in range(my_batches):
+                shard_out[b * n_box:(b + 1) * n_box].copy_(pipe.run(), non_blocking=True)
+            poses = shard_out
+        else:
+            poses = pipe.run()
         if world > 1:
             # the single collective of the path: KB-sized all-gather of the poses over RCCL/xGMI
             if use_base_gather:
@@ -651,7 +691,7 @@ def main():
             torch.distributed.barrier()
         return
 
-    crops_per_step = world * n_box * args.num_aug
+    crops_per_step = args.total_crops if strong else world * n_box * args.num_aug
     value = crops_per_step * args.steps / elapsed
 
     # PCIe-inclusive variant (NOT `value`): the frames arrive from pinned host memory every step
@@ -792,10 +832,13 @@ def main():
         'metric': 'crops/sec (256px, 72 depth bins) at 1/2/4/8 MI355X; MPJPE vs ref',
         'value': value, 'unit': 'crops/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
         'dtype': args.precision, 'data': 'synthetic',
-        'config': {'workload': f'configs[1]: {args.backbone} {args.res}px, batch {n_crops} crops/GPU, '
-                               f'num_aug={args.num_aug}, {args.frames} 1080p uint8 frames/step, '
+        'config': {'workload': (f'configs[2]: {args.backbone} {args.res}px, {args.total_crops} crops/step in '
+                                f'internal batches of {n_crops} dealt round-robin to {world} rank(s), '
+                                if strong else
+                                f'configs[1]: {args.backbone} {args.res}px, batch {n_crops} crops/GPU, ') +
+                               f'num_aug={args.num_aug}, {args.frames} 1080p uint8 frames per internal batch, '
                                f'J={J}, D={D}, random weights',
                    'global_batch': crops_per_step, 'parallelism': f'dp{world} (crops sharded, one '
                    f'all-gather of poses)' if world > 1 else 'single GPU',
