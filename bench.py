@@ -664,8 +664,13 @@ def main():
             # the single collective of the path: KB-sized all-gather of the poses over RCCL/xGMI
             if use_base_gather:
                 torch.distributed.all_gather_into_tensor(gathered, poses.contiguous())
-            else:  # gloo (test harness only)
-                torch.distributed.all_gather(list(gathered.chunk(world)), poses.contiguous())
+            else:  # gloo (test harness only: two ranks sharing a GPU): through the host -- gloo's own
+                # CUDA path stalls for tens of seconds now and then when its input is still being
+                # written by a graph replay (tools/experiments/n2_debug2.py)
+                host = poses.contiguous().cpu()
+                parts = [torch.empty_like(host) for _ in range(world)]
+                torch.distributed.all_gather(parts, host)
+                gathered.copy_(torch.cat(parts), non_blocking=True)
 
     for _ in range(args.warmup):
         step()
