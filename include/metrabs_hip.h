@@ -218,6 +218,17 @@ int mtr_crop_geometry(const float* boxes, int box_stride, const float* intrinsic
 int mtr_warp_crops(const float* level0, const float* level1, const float* level2, int N, int Hi,
                    int Wi, const float* warp_params, int n_crops, int res, int antialias,
                    int out_dtype, int out_layout, void* out, mtr_stream_t stream);
+/* antialias_factor > 4 (multiperson_model.py:312-315): the crops are sampled at res*aa x res*aa
+ * (mtr_warp_crops[_u8] with res = res*aa, antialias = 1 and gamma exponents of 1 in warp_params[33])
+ * and shrunk here the way torchvision.transforms.functional.resize(antialias=True) = aten's
+ * separable antialiased bilinear filter does, with the per-crop `** (gamma / 2.2)` (:319) on the way
+ * out.  crops_big [n_crops,3,res*aa,res*aa] f32 linear light; warp_params: the ORIGINAL rows (their
+ * [33] is the exponent applied); workspace: mtr_crops_shrink_workspace_bytes(...) bytes;
+ * 2 <= antialias <= 19. */
+size_t mtr_crops_shrink_workspace_bytes(int n_crops, int res, int antialias);
+int mtr_crops_shrink_antialiased(const float* crops_big, const float* warp_params, int n_crops, int res,
+                                 int antialias, int out_dtype, int out_layout, void* out,
+                                 void* workspace, size_t workspace_bytes, mtr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K7 (first "next" row): post-processing of the crop-model output in one launch.

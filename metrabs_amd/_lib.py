@@ -65,6 +65,9 @@ SIGNATURES = {
     'mtr_head_fused_opts': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                     c_int, POINTER(HeadParams), POINTER(HeadOptions), c_void_p, c_void_p,
                                     c_void_p]),
+    'mtr_crops_shrink_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'mtr_crops_shrink_antialiased': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                             c_void_p, c_size_t, c_void_p]),
     'mtr_reconstruct_workspace_bytes': (c_size_t, [c_int, c_int]),
     'mtr_reconstruct_absolute': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int,
                                          POINTER(ReconParams), c_void_p, c_void_p, c_size_t,

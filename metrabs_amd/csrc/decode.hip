@@ -211,6 +211,84 @@ static int dispatch_decode(const void* logits, int B, int J, int D, int H, int W
   return launch_decode<T, 1, 64>(logits, B, J, D, H, W, hs, c2d, c3d, stream);
 }
 
+// ---- NHWC logits [B, H, W, J*(1+D)] (the TF twin's layout, 'b h w (d j)',
+// metrabs_tf/models/metrabs.py:100-101): a position's channels are contiguous, so lanes walk the
+// CHANNELS (one wave-wide load = 256 consecutive bytes of a position) and every lane keeps the online
+// softmax state of its own channel row over the positions: running max (f32), sum of e, sum of e*w,
+// sum of e*h (f64).  The rows of a joint -- its 2D row n = j and its depth slices n = J + d*J + j,
+// J channels apart -- then meet in LDS, where one thread per joint merges them like an online
+// softmax over slices.  One workgroup per crop; every logit is read once, coalesced.
+template <typename T>
+__global__ __launch_bounds__(256) void decode_nhwc_kernel(const T* __restrict__ logits, int B, int J,
+                                                          int D, int H, int W, HeadScale hs, AxisInv ai,
+                                                          float* __restrict__ coords2d,
+                                                          float* __restrict__ coords3d_rel) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int N = J * (1 + D), HW = H * W;
+  float* row_m = reinterpret_cast<float*>(smem_raw);                      // [N]
+  double* row_s = reinterpret_cast<double*>(smem_raw + ((N * 4 + 15) & ~15));  // [N][3]
+  const int b = blockIdx.x;
+  const T* x = logits + (size_t)b * HW * N;
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    float m = -INFINITY;
+    double s = 0.0, sx = 0.0, sy = 0.0;
+    int h = 0, w = 0;
+    for (int p = 0; p < HW; ++p) {
+      const float v = to_f32(x[(size_t)p * N + n]);
+      if (v > m) {  // rescale what has been summed under the old maximum
+        const double f = (double)__expf(m - v);  // (m = -inf: exp(-inf) = 0)
+        s *= f; sx *= f; sy *= f;
+        m = v;
+      }
+      const double e = (double)exp_shifted(v, -m * kLog2e);
+      s += e; sx += e * (double)w; sy += e * (double)h;
+      if (++w == W) { w = 0; ++h; }
+    }
+    row_m[n] = m;
+    row_s[n * 3 + 0] = s; row_s[n * 3 + 1] = sx; row_s[n * 3 + 2] = sy;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < J; j += blockDim.x) {
+    const size_t o = (size_t)b * J + j;
+    {
+      const double i2 = fast_rcp64(row_s[j * 3]);
+      coords2d[o * 2 + 0] = heatmap_to_px(axis_coord_rcp(row_s[j * 3 + 1], i2, ai.w), hs);
+      coords2d[o * 2 + 1] = heatmap_to_px(axis_coord_rcp(row_s[j * 3 + 2], i2, ai.h), hs);
+    }
+    float M = -INFINITY;
+    for (int d = 0; d < D; ++d) M = fmaxf(M, row_m[J + d * J + j]);
+    double S = 0.0, SX = 0.0, SY = 0.0, SZ = 0.0;
+    for (int d = 0; d < D; ++d) {
+      const int n = J + d * J + j;
+      const double f = exp_neg64((double)row_m[n] - (double)M);
+      const double sd = row_s[n * 3] * f;
+      S += sd; SX += row_s[n * 3 + 1] * f; SY += row_s[n * 3 + 2] * f; SZ += sd * (double)d;
+    }
+    const double i3 = fast_rcp64(S);
+    coords3d_rel[o * 3 + 0] = heatmap_to_mm_xy(axis_coord_rcp(SX, i3, ai.w), hs);
+    coords3d_rel[o * 3 + 1] = heatmap_to_mm_xy(axis_coord_rcp(SY, i3, ai.h), hs);
+    coords3d_rel[o * 3 + 2] = heatmap_to_mm_z(axis_coord_rcp(SZ, i3, ai.d), hs);
+  }
+}
+
+template <typename T>
+static int launch_decode_nhwc(const void* logits, int B, int J, int D, int H, int W, const HeadScale& hs,
+                              float* c2d, float* c3d, hipStream_t stream) {
+  const long long N = (long long)J * (1 + D);
+  const size_t lds = (size_t)((N * 4 + 15) & ~15LL) + (size_t)N * 24;
+  if (lds > 160 * 1024 - 256) return MTR_E_SHAPE;  // > 5,800 channels per position
+  auto kern = decode_nhwc_kernel<T>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  MTR_CLEAR_STALE();
+  hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(256), lds, stream, (const T*)logits, B, J, D, H, W, hs,
+                     make_axis_inv(W, H, D), c2d, c3d);
+  MTR_CHECK_LAUNCH();
+  return MTR_OK;
+}
+
 }  // namespace mtr
 
 extern "C" int mtr_softargmax_decode(const void* logits, int dtype, int layout, int B, int J, int D,
@@ -219,10 +297,18 @@ extern "C" int mtr_softargmax_decode(const void* logits, int dtype, int layout, 
   if (!logits || !p || !coords2d || !coords3d_rel) return MTR_E_NULL;
   if (B < 0 || J <= 0 || D <= 0 || H <= 0 || W <= 0) return MTR_E_SHAPE;
   if (p->proc_side <= 0 || p->stride_test <= 0) return MTR_E_PARAM;
-  if (layout != MTR_NCHW) return MTR_E_DTYPE;  // NHWC logits only exist inside the fused head
+  if (layout != MTR_NCHW && layout != MTR_NHWC) return MTR_E_DTYPE;
   if (B == 0) return MTR_OK;
   const mtr::HeadScale hs = mtr::make_head_scale(*p);
   hipStream_t s = (hipStream_t)stream;
+  if (layout == MTR_NHWC) {
+    switch (dtype) {
+      case MTR_F32: return mtr::launch_decode_nhwc<float>(logits, B, J, D, H, W, hs, coords2d, coords3d_rel, s);
+      case MTR_F16: return mtr::launch_decode_nhwc<__half>(logits, B, J, D, H, W, hs, coords2d, coords3d_rel, s);
+      case MTR_BF16: return mtr::launch_decode_nhwc<__hip_bfloat16>(logits, B, J, D, H, W, hs, coords2d, coords3d_rel, s);
+      default: return MTR_E_DTYPE;
+    }
+  }
   switch (dtype) {
     case MTR_F32: return mtr::dispatch_decode<float>(logits, B, J, D, H, W, hs, coords2d, coords3d_rel, s);
     case MTR_F16: return mtr::dispatch_decode<__half>(logits, B, J, D, H, W, hs, coords2d, coords3d_rel, s);

@@ -15,6 +15,7 @@
 // the whole internal batch is ONE launch.  Bound: HBM for the streaming output (3*res^2*sizeof(out)
 // per crop) plus the clipped source footprint, which normally stays in L2 / Infinity Cache.
 #include "common.h"
+#include "resize_aa.h"
 
 // developer-only timing ablations of warp_crops_kernel (tools/experiments/ablate_warp.py); 0 in the product
 #ifndef MTR_WARP_ABLATE
@@ -640,6 +641,60 @@ static int warp_entry(const void* level0, const float* lut, const float* level1,
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// antialias_factor > 4 (multiperson_model.py:312-315): the reference samples the crop at
+// res*aa x res*aa and shrinks it with torchvision's antialiased bilinear resize = aten's separable
+// _upsample_bilinear2d_aa: a horizontal pass into an f32 intermediate [rows_in, res], then a
+// vertical pass; triangle filter of support aa, weights in float with aten's double-typed
+// intermediate roundings, normalised by their in-order float sum, taps accumulated as
+// t = fma(v_j, w_j, t) from t = 0 (resize_aa.h; bit-exact against torch for K9's resize).  The
+// per-crop gamma (crops **= gamma / 2.2, :319) rides on the vertical pass.
+// One thread per output value; the 2*aa + 1 taps of neighbouring threads overlap in L1 / L2.
+__device__ __forceinline__ float aa_filtered(const float* __restrict__ src, int stride, const AxisSpan& sp) {
+  float total = 0.0f;
+  for (int j = 0; j < sp.isize; ++j) total = __fadd_rn(total, axis_raw_weight(sp, j, 1));
+  float acc = 0.0f;
+  for (int j = 0; j < sp.isize; ++j) {
+    float w = axis_raw_weight(sp, j, 1);
+    if (total != 0.0f) w = __fdiv_rn(w, total);
+    acc = __fmaf_rn(src[(size_t)(sp.imin + j) * stride], w, acc);
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(256) void aa_shrink_rows_kernel(const float* __restrict__ src, long long planes,
+                                                             int R, int res, float* __restrict__ tmp) {
+  // src [planes, R, R] -> tmp [planes, R, res]
+  const long long total = planes * R * res;
+  const AxisGeom gx{R, res, 1};
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(t % res);
+    const long long row = t / res;  // plane * R + y
+    tmp[t] = aa_filtered(src + row * R, 1, axis_span(ox, gx));
+  }
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void aa_shrink_cols_kernel(const float* __restrict__ tmp, int n_crops,
+                                                             int R, int res, const float* __restrict__ wp_all,
+                                                             int nhwc, OutT* __restrict__ out) {
+  // tmp [n_crops*3, R, res] -> out [n_crops, 3, res, res] (or NHWC), ** gamma/2.2 of the crop
+  const long long total = (long long)n_crops * 3 * res * res;
+  const AxisGeom gy{R, res, 1};
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(t % res), oy = (int)((t / res) % res);
+    const long long plane = t / ((long long)res * res);
+    const int crop = (int)(plane / 3), c = (int)(plane % 3);
+    float v = aa_filtered(tmp + plane * R * res + ox, res, axis_span(oy, gy));
+    const float gexp = wp_all[(size_t)crop * MTR_WARP_PARAM_FLOATS + 33];
+    if (gexp != 1.0f) v = fast_pow_unit(v, gexp);
+    const size_t o = nhwc ? (((size_t)crop * res + oy) * res + ox) * 3 + c : (size_t)t;
+    out[o] = from_f32<OutT>(v);
+  }
+}
+
 }  // namespace mtr
 
 // wide path: whole 8x8 tiles, rows aligned for the 8 / 16 / 8-byte vectors of the three levels
@@ -746,4 +801,48 @@ extern "C" int mtr_warp_crops_u8(const uint8_t* level0_u8, const float* lut, con
                                  void* out, mtr_stream_t stream) {
   return mtr::warp_entry<true>(level0_u8, lut, level1, level2, N, Hi, Wi, warp_params, n_crops, res,
                                antialias, out_dtype, out_layout, out, (hipStream_t)stream);
+}
+
+extern "C" size_t mtr_crops_shrink_workspace_bytes(int n_crops, int res, int antialias) {
+  if (n_crops <= 0 || res <= 0 || antialias <= 0) return 0;
+  return (size_t)n_crops * 3 * (size_t)(res * antialias) * res * sizeof(float);
+}
+
+extern "C" int mtr_crops_shrink_antialiased(const float* crops_big, const float* warp_params, int n_crops,
+                                            int res, int antialias, int out_dtype, int out_layout,
+                                            void* out, void* workspace, size_t workspace_bytes,
+                                            mtr_stream_t stream) {
+  if (!crops_big || !warp_params || !out || !workspace) return MTR_E_NULL;
+  if (n_crops < 0 || res <= 0 || antialias < 1) return MTR_E_SHAPE;
+  if (2 * antialias + 2 > mtr::kDTaps) return MTR_E_SHAPE;  // taps per output value
+  if (out_layout != MTR_NCHW && out_layout != MTR_NHWC) return MTR_E_DTYPE;
+  if (workspace_bytes < mtr_crops_shrink_workspace_bytes(n_crops, res, antialias)) return MTR_E_WORKSPACE;
+  if (n_crops == 0) return MTR_OK;
+  const int R = res * antialias;
+  hipStream_t s = (hipStream_t)stream;
+  const long long planes = (long long)n_crops * 3;
+  auto blocks_for = [](long long n) { return (unsigned)((n + 255) / 256 > 65535LL * 16 ? 65535 * 16 : (n + 255) / 256); };
+  MTR_CLEAR_STALE();
+  hipLaunchKernelGGL(mtr::aa_shrink_rows_kernel, dim3(blocks_for(planes * R * res)), dim3(256), 0, s,
+                     crops_big, planes, R, res, (float*)workspace);
+  MTR_CHECK_LAUNCH();
+  const unsigned nb = blocks_for(planes * res * res);
+  const int nhwc = out_layout == MTR_NHWC;
+  switch (out_dtype) {
+    case MTR_F32:
+      hipLaunchKernelGGL(mtr::aa_shrink_cols_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)workspace,
+                         n_crops, R, res, warp_params, nhwc, (float*)out);
+      break;
+    case MTR_F16:
+      hipLaunchKernelGGL(mtr::aa_shrink_cols_kernel<__half>, dim3(nb), dim3(256), 0, s, (const float*)workspace,
+                         n_crops, R, res, warp_params, nhwc, (__half*)out);
+      break;
+    case MTR_BF16:
+      hipLaunchKernelGGL(mtr::aa_shrink_cols_kernel<__hip_bfloat16>, dim3(nb), dim3(256), 0, s,
+                         (const float*)workspace, n_crops, R, res, warp_params, nhwc, (__hip_bfloat16*)out);
+      break;
+    default: return MTR_E_DTYPE;
+  }
+  MTR_CHECK_LAUNCH();
+  return MTR_OK;
 }

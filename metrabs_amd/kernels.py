@@ -18,7 +18,11 @@ def softargmax_decode(logits, n_points, cfg, out=None):
     MetrabsHeads.forward after the conv (metrabs_pytorch/models/metrabs.py:78-85)."""
     require_cuda(logits)
     lib = _lib.load()
-    logits = logits.contiguous()
+    # torch channels_last logits (what a channels_last conv_final emits; the TF twin's
+    # 'b h w (d j)' layout, metrabs_tf/models/metrabs.py:100-101) are decoded in place
+    nhwc = _is_channels_last(logits)
+    if not nhwc:
+        logits = logits.contiguous()
     B, n_out, H, W = logits.shape
     J = int(n_points)
     D = n_out // J - 1
@@ -31,8 +35,8 @@ def softargmax_decode(logits, n_points, cfg, out=None):
         c2d, c3d = out
     hp = cfg.head_params()
     check(lib.mtr_softargmax_decode(
-        _ptr(logits), dtype_code(logits.dtype), _lib.MTR_NCHW, B, J, D, H, W, ctypes.byref(hp),
-        _ptr(c2d), _ptr(c3d), current_stream_ptr(logits.device)), 'mtr_softargmax_decode')
+        _ptr(logits), dtype_code(logits.dtype), _lib.MTR_NHWC if nhwc else _lib.MTR_NCHW, B, J, D, H, W,
+        ctypes.byref(hp), _ptr(c2d), _ptr(c3d), current_stream_ptr(logits.device)), 'mtr_softargmax_decode')
     return c2d, c3d
 
 
@@ -185,6 +189,12 @@ def warp_crops(pyramid, warp_params, res, antialias=1, out_dtype=torch.float32,
     require_cuda(warp_params)
     n = warp_params.shape[0]
     dev = warp_params.device
+    if antialias > 4:
+        return _warp_crops_big_antialias(pyramid, warp_params, res, antialias, out_dtype, channels_last, out)
+    if antialias not in (1, 2, 4):
+        # (the reference warps at res*aa and only shrinks for 2, 4 and > 4: its reshape to
+        #  [num_aug, n, 3, res, res] fails for 3, multiperson_model.py:307-316)
+        raise ValueError(f'antialias_factor must be 1, 2, 4 or > 4 (got {antialias})')
     if out is None:
         if channels_last:
             out = torch.empty(n, res, res, 3, device=dev, dtype=out_dtype).permute(0, 3, 1, 2)
@@ -199,6 +209,37 @@ def warp_crops(pyramid, warp_params, res, antialias=1, out_dtype=torch.float32,
                                             _ptr(l2), *tail), 'mtr_warp_crops_u8')
     else:
         check(_lib.load().mtr_warp_crops(_ptr(l0), _ptr(l1), _ptr(l2), *tail), 'mtr_warp_crops')
+    return out
+
+
+def _warp_crops_big_antialias(pyramid, warp_params, res, antialias, out_dtype, channels_last, out):
+    """antialias_factor > 4 (multiperson_model.py:312-315): sample at res*aa x res*aa in linear light
+    (gamma exponent 1), shrink with aten's antialiased separable bilinear filter + the per-crop gamma
+    (mtr_crops_shrink_antialiased).  The res*aa crops are 3 * (res*aa)^2 * 4 bytes each (50 MB at
+    256 px, aa = 8): they are produced and consumed in chunks of <= 1 GiB."""
+    lib = _lib.load()
+    n, dev = warp_params.shape[0], warp_params.device
+    if 2 * antialias + 2 > 40:
+        raise ValueError(f'antialias_factor {antialias} > 19 is not supported')
+    big = int(res) * int(antialias)
+    if out is None:
+        out = (torch.empty(n, res, res, 3, device=dev, dtype=out_dtype).permute(0, 3, 1, 2) if channels_last
+               else torch.empty(n, 3, res, res, device=dev, dtype=out_dtype))
+    wp_lin = warp_params.clone()
+    wp_lin[:, 33] = 1.0
+    per = 3 * big * big * 4
+    chunk = max(1, min(n, (1 << 30) // per))
+    flat_out = out.permute(0, 2, 3, 1) if channels_last else out  # the memory order, crop-major
+    for a in range(0, n, chunk):
+        b = min(n, a + chunk)
+        tmp_big = warp_crops(pyramid, wp_lin[a:b].contiguous(), big, 1, torch.float32, False)
+        ws = torch.empty(lib.mtr_crops_shrink_workspace_bytes(b - a, int(res), int(antialias)) // 4,
+                         device=dev, dtype=torch.float32)
+        check(lib.mtr_crops_shrink_antialiased(
+            _ptr(tmp_big), _ptr(warp_params[a:b].contiguous()), b - a, int(res), int(antialias),
+            dtype_code(out.dtype), _lib.MTR_NHWC if channels_last else _lib.MTR_NCHW,
+            flat_out[a:b].data_ptr(), _ptr(ws), ws.numel() * 4, current_stream_ptr(dev)),
+            'mtr_crops_shrink_antialiased')
     return out
 
 

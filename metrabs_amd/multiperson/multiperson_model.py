@@ -197,6 +197,11 @@ class Pose3dEstimator(torch.nn.Module):
         dev = self._device()
         if dev.type != 'cuda':
             raise RuntimeError('metrabs_amd.Pose3dEstimator needs the crop model on a GPU')
+        antialias_factor = int(antialias_factor)
+        if antialias_factor < 1 or antialias_factor == 3 or antialias_factor > 19:
+            # the reference shrinks only for 2, 4 and > 4 (multiperson_model.py:307-315): at 3 its
+            # reshape to [num_aug, n, 3, res, res] fails; > 19 exceeds the shrink filter's 40 taps
+            raise ValueError(f'antialias_factor must be 1, 2, 4 or 5..19 (got {antialias_factor})')
         images = torch.as_tensor(images).to(dev)
         n_images = len(images)
         intrinsic_matrix = _as_f32(intrinsic_matrix)  # (camera set-up happens on the host)

@@ -474,7 +474,10 @@ def get_crops(images_linear, intrinsic_matrix, distortion_coeffs, camspace_up, b
     elif antialias_factor == 4:
         crops = F.avg_pool2d(crops, 4, 4)
     elif antialias_factor > 4:
-        raise NotImplementedError('antialias_factor > 4 needs torchvision (not in this image)')
+        # torchvision.transforms.functional.resize(crops, (res, res), BILINEAR, antialias=True)
+        # (multiperson_model.py:312-315); torchvision's tensor path is exactly this call
+        # (transforms/_functional_tensor.py: resize -> torch.nn.functional.interpolate)
+        crops = F.interpolate(crops, size=[res, res], mode='bilinear', align_corners=False, antialias=True)
     crops = torch.reshape(crops, [num_aug, num_box, 3, res, res])
     crops **= torch.reshape(aug_gammas / 2.2, [-1, 1, 1, 1, 1])
     return crops, new_k, rot

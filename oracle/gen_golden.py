@@ -252,10 +252,12 @@ def build_reference_estimator(ref, case):
     return est
 
 
-def gen_e2e(ref):
+def gen_e2e(ref, only=None):
     import warnings
     warnings.filterwarnings('ignore', message='.*CUDA is not available.*')
     for name in cases.E2E_CASES:
+        if only and name != only:
+            continue
         case = cases.e2e_case(name)
         with rh.config(**cfg_kwargs(case['cfg'])), torch.inference_mode():
             est = build_reference_estimator(ref, case)
@@ -294,7 +296,7 @@ def main():
     groups = dict(heads=gen_heads, headconv=gen_headconv, recon=gen_recon, warp=gen_warp,
                   tta=gen_tta, e2e=gen_e2e, detpre=gen_detpre, filter=gen_filter, backbone=gen_backbone)
     for name in (sys.argv[1:] or groups):
-        if ':' in name:  # one case of a group (recon only: its lstsq goldens carry run-to-run jitter)
+        if ':' in name:  # one case of a group (recon, e2e: their lstsq goldens carry run-to-run jitter)
             group, only = name.split(':', 1)
             groups[group](ref, only=only)
         else:

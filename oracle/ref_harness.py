@@ -146,6 +146,8 @@ def _install_stubs():
                              align_corners=False, antialias=bool(antialias))
 
     tvf.resize = tv_resize
+    # (multiperson_model.py:314 names torchvision's enum; the stub's resize is bilinear whatever it gets)
+    tvf.InterpolationMode = types.SimpleNamespace(BILINEAR='bilinear', NEAREST='nearest', BICUBIC='bicubic')
 
     # ---- what metrabs_pytorch/backbones/efficientnet.py imports from torchvision (row f.4: the
     # backbone's parameter names and TF-'SAME' padding are part of the checkpoint format).  The three

@@ -120,6 +120,26 @@ def test_decode_large_batch_properties(hip_lib):
     assert float((c2d[idx].cpu() - o2d).abs().max()) <= 2e-4
 
 
+@pytest.mark.parametrize('name', list(cases.HEAD_CASES))
+def test_decode_channels_last_logits_vs_golden(name, hip_lib):
+    """NHWC logits (torch channels_last; the TF twin's 'b h w (d j)', metrabs_tf/models/metrabs.py:
+    100-101) through mtr_softargmax_decode(layout = MTR_NHWC): every golden heads_* case, same
+    bounds as the NCHW kernel."""
+    from metrabs_amd import kernels
+    g = load_golden(f'heads_{name}')
+    logits, J, cfg = cases.head_case(name)
+    for dtype in (torch.float32,) if name != 's256' else (torch.float32, torch.float16):
+        x = logits.to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+        assert kernels._is_channels_last(x) or x.shape[1] == 1 or x.shape[2] * x.shape[3] == 1
+        c2d, c3d = kernels.softargmax_decode(x, J, mcfg(cfg))
+        if dtype == torch.float32:
+            assert float((c3d.cpu() - torch.from_numpy(g['coords3d_rel'])).abs().max()) <= 1e-3
+            assert float((c2d.cpu() - torch.from_numpy(g['coords2d'])).abs().max()) <= 2e-4
+        n2d, n3d = kernels.softargmax_decode(logits.to(dtype).cuda(), J, mcfg(cfg))
+        tol = 1e-3 if dtype == torch.float32 else 2e-3
+        assert float((c3d - n3d).abs().max()) <= tol and float((c2d - n2d).abs().max()) <= 4e-4
+
+
 @pytest.mark.parametrize('name', list(cases.RECON_CASES))
 def test_reconstruct_vs_golden_and_oracle(name, hip_lib):
     """Identical coords -> absolute poses.  The reference solves with fp32 LAPACK lstsq (its own

@@ -133,6 +133,37 @@ def test_geometry_and_get_crops_vs_oracle(name, hip_lib):
     assert float(d.max()) <= 4 * LIN_MAX and float(d.mean()) <= 4 * LIN_MEAN
 
 
+@pytest.mark.parametrize('res,aa', [(16, 5), (32, 8), (24, 19), (8, 6)])
+def test_antialias_above_4_shrink_is_atens_filter(res, aa, hip_lib):
+    """antialias_factor > 4 (multiperson_model.py:312-315): mtr_crops_shrink_antialiased against
+    torch.nn.functional.interpolate(mode='bilinear', antialias=True) on the CPU -- the call
+    torchvision's resize makes.  With a gamma exponent of 1 the result must be BIT-EQUAL (weights,
+    normalisation and tap order mirror aten's separable kernel); with a real exponent the device
+    pow adds <= 4 ulp."""
+    import ctypes
+    from metrabs_amd import _lib, kernels
+    g = cases.gen(900 + res + aa)
+    n = 3
+    big = torch.rand(n, 3, res * aa, res * aa, generator=g)
+    want = F.interpolate(big, size=[res, res], mode='bilinear', align_corners=False, antialias=True)
+    lib = _lib.load()
+    for gexp in (1.0, 0.8 / 2.2):
+        wp = torch.zeros(n, 36)
+        wp[:, 33] = gexp
+        out = torch.empty(n, 3, res, res, device='cuda')
+        ws = torch.empty(lib.mtr_crops_shrink_workspace_bytes(n, res, aa) // 4, device='cuda')
+        rc = lib.mtr_crops_shrink_antialiased(big.cuda().data_ptr(), wp.cuda().data_ptr(), n, res, aa, 0, 0,
+                                              out.data_ptr(), ws.data_ptr(), ws.numel() * 4,
+                                              kernels.current_stream_ptr(out.device))
+        assert rc == 0
+        if gexp == 1.0:
+            assert torch.equal(out.cpu(), want), float((out.cpu() - want).abs().max())
+        else:
+            assert float((out.cpu() - want ** gexp).abs().max()) <= 2e-6
+    assert lib.mtr_crops_shrink_antialiased(big.cuda().data_ptr(), wp.cuda().data_ptr(), n, res, 20, 0, 0,
+                                            out.data_ptr(), ws.data_ptr(), ws.numel() * 4, None) == -2  # > 19
+
+
 def test_warp_output_formats(hip_lib):
     """fp16 / bf16 / channels_last outputs are the rounded / permuted fp32 result."""
     from metrabs_amd import kernels
