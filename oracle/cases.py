@@ -341,7 +341,7 @@ E2E_CASES = {
     'aug4_dist12': dict(seed=404, n_images=2, imh=120, imw=160, res=64, num_aug=4, aa=1,
                         dist=DISTORTION_12, ibs=3, average_aug=True, extr=True, skeleton=False,
                         jtm=False, known_k=True),
-    'aug2_aa8': dict(seed=406, n_images=2, imh=160, imw=200, res=32, num_aug=2, aa=8, dist=DISTORTION_5,
+    'aug2_aa8': dict(seed=409, n_images=3, imh=160, imw=200, res=32, num_aug=2, aa=8, dist=DISTORTION_5,
                      ibs=64, average_aug=True, extr=False, skeleton=False, jtm=False, known_k=True),
     'aug2_aa4_bigbox': dict(seed=405, n_images=1, imh=400, imw=600, res=32, num_aug=2, aa=4,
                             dist=None, ibs=64, average_aug=True, extr=False, skeleton=False,

@@ -147,12 +147,14 @@ def test_antialias_above_4_shrink_is_atens_filter(res, aa, hip_lib):
     big = torch.rand(n, 3, res * aa, res * aa, generator=g)
     want = F.interpolate(big, size=[res, res], mode='bilinear', align_corners=False, antialias=True)
     lib = _lib.load()
+    big_d = big.cuda()
     for gexp in (1.0, 0.8 / 2.2):
         wp = torch.zeros(n, 36)
         wp[:, 33] = gexp
+        wp_d = wp.cuda()
         out = torch.empty(n, 3, res, res, device='cuda')
         ws = torch.empty(lib.mtr_crops_shrink_workspace_bytes(n, res, aa) // 4, device='cuda')
-        rc = lib.mtr_crops_shrink_antialiased(big.cuda().data_ptr(), wp.cuda().data_ptr(), n, res, aa, 0, 0,
+        rc = lib.mtr_crops_shrink_antialiased(big_d.data_ptr(), wp_d.data_ptr(), n, res, aa, 0, 0,
                                               out.data_ptr(), ws.data_ptr(), ws.numel() * 4,
                                               kernels.current_stream_ptr(out.device))
         assert rc == 0
@@ -160,7 +162,7 @@ def test_antialias_above_4_shrink_is_atens_filter(res, aa, hip_lib):
             assert torch.equal(out.cpu(), want), float((out.cpu() - want).abs().max())
         else:
             assert float((out.cpu() - want ** gexp).abs().max()) <= 2e-6
-    assert lib.mtr_crops_shrink_antialiased(big.cuda().data_ptr(), wp.cuda().data_ptr(), n, res, 20, 0, 0,
+    assert lib.mtr_crops_shrink_antialiased(big_d.data_ptr(), wp_d.data_ptr(), n, res, 20, 0, 0,
                                             out.data_ptr(), ws.data_ptr(), ws.numel() * 4, None) == -2  # > 19
 
 
