@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline"
+BENCH="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-depth72"  # (the step and its probes only: no backbone variants)
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -o kt -- $BENCH > $O/prof_kt.log 2>&1
 python $R/tools/rocprof_summary.py /tmp/prof_kt $O/${TAG}_kernel_trace_bench_f32.md
 PMC="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-depth72"
@@ -19,8 +19,14 @@ python $R/tools/rocprof_summary.py /tmp/prof_write $O/${TAG}_pmc_write_size.md -
 python $R/tools/pmc_traffic.py /tmp/prof_fetch /tmp/prof_write --tag $TAG --command "bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-depth72" --out $O/${TAG}_traffic.json
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d /tmp/prof_mfma -o m -- python $R/tools/_pmc_head.py 64 f32 > $O/prof_mfma.log 2>&1
 python $R/tools/rocprof_summary.py /tmp/prof_mfma $O/${TAG}_pmc_head_mfma.md --ours-only
+# the sampler's issue / wait / LDS counters (two passes of 8 SQ counters)
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/prof_w1 -o a -- python $R/tools/experiments/pmc_warp.py > /dev/null 2>&1
+python $R/tools/rocprof_summary.py /tmp/prof_w1 $O/${TAG}_pmc_warp_insts.md --ours-only
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d /tmp/prof_w2 -o b -- python $R/tools/experiments/pmc_warp.py > /dev/null 2>&1
+python $R/tools/rocprof_summary.py /tmp/prof_w2 $O/${TAG}_pmc_warp_cycles.md --ours-only
 cd $R
 python tools/microbench.py > $O/${TAG}_microbench.jsonl 2>/dev/null
+timeout 300 python tools/experiments/head_rt_ab.py $TAG > $O/${TAG}_head_rt_ab.jsonl 2>/dev/null
 python tools/experiments/fused_vs_unfused.py > $O/${TAG}_fused_vs_library.txt 2>/dev/null
 cp $O/${TAG}_traffic.json profiles/traffic.json   # the bench line below reports this round's traffic
 python bench.py > $O/${TAG}_bench_f32.json 2> $O/${TAG}_bench.err
