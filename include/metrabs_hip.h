@@ -117,6 +117,9 @@ typedef struct mtr_head_options {
   int32_t groups_per_workgroup;    /* 16-bit: joint groups per workgroup, 1..3; 0 = by launch size        */
   int32_t dma_staging;             /* 16-bit: 1 = global_load_lds where possible, 0 = through registers,
                                       -1 = library's choice (NB: a zeroed struct selects registers)    */
+  int32_t rt_column_blocks;        /* f32, maps of > 64 positions: 64-position column blocks per workgroup
+                                      tile, 2..4 (one K loop for all of them); 1 = one K loop per column
+                                      block; 0 = by launch size                                         */
 } mtr_head_options;
 
 /* host-only, no GPU work: the row order of the f32 row-tile kernel.  conv_final's J*(1+D) channels

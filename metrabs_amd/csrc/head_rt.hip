@@ -46,19 +46,32 @@ using v4f = __attribute__((ext_vector_type(4))) float;
 // small-launch configuration: one workgroup per CU, nothing else to hide the first HBM misses) keep
 // 3 stages in flight; 4- and 5-tile blocks run with one stage in flight and two workgroups per CU
 // (the other workgroup covers the latency; measured equal to the deep ring at every launch size,
-// tools/experiments/ablate_rt.py) so that 5 tiles' accumulators and their LDS fit twice.
-__host__ __device__ constexpr int rt_nbuf(int rtmax) { return MTR_RT_NBUF ? MTR_RT_NBUF : (rtmax <= 3 ? 4 : 2); }
-constexpr int kRtLP = 68;         // logits row pitch in LDS (floats)
+// tools/experiments/ablate_rt.py) so that 5 tiles' accumulators and their LDS fit twice.  Tiles of
+// several column blocks: the deep ring while it fits the 160 KiB.
+constexpr int kRtLP = 68;         // logits row pitch in LDS (floats) per 64-position column block
 constexpr int kRtChunkNCHW = 1088;  // 4 channel rows of 64 positions + 64 B: the two channel groups
                                     // a 32-lane ds_read_b32 group touches land 16 banks apart
 
-__host__ __device__ constexpr int rt_stage_bytes(int rt, bool nhwc) {
-  return rt * 2048 + (nhwc ? 8192 : 8 * kRtChunkNCHW);
+// A workgroup's tile is RT row tiles (16 output channels each) x NP column blocks (64 positions
+// each): one K loop with RT * NP accumulators per wave (wave w: positions 16 w .. 16 w + 15 of every
+// column block).  NP > 1 is for maps of more than 64 positions on launches that do not fill the
+// chip with multi-tile blocks: 8 * RT * NP MFMAs per stage and wave from RT + NP fragment reads.
+__host__ __device__ constexpr int rt_feat_chunk(bool nhwc) { return nhwc ? 8192 : 8 * kRtChunkNCHW; }
+__host__ __device__ constexpr int rt_stage_bytes(int rt, int np, bool nhwc) {
+  return rt * 2048 + np * rt_feat_chunk(nhwc);
 }
-__host__ __device__ constexpr int rt_lds_bytes(int rtmax, bool nhwc) {
-  // ring + logits [R][68] + per row: max, unit max, bias (f32), label (i32), 3 f64 sums, and the
-  // unit's running (max, 4 sums) across column blocks (5 f64)
-  return rt_nbuf(rtmax) * rt_stage_bytes(rtmax, nhwc) + rtmax * 16 * (kRtLP * 4 + 16 + 24 + 40);
+// logits [R][NP * 68] + per row: max, unit max, bias (f32), label (i32), 3 f64 sums, and the unit's
+// running (max, 4 sums) across column blocks (5 f64)
+__host__ __device__ constexpr int rt_epilogue_bytes(int rtmax, int np) {
+  return rtmax * 16 * (np * kRtLP * 4 + 16 + 24 + 40);
+}
+__host__ __device__ constexpr int rt_nbuf(int rtmax, int np, bool nhwc) {
+  if (MTR_RT_NBUF) return MTR_RT_NBUF;
+  if (rtmax * np > 4 || (np == 1 && rtmax > 3)) return 2;
+  return 4 * rt_stage_bytes(rtmax, np, nhwc) + rt_epilogue_bytes(rtmax, np) <= 160 * 1024 ? 4 : 2;
+}
+__host__ __device__ constexpr int rt_lds_bytes(int rtmax, int np, bool nhwc) {
+  return rt_nbuf(rtmax, np, nhwc) * rt_stage_bytes(rtmax, np, nhwc) + rt_epilogue_bytes(rtmax, np);
 }
 
 __global__ void head_rt_pack_kernel(const float* __restrict__ w, const float* __restrict__ bias, int C,
@@ -122,47 +135,52 @@ struct RtArgs {
 
 constexpr int kRtCarry = 8;  // stages (of 32 channels) summed in f32 before the sum goes into f64
 
-template <int RT>
+template <int RT, int NP>
 struct RtRegs {
-  double acc[RT][4];   // f64 totals
-  v4f run[RT];         // f32 sum of the finished chains of up to kRtCarry stages
-  v4f part[2][RT];     // the 32-channel MFMA chain of a stage, by stage parity
-  v4f ya[RT], yb;      // fragments of the previous stage's second half (consumed one barrier late)
+  double acc[RT * NP][4];   // f64 totals; accumulator q = (row tile q % RT, column block q / RT)
+  v4f run[RT * NP];         // f32 sum of the finished chains of up to kRtCarry stages
+  v4f part[2][RT * NP];     // the 32-channel MFMA chain of a stage, by stage parity
+  v4f ya[RT], yb[NP];       // fragments of the previous stage's second half (consumed one barrier late)
 };
 
-template <int RT, bool NHWC>
+template <int RT, int NP, bool NHWC>
 __device__ __forceinline__ void rt_read_frags(const char* buf, int a_addr, int b_addr, v4f (&fa)[RT],
-                                              v4f& fb) {
+                                              v4f (&fb)[NP]) {
   if (MTR_RT_ABLATE & 16) {
 #pragma unroll
     for (int t = 0; t < RT; ++t) fa[t] = v4f{(float)a_addr, 1.f, 2.f, (float)t};
-    fb = v4f{(float)b_addr, 1.f, 2.f, 3.f};
+#pragma unroll
+    for (int p = 0; p < NP; ++p) fb[p] = v4f{(float)b_addr, 1.f, 2.f, (float)p};
     return;
   }
 #pragma unroll
   for (int t = 0; t < RT; ++t) fa[t] = *reinterpret_cast<const v4f*>(buf + t * 2048 + a_addr);
-  if constexpr (NHWC) {
-    fb = *reinterpret_cast<const v4f*>(buf + RT * 2048 + b_addr);
-  } else {
-    const float* p = reinterpret_cast<const float*>(buf + RT * 2048 + b_addr);
-    fb = v4f{p[0], p[64], p[128], p[192]};  // channels k .. k + 3 of this lane's position
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    if constexpr (NHWC) {
+      fb[p] = *reinterpret_cast<const v4f*>(buf + RT * 2048 + p * rt_feat_chunk(true) + b_addr);
+    } else {
+      const float* q = reinterpret_cast<const float*>(buf + RT * 2048 + p * rt_feat_chunk(false) + b_addr);
+      fb[p] = v4f{q[0], q[64], q[128], q[192]};  // channels k .. k + 3 of this lane's position
+    }
   }
 }
 
-// One MFMA slot: slot n of a half stage is tile n % RT, k-step n / RT (tile-major inside a k-step,
-// so consecutive MFMAs never share an accumulator).  A stage's chain starts from zero in the first
-// k-step of its first half.
-template <int RT>
-__device__ __forceinline__ void rt_mfma_slot(v4f (&chain)[RT], const v4f (&fa)[RT], const v4f& fb, int n,
-                                             bool first_half) {
-  const int t = n % RT, k = n / RT;
+// One MFMA slot: slot n of a half stage is accumulator n % (RT NP), k-step n / (RT NP)
+// (accumulator-major inside a k-step, so consecutive MFMAs never share an accumulator).  A stage's
+// chain starts from zero in the first k-step of its first half.
+template <int RT, int NP>
+__device__ __forceinline__ void rt_mfma_slot(v4f (&chain)[RT * NP], const v4f (&fa)[RT],
+                                             const v4f (&fb)[NP], int n, bool first_half) {
+  const int q = n % (RT * NP), k = n / (RT * NP);
+  const int t = q % RT, p = q / RT;
   if (MTR_RT_ABLATE & 2) {
-    chain[t][0] += fa[t][k] * fb[k];
+    chain[q][0] += fa[t][k] * fb[p][k];
     return;
   }
-  chain[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-      fa[t][k], fb[k], (first_half && k == 0 && !(MTR_RT_ABLATE & 8)) ? v4f{0.f, 0.f, 0.f, 0.f} : chain[t],
-      0, 0, 0);
+  chain[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+      fa[t][k], fb[p][k],
+      (first_half && k == 0 && !(MTR_RT_ABLATE & 8)) ? v4f{0.f, 0.f, 0.f, 0.f} : chain[q], 0, 0, 0);
 }
 // element pair e2 (two adjacent registers of tile e2 / 2) of a finished chain into the f32 running sum
 template <int RT>
@@ -183,15 +201,18 @@ __device__ __forceinline__ void rt_flush(double (&acc)[RT][4], v4f (&run)[RT]) {
   }
 }
 
-template <int RT, int RTMAX, bool NHWC>
+template <int RT, int NP, int RTMAX, bool NHWC>
 __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, int t0) {
-  constexpr int STAGE = rt_stage_bytes(RT, NHWC);
-  constexpr int kRtNbuf = rt_nbuf(RTMAX);
-  constexpr int JOBS = 2 * RT + 8;       // 1 KiB copies per stage: 2 per weight tile, 8 of features
+  constexpr int STAGE = rt_stage_bytes(RT, NP, NHWC);
+  constexpr int kRtNbuf = rt_nbuf(RTMAX, NP, NHWC);
+  constexpr int CHUNK = rt_feat_chunk(NHWC);   // LDS bytes of one column block's features per stage
+  constexpr int JOBS = 2 * RT + 8 * NP;  // 1 KiB copies per stage: 2 per weight tile, 8 per column block
   constexpr int JPW = (JOBS + 3) / 4;    // per wave (upper bound)
   constexpr int R = RT * 16;
-  float* Ls = reinterpret_cast<float*>(smem + kRtNbuf * rt_stage_bytes(RTMAX, NHWC));
-  float* rowmax = Ls + RTMAX * 16 * kRtLP;
+  constexpr int NA = RT * NP;            // accumulators per wave
+  constexpr int LP = NP * kRtLP;         // logits row pitch (floats)
+  float* Ls = reinterpret_cast<float*>(smem + kRtNbuf * rt_stage_bytes(RTMAX, NP, NHWC));
+  float* rowmax = Ls + RTMAX * 16 * LP;
   float* unitmax = rowmax + RTMAX * 16;
   float* bias_s = unitmax + RTMAX * 16;
   int* info_s = reinterpret_cast<int*>(bias_s + RTMAX * 16);
@@ -226,7 +247,7 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
   }
 
   const int n_cb = (HW + 63) >> 6;
-  for (int cb = 0; cb < n_cb; ++cb) {
+  for (int cb0 = 0; cb0 < n_cb; cb0 += NP) {  // groups of NP column blocks: one K loop each
     // ---- this wave's copies: job j = wid + 4 i (0 .. 2RT-1: weight tiles, then 8 feature chunks).
     // Every wave issues JPW copies per stage so that one counted s_waitcnt serves all of them;
     // a wave whose last index falls behind the list repeats its previous copy (same bytes to the
@@ -242,20 +263,21 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
         voff[i] = lane * 16;
         ldso[i] = j * 1024;
       } else {
-        const int jb = j - 2 * RT;
+        const int jf = j - 2 * RT;  // column block of the group, 1-KiB chunk inside it
+        const int np = NP == 1 ? 0 : jf >> 3, jb = NP == 1 ? jf : jf & 7;
         gbase[i] = fcrop;
         if constexpr (NHWC) {
           const int pos = jb * 8 + (lane >> 3), slot = (lane & 7) ^ ((pos >> 1) & 7);
-          const int P = cb * 64 + pos;
+          const int P = (cb0 + np) * 64 + pos;
           gstride[i] = 128;
           voff[i] = (unsigned)(P < HW ? P : 0) * (unsigned)a.C * 4u + slot * 16;
-          ldso[i] = RT * 2048 + jb * 1024;
+          ldso[i] = RT * 2048 + np * CHUNK + jb * 1024;
         } else {
           const int ch = jb * 4 + (lane >> 4);
-          const int p = cb * 64 + (lane & 15) * 4;
+          const int p = (cb0 + np) * 64 + (lane & 15) * 4;
           gstride[i] = 32u * (unsigned)HW * 4u;
           voff[i] = (unsigned)ch * (unsigned)HW * 4u + (unsigned)(p < HW ? p : 0) * 4u;
-          ldso[i] = RT * 2048 + jb * kRtChunkNCHW;
+          ldso[i] = RT * 2048 + np * CHUNK + jb * kRtChunkNCHW;
         }
       }
       gbase[i] = uniform_ptr(gbase[i]);
@@ -273,7 +295,7 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
       for (int i = 0; i < JPW; ++i) {
         const int j = wid + 4 * i < JOBS ? wid + 4 * i : wid + 4 * (i - 1);
         if (j < 2 * RT) continue;
-        const int jb = j - 2 * RT;
+        const int jb = NP == 1 ? j - 2 * RT : (j - 2 * RT) & 7;
         if constexpr (NHWC) {
           const int pos = jb * 8 + (lane >> 3), slot = (lane & 7) ^ ((pos >> 1) & 7);
           if (c0_last + slot * 4 >= a.C) voff[i] -= (unsigned)(slot * 16);  // -> channel slot 0
@@ -288,14 +310,17 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
       if (c_tail && issued == n_stages - 1) redirect_tail();
     };
 
-    RtRegs<RT> rg;
+    RtRegs<RT, NP> rg;
 #pragma unroll
-    for (int t = 0; t < RT; ++t) {
+    for (int q = 0; q < NA; ++q) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) rg.acc[t][r] = 0.0;
-      rg.part[0][t] = rg.part[1][t] = rg.run[t] = rg.ya[t] = v4f{0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < 4; ++r) rg.acc[q][r] = 0.0;
+      rg.part[0][q] = rg.part[1][q] = rg.run[q] = v4f{0.f, 0.f, 0.f, 0.f};
     }
-    rg.yb = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < RT; ++t) rg.ya[t] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < NP; ++p) rg.yb[p] = v4f{0.f, 0.f, 0.f, 0.f};
 
     // prologue: stages 0 .. NBUF-2 in flight
     if (c_tail && n_stages == 1) redirect_tail();
@@ -327,25 +352,25 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
     if (more) rt_wait_vmcnt<(kRtNbuf - 2) * JPW>(); else rt_wait_vmcnt<0>();                      \
     __syncthreads();                                                                              \
     const char* buf = smem + (BUF) * STAGE;                                                       \
-    v4f xa[RT], xb;                                                                               \
-    rt_read_frags<RT, NHWC>(buf, a_off, b_off, xa, xb);                                           \
+    v4f xa[RT], xb[NP];                                                                           \
+    rt_read_frags<RT, NP, NHWC>(buf, a_off, b_off, xa, xb);                                       \
     __builtin_amdgcn_sched_barrier(0);                                                            \
-    _Pragma("unroll") for (int n = 0; n < 4 * RT; ++n) {                                          \
-      rt_mfma_slot<RT>(rg.part[(P) ^ 1], rg.ya, rg.yb, n, false);                                 \
+    _Pragma("unroll") for (int n = 0; n < 4 * NA; ++n) {                                          \
+      rt_mfma_slot<RT, NP>(rg.part[(P) ^ 1], rg.ya, rg.yb, n, false);                             \
       if (n < JPW && more && !(MTR_RT_ABLATE & 4)) issue_job(n, ((BUF) + kRtNbuf - 1) % kRtNbuf); \
       if (n == JPW && more) stage_issued();                                                       \
       __builtin_amdgcn_sched_barrier(0);                                                          \
     }                                                                                             \
-    rt_read_frags<RT, NHWC>(buf, a_off ^ 64, b_q1, rg.ya, rg.yb);                                 \
+    rt_read_frags<RT, NP, NHWC>(buf, a_off ^ 64, b_q1, rg.ya, rg.yb);                             \
     __builtin_amdgcn_sched_barrier(0);                                                            \
-    _Pragma("unroll") for (int n = 0; n < 4 * RT; ++n) {                                          \
-      rt_mfma_slot<RT>(rg.part[P], xa, xb, n, true);                                              \
-      if (n % 2 == 1) rt_run_add<RT>(rg.run, rg.part[(P) ^ 1], n / 2);                            \
+    _Pragma("unroll") for (int n = 0; n < 4 * NA; ++n) {                                          \
+      rt_mfma_slot<RT, NP>(rg.part[P], xa, xb, n, true);                                          \
+      if (n % 2 == 1) rt_run_add<NA>(rg.run, rg.part[(P) ^ 1], n / 2);                            \
       __builtin_amdgcn_sched_barrier(0);                                                          \
     }                                                                                             \
   }
     static_assert(kRtNbuf == 4 || kRtNbuf == 2, "the main loop is unrolled over a ring of 4 or 2 slots");
-    static_assert(JPW < 4 * RT, "the copies fit the first half stage");
+    static_assert(JPW < 4 * NA, "the copies fit the first half stage");
     int s = 0;
     // main loop: every iteration issues a stage.  run holds the stages up to s - 2 at the top of
     // iteration s; it is emptied into f64 every kRtCarry stages (any point between two iterations
@@ -353,7 +378,7 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
     if constexpr (kRtNbuf == 4) {
       for (; s + kRtNbuf - 1 + 3 < n_stages; s += 4) {
         RT_ITER(s, 0, 0, true)
-        if (s >= kRtCarry && s % kRtCarry == 0) rt_flush<RT>(rg.acc, rg.run);
+        if (s >= kRtCarry && s % kRtCarry == 0) rt_flush<NA>(rg.acc, rg.run);
         RT_ITER(s + 1, 1, 1, true)
         RT_ITER(s + 2, 0, 2, true)
         RT_ITER(s + 3, 1, 3, true)
@@ -361,13 +386,13 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
     } else {
       for (; s + kRtNbuf - 1 + 1 < n_stages; s += 2) {
         RT_ITER(s, 0, 0, true)
-        if (s >= kRtCarry && s % kRtCarry == 0) rt_flush<RT>(rg.acc, rg.run);
+        if (s >= kRtCarry && s % kRtCarry == 0) rt_flush<NA>(rg.acc, rg.run);
         RT_ITER(s + 1, 1, 1, true)
       }
     }
     // remainder (the last issuing iterations + the NBUF - 1 that only consume)
     for (; s < n_stages; ++s) {
-      if (s >= 2 && (s - 1) % kRtCarry == 0) rt_flush<RT>(rg.acc, rg.run);
+      if (s >= 2 && (s - 1) % kRtCarry == 0) rt_flush<NA>(rg.acc, rg.run);
       const bool more_rt = s + kRtNbuf - 1 < n_stages;
       if constexpr (kRtNbuf == 4) {
         switch (s & 3) {
@@ -384,15 +409,15 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
     // drain: second half of the last stage's chain (parity PL), then the sums
 #define RT_DRAIN(PL)                                                                              \
   {                                                                                               \
-    _Pragma("unroll") for (int n = 0; n < 4 * RT; ++n) {                                          \
-      rt_mfma_slot<RT>(rg.part[PL], rg.ya, rg.yb, n, false);                                      \
+    _Pragma("unroll") for (int n = 0; n < 4 * NA; ++n) {                                          \
+      rt_mfma_slot<RT, NP>(rg.part[PL], rg.ya, rg.yb, n, false);                                  \
       __builtin_amdgcn_sched_barrier(0);                                                          \
     }                                                                                             \
-    _Pragma("unroll") for (int e2 = 0; e2 < 2 * RT; ++e2) rt_run_add<RT>(rg.run, rg.part[PL], e2); \
+    _Pragma("unroll") for (int e2 = 0; e2 < 2 * NA; ++e2) rt_run_add<NA>(rg.run, rg.part[PL], e2); \
     if (MTR_RT_ABLATE & 8) {                                                                      \
-      _Pragma("unroll") for (int t = 0; t < RT; ++t) rg.run[t] = rg.part[0][t] + rg.part[1][t];   \
+      _Pragma("unroll") for (int t = 0; t < NA; ++t) rg.run[t] = rg.part[0][t] + rg.part[1][t];   \
     }                                                                                             \
-    rt_flush<RT>(rg.acc, rg.run);                                                                 \
+    rt_flush<NA>(rg.acc, rg.run);                                                                 \
   }
     if ((n_stages - 1) & 1) RT_DRAIN(1) else RT_DRAIN(0)
 #undef RT_DRAIN
@@ -403,19 +428,24 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
       asm volatile("" : "+v"(lane_e));  // (as below: addresses computed here, not held through the K loop)
       const int col = wid * 16 + (lane_e & 15), row0 = (lane_e >> 4) * 4;
 #pragma unroll
-      for (int t = 0; t < RT; ++t)
+      for (int q = 0; q < NA; ++q)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = t * 16 + row0 + r;
-          Ls[row * kRtLP + col] = (float)(rg.acc[t][r] + (double)bias_s[row]);
+          const int row = (q % RT) * 16 + row0 + r;
+          Ls[row * LP + (q / RT) * kRtLP + col] = (float)(rg.acc[q][r] + (double)bias_s[row]);
         }
     }
     __syncthreads();
 
     if (MTR_RT_ABLATE & 1) {  // no decode: one store per workgroup keeps the GEMM alive
-      if (tid == 0 && cb == n_cb - 1) a.c2d[(size_t)crop * a.J * 2] = Ls[0];
+      if (tid == 0 && cb0 + NP >= n_cb) a.c2d[(size_t)crop * a.J * 2] = Ls[0];
       continue;
     }
+#pragma unroll 1
+   for (int np = 0; np < NP; ++np) {  // decode the group's column blocks one after the other
+    const int cb = NP == 1 ? cb0 : cb0 + np;
+    if (NP > 1 && cb >= n_cb) break;
+    const float* Lb = Ls + np * kRtLP;  // this column block's 64 columns (row pitch LP)
     // ---- decode, a 16-lane group per row (RT rounds of 16 rows)
     // (the addresses below do not depend on the column block; the empty asm keeps the compiler from
     //  computing them once in front of the K loop and holding them in registers through it)
@@ -427,7 +457,7 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
 #pragma unroll
     for (int k = 0; k < RT; ++k) {
       const int row = k * 16 + grp;
-      x[k] = *reinterpret_cast<const v4f*>(Ls + row * kRtLP + l16 * 4);
+      x[k] = *reinterpret_cast<const v4f*>(Lb + row * LP + l16 * 4);
       float m = -INFINITY;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -517,8 +547,10 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
         }
       }
     }
-    // (the next column block's copies only touch the ring, which every wave left before the
-    //  barrier behind the logits store; its logits store is many barriers away)
+    if (NP > 1) __syncthreads();  // (the next column block re-uses rowmax / rowsum)
+   }
+    // (the next group's copies only touch the ring, which every wave left before the barrier behind
+    //  the logits store; its logits store is many barriers away)
   }
 }
 
@@ -534,19 +566,36 @@ __global__ __launch_bounds__(256, RTMAX <= 3 ? 1 : 2) void head_rt_kernel(RtArgs
   if (crop >= a.B) return;
   const int t0 = blk * a.rtg;
   const int rt = min(a.rtg, a.n_tiles - t0);
-  if (rt == 1) rt_block<1, RTMAX, NHWC>(a, smem, crop, t0);
-  if (rt == 2) rt_block<2, RTMAX, NHWC>(a, smem, crop, t0);
-  if (rt == 3) rt_block<3, RTMAX, NHWC>(a, smem, crop, t0);
+  if (rt == 1) rt_block<1, 1, RTMAX, NHWC>(a, smem, crop, t0);
+  if (rt == 2) rt_block<2, 1, RTMAX, NHWC>(a, smem, crop, t0);
+  if (rt == 3) rt_block<3, 1, RTMAX, NHWC>(a, smem, crop, t0);
   if constexpr (RTMAX >= 5) {
-    if (rt == 4) rt_block<4, RTMAX, NHWC>(a, smem, crop, t0);
-    if (rt == 5) rt_block<5, RTMAX, NHWC>(a, smem, crop, t0);
+    if (rt == 4) rt_block<4, 1, RTMAX, NHWC>(a, smem, crop, t0);
+    if (rt == 5) rt_block<5, 1, RTMAX, NHWC>(a, smem, crop, t0);
   }
 }
 
-template <int RTMAX, bool NHWC>
-static int rt_launch_t(const RtArgs& a, hipStream_t stream) {
-  constexpr int lds = rt_lds_bytes(RTMAX, NHWC);
-  auto kern = head_rt_kernel<RTMAX, NHWC>;
+// Tiles of several column blocks (maps of more than 64 positions): RT row tiles x NP column blocks
+// per workgroup, RT * NP <= 4.  Same grid mapping; a ragged last block (RT = 2, odd tile count)
+// runs the one-tile body.
+template <int RT, int NP, bool NHWC>
+__global__ __launch_bounds__(256, 1) void head_rt_np_kernel(RtArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int chunk = 8 * a.n_blocks;
+  const int id = blockIdx.x;
+  const int crop = (id / chunk) * 8 + (id % 8);
+  const int blk = (id % chunk) / 8;
+  if (crop >= a.B) return;
+  const int t0 = blk * a.rtg;
+  const int rt = min(a.rtg, a.n_tiles - t0);
+  if (rt == RT) rt_block<RT, NP, RT, NHWC>(a, smem, crop, t0);
+  if constexpr (RT == 2) {
+    if (rt == 1) rt_block<1, NP, RT, NHWC>(a, smem, crop, t0);
+  }
+}
+
+template <typename Kern>
+static int rt_launch_kernel(Kern kern, int lds, const RtArgs& a, hipStream_t stream) {
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
@@ -557,6 +606,15 @@ static int rt_launch_t(const RtArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, a);
   MTR_CHECK_LAUNCH();
   return MTR_OK;
+}
+
+template <int RTMAX, bool NHWC>
+static int rt_launch_t(const RtArgs& a, hipStream_t stream) {
+  return rt_launch_kernel(head_rt_kernel<RTMAX, NHWC>, rt_lds_bytes(RTMAX, 1, NHWC), a, stream);
+}
+template <int RT, int NP, bool NHWC>
+static int rt_launch_np(const RtArgs& a, hipStream_t stream) {
+  return rt_launch_kernel(head_rt_np_kernel<RT, NP, NHWC>, rt_lds_bytes(RT, NP, NHWC), a, stream);
 }
 
 int rt_pack(const float* weight, const float* bias, int C, int J, int D, void* section,
@@ -574,7 +632,7 @@ int rt_pack(const float* weight, const float* bias, int C, int J, int D, void* s
 }
 
 int rt_launch(const float* feat, int layout, const void* section, int B, int C, int H, int W, int J,
-              int D, const HeadScale& hs, float* coords2d, float* coords3d_rel, int rtg_hint,
+              int D, const HeadScale& hs, float* coords2d, float* coords3d_rel, int rtg_hint, int np_hint,
               hipStream_t stream) {
   const RtGeom g = rt_geom(J, D);
   RtArgs a;
@@ -585,9 +643,38 @@ int rt_launch(const float* feat, int layout, const void* section, int B, int C, 
   a.info = (const int*)(a.bias_p + g.n_tiles * 16);
   a.B = B; a.C = C; a.H = H; a.W = W; a.J = J; a.D = D;
   a.n_tiles = g.n_tiles;
+  a.hs = hs;
+  a.inv = make_axis_inv(W, H, D);
+  a.c2d = coords2d;
+  a.c3d = coords3d_rel;
+  const bool nhwc = layout == MTR_NHWC;
+  const long long crops8 = (long long)((B + 7) / 8) * 8;
+  const int n_cb = (H * W + 63) / 64;
+  // ---- maps of several column blocks, one-tile atoms: RT x NP tiles (one K loop for NP column
+  // blocks) while the launch is one round of workgroups or so -- a workgroup of one row tile that
+  // runs n_cb K loops of 8 MFMAs per stage back to back is bound by its per-stage overhead, not by
+  // the matrix pipe.  np_hint: 1 = never, 2..4 = that many column blocks, 0 = this rule.
+  if (g.a == 1 && n_cb >= 2 && np_hint != 1) {
+    int np = np_hint;
+    if (np == 0) {
+      np = n_cb == 2 ? 2 : (n_cb == 3 ? 3 : 4);
+      if (n_cb > 4 && (n_cb + 2) / 3 * 3 - n_cb < (n_cb + 3) / 4 * 4 - n_cb) np = 3;  // less padding
+      if (crops8 * g.n_tiles > 2048) np = 1;  // many rounds: equal multi-tile blocks (below)
+    }
+    if (np >= 2) {
+      if (np > 4) np = 4;
+      a.rtg = (np == 2 && (rtg_hint == 2 || (rtg_hint == 0 && crops8 * g.n_tiles >= 1024))) ? 2 : 1;
+      a.n_blocks = (g.n_tiles + a.rtg - 1) / a.rtg;
+      if (a.rtg == 2) return nhwc ? rt_launch_np<2, 2, true>(a, stream) : rt_launch_np<2, 2, false>(a, stream);
+      switch (np) {
+        case 2: return nhwc ? rt_launch_np<1, 2, true>(a, stream) : rt_launch_np<1, 2, false>(a, stream);
+        case 3: return nhwc ? rt_launch_np<1, 3, true>(a, stream) : rt_launch_np<1, 3, false>(a, stream);
+        default: return nhwc ? rt_launch_np<1, 4, true>(a, stream) : rt_launch_np<1, 4, false>(a, stream);
+      }
+    }
+  }
   if (g.a == 1 && rtg_hint == 0) {
     // one-tile atoms: how many tiles a workgroup takes.
-    const long long crops8 = (long long)((B + 7) / 8) * 8;
     if (crops8 * ((g.n_tiles + 2) / 3) <= 512) {
       // small launches (one round of at most 2 workgroups per CU): 3 tiles per workgroup, fewer
       // when that would leave CUs without one (few crops, large maps)
@@ -606,11 +693,6 @@ int rt_launch(const float* feat, int layout, const void* section, int B, int C, 
   }
   a.rtg = rt_block_tiles(g, rtg_hint);
   a.n_blocks = (g.n_tiles + a.rtg - 1) / a.rtg;
-  a.hs = hs;
-  a.inv = make_axis_inv(W, H, D);
-  a.c2d = coords2d;
-  a.c3d = coords3d_rel;
-  const bool nhwc = layout == MTR_NHWC;
   if (a.rtg <= 3)
     return nhwc ? rt_launch_t<3, true>(a, stream) : rt_launch_t<3, false>(a, stream);
   return nhwc ? rt_launch_t<5, true>(a, stream) : rt_launch_t<5, false>(a, stream);

@@ -355,12 +355,45 @@ def test_every_row_tile_block_size_gives_the_same_bits(rt_tiles, hip_lib):
             assert torch.equal(l3d.cpu(), a3d) and torch.equal(l2d.cpu(), a2d), shape
 
 
+@pytest.mark.parametrize('shape', [(2, 33, 17, 8, 12, 12), (1, 64, 3, 8, 16, 16), (2, 48, 17, 8, 24, 24),
+                                   (1, 40, 5, 8, 20, 36), (2, 40, 6, 16, 10, 10), (3, 96, 30, 4, 10, 10),
+                                   (2, 32, 122, 8, 12, 12), (33, 64, 17, 8, 12, 12), (2, 65, 17, 8, 8, 16)])
+def test_column_block_tiles_give_the_same_bits(shape, hip_lib):
+    """Maps of more than 64 positions: a workgroup tile of RT row tiles x NP column blocks runs ONE
+    K loop for its NP blocks (small launches) instead of one per block.  The MFMA chains, the f32
+    running sums, the f64 carries and the order in which column blocks are merged are the same, so
+    every mtr_head_options.rt_column_blocks (1 = one K loop per block, 2..4) and the 2-tile variant
+    must give bit-identical coordinates -- incl. ragged last groups (9 blocks in groups of 4), a
+    ragged last column block (144 = 64 + 64 + 16), NHWC, C not a multiple of the stage."""
+    from metrabs_amd import kernels
+    B, C, J, D, H, W = shape
+    cfg = cpu_ref.HeadConfig(depth=D, proc_side=max(H, W) * 8, stride_test=8, stride_train=8)
+    g = cases.gen(8400 + sum(shape))
+    feat = torch.randn(B, C, H, W, generator=g)
+    w, b = cases.default_conv_init(J * (1 + D), C, g)
+    w, b = w * 3, b * 3
+    with torch.inference_mode():
+        o2d, o3d = cpu_ref.heads_forward(feat, w, b, J, cfg)
+    a2d, a3d = run_fused(feat, w, b, J, cfg, rt_column_blocks=1)
+    assert float((a3d - o3d).abs().max()) <= 2e-3 and cpu_ref.mpjpe(a3d, o3d) <= 1e-3
+    variants = [dict(), dict(rt_column_blocks=2), dict(rt_column_blocks=3), dict(rt_column_blocks=4),
+                dict(rt_column_blocks=2, rt_tiles=2), dict(rt_column_blocks=2, rt_tiles=1)]
+    for options in variants:
+        v2d, v3d = run_fused(feat, w, b, J, cfg, **options)
+        assert torch.equal(v3d, a3d) and torch.equal(v2d, a2d), (shape, options)
+        if C % 4 == 0:
+            packed = kernels.head_pack_weights(w.cuda(), b.cuda(), J, D)
+            l2d, l3d = kernels.head_fused(feat.cuda().contiguous(memory_format=torch.channels_last),
+                                          packed, C, J, mcfg(cfg), **options)
+            assert torch.equal(l3d.cpu(), a3d) and torch.equal(l2d.cpu(), a2d), (shape, options, 'nhwc')
+
+
 def test_head_options_are_validated(hip_lib):
     from metrabs_amd import kernels
     from metrabs_amd.config import MetrabsConfig
     w, b = cases.default_conv_init(153, 64, cases.gen(1))
     packed = kernels.head_pack_weights(w.cuda(), b.cuda(), 17, 8)
     feat = torch.randn(2, 64, 8, 8, device='cuda')
-    for bad in (dict(rt_tiles=6), dict(groups_per_workgroup=4), dict(dma_staging=2)):
+    for bad in (dict(rt_tiles=6), dict(groups_per_workgroup=4), dict(dma_staging=2), dict(rt_column_blocks=5)):
         with pytest.raises(RuntimeError):
             kernels.head_fused(feat, packed, 64, 17, MetrabsConfig(), **bad)

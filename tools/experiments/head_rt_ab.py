@@ -51,6 +51,12 @@ SHAPES = [(64, 1280, 17, 8, 8, False), (64, 1280, 17, 8, 8, True), (256, 1280, 1
           (64, 1280, 17, 72, 8, False), (1024, 1280, 17, 72, 8, False), (32, 1280, 122, 8, 12, False),
           (64, 512, 17, 8, 8, False), (16, 1280, 17, 8, 24, False)]
 tag = sys.argv[1] if len(sys.argv) > 1 else 'default'
+# HEAD_NP=n in the environment of THIS tool: mtr_head_options.rt_column_blocks for the fused path
+NP = int(os.environ.get('HEAD_NP', '0'))
+if NP:
+    from metrabs_amd import kernels as _k
+    _orig = _k.head_fused
+    _k.head_fused = lambda *a, **k: _orig(*a, rt_column_blocks=NP, **k)
 only_fused = os.environ.get('HEAD_AB_ONLY_FUSED') == '1'
 for (B, C, J, D, H, nhwc) in SHAPES:
     cfg = MetrabsConfig(depth=D, proc_side=H * 32)
