@@ -651,19 +651,22 @@ int rt_launch(const float* feat, int layout, const void* section, int B, int C, 
   const long long crops8 = (long long)((B + 7) / 8) * 8;
   const int n_cb = (H * W + 63) / 64;
   // ---- maps of several column blocks, one-tile atoms: RT x NP tiles (one K loop for NP column
-  // blocks) while the launch is one round of workgroups or so -- a workgroup of one row tile that
-  // runs n_cb K loops of 8 MFMAs per stage back to back is bound by its per-stage overhead, not by
-  // the matrix pipe.  np_hint: 1 = never, 2..4 = that many column blocks, 0 = this rule.
+  // blocks) -- a workgroup of one row tile that runs n_cb K loops of 8 MFMAs per stage back to back
+  // is bound by its per-stage overhead, not by the matrix pipe.  Such a tile needs 70 - 160 KB of
+  // LDS, i.e. one workgroup per CU, so it only pays while the launch is ONE round of workgroups
+  // (measured, tools/experiments/head_rt_ab.py: B=16 24x24, 160 workgroups: 84 us against 103;
+  // B=32 12x12, 320 workgroups = two rounds on a quarter of the CUs: 57 against 54; B=64 16x16,
+  // 640: 115 against 97).  np_hint: 1 = never, 2..4 = that many column blocks, 0 = this rule.
   if (g.a == 1 && n_cb >= 2 && np_hint != 1) {
     int np = np_hint;
     if (np == 0) {
       np = n_cb == 2 ? 2 : (n_cb == 3 ? 3 : 4);
       if (n_cb > 4 && (n_cb + 2) / 3 * 3 - n_cb < (n_cb + 3) / 4 * 4 - n_cb) np = 3;  // less padding
-      if (crops8 * g.n_tiles > 2048) np = 1;  // many rounds: equal multi-tile blocks (below)
+      if (crops8 * g.n_tiles > 256) np = 1;  // more than one round: two workgroups per CU (below)
     }
     if (np >= 2) {
       if (np > 4) np = 4;
-      a.rtg = (np == 2 && (rtg_hint == 2 || (rtg_hint == 0 && crops8 * g.n_tiles >= 1024))) ? 2 : 1;
+      a.rtg = (np == 2 && rtg_hint == 2) ? 2 : 1;
       a.n_blocks = (g.n_tiles + a.rtg - 1) / a.rtg;
       if (a.rtg == 2) return nhwc ? rt_launch_np<2, 2, true>(a, stream) : rt_launch_np<2, 2, false>(a, stream);
       switch (np) {
