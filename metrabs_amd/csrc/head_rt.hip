@@ -41,6 +41,10 @@ using v4f = __attribute__((ext_vector_type(4))) float;
 #ifndef MTR_RT_NBUF
 #define MTR_RT_NBUF 0       // 0: by block size (rt_nbuf)
 #endif
+#ifndef MTR_RT_EXP32
+#define MTR_RT_EXP32 1      // 1: v_exp_f32 in the decode epilogue (f64 sums; measured -0.9 us at B=64, -11 us at
+                            // B=1024, parity unchanged: the stand-alone decode does the same); 0: f64 polynomial
+#endif
 
 // LDS ring: NBUF - 1 stages in flight behind the one being consumed.  Blocks of <= 3 tiles (the
 // small-launch configuration: one workgroup per CU, nothing else to hide the first HBM misses) keep
@@ -480,7 +484,8 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
       for (int q = 0; q < 4; ++q) {
         const int p = pbase + q;
         if (p < HW && kind != 0) {
-          const double e = exp_neg64((double)x[k][q] - (double)m);
+          const double e = MTR_RT_EXP32 ? (double)exp_shifted(x[k][q], -m * kLog2e)
+                                        : exp_neg64((double)x[k][q] - (double)m);
           const int h = p / a.W, w = p - h * a.W;
           s += e;
           sx += e * (double)w;

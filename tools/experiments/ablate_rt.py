@@ -13,7 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, 'tools', 'experiments', '_build')
-VARIANTS = {'full': [], 'nodecode': ['-DMTR_RT_ABLATE=1'], 'nomfma': ['-DMTR_RT_ABLATE=2'],
+VARIANTS = {'full': [], 'exp32': ['-DMTR_RT_EXP32=1'], 'nodecode': ['-DMTR_RT_ABLATE=1'], 'nomfma': ['-DMTR_RT_ABLATE=2'],
             'nodma': ['-DMTR_RT_ABLATE=4'], 'nocarry': ['-DMTR_RT_ABLATE=8'],
             'nodma_nocarry': ['-DMTR_RT_ABLATE=12'], 'nofrag': ['-DMTR_RT_ABLATE=16'],
             'mfma_only': ['-DMTR_RT_ABLATE=29'], 'nbuf2': ['-DMTR_RT_NBUF=2'], 'nbuf4': ['-DMTR_RT_NBUF=4']}
