@@ -485,11 +485,14 @@ __global__ __launch_bounds__(256) void warp_crops_kernel(
               acc[p][c] += fmaf(b2.b, w11, fmaf(b2.a, w10, fmaf(t.b, w01, t.a * w00)));
             }
           } else {
+            unsigned long long tw_keep = 0, bw_keep = 0;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
               const int ot = img_off + c * plane_elems + ys * W + xs, ob = ot + W;  // byte offsets
               unsigned long long tw, bw;
-              if (MTR_WARP_ABLATE & 1) {
+              if ((MTR_WARP_ABLATE & 16) && c > 0) {  // timing probe: one gather pair serves all channels
+                tw = tw_keep; bw = bw_keep;
+              } else if (MTR_WARP_ABLATE & 1) {
                 tw = (unsigned long long)(unsigned)ot * 2654435761ull;
                 bw = (unsigned long long)(unsigned)ob * 2654435761ull;
               } else {
@@ -498,6 +501,7 @@ __global__ __launch_bounds__(256) void warp_crops_kernel(
                 tw = __builtin_bit_cast(unsigned long long, top) >> ((ot & 3) * 8);
                 bw = __builtin_bit_cast(unsigned long long, bot) >> ((ob & 3) * 8);
               }
+              if (MTR_WARP_ABLATE & 16) { tw_keep = tw; bw_keep = bw; }
               float ta, tb, ba, bb;
               if (MTR_WARP_ABLATE & 2) {
                 ta = (float)(tw & 0xff); tb = (float)((tw >> 8) & 0xff);
