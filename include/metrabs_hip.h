@@ -341,6 +341,15 @@ int mtr_bias_act_rowmean_nchw(void* y, int dtype, const float* bias /*[C] f32*/,
 int mtr_depthwise3x3_bias_act(const void* x, int dtype, const float* weight, const float* bias, int act,
                               long long B, int C, int H, int W, int stride, int pad, void* y,
                               float* row_mean, mtr_stream_t stream);
+/* The same layer with the explicit asymmetric zero padding the reference's TF-'SAME' stride-2 layers
+ * put in front of an unpadded convolution (efficientnet.py:1127-1161: (0,1,0,1), or (0,2,0,2) for the
+ * `bottomright_stride` layer) folded in: pad_top, pad_left in {0, 1}, pad_bottom, pad_right in 0..2;
+ * OH = (H + pad_top + pad_bottom - 3) / stride + 1, OW likewise and a multiple of 4.  x is the
+ * UNPADDED activation: the ZeroPad2d pass and its padded copy disappear. */
+int mtr_depthwise3x3_bias_act_padded(const void* x, int dtype, const float* weight, const float* bias,
+                                     int act, long long B, int C, int H, int W, int stride, int pad_top,
+                                     int pad_left, int pad_bottom, int pad_right, void* y,
+                                     float* row_mean, mtr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -101,6 +101,9 @@ SIGNATURES = {
                                  ctypes.c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'mtr_depthwise3x3_bias_act': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, ctypes.c_longlong,
                                           c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'mtr_depthwise3x3_bias_act_padded': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, ctypes.c_longlong,
+                                                 c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                 c_void_p, c_void_p, c_void_p]),
     'mtr_bias_act_rowmean_nchw': (c_int, [c_void_p, c_int, c_void_p, c_int, ctypes.c_longlong, c_int, c_int,
                                           c_void_p, c_void_p]),
     'mtr_bias_act_nchw': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, ctypes.c_longlong, c_int,

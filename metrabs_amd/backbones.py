@@ -297,6 +297,9 @@ class DepthwiseBiasAct(nn.Module):
         self.weight = nn.Parameter(conv.weight.detach().float().contiguous(), requires_grad=False)
         self.register_buffer('bias', bias.detach().float().contiguous())
         self.stride, self.pad = conv.stride[0], conv.padding[0]
+        # (left, right, top, bottom) of a ZeroPad2d that stood in front of the layer and was folded
+        # in by fold_batchnorm (the TF-'SAME' padding of the stride-2 layers); None: self.pad all round
+        self.pads = None
         self.act = act
         self.act_name = None if act is None else _ACT_NAMES[type(act)]
         self.emit_mean = False
@@ -312,19 +315,23 @@ class DepthwiseBiasAct(nn.Module):
     take_mean = ConvBiasAct.take_mean
 
     def forward(self, x):
-        ow = (x.shape[3] + 2 * self.pad - 3) // self.stride + 1
+        pl, pr = (self.pad, self.pad) if self.pads is None else self.pads[:2]
+        ow = (x.shape[3] + pl + pr - 3) // self.stride + 1
+        pad = self.pad if self.pads is None else self.pads
         if x.is_cuda and x.is_contiguous() and ow % 4 == 0 and \
                 x.dtype in (torch.float32, torch.float16, torch.bfloat16):
             from . import kernels
             if self.emit_mean:
                 y, mean = kernels.depthwise3x3_bias_act(x, self.weight, self.bias, self.act_name,
-                                                        self.stride, self.pad, want_mean=True)
+                                                        self.stride, pad, want_mean=True)
                 self._mean = (y, mean)
                 return y
             return kernels.depthwise3x3_bias_act(x, self.weight, self.bias, self.act_name,
-                                                 self.stride, self.pad)
-        y = F.conv2d(x, self.weight.to(x.dtype), self.bias.to(x.dtype), self.stride, self.pad,
-                     groups=self.weight.shape[0])
+                                                 self.stride, pad)
+        if self.pads is not None:
+            x = F.pad(x, self.pads)
+        y = F.conv2d(x, self.weight.to(x.dtype), self.bias.to(x.dtype), self.stride,
+                     self.pad if self.pads is None else 0, groups=self.weight.shape[0])
         return y if self.act is None else self.act(y)
 
 
@@ -372,6 +379,19 @@ def fold_batchnorm(backbone, fused_epilogue=False):
             m[1] = nn.Identity()
     if any(isinstance(m, nn.BatchNorm2d) for m in folded.modules()):
         raise ValueError('a BatchNorm2d outside a ConvBNAct block cannot be folded here')
+    if fused_epilogue:  # ZeroPad2d -> depthwise 3x3: the padding becomes an argument of K11
+        for seq in folded.modules():
+            if not isinstance(seq, nn.Sequential) or isinstance(seq, ConvBNAct):
+                continue
+            names = list(seq._modules)
+            for n_pad, n_conv in zip(names, names[1:]):
+                pad, blk = seq._modules[n_pad], seq._modules[n_conv]
+                if isinstance(pad, nn.ZeroPad2d) and isinstance(blk, ConvBNAct) and \
+                        isinstance(blk[0], DepthwiseBiasAct) and blk[0].pad == 0:
+                    l, r, t, b = (int(p) for p in pad.padding)
+                    if 0 <= l <= 1 and 0 <= t <= 1 and 0 <= r <= 2 and 0 <= b <= 2:
+                        blk[0].pads = (l, r, t, b)
+                        seq._modules[n_pad] = nn.Identity()
     if fused_epilogue:  # conv -> squeeze-excite: the epilogue pass also emits the channel means
         for seq in folded.modules():
             if not isinstance(seq, nn.Sequential) or isinstance(seq, ConvBNAct):

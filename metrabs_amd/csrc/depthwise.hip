@@ -22,7 +22,8 @@ namespace mtr {
 // stride 2 = two vectors + the left edge element.
 struct DwGeom {
   int n_planes;
-  int C, H, W, OH, OW, pad;
+  int C, H, W, OH, OW;
+  int pad, pad_left;  // top / left zero padding (bottom / right follow from OH, OW)
   int lpp;        // lanes per plane inside an item (power of two <= 64)
   int chunks;     // items per plane group (> 1: planes of more than 64 groups)
   int groups;     // groups of four outputs per plane = OH * OW / 4
@@ -59,16 +60,24 @@ __device__ __forceinline__ void dw_issue(const T* __restrict__ x, const float* _
     iy = iy < 0 ? 0 : (iy >= g.H ? g.H - 1 : iy);  // clamped: masked when the item is finished
     const T* row = xp + iy * g.W;
     if constexpr (VEC) {
-      const int ix0 = ox0 * STRIDE;  // first centre column (pad 1: column ix0 - 1 is the left edge)
+      // the 4 STRIDE aligned columns from ix0 on + one edge element: column ix0 - 1 with left
+      // padding 1; with left padding 0 (stride 2 behind TF-'SAME' / bottom-right padding) column
+      // ix0 + 8 on the right
+      const int ix0 = ox0 * STRIDE;
 #pragma unroll
       for (int n = 0; n < Raw::NV; ++n)
         r.mid[ky][n] = *reinterpret_cast<const typename Raw::V4*>(row + ix0 + 4 * n);
-      r.edge[ky][0] = row[ix0 > 0 ? ix0 - 1 : 0];
-      if constexpr (STRIDE == 1) r.edge[ky][1] = row[ix0 + 4 < g.W ? ix0 + 4 : 0];
+      if constexpr (STRIDE == 1) {
+        r.edge[ky][0] = row[ix0 > 0 ? ix0 - 1 : 0];
+        r.edge[ky][1] = row[ix0 + 4 < g.W ? ix0 + 4 : 0];
+      } else {
+        const int ie = g.pad_left ? ix0 - 1 : ix0 + 8;
+        r.edge[ky][0] = row[ie < 0 ? 0 : (ie >= g.W ? g.W - 1 : ie)];
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < NIN; ++j) {
-        int ix = ox0 * STRIDE - g.pad + j;
+        int ix = ox0 * STRIDE - g.pad_left + j;
         ix = ix < 0 ? 0 : (ix >= g.W ? g.W - 1 : ix);
         r.tap[ky][j] = row[ix];
       }
@@ -91,16 +100,27 @@ __device__ __forceinline__ float dw_finish(T* __restrict__ y, const DwGeom& g, i
     float in[NIN];
     if constexpr (VEC) {
       const int ix0 = ox0 * STRIDE;
-      in[0] = (row_ok && ix0 > 0) ? to_f32(r.edge[ky][0]) : 0.0f;
+      // in[j] = column ix0 - pad_left + j
+      const int m0 = (STRIDE == 1 || g.pad_left) ? 1 : 0;  // where the aligned vectors start
 #pragma unroll
       for (int n = 0; n < STRIDE; ++n)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) in[1 + 4 * n + j] = row_ok ? to_f32(r.mid[ky][n].v[j]) : 0.0f;
-      if constexpr (STRIDE == 1) in[5] = (row_ok && ix0 + 4 < g.W) ? to_f32(r.edge[ky][1]) : 0.0f;
+        for (int j = 0; j < 4; ++j) {
+          const float v = row_ok ? to_f32(r.mid[ky][n].v[j]) : 0.0f;
+          if (STRIDE == 1 || g.pad_left) in[1 + 4 * n + j] = v; else in[4 * n + j] = v;
+        }
+      if constexpr (STRIDE == 1) {
+        in[0] = (row_ok && ix0 > 0) ? to_f32(r.edge[ky][0]) : 0.0f;
+        in[5] = (row_ok && ix0 + 4 < g.W) ? to_f32(r.edge[ky][1]) : 0.0f;
+      } else if (m0) {
+        in[0] = (row_ok && ix0 > 0) ? to_f32(r.edge[ky][0]) : 0.0f;
+      } else {
+        in[8] = (row_ok && ix0 + 8 < g.W) ? to_f32(r.edge[ky][0]) : 0.0f;
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < NIN; ++j) {
-        const int ix = ox0 * STRIDE - g.pad + j;
+        const int ix = ox0 * STRIDE - g.pad_left + j;
         in[j] = (row_ok && ix >= 0 && ix < g.W) ? to_f32(r.tap[ky][j]) : 0.0f;
       }
     }
@@ -285,11 +305,11 @@ static int ilog2_exact(int v) {
 template <typename T, int STRIDE>
 static int launch_depthwise(const void* x, const float* w, const float* bias, int act, void* y,
                             float* row_mean, long long n_planes, int C, int H, int W, int OH, int OW,
-                            int pad, hipStream_t stream) {
+                            int pad, int pad_left, bool symmetric, hipStream_t stream) {
   if (n_planes >= (1LL << 30)) return MTR_E_SHAPE;
   if constexpr (STRIDE == 1) {
     const int tw = ilog2_exact(W / 4), th = ilog2_exact(H / 4);
-    if (pad == 1 && (W & 3) == 0 && (H & 3) == 0 && tw >= 0 && tw <= 4 && th >= 0 && tw + th <= 6 &&
+    if (symmetric && pad == 1 && (W & 3) == 0 && (H & 3) == 0 && tw >= 0 && tw <= 4 && th >= 0 && tw + th <= 6 &&
         ((uintptr_t)x % 16) == 0 && n_planes < (1LL << 24)) {
       const int lp_log2 = tw + th;
       const long long lanes = n_planes << lp_log2;
@@ -313,6 +333,7 @@ static int launch_depthwise(const void* x, const float* w, const float* bias, in
   }
   DwGeom g;
   g.n_planes = (int)n_planes; g.C = C; g.H = H; g.W = W; g.OH = OH; g.OW = OW; g.pad = pad;
+  g.pad_left = pad_left;
   g.groups = OH * (OW / 4);
   g.lpp = 1;
   while (g.lpp < 64 && g.lpp < g.groups) g.lpp <<= 1;
@@ -323,7 +344,10 @@ static int launch_depthwise(const void* x, const float* w, const float* bias, in
   int blocks = (g.n_pg + 3) / 4;
   if (blocks > 256 * 4) blocks = 256 * 4;
   const dim3 grid((unsigned)blocks), block(256);
-  const bool vec = pad == 1 && (W & 3) == 0 && ((uintptr_t)x % 16) == 0 && (STRIDE == 1 || OW * 2 == W);
+  // aligned row vectors: stride 1 with symmetric padding 1; stride 2 when the 8 columns from
+  // 2 ox0 on exist for every group (OW * 2 == W), left padding 1 or 0
+  const bool vec = (W & 3) == 0 && ((uintptr_t)x % 16) == 0 &&
+                   (STRIDE == 1 ? (symmetric && pad == 1) : (OW * 2 == W && pad_left <= 1));
   MTR_CLEAR_STALE();
 #define MTR_DW_LAUNCH(A)                                                                            \
   if (vec)                                                                                          \
@@ -347,30 +371,48 @@ static int launch_depthwise(const void* x, const float* w, const float* bias, in
 template <typename T>
 static int dispatch_depthwise(const void* x, const float* w, const float* bias, int act, void* y,
                               float* row_mean, long long n_planes, int C, int H, int W, int OH,
-                              int OW, int stride, int pad, hipStream_t stream) {
+                              int OW, int stride, int pad, int pad_left, bool symmetric,
+                              hipStream_t stream) {
   if (stride == 1)
-    return launch_depthwise<T, 1>(x, w, bias, act, y, row_mean, n_planes, C, H, W, OH, OW, pad, stream);
-  return launch_depthwise<T, 2>(x, w, bias, act, y, row_mean, n_planes, C, H, W, OH, OW, pad, stream);
+    return launch_depthwise<T, 1>(x, w, bias, act, y, row_mean, n_planes, C, H, W, OH, OW, pad, pad_left,
+                                  symmetric, stream);
+  return launch_depthwise<T, 2>(x, w, bias, act, y, row_mean, n_planes, C, H, W, OH, OW, pad, pad_left,
+                                symmetric, stream);
 }
 
 }  // namespace mtr
+
+extern "C" int mtr_depthwise3x3_bias_act_padded(const void* x, int dtype, const float* weight,
+                                                const float* bias, int act, long long B, int C, int H,
+                                                int W, int stride, int pad_top, int pad_left,
+                                                int pad_bottom, int pad_right, void* y, float* row_mean,
+                                                mtr_stream_t stream) {
+  if (!x || !weight || !bias || !y) return MTR_E_NULL;
+  if (B < 0 || C <= 0 || H <= 0 || W <= 0) return MTR_E_SHAPE;
+  if (stride != 1 && stride != 2) return MTR_E_PARAM;
+  if (pad_top < 0 || pad_top > 1 || pad_left < 0 || pad_left > 1 || pad_bottom < 0 || pad_bottom > 2 ||
+      pad_right < 0 || pad_right > 2)
+    return MTR_E_PARAM;
+  if (H + pad_top + pad_bottom < 3 || W + pad_left + pad_right < 3) return MTR_E_SHAPE;
+  const int OH = (H + pad_top + pad_bottom - 3) / stride + 1, OW = (W + pad_left + pad_right - 3) / stride + 1;
+  if (OW % 4 != 0) return MTR_E_SHAPE;
+  if ((uintptr_t)y % 16) return MTR_E_ALIGN;
+  if (B == 0) return MTR_OK;
+  const bool symmetric = pad_top == pad_left && pad_bottom == pad_top && pad_right == pad_top;
+  hipStream_t s = (hipStream_t)stream;
+  switch (dtype) {
+    case MTR_F32: return mtr::dispatch_depthwise<float>(x, weight, bias, act, y, row_mean, B * C, C, H, W, OH, OW, stride, pad_top, pad_left, symmetric, s);
+    case MTR_F16: return mtr::dispatch_depthwise<__half>(x, weight, bias, act, y, row_mean, B * C, C, H, W, OH, OW, stride, pad_top, pad_left, symmetric, s);
+    case MTR_BF16: return mtr::dispatch_depthwise<__hip_bfloat16>(x, weight, bias, act, y, row_mean, B * C, C, H, W, OH, OW, stride, pad_top, pad_left, symmetric, s);
+    default: return MTR_E_DTYPE;
+  }
+}
 
 extern "C" int mtr_depthwise3x3_bias_act(const void* x, int dtype, const float* weight,
                                          const float* bias, int act, long long B, int C, int H, int W,
                                          int stride, int pad, void* y, float* row_mean,
                                          mtr_stream_t stream) {
-  if (!x || !weight || !bias || !y) return MTR_E_NULL;
-  if (B < 0 || C <= 0 || H <= 0 || W <= 0) return MTR_E_SHAPE;
-  if ((stride != 1 && stride != 2) || (pad != 0 && pad != 1)) return MTR_E_PARAM;
-  const int OH = (H + 2 * pad - 3) / stride + 1, OW = (W + 2 * pad - 3) / stride + 1;
-  if (H + 2 * pad < 3 || W + 2 * pad < 3 || OW % 4 != 0) return MTR_E_SHAPE;
-  if ((uintptr_t)y % 16) return MTR_E_ALIGN;
-  if (B == 0) return MTR_OK;
-  hipStream_t s = (hipStream_t)stream;
-  switch (dtype) {
-    case MTR_F32: return mtr::dispatch_depthwise<float>(x, weight, bias, act, y, row_mean, B * C, C, H, W, OH, OW, stride, pad, s);
-    case MTR_F16: return mtr::dispatch_depthwise<__half>(x, weight, bias, act, y, row_mean, B * C, C, H, W, OH, OW, stride, pad, s);
-    case MTR_BF16: return mtr::dispatch_depthwise<__hip_bfloat16>(x, weight, bias, act, y, row_mean, B * C, C, H, W, OH, OW, stride, pad, s);
-    default: return MTR_E_DTYPE;
-  }
+  if (pad != 0 && pad != 1) return (!x || !weight || !bias || !y) ? MTR_E_NULL : MTR_E_PARAM;
+  return mtr_depthwise3x3_bias_act_padded(x, dtype, weight, bias, act, B, C, H, W, stride, pad, pad, pad,
+                                          pad, y, row_mean, stream);
 }

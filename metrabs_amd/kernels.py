@@ -476,16 +476,19 @@ def bias_act_rowmean_(y, bias, act):
 
 def depthwise3x3_bias_act(x, weight, bias, act, stride, pad, want_mean=False):
     """K11: y = act(depthwise_conv3x3(x, weight) + bias) in one pass (+ the [B, C] f32 mean of y over
-    H*W if want_mean).  x NCHW-contiguous f32 / f16 / bf16, weight [C, 1, 3, 3] or [C, 3, 3]."""
+    H*W if want_mean).  x NCHW-contiguous f32 / f16 / bf16, weight [C, 1, 3, 3] or [C, 3, 3].
+    pad: one int (every side) or (left, right, top, bottom) like torch.nn.ZeroPad2d -- the explicit
+    padding in front of the reference's stride-2 layers, folded into the kernel."""
     require_cuda(x, weight, bias)
     if not x.is_contiguous():
         raise ValueError('depthwise3x3_bias_act needs an NCHW-contiguous tensor')
     B, C, H, W = x.shape
-    OH, OW = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
+    pl, pr, pt, pb = (pad,) * 4 if isinstance(pad, int) else tuple(int(p) for p in pad)
+    OH, OW = (H + pt + pb - 3) // stride + 1, (W + pl + pr - 3) // stride + 1
     y = torch.empty(B, C, OH, OW, device=x.device, dtype=x.dtype)
     mean = torch.empty(B, C, device=x.device, dtype=torch.float32) if want_mean else None
-    check(_lib.load().mtr_depthwise3x3_bias_act(
+    check(_lib.load().mtr_depthwise3x3_bias_act_padded(
         _ptr(x), dtype_code(x.dtype), _ptr(weight.contiguous().float()), _ptr(bias.contiguous().float()),
-        ACT_CODES[act], B, C, H, W, int(stride), int(pad), _ptr(y), None if mean is None else _ptr(mean),
-        current_stream_ptr(x.device)), 'mtr_depthwise3x3_bias_act')
+        ACT_CODES[act], B, C, H, W, int(stride), pt, pl, pb, pr, _ptr(y), None if mean is None else _ptr(mean),
+        current_stream_ptr(x.device)), 'mtr_depthwise3x3_bias_act_padded')
     return (y, mean) if want_mean else y

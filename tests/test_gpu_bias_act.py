@@ -79,6 +79,39 @@ def test_depthwise3x3_bias_act_vs_torch(cfg, dtype, hip_lib):
     assert float(((none.float() - want_none).abs() / (1 + want_none.abs())).max()) <= tol
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+@pytest.mark.parametrize('cfg', [(3, 960, 16, 16, 2, (0, 2, 0, 2)), (2, 256, 32, 32, 2, (0, 1, 0, 1)),
+                                 (2, 7, 8, 24, 2, (1, 0, 1, 0)), (2, 5, 16, 16, 1, (1, 1, 1, 1)),
+                                 (2, 6, 14, 10, 1, (0, 2, 1, 1)), (70, 3, 16, 16, 2, (0, 2, 0, 2))])
+def test_depthwise3x3_with_folded_zero_padding(cfg, dtype, hip_lib):
+    """The explicit ZeroPad2d of the reference's TF-'SAME' stride-2 layers (efficientnet.py:1127-1161:
+    (0,1,0,1); (0,2,0,2) for the bottomright_stride layer) as an argument of K11: vs F.pad + F.conv2d
+    on the padded copy.  Aligned-vector rows with the edge element on the right (left padding 0), on
+    the left (left padding 1), and the scalar path (stride 1 with asymmetric padding)."""
+    from metrabs_amd import kernels
+    B, C, H, W, stride, pads = cfg
+    g = torch.Generator(device='cuda').manual_seed(sum(cfg[:5]) + sum(pads))
+    x = torch.randn(B, C, H, W, device='cuda', generator=g).to(dtype)
+    w = torch.randn(C, 1, 3, 3, device='cuda', generator=g) * 0.4
+    b = torch.randn(C, device='cuda', generator=g)
+    want = F.silu(F.conv2d(F.pad(x.float(), pads), w, b, stride, 0, groups=C))
+    got, mean = kernels.depthwise3x3_bias_act(x, w, b, 'silu', stride, pads, want_mean=True)
+    assert got.shape == want.shape and got.dtype == dtype
+    tol = 3e-6 if dtype == torch.float32 else 2e-3
+    assert float(((got.float() - want).abs() / (1 + want.abs())).max()) <= tol
+    assert float((mean - got.float().mean((2, 3))).abs().max()) <= 1e-5 * (1 + float(want.abs().max()))
+
+
+def test_fold_batchnorm_folds_the_zero_padding_into_k11(hip_lib):
+    from metrabs_amd import backbones
+    net = backbones.build_backbone('effnetv2-s').eval()
+    fused = backbones.fold_batchnorm(net, fused_epilogue=True)
+    padded = [m for m in fused.modules() if isinstance(m, backbones.DepthwiseBiasAct) and m.pads is not None]
+    assert [m.pads for m in padded] == [(0, 2, 0, 2)]  # the bottomright_stride layer
+    n_pad = lambda n: sum(isinstance(m, torch.nn.ZeroPad2d) for m in n.modules())
+    assert n_pad(fused) == n_pad(net) - 1
+
+
 def test_bias_act_rejects_what_it_cannot_vectorise(hip_lib):
     from metrabs_amd import kernels
     y = torch.zeros(2, 3, 3, 3, device='cuda')  # H*W = 9: a 16-byte vector would straddle channels
