@@ -359,7 +359,8 @@ def backbone_epilogue_kernels(est, crops, iters):
         return orig[1](y, bias, act)
 
     def rec_dw(x, weight, bias, act, stride, pad, want_mean=False):
-        calls.append(('depthwise', tuple(x.shape), x.dtype, act, int(stride), int(pad), bool(want_mean)))
+        pad = (int(pad),) * 4 if isinstance(pad, int) else tuple(int(p) for p in pad)  # (l, r, t, b)
+        calls.append(('depthwise', tuple(x.shape), x.dtype, act, int(stride), pad, bool(want_mean)))
         return orig[2](x, weight, bias, act, stride, pad, want_mean)
 
     kernels.bias_act_, kernels.bias_act_rowmean_, kernels.depthwise3x3_bias_act = rec_bias, rec_rowmean, rec_dw
@@ -400,7 +401,7 @@ def backbone_epilogue_kernels(est, crops, iters):
         else:
             _, _, _, act, stride, pad, want_mean = sig
             H, W = shape[2], shape[3]
-            OH, OW = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
+            OH, OW = (H + pad[2] + pad[3] - 3) // stride + 1, (W + pad[0] + pad[1] - 3) // stride + 1
             nbytes = numel * es + B * C * OH * OW * es + C * 10 * 4 + (B * C * 4 if want_mean else 0)
             n_sets = max(2, min(64, -(-ROTATE_BYTES // (numel * es))))
             xs = [torch.randn(shape, device=dev, generator=g).to(dtype) for _ in range(n_sets)]

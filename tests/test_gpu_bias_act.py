@@ -82,7 +82,7 @@ def test_depthwise3x3_bias_act_vs_torch(cfg, dtype, hip_lib):
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
 @pytest.mark.parametrize('cfg', [(3, 960, 16, 16, 2, (0, 2, 0, 2)), (2, 256, 32, 32, 2, (0, 1, 0, 1)),
                                  (2, 7, 8, 24, 2, (1, 0, 1, 0)), (2, 5, 16, 16, 1, (1, 1, 1, 1)),
-                                 (2, 6, 14, 10, 1, (0, 2, 1, 1)), (70, 3, 16, 16, 2, (0, 2, 0, 2))])
+                                 (2, 6, 14, 12, 1, (0, 2, 1, 1)), (70, 3, 16, 16, 2, (0, 2, 0, 2))])
 def test_depthwise3x3_with_folded_zero_padding(cfg, dtype, hip_lib):
     """The explicit ZeroPad2d of the reference's TF-'SAME' stride-2 layers (efficientnet.py:1127-1161:
     (0,1,0,1); (0,2,0,2) for the bottomright_stride layer) as an argument of K11: vs F.pad + F.conv2d
