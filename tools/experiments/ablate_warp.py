@@ -12,7 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, 'tools', 'experiments', '_build')
-MASKS = [0, 16, 1, 2, 4, 8, 15]  # 16 = one gather pair serves all three channels (level-0 crops)  # 16 = one gather pair serves all three channels (level-0 crops)
+MASKS = [0, 16, 1, 2, 4, 8, 15]  # 16 = one gather pair serves all three channels (level-0 crops)
 
 
 def build():

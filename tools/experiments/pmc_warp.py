@@ -1,6 +1,9 @@
 """Launch the sampler a few times on the bench's shape (for rocprofv3 --pmc passes)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from metrabs_amd import _lib
+if os.environ.get('PMC_WARP_LIB'):  # an ablation build of tools/experiments/ablate_warp.py
+    _lib.load(os.environ['PMC_WARP_LIB'])
 from metrabs_amd import kernels
 from metrabs_amd.multiperson.multiperson_model import tta_parameters
 num_aug = int(sys.argv[1]) if len(sys.argv) > 1 else 1
