@@ -232,6 +232,32 @@ __device__ __forceinline__ double exp_neg64(double x) {
   return __builtin_bit_cast(double, bits);
 }
 
+// The same polynomial for a COLD path inside a kernel whose hot loop runs at its register limit:
+// `zero` is a run-time 0.0 the caller derives from data that only exists at the call site (x - x of
+// a finite value; not foldable without fast-math).  Adding it to every coefficient keeps LLVM from
+// materialising the twelve f64 constants once, in front of the hot loop, and holding them in 24
+// VGPRs through it (which is what made head_rt_kernel<5, NHWC> spill).
+__device__ __forceinline__ double exp_neg64_late(double x, double zero) {
+  const double t = x * (1.4426950408889634 + zero);
+  if (!(t > -1000.0)) return 0.0;
+  const double n = rint(t);
+  const double z = (t - n) * (0.6931471805599453 + zero);
+  double p = 2.505210838544172e-08 + zero;
+  p = fma(p, z, 2.755731922398589e-07 + zero);
+  p = fma(p, z, 2.755731922398589e-06 + zero);
+  p = fma(p, z, 2.48015873015873e-05 + zero);
+  p = fma(p, z, 1.984126984126984e-04 + zero);
+  p = fma(p, z, 1.388888888888889e-03 + zero);
+  p = fma(p, z, 8.333333333333333e-03 + zero);
+  p = fma(p, z, 4.166666666666666e-02 + zero);
+  p = fma(p, z, 1.666666666666667e-01 + zero);
+  p = fma(p, z, 0.5 + zero);
+  p = fma(p, z, 1.0 + zero);
+  p = fma(p, z, 1.0 + zero);
+  const long long bits = __builtin_bit_cast(long long, p) + ((long long)n << 52);
+  return __builtin_bit_cast(double, bits);
+}
+
 // Expectation of an axis index -> [0,1]: ptu.decode_heatmap dots with linspace(0,1,n)
 // (ptu.py:68-70); ptu.linspace(num==1) is the midpoint 0.5 (ptu.py:83-84).
 __device__ __forceinline__ float axis_coord(double weighted_index_sum, double total, int n) {

@@ -479,12 +479,13 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
       float m = -INFINITY;
       for (int kk = l16; kk < n; kk += 16) m = fmaxf(m, rowmax[first + kk]);
       m = group_max<16>(m);
+      const float nm = -m * kLog2e;
       double s = 0, sx = 0, sy = 0;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int p = pbase + q;
         if (p < HW && kind != 0) {
-          const double e = MTR_RT_EXP32 ? (double)exp_shifted(x[k][q], -m * kLog2e)
+          const double e = MTR_RT_EXP32 ? (double)exp_shifted(x[k][q], nm)
                                         : exp_neg64((double)x[k][q] - (double)m);
           const int h = p / a.W, w = p - h * a.W;
           s += e;
@@ -524,7 +525,8 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
         if (cb > 0) {
           const double pm = runstat[tid_c * 5];
           const double mn = fmax(pm, run_m);
-          const double f1 = exp_neg64(pm - mn), f2 = exp_neg64(run_m - mn);
+          const double zero = pm - pm;  // 0.0 at run time (the maxima are finite)
+          const double f1 = exp_neg64_late(pm - mn, zero), f2 = exp_neg64_late(run_m - mn, zero);
           run_s = runstat[tid_c * 5 + 1] * f1 + S * f2;
           run_x = runstat[tid_c * 5 + 2] * f1 + SX * f2;
           run_y = runstat[tid_c * 5 + 3] * f1 + SY * f2;
