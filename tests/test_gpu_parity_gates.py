@@ -55,11 +55,14 @@ RANDOM_HEAD_BOUNDS = {
 }
 # consistent heads, MPJPE ours-vs-oracle: 1e-3 mm everywhere (measured 4.4e-4 .. 9.0e-4) except the
 # two cases where the ORACLE's own fp32 result is farther than that from fp64:
-#  * configs[0] is ONE crop: MPJPE over its 17 joints is the error of one reference point, and the
-#    oracle's fp32 lstsq lands 1.9e-3 mm from fp64 on this crop (ours: 2.2e-4);
+#  * configs[0] is ONE crop: MPJPE over its 17 joints is the error of ONE reference point, and the
+#    oracle's fp32 LAPACK lstsq lands 6e-4 .. 2.1e-3 mm from fp64 on this crop depending on the host
+#    CPU of the box (three runs of the round: low regime 1.9e-3 / 5.9e-4 / 5.9e-4, peaked 9.7e-4 /
+#    9.7e-4 / 2.1e-3) while ours stays at 1.1e-4 / 1.5e-4 from fp64 in every run;
 #  * 72 depth bins, peaked: 1,241 output rows on K = 1280 make the minimum-norm features large
 #    (std 40): the oracle's conv is 1.5e-3 mm from fp64 (ours: 5.3e-4).
 CONSISTENT_BOUND = {('configs[0] ResNet-18 256 B=1', 'consistent_low'): 3e-3,
+                    ('configs[0] ResNet-18 256 B=1', 'consistent_peaked'): 3e-3,
                     ('metric string: 72 depth bins, 256 px, B=64', 'consistent_peaked'): 2.5e-3}
 # ... and MPJPE ours-vs-fp64: 5e-4 mm everywhere (measured 1.2e-4 .. 3.3e-4), 1e-3 for the second one
 CONSISTENT_FP64_BOUND = {('metric string: 72 depth bins, 256 px, B=64', 'consistent_peaked'): 1e-3}
