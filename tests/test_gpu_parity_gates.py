@@ -4,8 +4,9 @@ metrabs_pytorch CPU path -- as HARD gates at every BASELINE.json config shape, i
 * 'consistent_low' / 'consistent_peaked': features + default-initialised conv_final whose logits
   describe a plausible pose (cases.consistent_head_case: Gaussian bumps of height 4, |logit| <= 5,
   or height 25 around each joint; the person fills the crop 2.5 - 4.5 m from the camera).
-  Gate: MPJPE(ours, oracle) <= 1e-3 mm and MPJPE(ours, fp64) <= 5e-4 mm as fixed numbers (two
-  documented exceptions where the oracle itself is > 1e-3 mm from fp64: CONSISTENT_BOUND).
+  Gate: MPJPE(ours, fp64) <= 5e-4 mm in both; MPJPE(ours, oracle) <= 1e-3 mm in the low regime and
+  <= 1.5e-3 mm in the peaked one (where the oracle itself sits 7e-4 .. 1e-3 mm from fp64) -- fixed
+  numbers, with the documented exceptions of CONSISTENT_BOUND where the oracle is farther still.
 * 'random_head': N(0,1) features x default-initialised conv_final x 8 (logits +-25), the kind of
   input bench.py's random network produces.  Its heatmaps are nearly uniform, all joints decode to
   the crop centre and the reference-point depth -- the ratio of two vanishing spreads -- is
@@ -123,7 +124,11 @@ def run_case(name, regime):
 @pytest.mark.parametrize('name', list(SHAPES))
 def test_plausible_poses_are_within_1e3_mm_of_the_reference(name, regime, hip_lib):
     r = run_case(name, regime)
-    bound = CONSISTENT_BOUND.get((name, regime), 1e-3)
+    # low regime: the north-star 1e-3 mm (measured 4.4e-4 .. 7.2e-4).  Peaked regime: measured
+    # 6.9e-4 .. 9.1e-4 = the oracle's OWN distance to fp64 (6.7e-4 .. 9.7e-4, host-CPU dependent):
+    # fixed 1.5e-3 so that another box's oneDNN / LAPACK code path cannot fail it, with the hard
+    # ours-vs-fp64 bound below doing the real work
+    bound = CONSISTENT_BOUND.get((name, regime), 1e-3 if regime == 'consistent_low' else 1.5e-3)
     assert r['median_depth_mm'] > 1500  # a person in front of the camera, not a degenerate solve
     assert (r['logits_absmax'] <= 5.5) if regime == 'consistent_low' else (r['logits_absmax'] >= 20)
     assert r['mpjpe_ours_vs_ref'] <= bound, r
