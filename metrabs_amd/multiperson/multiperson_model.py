@@ -15,7 +15,7 @@ Differences to the reference, all documented in DESIGN.md:
 import numpy as np
 import torch
 
-from metrabs_amd import distributed, kernels, pipeline, ptu, ptu3d
+from metrabs_amd import distributed, kernels, pipeline, ptu3d
 from metrabs_amd.joint_info import JointInfo
 from metrabs_amd.multiperson import warping
 
@@ -26,13 +26,26 @@ DEFAULT_DISTORTION = (0, 0, 0, 0, 0)
 DEFAULT_WORLD_UP = (0, -1, 0)
 
 
+def tta_linspace(start, stop, num, endpoint=True):
+    """The reference's linspace for the augmentation tables (ptu.py:78-92): a single endpoint-
+    inclusive sample is the MIDPOINT of the range (num_aug = 1: gamma 0.8, angle 0), an
+    endpoint-exclusive range stops one step short.  The values have to be torch.linspace's own,
+    bit for bit (golden `tta_params`), so it is torch.linspace that produces them."""
+    start, stop = torch.as_tensor(start), torch.as_tensor(stop)
+    if endpoint and num == 1:
+        return ((start + stop) / 2).reshape(1)
+    if not endpoint and num > 1:
+        stop = stop - (stop - start) / num
+    return torch.linspace(start, stop, num)
+
+
 def tta_parameters(num_aug, rot_aug_degrees=25):
     """Test-time-augmentation table (multiperson_model.py:108-137)."""
-    gammas = ptu.linspace(np.float32(0.6), np.float32(1.0), num_aug)
+    gammas = tta_linspace(np.float32(0.6), np.float32(1.0), num_aug)
     angle_range = np.float32(np.deg2rad(rot_aug_degrees))
-    angles = ptu.linspace(-angle_range, angle_range, num_aug)
+    angles = tta_linspace(-angle_range, angle_range, num_aug)
     scales = torch.cat([
-        ptu.linspace(0.8, 1.0, num_aug // 2, endpoint=False),
+        tta_linspace(0.8, 1.0, num_aug // 2, endpoint=False),
         torch.linspace(1.0, 1.1, num_aug - num_aug // 2)], dim=0)
     should_flip = (torch.arange(0, num_aug) - num_aug // 2) % 2 != 0
     flipmat = torch.tensor([[-1, 0, 0], [0, 1, 0], [0, 0, 1]], dtype=torch.float32)

@@ -19,12 +19,12 @@ def test_tta_parameters_match_reference_golden():
 
 
 def test_linspace_semantics():
-    from metrabs_amd import ptu
-    assert ptu.linspace(0.6, 1.0, 1).tolist() == pytest.approx([0.8])       # midpoint
-    assert ptu.linspace(0.8, 1.0, 2, endpoint=False).tolist() == pytest.approx([0.8, 0.9])
+    from metrabs_amd.multiperson.multiperson_model import tta_linspace
+    assert tta_linspace(0.6, 1.0, 1).tolist() == pytest.approx([0.8])       # midpoint
+    assert tta_linspace(0.8, 1.0, 2, endpoint=False).tolist() == pytest.approx([0.8, 0.9])
     for n in (1, 2, 5):
         for ep in (True, False):
-            assert torch.equal(ptu.linspace(0.8, 1.0, n, endpoint=ep),
+            assert torch.equal(tta_linspace(0.8, 1.0, n, endpoint=ep),
                                cpu_ref.ref_linspace(0.8, 1.0, n, endpoint=ep))
 
 
