@@ -16,9 +16,36 @@
 //     fma + one v_exp_f32; the depth sums of a column run in fp32 (<= 8 terms) and are promoted to
 //     fp64 once per column; the four moment sums (total, x, y, z) are fp64 and are merged across
 //     the group with DPP butterflies.
+#include <type_traits>
+
 #include "common.h"
 
 namespace mtr {
+
+// f16 logits, 8 per lane: the 16 loaded bytes stay packed.  The running maximum is taken on the
+// packed halves (v_pk_max_f16: two elements per instruction, no conversion) and the exponent's
+// argument is formed straight from the half (fmaf((float)h, log2e, -m log2e) = one v_fma_mix_f32),
+// so an element costs fma-mix + v_exp_f32 + two accumulates instead of two conversions (the
+// compiler re-converted after the group-wide maximum rather than hold 72 floats) + max + fma + ...
+using h2 = __attribute__((ext_vector_type(2))) _Float16;
+struct RawH8 { h2 p[4]; };
+
+template <int AUX>
+__device__ __forceinline__ RawH8 buffer_load_h8(buffer_rsrc_t rsrc, int voff_bytes, int soff_bytes) {
+  const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_bytes, soff_bytes, AUX);
+  static_assert(sizeof(raw) == 16, "b128 load");
+  return __builtin_bit_cast(RawH8, raw);
+}
+// (inline asm: the builtin maximum canonicalises every operand first -- one more v_pk_max_f16 per
+//  loaded dword; logits are finite, a NaN would poison the softmax either way)
+__device__ __forceinline__ h2 pk_max(h2 a, h2 b) {
+  h2 r;
+  asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ h2 raw_max(const RawH8& r) {
+  return pk_max(pk_max(r.p[0], r.p[1]), pk_max(r.p[2], r.p[3]));
+}
 
 template <int VEC>
 __device__ __forceinline__ float vec_max(const float (&v)[VEC]) {
@@ -35,6 +62,7 @@ __global__ __launch_bounds__(256) void decode_nchw_kernel(
   constexpr int JPW = kWave / LPJ;  // joints per wave
   constexpr int CH = 8;             // depth slices fetched per round
   constexpr int kLoadAux = AUX;  // 2 = non-temporal: the logits are read exactly once
+  constexpr bool kH8 = std::is_same<T, __half>::value && VEC == 8;  // packed-half path (above)
   const int HW = H * W;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(
@@ -81,35 +109,77 @@ __global__ __launch_bounds__(256) void decode_nchw_kernel(
 
     // ---- the 2D heatmap load is issued together with the first round of depth slices
     float v2[VEC];
-    buffer_load_vec<T, VEC, kLoadAux>(rsrc, voff, 0, v2);
+    RawH8 r2;
+    if constexpr (kH8) r2 = buffer_load_h8<kLoadAux>(rsrc, voff, 0);
+    else buffer_load_vec<T, VEC, kLoadAux>(rsrc, voff, 0, v2);
 
     for (int d0 = 0; d0 < D; d0 += CH) {
-      float v3[CH][VEC];
+      float v3[kH8 ? 1 : CH][VEC];
+      RawH8 r3[kH8 ? CH : 1];
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
         const int d = (d0 + k < D) ? d0 + k : D - 1;  // tail rounds re-read slice D-1, weight 0
-        buffer_load_vec<T, VEC, kLoadAux>(rsrc, voff, (J * HW) * (int)sizeof(T) + d * slice_bytes, v3[k]);
+        const int soff = (J * HW) * (int)sizeof(T) + d * slice_bytes;
+        if constexpr (kH8) r3[k] = buffer_load_h8<kLoadAux>(rsrc, voff, soff);
+        else buffer_load_vec<T, VEC, kLoadAux>(rsrc, voff, soff, v3[k]);
       }
+      // element v of the 2D row / of depth slice k as the argument of exp_shifted
+      auto x2 = [&](int v) -> float {
+        if constexpr (kH8) return (float)r2.p[v >> 1][v & 1]; else return v2[v];
+      };
+      auto x3 = [&](int k, int v) -> float {
+        if constexpr (kH8) return (float)r3[k].p[v >> 1][v & 1]; else return v3[k][v];
+      };
       if (d0 == 0) {
-        const float cm = group_max<LPJ>(pos_ok ? vec_max<VEC>(v2) : -INFINITY);
+        float lm;
+        if constexpr (kH8) {
+          const h2 m = raw_max(r2);
+          lm = fmaxf((float)m[0], (float)m[1]);
+        } else {
+          lm = vec_max<VEC>(v2);
+        }
+        const float cm = group_max<LPJ>(pos_ok ? lm : -INFINITY);
         if (cm > m2) {  // group-uniform
           const double r = (double)exp_shifted(m2, -cm * kLog2e);
           s2 *= r; sx2 *= r; sy2 *= r;
           m2 = cm;
         }
         const float nm = pos_ok ? -m2 * kLog2e : -INFINITY;  // exp2(-inf) = 0: masked lanes
+        if constexpr (VEC > 1) {
+          // the lane's VEC positions are consecutive in ONE map row (W % VEC == 0): x = w0 + v,
+          // y = h0 -> sum e and sum v e per lane, the row / column offsets applied once
+          double S = 0.0, Sv = 0.0;
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          const double e = (double)exp_shifted(v2[v], nm);
-          s2 += e;
-          sx2 += e * (double)fx[v];
-          sy2 += e * (double)fy[v];
+          for (int v = 0; v < VEC; ++v) {
+            const double e = (double)exp_shifted(x2(v), nm);
+            S += e;
+            if (v) Sv = fma(e, (double)v, Sv);
+          }
+          s2 += S;
+          sx2 += fma(S, (double)fx[0], Sv);
+          sy2 = fma(S, (double)fy[0], sy2);
+        } else {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            const double e = (double)exp_shifted(x2(v), nm);
+            s2 += e;
+            sx2 += e * (double)fx[v];
+            sy2 += e * (double)fy[v];
+          }
         }
       }
       {
-        float cm = vec_max<VEC>(v3[0]);
+        float cm;
+        if constexpr (kH8) {
+          h2 m = raw_max(r3[0]);
 #pragma unroll
-        for (int k = 1; k < CH; ++k) cm = fmaxf(cm, vec_max<VEC>(v3[k]));
+          for (int k = 1; k < CH; ++k) m = pk_max(m, raw_max(r3[k]));
+          cm = fmaxf((float)m[0], (float)m[1]);
+        } else {
+          cm = vec_max<VEC>(v3[0]);
+#pragma unroll
+          for (int k = 1; k < CH; ++k) cm = fmaxf(cm, vec_max<VEC>(v3[k]));
+        }
         cm = group_max<LPJ>(pos_ok ? cm : -INFINITY);
         if (cm > m3) {
           const double r = (double)exp_shifted(m3, -cm * kLog2e);
@@ -128,18 +198,35 @@ __global__ __launch_bounds__(256) void decode_nchw_kernel(
           const float nmk = (d0 + k < D) ? nm : -INFINITY;  // wave-uniform select
 #pragma unroll
           for (int v = 0; v < VEC; ++v) {
-            const float e = exp_shifted(v3[k][v], nmk);
+            const float e = exp_shifted(x3(k, v), nmk);
             col[v] += e;
             colz[v] = fmaf(e, fz, colz[v]);
           }
         }
+        if constexpr (VEC > 1) {
+          double S = 0.0, Sv = 0.0;
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          const double c = (double)col[v];
-          s3 += c;
-          sx3 += c * (double)fx[v];
-          sy3 += c * (double)fy[v];
-          sz3 += (double)colz[v];
+          for (int v = 0; v < VEC; ++v) {
+            const double c = (double)col[v];
+            S += c;
+            if (v) Sv = fma(c, (double)v, Sv);
+          }
+          double Z = 0.0;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) Z += (double)colz[v];
+          s3 += S;
+          sx3 += fma(S, (double)fx[0], Sv);
+          sy3 = fma(S, (double)fy[0], sy3);
+          sz3 += Z;
+        } else {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            const double c = (double)col[v];
+            s3 += c;
+            sx3 += c * (double)fx[v];
+            sy3 += c * (double)fy[v];
+            sz3 += (double)colz[v];
+          }
         }
       }
     }
