@@ -764,7 +764,7 @@ def main():
     hw_kernels = {
         'pyramid': dict(kernel='build_pyramid_u8_wide_kernel', bound='hbm', launches=1,
                         seconds=rot['pyramid'], bytes=pyr_bytes, hot_us=stages['pyramid'] * 1e6),
-        'warp': dict(kernel='warp_crops_kernel', bound='hbm', launches=1, seconds=rot['warp'],
+        'warp': dict(kernel='warp_rows_kernel', bound='hbm', launches=1, seconds=rot['warp'],
                      bytes=n_crops * 3 * args.res ** 2 * out_bytes + src_bytes,
                      hot_us=stages['warp'] * 1e6),
         'head_fused': dict(kernel=head_kernel, bound='hbm' if h16 else 'mfma', launches=1,

@@ -18,6 +18,9 @@
 #include "resize_aa.h"
 
 // developer-only timing ablations of warp_crops_kernel (tools/experiments/ablate_warp.py); 0 in the product
+#ifndef MTR_WARP_PX
+#define MTR_WARP_PX 4  // output pixels per thread (a multiple of 4 for the vector stores)
+#endif
 #ifndef MTR_WARP_ABLATE
 #define MTR_WARP_ABLATE 0
 #endif
@@ -553,13 +556,20 @@ __global__ __launch_bounds__(256) void warp_crops_kernel(
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       OutT* dst = out + (((size_t)crop * 3 + c) * res + v) * res + u0;
-      if (full && PX == 4 && sizeof(OutT) == 4) {
-        *reinterpret_cast<float4*>(dst) =
-            make_float4(res_v[0][c], res_v[1][c], res_v[2][c], res_v[3][c]);
-      } else if (full && PX == 4 && sizeof(OutT) == 2) {
-        OutT tmp[4] = {from_f32<OutT>(res_v[0][c]), from_f32<OutT>(res_v[1][c]),
-                       from_f32<OutT>(res_v[2][c]), from_f32<OutT>(res_v[3][c])};
-        *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<uint2*>(tmp);
+      if (full && PX % 4 == 0 && sizeof(OutT) == 4) {
+#pragma unroll
+        for (int q = 0; q < PX; q += 4)
+          *reinterpret_cast<float4*>(dst + q) =
+              make_float4(res_v[q][c], res_v[q + 1][c], res_v[q + 2][c], res_v[q + 3][c]);
+      } else if (full && PX % 4 == 0 && sizeof(OutT) == 2) {
+#pragma unroll
+        for (int q = 0; q < PX; q += 4) {
+          OutT tmp[4] = {from_f32<OutT>(res_v[q][c]), from_f32<OutT>(res_v[q + 1][c]),
+                         from_f32<OutT>(res_v[q + 2][c]), from_f32<OutT>(res_v[q + 3][c])};
+          *reinterpret_cast<uint2*>(dst + q) = *reinterpret_cast<uint2*>(tmp);
+        }
+      } else if (full && PX == 2 && sizeof(OutT) == 4) {
+        *reinterpret_cast<float2*>(dst) = make_float2(res_v[0][c], res_v[1][c]);
       } else {
 #pragma unroll
         for (int p = 0; p < PX; ++p)
@@ -577,11 +587,195 @@ __global__ __launch_bounds__(256) void warp_crops_kernel(
   }
 }
 
+// ---- row-walking variant of the sampler ---------------------------------------------------------
+// Same arithmetic per sample as warp_crops_kernel (bit-identical crops), different schedule: a lane
+// owns ONE output column and walks ROWS rows; the taps of sample s+1 are requested before sample s
+// is finished, and a finished pixel is stored at once (64 lanes x 4 B = 256 contiguous bytes per
+// channel).  Stores therefore leave a wave as a steady stream instead of one burst at its end, and
+// -- gfx9 counts loads and stores in the same in-order vmcnt -- the next taps are always OLDER than
+// the previous pixel's stores, so waiting for taps never waits for a store.
+struct TapSet {
+  unsigned long long raw[6];  // [channel][top, bottom]: the two x-taps of a row (f32 pair / byte window)
+  float w00, w01, w10, w11;
+  int off;                    // element (f32 levels) or byte (uint8 level 0) offset of the top-left tap
+};
+
+template <typename OutT, int AA, int ROWS, bool L0U8>
+__global__ __launch_bounds__(256) void warp_rows_kernel(
+    const void* __restrict__ l0_any, const float* __restrict__ l1, const float* __restrict__ l2,
+    const float* __restrict__ lut_g, LevelDims dims, unsigned u8_bytes,
+    const float* __restrict__ wp_all, int n_crops, int res, int nhwc, OutT* __restrict__ out) {
+  __shared__ float lut[L0U8 ? 256 : 1];
+  if (L0U8) {
+    lut[threadIdx.x] = lut_g[threadIdx.x];
+    __syncthreads();
+  }
+  const float* __restrict__ l0 = (const float*)l0_any;
+  // block = 64 columns x 4*ROWS rows (wave w owns rows [w*ROWS, (w+1)*ROWS) of the tile); all tiles
+  // of a crop on one XCD, as in warp_crops_kernel
+  const int row_tiles = (res + 4 * ROWS - 1) / (4 * ROWS);
+  const int x_tiles = (res + 63) / 64;
+  const int per_crop = row_tiles * x_tiles;
+  const int id = blockIdx.x;
+  const int crop = (id / (8 * per_crop)) * 8 + (id % 8);
+  if (crop >= n_crops) return;
+  const int tile = (id / 8) % per_crop;
+  const int ty = tile / x_tiles, tx = tile - ty * x_tiles;
+
+  const float* __restrict__ wp = wp_all + (size_t)crop * MTR_WARP_PARAM_FLOATS;
+  const float h0 = wp[0], h1 = wp[1], h2 = wp[2], h3 = wp[3], h4 = wp[4], h5 = wp[5], h6 = wp[6],
+              h7 = wp[7], h8 = wp[8];
+  const float k0 = wp[9], k1 = wp[10], k2 = wp[11], k3 = wp[12], k4 = wp[13], k5 = wp[14];
+  const bool has_dist = wp[30] != 0.0f;
+  // (wave-uniform by construction; said explicitly so that every descriptor / scalar offset below
+  //  stays in SGPRs across the unrolled sample pipeline)
+  const int level = __builtin_amdgcn_readfirstlane((int)wp[31]);
+  const int img = __builtin_amdgcn_readfirstlane((int)wp[32]);
+  const float gexp = wp[33];
+  const int W = __builtin_amdgcn_readfirstlane(dims.W[level]);
+  const int H = __builtin_amdgcn_readfirstlane(dims.H[level]);
+  const bool bytes0 = L0U8 && level == 0;  // wave-uniform
+  const float* __restrict__ lvl = level == 0 ? l0 : (level == 1 ? l1 : l2);
+  const float* __restrict__ planes = lvl + (size_t)img * 3 * H * W;
+  const int plane_elems = __builtin_amdgcn_readfirstlane(H * W);
+  const int img_off = __builtin_amdgcn_readfirstlane(bytes0 ? img * 3 * plane_elems : 0);
+  // ONE request path for both kinds of level: byte offset of the top-left tap = ((ys*W + xs) << sh)
+  // + base, six loads at (offset & ~3) through one descriptor (uint8 level 0: the whole frame
+  // tensor, see warp_crops_kernel; f32 levels: the image's three planes)
+  const int sh = bytes0 ? 0 : 2;
+  const int plane_bytes = __builtin_amdgcn_readfirstlane(plane_elems << sh);
+  const int row_bytes = __builtin_amdgcn_readfirstlane(W << sh);
+  const buffer_rsrc_t rsrc =
+      bytes0 ? make_rsrc(uniform_ptr((const uint8_t*)l0_any), (unsigned)u8_bytes)
+             : make_rsrc(uniform_ptr(planes), (unsigned)(3 * plane_elems) * 4u);
+
+  const int x = tx * 64 + (threadIdx.x & 63);
+  const int v_first = ty * 4 * ROWS + (threadIdx.x >> 6) * ROWS;
+  if (x >= res || v_first >= res) return;
+  const float fW = (float)W, fH = (float)H;
+
+  // sample s of this lane: row s / (AA*AA), sub-sample (sj, si) in the reference's loop order
+  auto request = [&](int s) -> TapSet {
+    const int r = s / (AA * AA), sj = (s / AA) % AA, si = s % AA;
+    const float U = (float)(x * AA + si), V = (float)((v_first + r) * AA + sj);
+    const float ox = fmaf(h0, U, fmaf(h1, V, h2));
+    const float oy = fmaf(h3, U, fmaf(h4, V, h5));
+    const float oz = fmaf(h6, U, fmaf(h7, V, h8));
+    const float inv = __fdiv_rn(1.0f, oz);
+    float nx = ox * inv, ny = oy * inv;
+    if (has_dist) {
+      float pa, pb, pcx, pcy;
+      distortion_parts<float>(nx, ny, wp + 18, pa, pb, pcx, pcy);
+      const float sc = pa + pb;
+      nx = fmaf(nx, sc, pcx);
+      ny = fmaf(ny, sc, pcy);
+    }
+    const float ix = fmaf(k0, nx, fmaf(k1, ny, k2));
+    const float iy = fmaf(k3, nx, fmaf(k4, ny, k5));
+    const bool sane = (ix > -1.0f) && (iy > -1.0f) && (ix < fW) && (iy < fH);
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const int x0 = sane ? (int)fx0 : 0, y0 = sane ? (int)fy0 : 0;
+    const float tx1 = ix - fx0, tx0 = 1.0f - tx1;
+    const float ty1 = iy - fy0, ty0 = 1.0f - ty1;
+    const int xs = min(max(x0, 0), W - 2), ys = min(max(y0, 0), H - 2);
+    float wl, wr, wt, wb;
+    pair_weights(x0, xs, W, tx0, tx1, wl, wr);
+    pair_weights(y0, ys, H, ty0, ty1, wt, wb);
+    if (!sane) wl = wr = 0.0f;  // (also non-finite coordinates) the sample contributes nothing
+    TapSet t;
+    t.w00 = wl * wt; t.w01 = wr * wt; t.w10 = wl * wb; t.w11 = wr * wb;
+    t.off = ((ys * W + xs) << sh) + img_off;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int ot = t.off + c * plane_bytes, ob = ot + row_bytes;
+      t.raw[2 * c] = __builtin_bit_cast(unsigned long long,
+          __builtin_amdgcn_raw_buffer_load_b64(rsrc, ot & ~3, 0, 0));
+      t.raw[2 * c + 1] = __builtin_bit_cast(unsigned long long,
+          __builtin_amdgcn_raw_buffer_load_b64(rsrc, ob & ~3, 0, 0));
+    }
+    return t;
+  };
+
+  auto finish = [&](const TapSet& t, float* acc) {
+    struct F2 { float a, b; };
+    if (!bytes0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const F2 tp = __builtin_bit_cast(F2, t.raw[2 * c]), bt = __builtin_bit_cast(F2, t.raw[2 * c + 1]);
+        acc[c] += fmaf(bt.b, t.w11, fmaf(bt.a, t.w10, fmaf(tp.b, t.w01, tp.a * t.w00)));
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int ot = t.off + c * plane_bytes, ob = ot + row_bytes;
+        const unsigned long long tw = t.raw[2 * c] >> ((ot & 3) * 8);
+        const unsigned long long bw = t.raw[2 * c + 1] >> ((ob & 3) * 8);
+        const float ta = lut[tw & 0xff], tb = lut[(tw >> 8) & 0xff];
+        const float ba = lut[bw & 0xff], bb = lut[(bw >> 8) & 0xff];
+        acc[c] += fmaf(bb, t.w11, fmaf(ba, t.w10, fmaf(tb, t.w01, ta * t.w00)));
+      }
+    }
+  };
+
+  constexpr int NS = ROWS * AA * AA;
+  float acc[3] = {0.0f, 0.0f, 0.0f};
+  TapSet cur = request(0);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    TapSet nxt;
+    if (s + 1 < NS) nxt = request(s + 1);
+    finish(cur, acc);
+    if ((s + 1) % (AA * AA) == 0) {  // the pixel of row r is complete
+      const int v = v_first + s / (AA * AA);
+      float px[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float val = acc[c];
+        if (AA > 1) val = val * (1.0f / (AA * AA));
+        px[c] = gexp == 1.0f ? val : fast_pow_unit(val, gexp);
+        acc[c] = 0.0f;
+      }
+      if (v < res) {
+        if (!nhwc) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            out[(((size_t)crop * 3 + c) * res + v) * res + x] = from_f32<OutT>(px[c]);
+        } else {
+          OutT* dst = out + (((size_t)crop * res + v) * res + x) * 3;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) dst[c] = from_f32<OutT>(px[c]);
+        }
+      }
+    }
+    if (s + 1 < NS) cur = nxt;
+  }
+}
+
+#ifndef MTR_WARP_ROWS
+#define MTR_WARP_ROWS 4  // rows per wave of warp_rows_kernel; 0 = warp_crops_kernel everywhere
+#endif
+
 template <typename OutT, int AA, bool L0U8>
 static int launch_warp(const void* l0, const float* l1, const float* l2, const float* lut,
                        const LevelDims& dims, unsigned u8_bytes, const float* wp, int n_crops,
                        int res, int nhwc, void* out, hipStream_t stream) {
-  constexpr int PX = 4;
+  constexpr int ROWS = MTR_WARP_ROWS;
+  // (warp_crops_kernel keeps the degenerate pyramid levels -- fewer than two rows or columns --
+  //  and antialias 4, whose 16 samples per pixel it walks with fewer registers)
+  bool degenerate = false;
+  for (int l = 0; l < 3; ++l) degenerate |= dims.W[l] < 2 || dims.H[l] < 2;
+  if (ROWS > 0 && AA <= 2 && !degenerate) {
+    const long long tiles = (long long)((res + 63) / 64) * ((res + 4 * ROWS - 1) / (4 * ROWS));
+    const long long nblocks = (long long)((n_crops + 7) / 8) * 8 * tiles;
+    if (nblocks > 0x7fffffffLL) return MTR_E_SHAPE;
+    MTR_CLEAR_STALE();
+    hipLaunchKernelGGL((warp_rows_kernel<OutT, AA, ROWS ? ROWS : 1, L0U8>), dim3((unsigned)nblocks),
+                       dim3(256), 0, stream, l0, l1, l2, lut, dims, u8_bytes, wp, n_crops, res, nhwc,
+                       (OutT*)out);
+    MTR_CHECK_LAUNCH();
+    return MTR_OK;
+  }
+  constexpr int PX = MTR_WARP_PX;
   const long long per_crop = (long long)((res + 16 * PX - 1) / (16 * PX)) * ((res + 15) / 16);
   const long long blocks = (long long)((n_crops + 7) / 8) * 8 * per_crop;
   if (blocks > 0x7fffffffLL) return MTR_E_SHAPE;

@@ -13,6 +13,14 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, 'tools', 'experiments', '_build')
 MASKS = [0, 16, 1, 2, 4, 8, 15]  # 16 = one gather pair serves all three channels (level-0 crops)
+# variant name -> extra defines (MASKS entries are the variants 'a<mask>')
+VARIANTS = {f'{m}': [f'-DMTR_WARP_ABLATE={m}', '-DMTR_WARP_ROWS=0'] for m in MASKS}
+VARIANTS.update({f'rows{r}': [f'-DMTR_WARP_ROWS={r}'] for r in (1, 2, 4, 8, 16)})
+VARIANTS.update({'px8': ['-DMTR_WARP_PX=8'], 'px8_nostore': ['-DMTR_WARP_PX=8', '-DMTR_WARP_ABLATE=8'],
+                 'px16': ['-DMTR_WARP_PX=16'], 'px2': ['-DMTR_WARP_PX=2'], 'px1': ['-DMTR_WARP_PX=1'],
+                 'px2_nomem': ['-DMTR_WARP_PX=2', '-DMTR_WARP_ABLATE=15'], 'px8_nomem': ['-DMTR_WARP_PX=8', '-DMTR_WARP_ABLATE=15']})
+if os.environ.get('ABLATE_ONLY'):
+    VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ['ABLATE_ONLY'].split(',')}
 
 
 def build():
@@ -20,9 +28,9 @@ def build():
     csrc = os.path.join(ROOT, 'metrabs_amd', 'csrc')
     srcs = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith('.hip'))
     procs = [subprocess.Popen(['hipcc', '-O3', '-std=c++17', '-fPIC', '-shared', '--offload-arch=gfx950',
-                               f'-DMTR_WARP_ABLATE={m}', '-I', os.path.join(ROOT, 'include'), *srcs, '-o',
+                               *defs, '-I', os.path.join(ROOT, 'include'), *srcs, '-o',
                                os.path.join(OUT, f'libmtr_warp{m}.so')], stdout=subprocess.DEVNULL,
-                              stderr=subprocess.PIPE) for m in MASKS]
+                              stderr=subprocess.PIPE) for m, defs in VARIANTS.items()]
     for p in procs:
         _, err = p.communicate()
         if p.returncode:
@@ -39,7 +47,7 @@ def run_one(mask):
     g = torch.Generator().manual_seed(0)
     frames = torch.randint(0, 256, (8, 3, 1080, 1920), dtype=torch.uint8, generator=g).cuda()
     pyr = kernels.build_pyramid(frames)
-    n = 64
+    n = int(os.environ.get('ABLATE_CROPS', '64'))
     tta = {k: v.cuda() for k, v in tta_parameters(1).items()}
     bw = 60 + 340 * torch.rand(n, generator=g)
     bh = 150 + 750 * torch.rand(n, generator=g)
@@ -72,14 +80,15 @@ def run_one(mask):
         graph.replay()
     b.record()
     torch.cuda.synchronize()
-    print(json.dumps({'mask': mask, 'us': round(a.elapsed_time(b) / (n * 10) * 1e3, 1)}), flush=True)
+    print(json.dumps({'variant': mask, 'us': round(a.elapsed_time(b) / (n * 10) * 1e3, 1),
+                      'checksum': float(o.double().sum())}), flush=True)
 
 
 if __name__ == '__main__':
     if sys.argv[1] == 'build':
         build()
     elif sys.argv[1] == 'run':
-        for m in MASKS:
+        for m in VARIANTS:
             subprocess.run([sys.executable, __file__, 'one', str(m)])
     else:
         run_one(sys.argv[2])
