@@ -21,6 +21,9 @@
 #ifndef MTR_WARP_PX
 #define MTR_WARP_PX 4  // output pixels per thread (a multiple of 4 for the vector stores)
 #endif
+#ifndef MTR_WARP_RCP
+#define MTR_WARP_RCP 1  // 1/oz by v_rcp_f32 + one Newton step (<= 1 ulp) instead of the IEEE division sequence
+#endif
 #ifndef MTR_WARP_ABLATE
 #define MTR_WARP_ABLATE 0
 #endif
@@ -653,6 +656,11 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
   const int v_first = ty * 4 * ROWS + (threadIdx.x >> 6) * ROWS;
   if (x >= res || v_first >= res) return;
   const float fW = (float)W, fH = (float)H;
+  const bool same_shift = ((row_bytes | plane_bytes) & 3) == 0;
+  // crop stores through a descriptor over this crop: 32-bit offsets, the channel pitch in an SGPR
+  const buffer_rsrc_t orsrc = make_rsrc(uniform_ptr(out + (size_t)crop * 3 * res * res),
+                                        (unsigned)(3 * res * res) * (unsigned)sizeof(OutT));
+  const int chan_bytes = __builtin_amdgcn_readfirstlane(res * res * (int)sizeof(OutT));
 
   // sample s of this lane: row s / (AA*AA), sub-sample (sj, si) in the reference's loop order
   auto request = [&](int s) -> TapSet {
@@ -661,7 +669,12 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
     const float ox = fmaf(h0, U, fmaf(h1, V, h2));
     const float oy = fmaf(h3, U, fmaf(h4, V, h5));
     const float oz = fmaf(h6, U, fmaf(h7, V, h8));
+#if MTR_WARP_RCP
+    float inv = __builtin_amdgcn_rcpf(oz);  // 1 ulp, then one Newton step: <= 1 ulp of 1/oz
+    inv = fmaf(fmaf(-oz, inv, 1.0f), inv, inv);
+#else
     const float inv = __fdiv_rn(1.0f, oz);
+#endif
     float nx = ox * inv, ny = oy * inv;
     if (has_dist) {
       float pa, pb, pcx, pcy;
@@ -678,13 +691,15 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
     const float tx1 = ix - fx0, tx0 = 1.0f - tx1;
     const float ty1 = iy - fy0, ty0 = 1.0f - ty1;
     const int xs = min(max(x0, 0), W - 2), ys = min(max(y0, 0), H - 2);
-    float wl, wr, wt, wb;
-    pair_weights(x0, xs, W, tx0, tx1, wl, wr);
-    pair_weights(y0, ys, H, ty0, ty1, wt, wb);
+    // pair_weights as selects: the loaded pair is (xs, xs+1), the wanted taps (x0, x0+1); inside
+    // the sane range x0 - xs is 0 (both taps loaded), -1 (only tap x0+1 = 0) or +1 (only tap x0 = W-1)
+    const int dx = x0 - xs, dy = y0 - ys;
+    float wl = dx == 0 ? tx0 : (dx < 0 ? tx1 : 0.0f), wr = dx == 0 ? tx1 : (dx > 0 ? tx0 : 0.0f);
+    const float wt = dy == 0 ? ty0 : (dy < 0 ? ty1 : 0.0f), wb = dy == 0 ? ty1 : (dy > 0 ? ty0 : 0.0f);
     if (!sane) wl = wr = 0.0f;  // (also non-finite coordinates) the sample contributes nothing
     TapSet t;
     t.w00 = wl * wt; t.w01 = wr * wt; t.w10 = wl * wb; t.w11 = wr * wb;
-    t.off = ((ys * W + xs) << sh) + img_off;
+    t.off = ((__mul24(ys, W) + xs) << sh) + img_off;  // (full-rate 24-bit multiply: ys, W < 2^24)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const int ot = t.off + c * plane_bytes, ob = ot + row_bytes;
@@ -707,7 +722,9 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
     } else {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const int ot = t.off + c * plane_bytes, ob = ot + row_bytes;
+        // (when the row and plane pitches are multiples of 4 -- wave-uniform -- the six byte
+        //  windows of a sample share one shift)
+        const int ot = same_shift ? t.off : t.off + c * plane_bytes, ob = same_shift ? t.off : ot + row_bytes;
         const unsigned long long tw = t.raw[2 * c] >> ((ot & 3) * 8);
         const unsigned long long bw = t.raw[2 * c + 1] >> ((ob & 3) * 8);
         const float ta = lut[tw & 0xff], tb = lut[(tw >> 8) & 0xff];
@@ -736,14 +753,16 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
         acc[c] = 0.0f;
       }
       if (v < res) {
-        if (!nhwc) {
+        const int pix = v * res + x;
 #pragma unroll
-          for (int c = 0; c < 3; ++c)
-            out[(((size_t)crop * 3 + c) * res + v) * res + x] = from_f32<OutT>(px[c]);
-        } else {
-          OutT* dst = out + (((size_t)crop * res + v) * res + x) * 3;
-#pragma unroll
-          for (int c = 0; c < 3; ++c) dst[c] = from_f32<OutT>(px[c]);
+        for (int c = 0; c < 3; ++c) {
+          const OutT o = from_f32<OutT>(px[c]);
+          const int voff = (nhwc ? pix * 3 + c : pix) * (int)sizeof(OutT);
+          const int soff = nhwc ? 0 : c * chan_bytes;
+          if constexpr (sizeof(OutT) == 4)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), orsrc, voff, soff, 0);
+          else
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, o), orsrc, voff, soff, 0);
         }
       }
     }

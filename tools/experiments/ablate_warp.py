@@ -16,6 +16,7 @@ MASKS = [0, 16, 1, 2, 4, 8, 15]  # 16 = one gather pair serves all three channel
 # variant name -> extra defines (MASKS entries are the variants 'a<mask>')
 VARIANTS = {f'{m}': [f'-DMTR_WARP_ABLATE={m}', '-DMTR_WARP_ROWS=0'] for m in MASKS}
 VARIANTS.update({f'rows{r}': [f'-DMTR_WARP_ROWS={r}'] for r in (1, 2, 4, 8, 16)})
+VARIANTS.update({'rcp': ['-DMTR_WARP_RCP=1'], 'rcp8': ['-DMTR_WARP_RCP=1', '-DMTR_WARP_ROWS=8']})
 VARIANTS.update({'px8': ['-DMTR_WARP_PX=8'], 'px8_nostore': ['-DMTR_WARP_PX=8', '-DMTR_WARP_ABLATE=8'],
                  'px16': ['-DMTR_WARP_PX=16'], 'px2': ['-DMTR_WARP_PX=2'], 'px1': ['-DMTR_WARP_PX=1'],
                  'px2_nomem': ['-DMTR_WARP_PX=2', '-DMTR_WARP_ABLATE=15'], 'px8_nomem': ['-DMTR_WARP_PX=8', '-DMTR_WARP_ABLATE=15']})
