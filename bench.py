@@ -419,6 +419,11 @@ def backbone_epilogue_kernels(est, crops, iters):
         if e['slowest'] is None or frac < e['slowest']['frac_hbm']:
             e['slowest'] = dict(shape=list(shape), dtype=str(dtype).replace('torch.', ''), us=round(t * 1e6, 2),
                                 frac_hbm=round(frac, 4), options=[str(x) for x in sig[3:]])
+        if os.environ.get('MTR_BENCH_LAUNCH_TABLE'):  # developer aid: one line per distinct launch
+            with open(os.environ['MTR_BENCH_LAUNCH_TABLE'], 'a') as f:
+                f.write(json.dumps(dict(kernel=name, shape=list(shape), options=[str(x) for x in sig[2:]],
+                                        launches=n, us=round(t * 1e6, 2), MB=round(nbytes / 1e6, 2),
+                                        frac_hbm=round(frac, 4))) + '\n')
         del call
         torch.cuda.empty_cache()
     return out

@@ -21,6 +21,9 @@
 #ifndef MTR_WARP_PX
 #define MTR_WARP_PX 4  // output pixels per thread (a multiple of 4 for the vector stores)
 #endif
+#ifndef MTR_WARP_PREFETCH
+#define MTR_WARP_PREFETCH 1  // samples requested ahead of the one being finished
+#endif
 #ifndef MTR_WARP_RCP
 #define MTR_WARP_RCP 1  // 1/oz by v_rcp_f32 + one Newton step (<= 1 ulp) instead of the IEEE division sequence
 #endif
@@ -736,12 +739,16 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
 
   constexpr int NS = ROWS * AA * AA;
   float acc[3] = {0.0f, 0.0f, 0.0f};
-  TapSet cur = request(0);
+  // samples s+1 .. s+PD are in flight while sample s is finished (slot = s % (PD+1), all indices
+  // compile-time after unrolling)
+  constexpr int PD = MTR_WARP_PREFETCH < NS ? MTR_WARP_PREFETCH : NS - 1;
+  TapSet ring[PD + 1];
+#pragma unroll
+  for (int s = 0; s < PD; ++s) ring[s] = request(s);
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    TapSet nxt;
-    if (s + 1 < NS) nxt = request(s + 1);
-    finish(cur, acc);
+    if (s + PD < NS) ring[(s + PD) % (PD + 1)] = request(s + PD);
+    finish(ring[s % (PD + 1)], acc);
     if ((s + 1) % (AA * AA) == 0) {  // the pixel of row r is complete
       const int v = v_first + s / (AA * AA);
       float px[3];
@@ -766,7 +773,6 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
         }
       }
     }
-    if (s + 1 < NS) cur = nxt;
   }
 }
 

@@ -16,6 +16,7 @@ MASKS = [0, 16, 1, 2, 4, 8, 15]  # 16 = one gather pair serves all three channel
 # variant name -> extra defines (MASKS entries are the variants 'a<mask>')
 VARIANTS = {f'{m}': [f'-DMTR_WARP_ABLATE={m}', '-DMTR_WARP_ROWS=0'] for m in MASKS}
 VARIANTS.update({f'rows{r}': [f'-DMTR_WARP_ROWS={r}'] for r in (1, 2, 4, 8, 16)})
+VARIANTS.update({'pd1': [], 'pd2': ['-DMTR_WARP_PREFETCH=2'], 'pd3': ['-DMTR_WARP_PREFETCH=3'], 'pd2r8': ['-DMTR_WARP_PREFETCH=2', '-DMTR_WARP_ROWS=8'], 'pd0': ['-DMTR_WARP_PREFETCH=0']})
 VARIANTS.update({'rcp': ['-DMTR_WARP_RCP=1'], 'rcp8': ['-DMTR_WARP_RCP=1', '-DMTR_WARP_ROWS=8']})
 VARIANTS.update({'px8': ['-DMTR_WARP_PX=8'], 'px8_nostore': ['-DMTR_WARP_PX=8', '-DMTR_WARP_ABLATE=8'],
                  'px16': ['-DMTR_WARP_PX=16'], 'px2': ['-DMTR_WARP_PX=2'], 'px1': ['-DMTR_WARP_PX=1'],
@@ -48,6 +49,10 @@ def run_one(mask):
     g = torch.Generator().manual_seed(0)
     frames = torch.randint(0, 256, (8, 3, 1080, 1920), dtype=torch.uint8, generator=g).cuda()
     pyr = kernels.build_pyramid(frames)
+    # ABLATE_ROTATE=k: k frame sets (112 MB each with their pyramids), launches cycle through them
+    # so that the gathers miss the Infinity Cache
+    pyrs = [pyr] + [kernels.build_pyramid(torch.randint(0, 256, (8, 3, 1080, 1920), dtype=torch.uint8, generator=g).cuda())
+                    for _ in range(int(os.environ.get('ABLATE_ROTATE', '1')) - 1)]
     n = int(os.environ.get('ABLATE_CROPS', '64'))
     tta = {k: v.cuda() for k, v in tta_parameters(1).items()}
     bw = 60 + 340 * torch.rand(n, generator=g)
@@ -71,8 +76,8 @@ def run_one(mask):
         kernels.warp_crops(pyr, wp, 256, 1, out=o)
         st.synchronize()
         with torch.cuda.graph(graph, stream=st):
-            for _ in range(n):
-                kernels.warp_crops(pyr, wp, 256, 1, out=o)
+            for i in range(n):
+                kernels.warp_crops(pyrs[i % len(pyrs)], wp, 256, 1, out=o)
     graph.replay()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
