@@ -789,7 +789,7 @@ static int launch_warp(const void* l0, const float* l1, const float* l2, const f
   //  and antialias 4, whose 16 samples per pixel it walks with fewer registers)
   bool degenerate = false;
   for (int l = 0; l < 3; ++l) degenerate |= dims.W[l] < 2 || dims.H[l] < 2;
-  if (ROWS > 0 && AA <= 2 && !degenerate) {
+  if constexpr (ROWS > 0 && AA <= 2) if (!degenerate) {
     const long long tiles = (long long)((res + 63) / 64) * ((res + 4 * ROWS - 1) / (4 * ROWS));
     const long long nblocks = (long long)((n_crops + 7) / 8) * 8 * tiles;
     if (nblocks > 0x7fffffffLL) return MTR_E_SHAPE;
