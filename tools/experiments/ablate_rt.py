@@ -48,14 +48,18 @@ def run_one(name):
     g = torch.Generator(device='cuda').manual_seed(0)
     res = {'variant': name}
     lib.mtr_head_packed_bytes.restype = ctypes.c_size_t
-    for label, B, H, nhwc in [('B64', 64, 8, False), ('B64 nhwc', 64, 8, True), ('B1024', 1024, 8, False),
-                              ('B32 12x12', 32, 12, False), ('B256 12x12', 256, 12, False)]:
-        C, J, D = 1280, 17, 8
+    cases = [('B64', 64, 8, False, 8), ('B64 nhwc', 64, 8, True, 8), ('B1024', 1024, 8, False, 8),
+             ('B32 12x12', 32, 12, False, 8), ('B256 12x12', 256, 12, False, 8),
+             ('B64 D72', 64, 8, False, 72), ('B256 D72', 256, 8, False, 72)]
+    if os.environ.get('RT_CASES'):
+        cases = [c for c in cases if c[0] in os.environ['RT_CASES'].split(',')]
+    for label, B, H, nhwc, D in cases:
+        C, J = 1280, 17
         feat = torch.randn(B, C, H, H, device='cuda', generator=g)
         if nhwc:
             feat = feat.contiguous(memory_format=torch.channels_last)
-        w = torch.randn(153, C, device='cuda', generator=g) * 0.03
-        bias = torch.zeros(153, device='cuda')
+        w = torch.randn(J * (1 + D), C, device='cuda', generator=g) * 0.03
+        bias = torch.zeros(J * (1 + D), device='cuda')
         nb = lib.mtr_head_packed_bytes(C, J, D, 0)
         packed = torch.empty(nb // 4, device='cuda')
         vp = ctypes.c_void_p
