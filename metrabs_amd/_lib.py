@@ -23,7 +23,7 @@ class HeadParams(ctypes.Structure):
 class HeadOptions(ctypes.Structure):
     """mtr_head_options (include/metrabs_hip.h): explicit dispatch choices of mtr_head_fused_opts."""
     _fields_ = [('rt_tiles_per_workgroup', c_int32), ('groups_per_workgroup', c_int32),
-                ('dma_staging', c_int32), ('rt_column_blocks', c_int32)]
+                ('dma_staging', c_int32), ('rt_column_blocks', c_int32), ('rt_k_groups', c_int32)]
 
 
 class ReconParams(ctypes.Structure):

@@ -672,6 +672,7 @@ constexpr size_t head16_lds_bytes() {
 struct HeadOpts {
   int rt_tiles = 0;          // f32: row tiles per workgroup for one-tile atoms (1..5)
   int rt_np = 0;             // f32: column blocks per workgroup tile (1..4), maps of > 64 positions
+  int rt_ks = 0;             // f32: K groups per workgroup (1, 2), blocks of <= 3 tiles
   int groups_per_wg = 0;     // 16-bit: joint groups per workgroup (1..3)
   int dma = -1;              // 16-bit: -1 auto, 0 = stage through registers, 1 = global_load_lds
 };
@@ -847,10 +848,12 @@ extern "C" int mtr_head_fused_opts(const void* features, int feat_dtype, int lay
     if (options->rt_tiles_per_workgroup < 0 || options->rt_tiles_per_workgroup > 5 ||
         options->groups_per_workgroup < 0 || options->groups_per_workgroup > 3 ||
         options->dma_staging < -1 || options->dma_staging > 1 ||
-        options->rt_column_blocks < 0 || options->rt_column_blocks > 4)
+        options->rt_column_blocks < 0 || options->rt_column_blocks > 4 ||
+        options->rt_k_groups < 0 || options->rt_k_groups > 2)
       return MTR_E_PARAM;
     opt.rt_tiles = options->rt_tiles_per_workgroup;
     opt.rt_np = options->rt_column_blocks;
+    opt.rt_ks = options->rt_k_groups;
     opt.groups_per_wg = options->groups_per_workgroup;
     opt.dma = options->dma_staging;
   }
@@ -860,7 +863,7 @@ extern "C" int mtr_head_fused_opts(const void* features, int feat_dtype, int lay
     if (!mtr::rt_shape_ok(C, J, D)) return MTR_E_SHAPE;  // -> 1x1-conv GEMM + mtr_softargmax_decode
     if (B == 0) return MTR_OK;
     return mtr::rt_launch((const float*)features, layout, packed, B, C, H, W, J, D, hs, coords2d,
-                          coords3d_rel, opt.rt_tiles, opt.rt_np, s);
+                          coords3d_rel, opt.rt_tiles, opt.rt_np, opt.rt_ks, s);
   }
   // 16-bit joint-group kernels: a joint's 1 + D rows inside one 64-row tile, maps of <= 256 positions
   if (!mtr::h16_shape_ok(C, J, D) || H * W > 256) return MTR_E_SHAPE;

@@ -41,6 +41,18 @@ using v4f = __attribute__((ext_vector_type(4))) float;
 #ifndef MTR_RT_NBUF
 #define MTR_RT_NBUF 0       // 0: by block size (rt_nbuf)
 #endif
+#ifndef MTR_RT_KS_NBUF
+#define MTR_RT_KS_NBUF 2    // ring depth of each K group of head_rt_ks_kernel
+#endif
+#ifndef MTR_RT_KS_ALWAYS
+#define MTR_RT_KS_ALWAYS 0  // developer probe: two K groups at every launch size
+#endif
+#ifndef MTR_RT_ROTATE
+#define MTR_RT_ROTATE 0     // developer probe: every workgroup starts its K loop at another stage
+#endif
+#ifndef MTR_RT_KS_SLEEP
+#define MTR_RT_KS_SLEEP 0   // developer probe: s_sleep of the second K group behind every barrier
+#endif
 #ifndef MTR_RT_EXP32
 #define MTR_RT_EXP32 1      // 1: v_exp_f32 in the decode epilogue (f64 sums; measured -0.9 us at B=64, -11 us at
                             // B=1024, parity unchanged: the stand-alone decode does the same); 0: f64 polynomial
@@ -70,7 +82,7 @@ __host__ __device__ constexpr int rt_epilogue_bytes(int rtmax, int np) {
   return rtmax * 16 * (np * kRtLP * 4 + 16 + 24 + 40);
 }
 __host__ __device__ constexpr int rt_nbuf(int rtmax, int np, bool nhwc) {
-  if (MTR_RT_NBUF) return MTR_RT_NBUF;
+  if (MTR_RT_NBUF && rtmax <= 3 && np == 1) return MTR_RT_NBUF;  // (developer override: the small-launch configuration)
   if (rtmax * np > 4 || (np == 1 && rtmax > 3)) return 2;
   return 4 * rt_stage_bytes(rtmax, np, nhwc) + rt_epilogue_bytes(rtmax, np) <= 160 * 1024 ? 4 : 2;
 }
@@ -205,17 +217,23 @@ __device__ __forceinline__ void rt_flush(double (&acc)[RT][4], v4f (&run)[RT]) {
   }
 }
 
-template <int RT, int NP, int RTMAX, bool NHWC>
+// KS = 2 (head_rt_ks_kernel, 512 threads): waves 4 .. 7 are a second K group -- same tiles, same
+// positions, the ODD 32-channel stages through a ring of their own; the two groups' f64 sums meet
+// in LDS after the K loop.  Two waves per SIMD for the launches that give every CU one workgroup:
+// the matrix pipe works for one wave while the other sits at its barrier / fragment reads.
+template <int RT, int NP, int RTMAX, bool NHWC, int KS = 1>
 __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, int t0) {
   constexpr int STAGE = rt_stage_bytes(RT, NP, NHWC);
-  constexpr int kRtNbuf = rt_nbuf(RTMAX, NP, NHWC);
+  constexpr int kRtNbuf = KS == 2 ? MTR_RT_KS_NBUF : rt_nbuf(RTMAX, NP, NHWC);
+  constexpr int NG = 16 * KS;                   // 16-lane groups of the workgroup (decode: one row each)
+  constexpr int KR = (RT * 16 + NG - 1) / NG;   // decode rounds
   constexpr int CHUNK = rt_feat_chunk(NHWC);   // LDS bytes of one column block's features per stage
   constexpr int JOBS = 2 * RT + 8 * NP;  // 1 KiB copies per stage: 2 per weight tile, 8 per column block
   constexpr int JPW = (JOBS + 3) / 4;    // per wave (upper bound)
   constexpr int R = RT * 16;
   constexpr int NA = RT * NP;            // accumulators per wave
   constexpr int LP = NP * kRtLP;         // logits row pitch (floats)
-  float* Ls = reinterpret_cast<float*>(smem + kRtNbuf * rt_stage_bytes(RTMAX, NP, NHWC));
+  float* Ls = reinterpret_cast<float*>(smem + KS * kRtNbuf * rt_stage_bytes(RTMAX, NP, NHWC));
   float* rowmax = Ls + RTMAX * 16 * LP;
   float* unitmax = rowmax + RTMAX * 16;
   float* bias_s = unitmax + RTMAX * 16;
@@ -224,13 +242,15 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
   double* runstat = rowsum + RTMAX * 16 * 3;                        // [R][5], maps of > 64 positions
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wid = wave & 3, kg = KS == 2 ? wave >> 2 : 0;  // position group, K group
   const int HW = a.H * a.W;
-  const int n_stages = a.n_stages;
+  const int n_stages = KS == 2 ? a.n_stages / 2 : a.n_stages;  // of this K group (KS = 2: C % 64 == 0)
+  char* ring = smem + kg * kRtNbuf * STAGE;
   const int i16 = lane & 15, g4 = lane >> 4;
-  const unsigned lds0 = rt_lds_addr(smem);
+  const unsigned lds0 = rt_lds_addr(ring);
   const char* fcrop = reinterpret_cast<const char*>(a.feat) + (size_t)crop * a.C * HW * 4;
-  const bool c_tail = (a.C & 31) != 0;
+  const bool c_tail = KS == 1 && (a.C & 31) != 0;
   const int c0_last = (n_stages - 1) * 32;
 
   if (tid < R) {
@@ -253,9 +273,10 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
   const int n_cb = (HW + 63) >> 6;
   for (int cb0 = 0; cb0 < n_cb; cb0 += NP) {  // groups of NP column blocks: one K loop each
     // ---- this wave's copies: job j = wid + 4 i (0 .. 2RT-1: weight tiles, then 8 feature chunks).
-    // Every wave issues JPW copies per stage so that one counted s_waitcnt serves all of them;
-    // a wave whose last index falls behind the list repeats its previous copy (same bytes to the
-    // same place, served by the L1 it just filled).
+    // A wave issues JPW copies per stage, or JPW - 1 when its last index falls behind the list
+    // (wave-uniform; its counted s_waitcnt is one smaller per stage in flight).  Round 2: such a wave
+    // used to repeat its previous copy for the sake of one wait count -- 2 of 16 KiB per stage at
+    // 3 tiles, and the copies are what bounds the K loop (tools/experiments/ablate_rt.py, a27).
     const char* gbase[JPW];
     unsigned gstride[JPW], voff[JPW], ldso[JPW];
 #pragma unroll
@@ -285,12 +306,19 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
         }
       }
       gbase[i] = uniform_ptr(gbase[i]);
+      if constexpr (KS == 2) {  // K group g: stages g, g + 2, ...
+        voff[i] += (unsigned)kg * gstride[i];
+        gstride[i] *= 2;
+      }
     }
     // copy i of the next stage into ring slot `slot` (stages are issued in order: the per-lane
     // offset walks along K; the last stage of a C that is not a multiple of 32 redirects the lanes
     // whose channels do not exist to ones that do -- their products meet zero weights)
     int issued = 0;
+    // (a wave whose last index falls behind the job list has one copy less per stage: wave-uniform)
+    const bool short_wave = JOBS % 4 != 0 && wid + 4 * (JPW - 1) >= JOBS;
     auto issue_job = [&](int i, int slot) {
+      if (JOBS % 4 != 0 && i == JPW - 1 && short_wave) return;
       rt_dma16(gbase[i], voff[i], lds0 + (unsigned)slot * STAGE + ldso[i]);
       voff[i] += gstride[i];
     };
@@ -309,9 +337,18 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
         }
       }
     };
+    const int rot = MTR_RT_ROTATE ? (int)((blockIdx.x / 8) * 7u % (unsigned)n_stages) : 0;
+    if (MTR_RT_ROTATE) {
+#pragma unroll
+      for (int i = 0; i < JPW; ++i) voff[i] += (unsigned)rot * gstride[i];
+    }
     auto stage_issued = [&]() {
       ++issued;
       if (c_tail && issued == n_stages - 1) redirect_tail();
+      if (MTR_RT_ROTATE && issued == n_stages - rot) {
+#pragma unroll
+        for (int i = 0; i < JPW; ++i) voff[i] -= (unsigned)n_stages * gstride[i];
+      }
     };
 
     RtRegs<RT, NP> rg;
@@ -353,9 +390,12 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
 #define RT_ITER(S, P, BUF, MORE)                                                                  \
   {                                                                                               \
     const bool more = (MORE);                                                                     \
-    if (more) rt_wait_vmcnt<(kRtNbuf - 2) * JPW>(); else rt_wait_vmcnt<0>();                      \
+    if (!more || kRtNbuf == 2) rt_wait_vmcnt<0>();                                                \
+    else if (short_wave) rt_wait_vmcnt<(kRtNbuf - 2) * (JPW - 1)>();                              \
+    else rt_wait_vmcnt<(kRtNbuf - 2) * JPW>();                                                    \
     __syncthreads();                                                                              \
-    const char* buf = smem + (BUF) * STAGE;                                                       \
+    if (KS == 2 && MTR_RT_KS_SLEEP && kg) __builtin_amdgcn_s_sleep(MTR_RT_KS_SLEEP);              \
+    const char* buf = ring + (BUF) * STAGE;                                                       \
     v4f xa[RT], xb[NP];                                                                           \
     rt_read_frags<RT, NP, NHWC>(buf, a_off, b_off, xa, xb);                                       \
     __builtin_amdgcn_sched_barrier(0);                                                            \
@@ -373,13 +413,25 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
       __builtin_amdgcn_sched_barrier(0);                                                          \
     }                                                                                             \
   }
-    static_assert(kRtNbuf == 4 || kRtNbuf == 2, "the main loop is unrolled over a ring of 4 or 2 slots");
+    static_assert(kRtNbuf == 8 || kRtNbuf == 4 || kRtNbuf == 2, "the main loop is unrolled over a ring of 8, 4 or 2 slots");
     static_assert(JPW < 4 * NA, "the copies fit the first half stage");
     int s = 0;
     // main loop: every iteration issues a stage.  run holds the stages up to s - 2 at the top of
     // iteration s; it is emptied into f64 every kRtCarry stages (any point between two iterations
     // is a valid one).
-    if constexpr (kRtNbuf == 4) {
+    if constexpr (kRtNbuf == 8) {
+      for (; s + kRtNbuf - 1 + 7 < n_stages; s += 8) {
+        RT_ITER(s, 0, 0, true)
+        if (s >= kRtCarry && s % kRtCarry == 0) rt_flush<NA>(rg.acc, rg.run);
+        RT_ITER(s + 1, 1, 1, true)
+        RT_ITER(s + 2, 0, 2, true)
+        RT_ITER(s + 3, 1, 3, true)
+        RT_ITER(s + 4, 0, 4, true)
+        RT_ITER(s + 5, 1, 5, true)
+        RT_ITER(s + 6, 0, 6, true)
+        RT_ITER(s + 7, 1, 7, true)
+      }
+    } else if constexpr (kRtNbuf == 4) {
       for (; s + kRtNbuf - 1 + 3 < n_stages; s += 4) {
         RT_ITER(s, 0, 0, true)
         if (s >= kRtCarry && s % kRtCarry == 0) rt_flush<NA>(rg.acc, rg.run);
@@ -398,7 +450,18 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
     for (; s < n_stages; ++s) {
       if (s >= 2 && (s - 1) % kRtCarry == 0) rt_flush<NA>(rg.acc, rg.run);
       const bool more_rt = s + kRtNbuf - 1 < n_stages;
-      if constexpr (kRtNbuf == 4) {
+      if constexpr (kRtNbuf == 8) {
+        switch (s & 7) {
+          case 0: RT_ITER(s, 0, 0, more_rt) break;
+          case 1: RT_ITER(s, 1, 1, more_rt) break;
+          case 2: RT_ITER(s, 0, 2, more_rt) break;
+          case 3: RT_ITER(s, 1, 3, more_rt) break;
+          case 4: RT_ITER(s, 0, 4, more_rt) break;
+          case 5: RT_ITER(s, 1, 5, more_rt) break;
+          case 6: RT_ITER(s, 0, 6, more_rt) break;
+          default: RT_ITER(s, 1, 7, more_rt) break;
+        }
+      } else if constexpr (kRtNbuf == 4) {
         switch (s & 3) {
           case 0: RT_ITER(s, 0, 0, more_rt) break;
           case 1: RT_ITER(s, 1, 1, more_rt) break;
@@ -426,8 +489,25 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
     if ((n_stages - 1) & 1) RT_DRAIN(1) else RT_DRAIN(0)
 #undef RT_DRAIN
 
+    if constexpr (KS == 2) {  // the odd stages' sums join the even ones (the rings are free now)
+      __syncthreads();
+      double* xch = reinterpret_cast<double*>(smem);  // [position group][accumulator][reg][lane]
+      if (kg == 1) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xch[((wid * NA + q) * 4 + r) * 64 + lane] = rg.acc[q][r];
+      }
+      __syncthreads();
+      if (kg == 0) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) rg.acc[q][r] += xch[((wid * NA + q) * 4 + r) * 64 + lane];
+      }
+    }
     // ---- logits (+bias) -> LDS.  C/D layout of 16x16x4: col = l & 15, row = 4 (l >> 4) + reg
-    {
+    if (kg == 0) {
       int lane_e = lane;
       asm volatile("" : "+v"(lane_e));  // (as below: addresses computed here, not held through the K loop)
       const int col = wid * 16 + (lane_e & 15), row0 = (lane_e >> 4) * 4;
@@ -457,10 +537,11 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
     asm volatile("" : "+v"(tid_d));
     const int grp = tid_d >> 4, l16 = tid_d & 15;
     const int pbase = cb * 64 + l16 * 4;  // this lane's 4 positions
-    v4f x[RT];
+    v4f x[KR];
 #pragma unroll
-    for (int k = 0; k < RT; ++k) {
-      const int row = k * 16 + grp;
+    for (int k = 0; k < KR; ++k) {
+      const int row = k * NG + grp;
+      if (KR * NG > R && row >= R) continue;
       x[k] = *reinterpret_cast<const v4f*>(Lb + row * LP + l16 * 4);
       float m = -INFINITY;
 #pragma unroll
@@ -471,8 +552,9 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < RT; ++k) {
-      const int row = k * 16 + grp;
+    for (int k = 0; k < KR; ++k) {
+      const int row = k * NG + grp;
+      if (KR * NG > R && row >= R) continue;
       const unsigned inf = (unsigned)info_s[row];
       const int kind = inf & 3, d = (inf >> 2) & 0x3fff;
       const int first = kind == 2 ? row - d : row, n = kind == 2 ? a.D : 1;
@@ -509,8 +591,9 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
       // ...: 5 rows per lane instead of a 72-step chain in one thread; measured 170 -> 161 us at
       // B = 64, D = 72.  Short units keep the one-thread loop below: 8 rows, and 1 - 4 % faster)
   #pragma unroll
-      for (int k = 0; k < RT; ++k) {
-        const int row = k * 16 + grp;
+      for (int k = 0; k < KR; ++k) {
+        const int row = k * NG + grp;
+        if (KR * NG > R && row >= R) continue;
         const unsigned inf = (unsigned)info_s[row];
         const int kind = inf & 3, d = (inf >> 2) & 0x3fff, j = (int)(inf >> 16);
         if (!(kind == 1 || (kind == 2 && d == 0))) continue;  // (uniform in the group)
@@ -644,6 +727,29 @@ __global__ __launch_bounds__(256, RTMAX <= 3 ? 1 : 2) void head_rt_kernel(RtArgs
   }
 }
 
+// Two K groups per workgroup (see rt_block): blocks of <= 3 tiles, C a multiple of 64.
+template <int RTMAX, bool NHWC>
+__global__ __launch_bounds__(512, 1) void head_rt_ks_kernel(RtArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int chunk = 8 * a.n_blocks;
+  const int id = blockIdx.x;
+  const int crop = (id / chunk) * 8 + (id % 8);
+  const int blk = (id % chunk) / 8;
+  if (crop >= a.B) return;
+  const int t0 = blk * a.rtg;
+  const int rt = min(a.rtg, a.n_tiles - t0);
+  if (rt == 1) rt_block<1, 1, RTMAX, NHWC, 2>(a, smem, crop, t0);
+  if (rt == 2) rt_block<2, 1, RTMAX, NHWC, 2>(a, smem, crop, t0);
+  if (rt == 3) rt_block<3, 1, RTMAX, NHWC, 2>(a, smem, crop, t0);
+  if constexpr (RTMAX >= 5) {
+    if (rt == 4) rt_block<4, 1, RTMAX, NHWC, 2>(a, smem, crop, t0);
+    if (rt == 5) rt_block<5, 1, RTMAX, NHWC, 2>(a, smem, crop, t0);
+  }
+}
+__host__ __device__ constexpr int rt_ks_lds_bytes(int rtmax, bool nhwc) {
+  return 2 * MTR_RT_KS_NBUF * rt_stage_bytes(rtmax, 1, nhwc) + rt_epilogue_bytes(rtmax, 1);
+}
+
 // Tiles of several column blocks (maps of more than 64 positions): RT row tiles x NP column blocks
 // per workgroup, RT * NP <= 4.  Same grid mapping; a ragged last block (RT = 2, odd tile count)
 // runs the one-tile body.
@@ -664,7 +770,7 @@ __global__ __launch_bounds__(256, 1) void head_rt_np_kernel(RtArgs a) {
 }
 
 template <typename Kern>
-static int rt_launch_kernel(Kern kern, int lds, const RtArgs& a, hipStream_t stream) {
+static int rt_launch_kernel(Kern kern, int lds, const RtArgs& a, hipStream_t stream, int threads = 256) {
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
@@ -672,7 +778,7 @@ static int rt_launch_kernel(Kern kern, int lds, const RtArgs& a, hipStream_t str
   const long long blocks = (long long)((a.B + 7) / 8) * 8 * a.n_blocks;
   if (blocks > 0x7fffffffLL) return MTR_E_SHAPE;
   MTR_CLEAR_STALE();
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads), lds, stream, a);
   MTR_CHECK_LAUNCH();
   return MTR_OK;
 }
@@ -702,7 +808,7 @@ int rt_pack(const float* weight, const float* bias, int C, int J, int D, void* s
 
 int rt_launch(const float* feat, int layout, const void* section, int B, int C, int H, int W, int J,
               int D, const HeadScale& hs, float* coords2d, float* coords3d_rel, int rtg_hint, int np_hint,
-              hipStream_t stream) {
+              int ks_hint, hipStream_t stream) {
   const RtGeom g = rt_geom(J, D);
   RtArgs a;
   a.feat = feat;
@@ -765,6 +871,19 @@ int rt_launch(const float* feat, int layout, const void* section, int B, int C, 
   }
   a.rtg = rt_block_tiles(g, rtg_hint);
   a.n_blocks = (g.n_tiles + a.rtg - 1) / a.rtg;
+  // two K groups per workgroup (512 threads), ks_hint == 2 only.  Measured (ablate_rt.py): B = 64
+  // 26.7 -> 24.5 us, B = 32 12x12 53.5 -> 51.1 (launches that give a CU one workgroup = one wave per
+  // SIMD otherwise), but B = 1024 249 -> 274, D = 72 156 -> 169.  It is NOT chosen from the launch size:
+  // the even / odd split changes the f32 summation order under the f64 carry, i.e. the last bits of
+  // the logits, and the default path keeps a crop's result independent of the batch it arrives in
+  // (sharded == monolithic bit for bit, tests/test_gpu_sharded_estimator.py).
+  if (C % 64 == 0 && (ks_hint == 2 || MTR_RT_KS_ALWAYS)) {
+    if (a.rtg <= 3)
+      return nhwc ? rt_launch_kernel(head_rt_ks_kernel<3, true>, rt_ks_lds_bytes(3, true), a, stream, 512)
+                  : rt_launch_kernel(head_rt_ks_kernel<3, false>, rt_ks_lds_bytes(3, false), a, stream, 512);
+    return nhwc ? rt_launch_kernel(head_rt_ks_kernel<5, true>, rt_ks_lds_bytes(5, true), a, stream, 512)
+                : rt_launch_kernel(head_rt_ks_kernel<5, false>, rt_ks_lds_bytes(5, false), a, stream, 512);
+  }
   if (a.rtg <= 3)
     return nhwc ? rt_launch_t<3, true>(a, stream) : rt_launch_t<3, false>(a, stream);
   return nhwc ? rt_launch_t<5, true>(a, stream) : rt_launch_t<5, false>(a, stream);

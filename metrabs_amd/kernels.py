@@ -281,10 +281,11 @@ def head_pack_weights(weight2d, bias, n_points, depth, feat_dtype=torch.float32)
 
 
 def head_fused(features, packed, C, n_points, cfg, out=None, rt_tiles=0, groups_per_workgroup=0,
-               dma_staging=-1, rt_column_blocks=0):
+               dma_staging=-1, rt_column_blocks=0, rt_k_groups=0):
     """features [B,C,H,W] (f32/f16/bf16; NCHW-contiguous or torch channels_last = NHWC memory, which
     is consumed in place) -> (coords2d, coords3d_rel).  rt_tiles / groups_per_workgroup /
-    dma_staging: explicit dispatch choices (mtr_head_options; defaults = the library's own)."""
+    dma_staging / rt_column_blocks / rt_k_groups: explicit dispatch choices (mtr_head_options;
+    defaults = the library's own)."""
     require_cuda(features, packed)
     lib = _lib.load()
     nhwc = _is_channels_last(features)
@@ -301,9 +302,9 @@ def head_fused(features, packed, C, n_points, cfg, out=None, rt_tiles=0, groups_
         c2d, c3d = out
     hp = cfg.head_params()
     layout = _lib.MTR_NHWC if nhwc else _lib.MTR_NCHW
-    if rt_tiles or groups_per_workgroup or dma_staging != -1 or rt_column_blocks:
+    if rt_tiles or groups_per_workgroup or dma_staging != -1 or rt_column_blocks or rt_k_groups:
         opts = _lib.HeadOptions(int(rt_tiles), int(groups_per_workgroup), int(dma_staging),
-                                int(rt_column_blocks))
+                                int(rt_column_blocks), int(rt_k_groups))
         check(lib.mtr_head_fused_opts(
             _ptr(features), dtype_code(features.dtype), layout, B, C, H, W, _ptr(packed), J, D,
             ctypes.byref(hp), ctypes.byref(opts), _ptr(c2d), _ptr(c3d),

@@ -16,7 +16,12 @@ OUT = os.path.join(ROOT, 'tools', 'experiments', '_build')
 VARIANTS = {'full': [], 'exp32': ['-DMTR_RT_EXP32=1'], 'nodecode': ['-DMTR_RT_ABLATE=1'], 'nomfma': ['-DMTR_RT_ABLATE=2'],
             'nodma': ['-DMTR_RT_ABLATE=4'], 'nocarry': ['-DMTR_RT_ABLATE=8'],
             'nodma_nocarry': ['-DMTR_RT_ABLATE=12'], 'nofrag': ['-DMTR_RT_ABLATE=16'],
-            'mfma_only': ['-DMTR_RT_ABLATE=29'], 'nbuf2': ['-DMTR_RT_NBUF=2'], 'nbuf4': ['-DMTR_RT_NBUF=4']}
+            'mfma_only': ['-DMTR_RT_ABLATE=29'], 'nbuf2': ['-DMTR_RT_NBUF=2'], 'nbuf4': ['-DMTR_RT_NBUF=4'], 'nbuf8': ['-DMTR_RT_NBUF=8'], 'ks4': ['-DMTR_RT_KS_NBUF=4'], 'ks8': ['-DMTR_RT_KS_NBUF=8'],
+            'sleep2': ['-DMTR_RT_KS_SLEEP=2'], 'sleep5': ['-DMTR_RT_KS_SLEEP=5'],
+            'a18': ['-DMTR_RT_ABLATE=18'], 'a26': ['-DMTR_RT_ABLATE=26'], 'a27': ['-DMTR_RT_ABLATE=27'],
+            'rot': ['-DMTR_RT_ROTATE=1'], 'rot_a27': ['-DMTR_RT_ROTATE=1', '-DMTR_RT_ABLATE=27'],
+            'ksall': ['-DMTR_RT_KS_ALWAYS=1'],
+            'ks_nodecode': ['-DMTR_RT_ABLATE=1'], 'ks_nomfma': ['-DMTR_RT_ABLATE=2']}
 if os.environ.get('RT_VARIANTS'):
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ['RT_VARIANTS'].split(',')}
 
