@@ -120,14 +120,11 @@ typedef struct mtr_head_options {
   int32_t rt_column_blocks;        /* f32, maps of > 64 positions: 64-position column blocks per workgroup
                                       tile, 2..4 (one K loop for all of them); 1 = one K loop per column
                                       block; 0 = by launch size                                         */
-  int32_t rt_k_groups;             /* f32, one-tile atoms, C % 64 == 0: 2 = two K groups per workgroup (512
-                                      threads: even / odd 32-channel stages through two LDS rings, the
-                                      f64 sums joined in LDS); 0 / 1 = one (the default at every launch
-                                      size).  Opt-in because it changes the f32 summation order under
-                                      the f64 carry, i.e. the last bits of the logits: the default
-                                      keeps a crop's result independent of the batch it arrives in.
-                                      Faster on launches of <= 1 workgroup per CU (B=64: -8 %),
-                                      slower on large ones (B=1024: +10 %)                             */
+  int32_t rt_k_groups;             /* f32, blocks of <= 3 one-tile atoms, C % 64 == 0: 2 = two K groups per
+                                      workgroup (512 threads: the odd 32-channel stages run on waves
+                                      4..7 and their chains are handed to waves 0..3, which sum in the
+                                      one-group order: same bits), 1 = one; 0 = two for blocks of 2-3
+                                      tiles (the small-launch configuration)                          */
 } mtr_head_options;
 
 /* host-only, no GPU work: the row order of the f32 row-tile kernel.  conv_final's J*(1+D) channels

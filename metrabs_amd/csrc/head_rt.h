@@ -103,8 +103,8 @@ int rt_pack(const float* weight, const float* bias, int C, int J, int D, void* s
 // features f32 [B,C,H,W] / [B,H,W,C]; H*W % 4 == 0, NHWC: C % 4 == 0 (checked by the caller).
 // rtg_hint: tiles per workgroup for one-tile atoms (0 = pick from the launch size); np_hint: column
 // blocks of 64 positions per workgroup tile for maps of more than 64 positions (0 = pick, 1 = one
-// K loop per column block, 2..4); ks_hint: 2 = two K groups per workgroup where the
-// kernel can (C % 64 == 0), 0 / 1 = one.
+// K loop per column block, 2..4); ks_hint: K groups per workgroup, 0 = pick, 1 = one,
+// 2 = two wherever the kernel can (C % 64 == 0, blocks of <= 3 tiles).
 int rt_launch(const float* feat, int layout, const void* section, int B, int C, int H, int W, int J,
               int D, const HeadScale& hs, float* coords2d, float* coords3d_rel, int rtg_hint, int np_hint,
               int ks_hint, hipStream_t stream);

@@ -50,6 +50,10 @@ using v4f = __attribute__((ext_vector_type(4))) float;
 #ifndef MTR_RT_ROTATE
 #define MTR_RT_ROTATE 0     // developer probe: every workgroup starts its K loop at another stage
 #endif
+#ifndef MTR_RT_KS_PROBE
+#define MTR_RT_KS_PROBE 0   // developer timing probe (wrong results): 1 = even group skips the odd chains' adds,
+                            // 2 = no hand-over traffic at all, 4 = no f64 carries in the loop
+#endif
 #ifndef MTR_RT_KS_SLEEP
 #define MTR_RT_KS_SLEEP 0   // developer probe: s_sleep of the second K group behind every barrier
 #endif
@@ -218,9 +222,13 @@ __device__ __forceinline__ void rt_flush(double (&acc)[RT][4], v4f (&run)[RT]) {
 }
 
 // KS = 2 (head_rt_ks_kernel, 512 threads): waves 4 .. 7 are a second K group -- same tiles, same
-// positions, the ODD 32-channel stages through a ring of their own; the two groups' f64 sums meet
-// in LDS after the K loop.  Two waves per SIMD for the launches that give every CU one workgroup:
-// the matrix pipe works for one wave while the other sits at its barrier / fragment reads.
+// positions, the ODD 32-channel stages through a ring of their own.  Two waves per SIMD for the
+// launches that give every CU one workgroup: the matrix pipe works for one wave while the other
+// sits at its barrier / fragment reads.  The sums stay those of the one-group kernel BIT FOR BIT:
+// the odd group only runs the MFMA chains and hands every finished 32-channel chain to the even
+// group through LDS (hb: two buffers by iteration parity, a third for the drain); the even group adds the chains to
+// its f32 running sums in stage order c0, c1, c2, ... and carries them into f64 at the same
+// stage boundaries (after c7, c15, ...) as rt_block<KS = 1> does.
 template <int RT, int NP, int RTMAX, bool NHWC, int KS = 1>
 __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, int t0) {
   constexpr int STAGE = rt_stage_bytes(RT, NP, NHWC);
@@ -240,6 +248,9 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
   int* info_s = reinterpret_cast<int*>(bias_s + RTMAX * 16);
   double* rowsum = reinterpret_cast<double*>(info_s + RTMAX * 16);  // [R][3]
   double* runstat = rowsum + RTMAX * 16 * 3;                        // [R][5], maps of > 64 positions
+  // KS = 2: finished chains of the odd group, [iteration parity][position group][accumulator][lane]
+  v4f* hb = reinterpret_cast<v4f*>(smem + KS * kRtNbuf * rt_stage_bytes(RTMAX, NP, NHWC) +
+                                   rt_epilogue_bytes(RTMAX, NP));
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -363,6 +374,13 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
 #pragma unroll
     for (int p = 0; p < NP; ++p) rg.yb[p] = v4f{0.f, 0.f, 0.f, 0.f};
 
+    if constexpr (KS == 2) {  // the even group reads hb from its first iteration on: no chain yet = zeros
+      if (kg == 1) {
+#pragma unroll
+        for (int q = 0; q < 2 * NA; ++q)
+          hb[(q / NA * 4 + wid) * NA * 64 + (q % NA) * 64 + lane] = v4f{0.f, 0.f, 0.f, 0.f};
+      }
+    }
     // prologue: stages 0 .. NBUF-2 in flight
     if (c_tail && n_stages == 1) redirect_tail();
 #pragma unroll
@@ -387,7 +405,11 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
     // so the loop is unrolled over the ring (no index arithmetic), MORE is a literal in the main
     // loop (no branches around the copies), and an MFMA is followed by at most one copy or one
     // packed add, pinned by a scheduling fence.
-#define RT_ITER(S, P, BUF, MORE)                                                                  \
+    // ROLE (literal): 0 = the only K group; 1 = even group of two: before its own chain of stage
+    // 2S-2 (second block) it adds the odd group's chain of stage 2S-3 (first block; hb was zeroed
+    // for the iterations that have none), and carries into f64 between the two when 2S-3 = 7 (mod 8);
+    // 2 = odd group: no sums, every finished chain goes to hb[S & 1]
+#define RT_BODY(S, P, BUF, MORE, ROLE)                                                            \
   {                                                                                               \
     const bool more = (MORE);                                                                     \
     if (!more || kRtNbuf == 2) rt_wait_vmcnt<0>();                                                \
@@ -398,20 +420,37 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
     const char* buf = ring + (BUF) * STAGE;                                                       \
     v4f xa[RT], xb[NP];                                                                           \
     rt_read_frags<RT, NP, NHWC>(buf, a_off, b_off, xa, xb);                                       \
+    v4f lr[NA];                                                                                   \
+    if (ROLE == 1 && !(MTR_RT_KS_PROBE & 2)) {                                                    \
+      _Pragma("unroll") for (int q = 0; q < NA; ++q)                                              \
+        lr[q] = hb[((((S) + 1) & 1) * 4 + wid) * NA * 64 + q * 64 + lane];                        \
+    }                                                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                            \
     _Pragma("unroll") for (int n = 0; n < 4 * NA; ++n) {                                          \
       rt_mfma_slot<RT, NP>(rg.part[(P) ^ 1], rg.ya, rg.yb, n, false);                             \
       if (n < JPW && more && !(MTR_RT_ABLATE & 4)) issue_job(n, ((BUF) + kRtNbuf - 1) % kRtNbuf); \
       if (n == JPW && more) stage_issued();                                                       \
+      if (ROLE == 1 && n >= 2 * NA && !(MTR_RT_KS_PROBE & 3)) rt_run_add<NA>(rg.run, lr, n - 2 * NA); \
       __builtin_amdgcn_sched_barrier(0);                                                          \
     }                                                                                             \
+    if (ROLE == 1 && (S) >= 5 && ((S) - 1) % 4 == 0 && !(MTR_RT_KS_PROBE & 4)) rt_flush<NA>(rg.acc, rg.run); \
     rt_read_frags<RT, NP, NHWC>(buf, a_off ^ 64, b_q1, rg.ya, rg.yb);                             \
     __builtin_amdgcn_sched_barrier(0);                                                            \
     _Pragma("unroll") for (int n = 0; n < 4 * NA; ++n) {                                          \
       rt_mfma_slot<RT, NP>(rg.part[P], xa, xb, n, true);                                          \
-      if (n % 2 == 1) rt_run_add<NA>(rg.run, rg.part[(P) ^ 1], n / 2);                            \
+      if (ROLE != 2) {                                                                            \
+        if (n % 2 == 1) rt_run_add<NA>(rg.run, rg.part[(P) ^ 1], n / 2);                          \
+      } else if (n % 2 == 1 && n / 2 < NA && !(MTR_RT_KS_PROBE & 2)) {                            \
+        hb[(((S) & 1) * 4 + wid) * NA * 64 + (n / 2) * 64 + lane] = rg.part[(P) ^ 1][n / 2];      \
+      }                                                                                           \
       __builtin_amdgcn_sched_barrier(0);                                                          \
     }                                                                                             \
+  }
+#define RT_ITER(S, P, BUF, MORE)                                                                  \
+  {                                                                                               \
+    if constexpr (KS == 1) RT_BODY(S, P, BUF, MORE, 0)                                            \
+    else if (kg == 0) RT_BODY(S, P, BUF, MORE, 1)                                                 \
+    else RT_BODY(S, P, BUF, MORE, 2)                                                              \
   }
     static_assert(kRtNbuf == 8 || kRtNbuf == 4 || kRtNbuf == 2, "the main loop is unrolled over a ring of 8, 4 or 2 slots");
     static_assert(JPW < 4 * NA, "the copies fit the first half stage");
@@ -422,7 +461,7 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
     if constexpr (kRtNbuf == 8) {
       for (; s + kRtNbuf - 1 + 7 < n_stages; s += 8) {
         RT_ITER(s, 0, 0, true)
-        if (s >= kRtCarry && s % kRtCarry == 0) rt_flush<NA>(rg.acc, rg.run);
+        if (KS == 1 && s >= kRtCarry && s % kRtCarry == 0) rt_flush<NA>(rg.acc, rg.run);
         RT_ITER(s + 1, 1, 1, true)
         RT_ITER(s + 2, 0, 2, true)
         RT_ITER(s + 3, 1, 3, true)
@@ -434,7 +473,7 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
     } else if constexpr (kRtNbuf == 4) {
       for (; s + kRtNbuf - 1 + 3 < n_stages; s += 4) {
         RT_ITER(s, 0, 0, true)
-        if (s >= kRtCarry && s % kRtCarry == 0) rt_flush<NA>(rg.acc, rg.run);
+        if (KS == 1 && s >= kRtCarry && s % kRtCarry == 0) rt_flush<NA>(rg.acc, rg.run);
         RT_ITER(s + 1, 1, 1, true)
         RT_ITER(s + 2, 0, 2, true)
         RT_ITER(s + 3, 1, 3, true)
@@ -442,13 +481,13 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
     } else {
       for (; s + kRtNbuf - 1 + 1 < n_stages; s += 2) {
         RT_ITER(s, 0, 0, true)
-        if (s >= kRtCarry && s % kRtCarry == 0) rt_flush<NA>(rg.acc, rg.run);
+        if (KS == 1 && s >= kRtCarry && s % kRtCarry == 0) rt_flush<NA>(rg.acc, rg.run);
         RT_ITER(s + 1, 1, 1, true)
       }
     }
     // remainder (the last issuing iterations + the NBUF - 1 that only consume)
     for (; s < n_stages; ++s) {
-      if (s >= 2 && (s - 1) % kRtCarry == 0) rt_flush<NA>(rg.acc, rg.run);
+      if (KS == 1 && s >= 2 && (s - 1) % kRtCarry == 0) rt_flush<NA>(rg.acc, rg.run);
       const bool more_rt = s + kRtNbuf - 1 < n_stages;
       if constexpr (kRtNbuf == 8) {
         switch (s & 7) {
@@ -473,6 +512,7 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
       }
     }
 #undef RT_ITER
+#undef RT_BODY
     // drain: second half of the last stage's chain (parity PL), then the sums
 #define RT_DRAIN(PL)                                                                              \
   {                                                                                               \
@@ -480,32 +520,41 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
       rt_mfma_slot<RT, NP>(rg.part[PL], rg.ya, rg.yb, n, false);                                  \
       __builtin_amdgcn_sched_barrier(0);                                                          \
     }                                                                                             \
-    _Pragma("unroll") for (int e2 = 0; e2 < 2 * NA; ++e2) rt_run_add<NA>(rg.run, rg.part[PL], e2); \
-    if (MTR_RT_ABLATE & 8) {                                                                      \
-      _Pragma("unroll") for (int t = 0; t < NA; ++t) rg.run[t] = rg.part[0][t] + rg.part[1][t];   \
+    if constexpr (KS == 1) {                                                                      \
+      _Pragma("unroll") for (int e2 = 0; e2 < 2 * NA; ++e2) rt_run_add<NA>(rg.run, rg.part[PL], e2); \
+      if (MTR_RT_ABLATE & 8) {                                                                    \
+        _Pragma("unroll") for (int t = 0; t < NA; ++t) rg.run[t] = rg.part[0][t] + rg.part[1][t]; \
+      }                                                                                           \
+      rt_flush<NA>(rg.acc, rg.run);                                                               \
+    } else {                                                                                      \
+      /* "iteration n_stages" of the hand-over: the odd group's last chain (stage 2 n_stages - 1  */ \
+      /* of the K loop) goes to hb; the even group then adds, in stage order, the odd chain of    */ \
+      /* stage 2 n_stages - 3, its own last chain and the odd group's last one                    */ \
+      if (kg == 1) {                                                                              \
+        _Pragma("unroll") for (int q = 0; q < NA; ++q)                                            \
+          hb[(2 * 4 + wid) * NA * 64 + q * 64 + lane] = rg.part[PL][q];  /* a buffer of its own */ \
+      }                                                                                           \
+      __syncthreads();                                                                            \
+      if (kg == 0) {                                                                              \
+        if (n_stages >= 2) {                                                                      \
+          v4f la[NA];                                                                             \
+          _Pragma("unroll") for (int q = 0; q < NA; ++q)                                          \
+            la[q] = hb[(((n_stages - 1) & 1) * 4 + wid) * NA * 64 + q * 64 + lane];               \
+          _Pragma("unroll") for (int e2 = 0; e2 < 2 * NA; ++e2) rt_run_add<NA>(rg.run, la, e2);   \
+          if (n_stages >= 5 && (n_stages - 1) % 4 == 0) rt_flush<NA>(rg.acc, rg.run);             \
+        }                                                                                         \
+        _Pragma("unroll") for (int e2 = 0; e2 < 2 * NA; ++e2) rt_run_add<NA>(rg.run, rg.part[PL], e2); \
+        v4f lb[NA];                                                                               \
+        _Pragma("unroll") for (int q = 0; q < NA; ++q)                                            \
+          lb[q] = hb[(2 * 4 + wid) * NA * 64 + q * 64 + lane];                                    \
+        _Pragma("unroll") for (int e2 = 0; e2 < 2 * NA; ++e2) rt_run_add<NA>(rg.run, lb, e2);     \
+        rt_flush<NA>(rg.acc, rg.run);                                                             \
+      }                                                                                           \
     }                                                                                             \
-    rt_flush<NA>(rg.acc, rg.run);                                                                 \
   }
     if ((n_stages - 1) & 1) RT_DRAIN(1) else RT_DRAIN(0)
 #undef RT_DRAIN
 
-    if constexpr (KS == 2) {  // the odd stages' sums join the even ones (the rings are free now)
-      __syncthreads();
-      double* xch = reinterpret_cast<double*>(smem);  // [position group][accumulator][reg][lane]
-      if (kg == 1) {
-#pragma unroll
-        for (int q = 0; q < NA; ++q)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) xch[((wid * NA + q) * 4 + r) * 64 + lane] = rg.acc[q][r];
-      }
-      __syncthreads();
-      if (kg == 0) {
-#pragma unroll
-        for (int q = 0; q < NA; ++q)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) rg.acc[q][r] += xch[((wid * NA + q) * 4 + r) * 64 + lane];
-      }
-    }
     // ---- logits (+bias) -> LDS.  C/D layout of 16x16x4: col = l & 15, row = 4 (l >> 4) + reg
     if (kg == 0) {
       int lane_e = lane;
@@ -741,13 +790,10 @@ __global__ __launch_bounds__(512, 1) void head_rt_ks_kernel(RtArgs a) {
   if (rt == 1) rt_block<1, 1, RTMAX, NHWC, 2>(a, smem, crop, t0);
   if (rt == 2) rt_block<2, 1, RTMAX, NHWC, 2>(a, smem, crop, t0);
   if (rt == 3) rt_block<3, 1, RTMAX, NHWC, 2>(a, smem, crop, t0);
-  if constexpr (RTMAX >= 5) {
-    if (rt == 4) rt_block<4, 1, RTMAX, NHWC, 2>(a, smem, crop, t0);
-    if (rt == 5) rt_block<5, 1, RTMAX, NHWC, 2>(a, smem, crop, t0);
-  }
 }
 __host__ __device__ constexpr int rt_ks_lds_bytes(int rtmax, bool nhwc) {
-  return 2 * MTR_RT_KS_NBUF * rt_stage_bytes(rtmax, 1, nhwc) + rt_epilogue_bytes(rtmax, 1);
+  return 2 * MTR_RT_KS_NBUF * rt_stage_bytes(rtmax, 1, nhwc) + rt_epilogue_bytes(rtmax, 1) +
+         3 * 4 * rtmax * 1024;  // + the chain hand-over buffers (two by iteration parity + the drain's)
 }
 
 // Tiles of several column blocks (maps of more than 64 positions): RT row tiles x NP column blocks
@@ -857,7 +903,9 @@ int rt_launch(const float* feat, int layout, const void* section, int B, int C, 
       // small launches (one round of at most 2 workgroups per CU): 3 tiles per workgroup, fewer
       // when that would leave CUs without one (few crops, large maps)
       rtg_hint = 3;
-      while (rtg_hint > 1 && crops8 * ((g.n_tiles + rtg_hint - 1) / rtg_hint) < 256) --rtg_hint;
+      // (with two K groups available, 2-tile blocks on fewer CUs beat one-tile blocks on all of them)
+      const int floor_rtg = (C % 64 == 0 && ks_hint != 1) ? 2 : 1;
+      while (rtg_hint > floor_rtg && crops8 * ((g.n_tiles + rtg_hint - 1) / rtg_hint) < 256) --rtg_hint;
     } else {
       // several rounds of workgroups: equal blocks first (a crop's 10 tiles as 5 + 5 measured 270 us
       // at B = 1024 against 315 us as 3 + 3 + 3 + 1), then the larger block (fewer barriers, LDS
@@ -871,19 +919,15 @@ int rt_launch(const float* feat, int layout, const void* section, int B, int C, 
   }
   a.rtg = rt_block_tiles(g, rtg_hint);
   a.n_blocks = (g.n_tiles + a.rtg - 1) / a.rtg;
-  // two K groups per workgroup (512 threads), ks_hint == 2 only.  Measured (ablate_rt.py): B = 64
-  // 26.7 -> 24.5 us, B = 32 12x12 53.5 -> 51.1 (launches that give a CU one workgroup = one wave per
-  // SIMD otherwise), but B = 1024 249 -> 274, D = 72 156 -> 169.  It is NOT chosen from the launch size:
-  // the even / odd split changes the f32 summation order under the f64 carry, i.e. the last bits of
-  // the logits, and the default path keeps a crop's result independent of the batch it arrives in
-  // (sharded == monolithic bit for bit, tests/test_gpu_sharded_estimator.py).
-  if (C % 64 == 0 && (ks_hint == 2 || MTR_RT_KS_ALWAYS)) {
-    if (a.rtg <= 3)
-      return nhwc ? rt_launch_kernel(head_rt_ks_kernel<3, true>, rt_ks_lds_bytes(3, true), a, stream, 512)
-                  : rt_launch_kernel(head_rt_ks_kernel<3, false>, rt_ks_lds_bytes(3, false), a, stream, 512);
-    return nhwc ? rt_launch_kernel(head_rt_ks_kernel<5, true>, rt_ks_lds_bytes(5, true), a, stream, 512)
-                : rt_launch_kernel(head_rt_ks_kernel<5, false>, rt_ks_lds_bytes(5, false), a, stream, 512);
-  }
+  // two K groups per workgroup (512 threads; same bits as one group, see rt_block): blocks of 2 - 3
+  // tiles, i.e. the small-launch configuration, where a CU would otherwise run one wave per SIMD.
+  // Measured (tools/experiments/head_small_launch.py, ablate_rt.py): B = 64 26.8 -> 22.6 us, B = 64
+  // 16x16 98 -> 83, B = 32 12x12 (2-tile blocks) 50 -> 44; one-tile blocks lose (29 -> 32 at B = 64),
+  // 5-tile blocks lose (B = 1024 249 -> 274 in the sum-exchange prototype).  ks_hint: 0 = this rule,
+  // 1 = never, 2 = whenever the kernel can (C % 64 == 0, blocks of <= 3 tiles)
+  if (C % 64 == 0 && a.rtg <= 3 && ks_hint != 1 && (ks_hint == 2 || MTR_RT_KS_ALWAYS || a.rtg >= 2))
+    return nhwc ? rt_launch_kernel(head_rt_ks_kernel<3, true>, rt_ks_lds_bytes(3, true), a, stream, 512)
+                : rt_launch_kernel(head_rt_ks_kernel<3, false>, rt_ks_lds_bytes(3, false), a, stream, 512);
   if (a.rtg <= 3)
     return nhwc ? rt_launch_t<3, true>(a, stream) : rt_launch_t<3, false>(a, stream);
   return nhwc ? rt_launch_t<5, true>(a, stream) : rt_launch_t<5, false>(a, stream);
