@@ -50,6 +50,9 @@ using v4f = __attribute__((ext_vector_type(4))) float;
 #ifndef MTR_RT_ROTATE
 #define MTR_RT_ROTATE 0     // developer probe: every workgroup starts its K loop at another stage
 #endif
+#ifndef MTR_RT_NT
+#define MTR_RT_NT 0          // developer probe: non-temporal copies, 1 = features, 2 = weights, 3 = both
+#endif
 #ifndef MTR_RT_KS_PROBE
 #define MTR_RT_KS_PROBE 0   // developer timing probe (wrong results): 1 = even group skips the odd chains' adds,
                             // 2 = no hand-over traffic at all, 4 = no f64 carries in the loop
@@ -130,6 +133,13 @@ __device__ __forceinline__ unsigned rt_lds_addr(const void* p) {
 // lds_addr + 16 L.  sbase / lds_addr are wave-uniform (SGPRs), voff per lane.
 __device__ __forceinline__ void rt_dma16(const void* sbase, unsigned voff, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+               :
+               : "s"(lds_addr), "v"(voff), "s"(sbase)
+               : "memory");
+}
+
+__device__ __forceinline__ void rt_dma16_nt(const void* sbase, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt"
                :
                : "s"(lds_addr), "v"(voff), "s"(sbase)
                : "memory");
@@ -330,7 +340,10 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
     const bool short_wave = JOBS % 4 != 0 && wid + 4 * (JPW - 1) >= JOBS;
     auto issue_job = [&](int i, int slot) {
       if (JOBS % 4 != 0 && i == JPW - 1 && short_wave) return;
-      rt_dma16(gbase[i], voff[i], lds0 + (unsigned)slot * STAGE + ldso[i]);
+      if (MTR_RT_NT && ((wid + 4 * i < 2 * RT) ? (MTR_RT_NT & 2) : (MTR_RT_NT & 1)))
+        rt_dma16_nt(gbase[i], voff[i], lds0 + (unsigned)slot * STAGE + ldso[i]);
+      else
+        rt_dma16(gbase[i], voff[i], lds0 + (unsigned)slot * STAGE + ldso[i]);
       voff[i] += gstride[i];
     };
     auto redirect_tail = [&]() {  // (rare path: recomputed here rather than held in registers)

@@ -22,6 +22,7 @@ VARIANTS = {'full': [], 'exp32': ['-DMTR_RT_EXP32=1'], 'nodecode': ['-DMTR_RT_AB
             'rot': ['-DMTR_RT_ROTATE=1'], 'rot_a27': ['-DMTR_RT_ROTATE=1', '-DMTR_RT_ABLATE=27'],
             'ksall': ['-DMTR_RT_KS_ALWAYS=1'],
             'kp1': ['-DMTR_RT_KS_PROBE=1'], 'kp2': ['-DMTR_RT_KS_PROBE=2'], 'kp4': ['-DMTR_RT_KS_PROBE=4'], 'kp7': ['-DMTR_RT_KS_PROBE=7'], 'ks1': ['-DMTR_RT_KS_OFF=1'],
+            'nt1': ['-DMTR_RT_NT=1'], 'nt2': ['-DMTR_RT_NT=2'], 'nt3': ['-DMTR_RT_NT=3'],
             'ks_nodecode': ['-DMTR_RT_ABLATE=1'], 'ks_nomfma': ['-DMTR_RT_ABLATE=2']}
 if os.environ.get('RT_VARIANTS'):
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ['RT_VARIANTS'].split(',')}
