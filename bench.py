@@ -225,8 +225,18 @@ def backbone_variant(args, dev, im_h, im_w, n_box, fold_bn, fused_epilogue, note
 
 def head_kernel_name(hw, n_crops, J, D, precision='f32', C=1280):
     """Which kernel mtr_head_fused dispatches to (metrabs_amd/csrc/head_fused.hip:mtr_head_fused)."""
-    if precision == 'f32':
-        return 'head_rt_kernel'  # row-tile core: any map size, D <= 80
+    if precision == 'f32':  # row-tile core: any map size, D <= 80 (the rules of head_rt.hip:rt_launch)
+        n_tiles, atom = -(-(J * (1 + D)) // 16), 1 if 1 + D <= 16 else -(-(8 + D) // 16)
+        crops8 = -(-n_crops // 8) * 8
+        if atom == 1 and hw > 64 and crops8 * n_tiles <= 256:
+            return 'head_rt_np_kernel'          # one K loop for several column blocks
+        if atom == 1 and crops8 * -(-n_tiles // 3) <= 512:
+            rtg, floor = 3, 2 if C % 64 == 0 else 1
+            while rtg > floor and crops8 * -(-n_tiles // rtg) < 256:
+                rtg -= 1
+            if C % 64 == 0 and rtg >= 2:
+                return 'head_rt_ks_kernel'      # two K groups per workgroup (small launches)
+        return 'head_rt_kernel'
     if C % 8 == 0:
         # f16 / bf16 MFMA, a staging loop bounded by the feature bytes; DMA-staged when whole
         # 16-byte chunks per channel row exist (NCHW: H*W % 8 == 0 and >= 64)

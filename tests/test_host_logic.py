@@ -170,7 +170,9 @@ def test_bench_cli_contract_and_kernel_naming(monkeypatch):
     monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '8', '--steps', '7', '--warmup', '2'])
     a = bench.parse_args()
     assert (a.gpus, a.steps, a.warmup) == (8, 7, 2)
-    assert bench.head_kernel_name(64, 64, 17, 8) == 'head_rt_kernel'                 # config 2, f32
+    assert bench.head_kernel_name(64, 64, 17, 8) == 'head_rt_ks_kernel'              # config 2, f32: 3-tile blocks, two K groups
+    assert bench.head_kernel_name(64, 1024, 17, 8) == 'head_rt_kernel'               # large launch: 5-tile blocks
+    assert bench.head_kernel_name(64, 64, 17, 8, 'f32', 1283) == 'head_rt_kernel'    # C % 64 != 0
     assert bench.head_kernel_name(144, 32, 17, 72) == 'head_rt_kernel'               # any map, D <= 80
     assert bench.head_kernel_name(64, 64, 17, 8, 'f16', 1280) == 'head_fused16dma_kernel'
     assert bench.head_kernel_name(36, 64, 17, 8, 'f16', 1280) == 'head_fused16_kernel'   # 6x6: registers
