@@ -21,6 +21,11 @@
 #ifndef MTR_WARP_PX
 #define MTR_WARP_PX 4  // output pixels per thread (a multiple of 4 for the vector stores)
 #endif
+#ifndef MTR_WARP_LX
+#define MTR_WARP_LX 32       // lanes of a wave along x in warp_rows_kernel (64 / LX rows per iteration):
+                             // 32 x 2 keeps a rotated crop's wave on fewer source lines than 64 x 1
+                             // (320 TTA crops 157.6 -> 140.7 us, plain 64 crops 25.2 -> 23.9; 16 x 4: 145.9 / 25.6)
+#endif
 #ifndef MTR_WARP_PREFETCH
 #define MTR_WARP_PREFETCH 1  // samples requested ahead of the one being finished
 #endif
@@ -594,10 +599,12 @@ __global__ __launch_bounds__(256) void warp_crops_kernel(
 }
 
 // ---- row-walking variant of the sampler ---------------------------------------------------------
-// Same arithmetic per sample as warp_crops_kernel (bit-identical crops), different schedule: a lane
-// owns ONE output column and walks ROWS rows; the taps of sample s+1 are requested before sample s
-// is finished, and a finished pixel is stored at once (64 lanes x 4 B = 256 contiguous bytes per
-// channel).  Stores therefore leave a wave as a steady stream instead of one burst at its end, and
+// Same arithmetic per sample as warp_crops_kernel (1 / z by v_rcp_f32 + a Newton step instead of
+// the IEEE division sequence: the only difference), different schedule: a lane owns ONE output
+// column and walks ROWS rows of it (a wave = LX columns x 64 / LX rows per step); the taps of
+// sample s+1 are requested before sample s is finished, and a finished pixel is stored at once
+// (LX lanes x 4 B = 128 contiguous bytes per row and channel).  Stores therefore leave a wave as a
+// steady stream instead of one burst at its end, and
 // -- gfx9 counts loads and stores in the same in-order vmcnt -- the next taps are always OLDER than
 // the previous pixel's stores, so waiting for taps never waits for a store.
 struct TapSet {
@@ -617,10 +624,11 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
     __syncthreads();
   }
   const float* __restrict__ l0 = (const float*)l0_any;
-  // block = 64 columns x 4*ROWS rows (wave w owns rows [w*ROWS, (w+1)*ROWS) of the tile); all tiles
-  // of a crop on one XCD, as in warp_crops_kernel
-  const int row_tiles = (res + 4 * ROWS - 1) / (4 * ROWS);
-  const int x_tiles = (res + 63) / 64;
+  // block = LX columns x 4*ROWS*RI rows (wave w owns the w-th band of ROWS*RI rows and walks it RI
+  // rows at a time); all tiles of a crop on one XCD, as in warp_crops_kernel
+  constexpr int LX = MTR_WARP_LX, RI = 64 / LX;  // a wave iteration covers LX columns x RI rows
+  const int row_tiles = (res + 4 * ROWS * RI - 1) / (4 * ROWS * RI);
+  const int x_tiles = (res + LX - 1) / LX;
   const int per_crop = row_tiles * x_tiles;
   const int id = blockIdx.x;
   const int crop = (id / (8 * per_crop)) * 8 + (id % 8);
@@ -655,8 +663,8 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
       bytes0 ? make_rsrc(uniform_ptr((const uint8_t*)l0_any), (unsigned)u8_bytes)
              : make_rsrc(uniform_ptr(planes), (unsigned)(3 * plane_elems) * 4u);
 
-  const int x = tx * 64 + (threadIdx.x & 63);
-  const int v_first = ty * 4 * ROWS + (threadIdx.x >> 6) * ROWS;
+  const int x = tx * LX + (threadIdx.x & (LX - 1));
+  const int v_first = (ty * 4 + (threadIdx.x >> 6)) * ROWS * RI + ((threadIdx.x & 63) / LX);
   if (x >= res || v_first >= res) return;
   const float fW = (float)W, fH = (float)H;
   const bool same_shift = ((row_bytes | plane_bytes) & 3) == 0;
@@ -668,7 +676,7 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
   // sample s of this lane: row s / (AA*AA), sub-sample (sj, si) in the reference's loop order
   auto request = [&](int s) -> TapSet {
     const int r = s / (AA * AA), sj = (s / AA) % AA, si = s % AA;
-    const float U = (float)(x * AA + si), V = (float)((v_first + r) * AA + sj);
+    const float U = (float)(x * AA + si), V = (float)((v_first + r * RI) * AA + sj);
     const float ox = fmaf(h0, U, fmaf(h1, V, h2));
     const float oy = fmaf(h3, U, fmaf(h4, V, h5));
     const float oz = fmaf(h6, U, fmaf(h7, V, h8));
@@ -750,7 +758,7 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
     if (s + PD < NS) ring[(s + PD) % (PD + 1)] = request(s + PD);
     finish(ring[s % (PD + 1)], acc);
     if ((s + 1) % (AA * AA) == 0) {  // the pixel of row r is complete
-      const int v = v_first + s / (AA * AA);
+      const int v = v_first + (s / (AA * AA)) * RI;
       float px[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -790,7 +798,8 @@ static int launch_warp(const void* l0, const float* l1, const float* l2, const f
   bool degenerate = false;
   for (int l = 0; l < 3; ++l) degenerate |= dims.W[l] < 2 || dims.H[l] < 2;
   if constexpr (ROWS > 0 && AA <= 2) if (!degenerate) {
-    const long long tiles = (long long)((res + 63) / 64) * ((res + 4 * ROWS - 1) / (4 * ROWS));
+    constexpr int LX = MTR_WARP_LX, RI = 64 / LX;
+    const long long tiles = (long long)((res + LX - 1) / LX) * ((res + 4 * ROWS * RI - 1) / (4 * ROWS * RI));
     const long long nblocks = (long long)((n_crops + 7) / 8) * 8 * tiles;
     if (nblocks > 0x7fffffffLL) return MTR_E_SHAPE;
     MTR_CLEAR_STALE();

@@ -17,6 +17,7 @@ MASKS = [0, 16, 1, 2, 4, 8, 15]  # 16 = one gather pair serves all three channel
 VARIANTS = {f'{m}': [f'-DMTR_WARP_ABLATE={m}', '-DMTR_WARP_ROWS=0'] for m in MASKS}
 VARIANTS.update({f'rows{r}': [f'-DMTR_WARP_ROWS={r}'] for r in (1, 2, 4, 8, 16)})
 VARIANTS.update({'pd1': [], 'pd2': ['-DMTR_WARP_PREFETCH=2'], 'pd3': ['-DMTR_WARP_PREFETCH=3'], 'pd2r8': ['-DMTR_WARP_PREFETCH=2', '-DMTR_WARP_ROWS=8'], 'pd0': ['-DMTR_WARP_PREFETCH=0']})
+VARIANTS.update({'lx64': [], 'lx32': ['-DMTR_WARP_LX=32'], 'lx16': ['-DMTR_WARP_LX=16'], 'lx32r2': ['-DMTR_WARP_LX=32', '-DMTR_WARP_ROWS=2'], 'lx16r2': ['-DMTR_WARP_LX=16', '-DMTR_WARP_ROWS=2'], 'lx16r1': ['-DMTR_WARP_LX=16', '-DMTR_WARP_ROWS=1']})
 VARIANTS.update({'rcp': ['-DMTR_WARP_RCP=1'], 'rcp8': ['-DMTR_WARP_RCP=1', '-DMTR_WARP_ROWS=8']})
 VARIANTS.update({'px8': ['-DMTR_WARP_PX=8'], 'px8_nostore': ['-DMTR_WARP_PX=8', '-DMTR_WARP_ABLATE=8'],
                  'px16': ['-DMTR_WARP_PX=16'], 'px2': ['-DMTR_WARP_PX=2'], 'px1': ['-DMTR_WARP_PX=1'],
@@ -54,7 +55,9 @@ def run_one(mask):
     pyrs = [pyr] + [kernels.build_pyramid(torch.randint(0, 256, (8, 3, 1080, 1920), dtype=torch.uint8, generator=g).cuda())
                     for _ in range(int(os.environ.get('ABLATE_ROTATE', '1')) - 1)]
     n = int(os.environ.get('ABLATE_CROPS', '64'))
-    tta = {k: v.cuda() for k, v in tta_parameters(1).items()}
+    aug = int(os.environ.get('ABLATE_AUG', '1'))  # 5 = the TTA table (rotations of +-25 degrees, flips, scales)
+    n //= aug
+    tta = {k: v.cuda() for k, v in tta_parameters(aug).items()}
     bw = 60 + 340 * torch.rand(n, generator=g)
     bh = 150 + 750 * torch.rand(n, generator=g)
     boxes = torch.stack([torch.rand(n, generator=g) * (1920 - bw),
@@ -64,7 +67,7 @@ def run_one(mask):
     ids = (torch.arange(n) % 8).int().cuda()
     _, _, wp = kernels.crop_geometry(boxes, K, torch.zeros(n, 12).cuda(), up, ids, tta['rotflipmat'],
                                      tta['scales'], tta['gammas'], 256, 1)
-    o = torch.empty(n, 3, 256, 256, device='cuda')
+    o = torch.empty(n * aug, 3, 256, 256, device='cuda')
     for _ in range(5):
         kernels.warp_crops(pyr, wp, 256, 1, out=o)
     torch.cuda.synchronize()
