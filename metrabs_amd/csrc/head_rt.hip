@@ -44,22 +44,6 @@ using v4f = __attribute__((ext_vector_type(4))) float;
 #ifndef MTR_RT_KS_NBUF
 #define MTR_RT_KS_NBUF 2    // ring depth of each K group of head_rt_ks_kernel
 #endif
-#ifndef MTR_RT_KS_ALWAYS
-#define MTR_RT_KS_ALWAYS 0  // developer probe: two K groups at every launch size
-#endif
-#ifndef MTR_RT_ROTATE
-#define MTR_RT_ROTATE 0     // developer probe: every workgroup starts its K loop at another stage
-#endif
-#ifndef MTR_RT_NT
-#define MTR_RT_NT 0          // developer probe: non-temporal copies, 1 = features, 2 = weights, 3 = both
-#endif
-#ifndef MTR_RT_KS_PROBE
-#define MTR_RT_KS_PROBE 0   // developer timing probe (wrong results): 1 = even group skips the odd chains' adds,
-                            // 2 = no hand-over traffic at all, 4 = no f64 carries in the loop
-#endif
-#ifndef MTR_RT_KS_SLEEP
-#define MTR_RT_KS_SLEEP 0   // developer probe: s_sleep of the second K group behind every barrier
-#endif
 #ifndef MTR_RT_EXP32
 #define MTR_RT_EXP32 1      // 1: v_exp_f32 in the decode epilogue (f64 sums; measured -0.9 us at B=64, -11 us at
                             // B=1024, parity unchanged: the stand-alone decode does the same); 0: f64 polynomial
@@ -133,13 +117,6 @@ __device__ __forceinline__ unsigned rt_lds_addr(const void* p) {
 // lds_addr + 16 L.  sbase / lds_addr are wave-uniform (SGPRs), voff per lane.
 __device__ __forceinline__ void rt_dma16(const void* sbase, unsigned voff, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-               :
-               : "s"(lds_addr), "v"(voff), "s"(sbase)
-               : "memory");
-}
-
-__device__ __forceinline__ void rt_dma16_nt(const void* sbase, unsigned voff, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt"
                :
                : "s"(lds_addr), "v"(voff), "s"(sbase)
                : "memory");
@@ -340,10 +317,7 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
     const bool short_wave = JOBS % 4 != 0 && wid + 4 * (JPW - 1) >= JOBS;
     auto issue_job = [&](int i, int slot) {
       if (JOBS % 4 != 0 && i == JPW - 1 && short_wave) return;
-      if (MTR_RT_NT && ((wid + 4 * i < 2 * RT) ? (MTR_RT_NT & 2) : (MTR_RT_NT & 1)))
-        rt_dma16_nt(gbase[i], voff[i], lds0 + (unsigned)slot * STAGE + ldso[i]);
-      else
-        rt_dma16(gbase[i], voff[i], lds0 + (unsigned)slot * STAGE + ldso[i]);
+      rt_dma16(gbase[i], voff[i], lds0 + (unsigned)slot * STAGE + ldso[i]);
       voff[i] += gstride[i];
     };
     auto redirect_tail = [&]() {  // (rare path: recomputed here rather than held in registers)
@@ -361,18 +335,9 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
         }
       }
     };
-    const int rot = MTR_RT_ROTATE ? (int)((blockIdx.x / 8) * 7u % (unsigned)n_stages) : 0;
-    if (MTR_RT_ROTATE) {
-#pragma unroll
-      for (int i = 0; i < JPW; ++i) voff[i] += (unsigned)rot * gstride[i];
-    }
     auto stage_issued = [&]() {
       ++issued;
       if (c_tail && issued == n_stages - 1) redirect_tail();
-      if (MTR_RT_ROTATE && issued == n_stages - rot) {
-#pragma unroll
-        for (int i = 0; i < JPW; ++i) voff[i] -= (unsigned)n_stages * gstride[i];
-      }
     };
 
     RtRegs<RT, NP> rg;
@@ -429,12 +394,11 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
     else if (short_wave) rt_wait_vmcnt<(kRtNbuf - 2) * (JPW - 1)>();                              \
     else rt_wait_vmcnt<(kRtNbuf - 2) * JPW>();                                                    \
     __syncthreads();                                                                              \
-    if (KS == 2 && MTR_RT_KS_SLEEP && kg) __builtin_amdgcn_s_sleep(MTR_RT_KS_SLEEP);              \
     const char* buf = ring + (BUF) * STAGE;                                                       \
     v4f xa[RT], xb[NP];                                                                           \
     rt_read_frags<RT, NP, NHWC>(buf, a_off, b_off, xa, xb);                                       \
     v4f lr[NA];                                                                                   \
-    if (ROLE == 1 && !(MTR_RT_KS_PROBE & 2)) {                                                    \
+    if (ROLE == 1) {                                                                              \
       _Pragma("unroll") for (int q = 0; q < NA; ++q)                                              \
         lr[q] = hb[((((S) + 1) & 1) * 4 + wid) * NA * 64 + q * 64 + lane];                        \
     }                                                                                             \
@@ -443,17 +407,17 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
       rt_mfma_slot<RT, NP>(rg.part[(P) ^ 1], rg.ya, rg.yb, n, false);                             \
       if (n < JPW && more && !(MTR_RT_ABLATE & 4)) issue_job(n, ((BUF) + kRtNbuf - 1) % kRtNbuf); \
       if (n == JPW && more) stage_issued();                                                       \
-      if (ROLE == 1 && n >= 2 * NA && !(MTR_RT_KS_PROBE & 3)) rt_run_add<NA>(rg.run, lr, n - 2 * NA); \
+      if (ROLE == 1 && n >= 2 * NA) rt_run_add<NA>(rg.run, lr, n - 2 * NA);                       \
       __builtin_amdgcn_sched_barrier(0);                                                          \
     }                                                                                             \
-    if (ROLE == 1 && (S) >= 5 && ((S) - 1) % 4 == 0 && !(MTR_RT_KS_PROBE & 4)) rt_flush<NA>(rg.acc, rg.run); \
+    if (ROLE == 1 && (S) >= 5 && ((S) - 1) % 4 == 0) rt_flush<NA>(rg.acc, rg.run);                \
     rt_read_frags<RT, NP, NHWC>(buf, a_off ^ 64, b_q1, rg.ya, rg.yb);                             \
     __builtin_amdgcn_sched_barrier(0);                                                            \
     _Pragma("unroll") for (int n = 0; n < 4 * NA; ++n) {                                          \
       rt_mfma_slot<RT, NP>(rg.part[P], xa, xb, n, true);                                          \
       if (ROLE != 2) {                                                                            \
         if (n % 2 == 1) rt_run_add<NA>(rg.run, rg.part[(P) ^ 1], n / 2);                          \
-      } else if (n % 2 == 1 && n / 2 < NA && !(MTR_RT_KS_PROBE & 2)) {                            \
+      } else if (n % 2 == 1 && n / 2 < NA) {                                                      \
         hb[(((S) & 1) * 4 + wid) * NA * 64 + (n / 2) * 64 + lane] = rg.part[(P) ^ 1][n / 2];      \
       }                                                                                           \
       __builtin_amdgcn_sched_barrier(0);                                                          \
@@ -938,7 +902,7 @@ int rt_launch(const float* feat, int layout, const void* section, int B, int C, 
   // 16x16 98 -> 83, B = 32 12x12 (2-tile blocks) 50 -> 44; one-tile blocks lose (29 -> 32 at B = 64),
   // 5-tile blocks lose (B = 1024 249 -> 274 in the sum-exchange prototype).  ks_hint: 0 = this rule,
   // 1 = never, 2 = whenever the kernel can (C % 64 == 0, blocks of <= 3 tiles)
-  if (C % 64 == 0 && a.rtg <= 3 && ks_hint != 1 && (ks_hint == 2 || MTR_RT_KS_ALWAYS || a.rtg >= 2))
+  if (C % 64 == 0 && a.rtg <= 3 && ks_hint != 1 && (ks_hint == 2 || a.rtg >= 2))
     return nhwc ? rt_launch_kernel(head_rt_ks_kernel<3, true>, rt_ks_lds_bytes(3, true), a, stream, 512)
                 : rt_launch_kernel(head_rt_ks_kernel<3, false>, rt_ks_lds_bytes(3, false), a, stream, 512);
   if (a.rtg <= 3)

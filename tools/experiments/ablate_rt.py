@@ -3,8 +3,11 @@
     python tools/experiments/ablate_rt.py build      # here (hipcc cross-compiles): one .so per variant
     python tools/experiments/ablate_rt.py run        # on the GPU box: times every variant
 
-MTR_RT_ABLATE bits (metrabs_amd/csrc/head_rt.hip): 1 = no decode epilogue, 2 = no MFMA, 4 = no copies
-inside the K loop, 8 = no f64 carry, 16 = no fragment reads.  MTR_RT_NBUF = ring depth.
+MTR_RT_ABLATE bits (metrabs_amd/csrc/head_rt.hip): 1 = no decode epilogue, 2 = no MFMA, 8 = no f64
+carry, 16 = no fragment reads (27 = the copies + barriers alone).  MTR_RT_NBUF / MTR_RT_KS_NBUF = ring depth.
+Probes that were built on top of this tool in round 2 and removed again after their result went into
+DESIGN.md: K order rotated per workgroup, non-temporal copies, s_sleep stagger of the second K group,
+two K groups at every launch size, hand-over cost split (no adds / no LDS traffic / no carries).
 """
 import json
 import os
@@ -14,16 +17,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, 'tools', 'experiments', '_build')
 VARIANTS = {'full': [], 'exp32': ['-DMTR_RT_EXP32=1'], 'nodecode': ['-DMTR_RT_ABLATE=1'], 'nomfma': ['-DMTR_RT_ABLATE=2'],
-            'nodma': ['-DMTR_RT_ABLATE=4'], 'nocarry': ['-DMTR_RT_ABLATE=8'],
-            'nodma_nocarry': ['-DMTR_RT_ABLATE=12'], 'nofrag': ['-DMTR_RT_ABLATE=16'],
-            'mfma_only': ['-DMTR_RT_ABLATE=29'], 'nbuf2': ['-DMTR_RT_NBUF=2'], 'nbuf4': ['-DMTR_RT_NBUF=4'], 'nbuf8': ['-DMTR_RT_NBUF=8'], 'ks4': ['-DMTR_RT_KS_NBUF=4'], 'ks8': ['-DMTR_RT_KS_NBUF=8'],
-            'sleep2': ['-DMTR_RT_KS_SLEEP=2'], 'sleep5': ['-DMTR_RT_KS_SLEEP=5'],
-            'a18': ['-DMTR_RT_ABLATE=18'], 'a26': ['-DMTR_RT_ABLATE=26'], 'a27': ['-DMTR_RT_ABLATE=27'],
-            'rot': ['-DMTR_RT_ROTATE=1'], 'rot_a27': ['-DMTR_RT_ROTATE=1', '-DMTR_RT_ABLATE=27'],
-            'ksall': ['-DMTR_RT_KS_ALWAYS=1'],
-            'kp1': ['-DMTR_RT_KS_PROBE=1'], 'kp2': ['-DMTR_RT_KS_PROBE=2'], 'kp4': ['-DMTR_RT_KS_PROBE=4'], 'kp7': ['-DMTR_RT_KS_PROBE=7'], 'ks1': ['-DMTR_RT_KS_OFF=1'],
-            'nt1': ['-DMTR_RT_NT=1'], 'nt2': ['-DMTR_RT_NT=2'], 'nt3': ['-DMTR_RT_NT=3'],
-            'ks_nodecode': ['-DMTR_RT_ABLATE=1'], 'ks_nomfma': ['-DMTR_RT_ABLATE=2']}
+            'nocarry': ['-DMTR_RT_ABLATE=8'],
+            'nofrag': ['-DMTR_RT_ABLATE=16'],
+            'nbuf2': ['-DMTR_RT_NBUF=2'], 'nbuf4': ['-DMTR_RT_NBUF=4'], 'nbuf8': ['-DMTR_RT_NBUF=8'], 'a18': ['-DMTR_RT_ABLATE=18'], 'a26': ['-DMTR_RT_ABLATE=26'], 'a27': ['-DMTR_RT_ABLATE=27'],
+            'ks4': ['-DMTR_RT_KS_NBUF=4']}
 if os.environ.get('RT_VARIANTS'):
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ['RT_VARIANTS'].split(',')}
 
