@@ -13,7 +13,7 @@ metrabs_pytorch CPU path -- as HARD gates at every BASELINE.json config shape, i
   ill-conditioned (median depth ~0 mm): the reference's own fp32 result is 1e-3 ... 4e-3 mm from an
   fp64 evaluation of the same formulas, so no implementation can sit within 1e-3 mm of it.  Gates
   there: FIXED numbers per case (~2x the values measured when they were set,
-  profiles/r02i_parity_report.jsonl) on ours-vs-fp64 and on ours-vs-oracle, so that a head that
+  profiles/r02j_parity_report.jsonl) on ours-vs-fp64 and on ours-vs-oracle, so that a head that
   gets noisier fails whatever the oracle's own floor does.
 
 f16 features (configs[4]): the oracle evaluates the f32 conv on the same rounded features and
@@ -42,8 +42,8 @@ SHAPES = {
     'metric string: 72 depth bins, 256 px, B=64': (64, 1280, 17, 8, 256, 72, torch.float32),
 }
 
-# mm: (MPJPE ours-vs-fp64, MPJPE ours-vs-oracle, max-abs ours-vs-oracle); measured r02b (re-measured r02i) (profiles/
-# r02i_parity_report.jsonl): ours-vs-fp64 2.7e-4 .. 6.6e-4, ours-vs-oracle 7.3e-4 .. 1.5e-3 (= the
+# mm: (MPJPE ours-vs-fp64, MPJPE ours-vs-oracle, max-abs ours-vs-oracle); measured r02b (re-measured r02j) (profiles/
+# r02j_parity_report.jsonl): ours-vs-fp64 2.7e-4 .. 6.6e-4, ours-vs-oracle 7.3e-4 .. 1.5e-3 (= the
 # oracle's own 6.7e-4 .. 1.3e-3 from fp64), max 2.9e-3 .. 5.9e-3
 RANDOM_HEAD_BOUNDS = {
     'configs[0] ResNet-18 256 B=1': (6e-4, 3e-3, 6e-3),
