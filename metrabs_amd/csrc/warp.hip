@@ -843,6 +843,8 @@ static int warp_entry(const void* level0, const float* lut, const float* level1,
       (L0U8 && !lut))
     return MTR_E_NULL;
   if ((long long)N * 3 * Hi * Wi >= 0x7fffffffLL) return MTR_E_SHAPE;  // (32-bit byte offsets in the kernel)
+  // an f32 level 0: the kernels address one image's three planes with 32-bit byte offsets
+  if (!L0U8 && (long long)Hi * Wi * 12 >= 0x7fffffffLL) return MTR_E_SHAPE;
   // Range of the uint8 descriptor: the tensor's bytes rounded up to a whole dword (a dword
   // straddling num_records reads as zero, and the byte pair of the last texels may sit in the
   // dword that holds the tensor's last byte).  The <= 3 bytes past the tensor are in the SAME
