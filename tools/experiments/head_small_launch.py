@@ -39,7 +39,10 @@ def main():
     w = torch.randn(J * (1 + D), C, device='cuda', generator=g) * 0.03
     b = torch.zeros(J * (1 + D), device='cuda')
     packed = kernels.head_pack_weights(w, b, J, D)
-    for B, H in [(32, 12), (16, 24), (64, 16), (8, 12), (64, 8)]:
+    shapes = [(32, 12), (16, 24), (64, 16), (8, 12), (64, 8)]
+    if os.environ.get('SMALL_SHAPES'):
+        shapes = [tuple(int(x) for x in t.split('x')) for t in os.environ['SMALL_SHAPES'].split(',')]
+    for B, H in shapes:
         cfg = MetrabsConfig(proc_side=H * 32, stride_test=32)
         feat = torch.randn(B, C, H, H, device='cuda', generator=g)
         out = (torch.empty(B, J, 2, device='cuda'), torch.empty(B, J, 3, device='cuda'))
