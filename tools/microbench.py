@@ -142,8 +142,15 @@ def bench_warp_pyramid():
         o = torch.empty(n * num_aug, 3, 256, 256, device='cuda', dtype=dt)
         t = timeit(lambda: kernels.warp_crops(pyr, wp, 256, aa, out=o))
         nbytes = o.numel() * o.element_size()
+        # algorithmic bytes = the crops written + the clipped source footprint of every crop quad
+        # (bench.source_footprint_bytes); the same 8 frames every launch, i.e. the
+        # gathers are Infinity-Cache-assisted (bench.py times the 64-crop shape on rotating frames too)
+        import bench
+        src = bench.source_footprint_bytes(wp, 256 * aa, 1080, 1920)
         out.append(dict(kernel='warp', case=name, us=round(t * 1e6, 1), geometry_us=round(tg * 1e6, 1),
-                        out_GBps=round(nbytes / t / 1e9, 1), crops_per_s=round(n * num_aug / t)))
+                        out_GBps=round(nbytes / t / 1e9, 1), crops_per_s=round(n * num_aug / t),
+                        algorithmic_MB=round((nbytes + src) / 1e6, 1),
+                        frac_hbm_cache_assisted=round((nbytes + src) / t / HBM, 3)))
     return out
 
 
