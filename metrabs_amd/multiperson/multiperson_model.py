@@ -15,7 +15,7 @@ Differences to the reference, all documented in DESIGN.md:
 import numpy as np
 import torch
 
-from metrabs_amd import distributed, kernels, pipeline, ptu3d
+from metrabs_amd import distributed, kernels, pipeline
 from metrabs_amd.joint_info import JointInfo
 from metrabs_amd.multiperson import warping
 
@@ -50,9 +50,33 @@ def tta_parameters(num_aug, rot_aug_degrees=25):
     should_flip = (torch.arange(0, num_aug) - num_aug // 2) % 2 != 0
     flipmat = torch.tensor([[-1, 0, 0], [0, 1, 0], [0, 0, 1]], dtype=torch.float32)
     maybe_flipmat = torch.where(should_flip[:, np.newaxis, np.newaxis], flipmat, torch.eye(3))
-    rotflipmat = maybe_flipmat @ ptu3d.rotation_mat(-angles, rot_axis='z')
+    rotflipmat = maybe_flipmat @ rotation_about_z(-angles)
     return dict(gammas=gammas, angles=angles, scales=scales, should_flip=should_flip,
                 rotflipmat=rotflipmat)
+
+
+def rotation_about_z(angle):
+    """[..., 3, 3] rotation by `angle` about the optical axis, float32 sin / cos as the reference
+    evaluates them (ptu3d.py:164-184 with rot_axis='z'; the TTA table is compared bit for bit)."""
+    c, s_ = torch.cos(angle), torch.sin(angle)
+    o, z = torch.ones_like(angle), torch.zeros_like(angle)
+    return torch.stack([c, -s_, z, s_, c, z, z, z, o], dim=-1).reshape(*angle.shape, 3, 3)
+
+
+def intrinsics_from_fov(fov_degrees, image_hw):
+    """[1, 3, 3] pinhole matrix for a field of view over the longer image side, principal point at
+    the image centre (ptu3d.py:149-161), in float32 like the reference."""
+    h, w = (torch.tensor(float(v), dtype=torch.float32) for v in image_hw)
+    half_fov = fov_degrees * torch.tensor(np.pi / 180, dtype=torch.float32) / 2
+    f = torch.maximum(h, w) / (torch.tan(half_fov) * 2)
+    K = torch.zeros(1, 3, 3)
+    K[0, 0, 0] = K[0, 1, 1] = f
+    K[0, 0, 2], K[0, 1, 2], K[0, 2, 2] = w / 2, h / 2, 1.0
+    return K
+
+
+def homogeneous(x):
+    return torch.cat([x, torch.ones_like(x[..., :1])], dim=-1)
 
 
 def distort_points(points, coeffs12):
@@ -225,8 +249,7 @@ class Pose3dEstimator(torch.nn.Module):
         # camera set-up on the host (tiny), then one transfer (multiperson_model.py:79-105)
         if len(intrinsic_matrix) == 1:
             if torch.all(intrinsic_matrix == -1):
-                intrinsic_matrix = ptu3d.intrinsic_matrix_from_field_of_view(
-                    default_fov_degrees, images.shape[2:4])
+                intrinsic_matrix = intrinsics_from_fov(default_fov_degrees, images.shape[2:4])
             intrinsic_matrix = torch.repeat_interleave(intrinsic_matrix, n_images, dim=0)
         if len(distortion_coeffs) == 1:
             distortion_coeffs = torch.repeat_interleave(distortion_coeffs, n_images, dim=0)
@@ -279,8 +302,8 @@ class Pose3dEstimator(torch.nn.Module):
             if self.joint_transform_matrix is not None:
                 poses3d_flat = torch.einsum(
                     'bank,nN->baNk', poses3d_flat, self.joint_transform_matrix.to(dev))
-            poses2d_flat_normalized = ptu3d.to_homogeneous(
-                distort_points(ptu3d.project(poses3d_flat), distortion_b))
+            poses2d_flat_normalized = homogeneous(
+                distort_points(poses3d_flat[..., :2] / poses3d_flat[..., 2:3], distortion_b))
             poses2d_flat = torch.einsum(
                 'bank,bjk->banj', poses2d_flat_normalized, intrinsic_matrix_b[:, :2, :])
             if suppress and sum(counts):
@@ -299,7 +322,7 @@ class Pose3dEstimator(torch.nn.Module):
                 inv_extrinsics_b = inv_extrinsics_b[sel]
                 counts = [len(k) for k in keep]
             poses3d_flat = torch.einsum(
-                'bank,bjk->banj', ptu3d.to_homogeneous(poses3d_flat), inv_extrinsics_b[:, :3, :])
+                'bank,bjk->banj', homogeneous(poses3d_flat), inv_extrinsics_b[:, :3, :])
             poses3d_flat = poses3d_flat[..., idx, :]
             poses2d_flat = poses2d_flat[..., idx, :]
             if average_aug:
