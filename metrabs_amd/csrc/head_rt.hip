@@ -41,6 +41,10 @@ using v4f = __attribute__((ext_vector_type(4))) float;
 #ifndef MTR_RT_NBUF
 #define MTR_RT_NBUF 0       // 0: by block size (rt_nbuf)
 #endif
+#ifndef MTR_RT_PAIR
+#define MTR_RT_PAIR 1       // 1: 4-slot rings are filled two stages ahead and the workgroup meets at a barrier
+                            // every SECOND stage (one K group only)
+#endif
 #ifndef MTR_RT_KS_NBUF
 #define MTR_RT_KS_NBUF 2    // ring depth of each K group of head_rt_ks_kernel
 #endif
@@ -220,6 +224,8 @@ template <int RT, int NP, int RTMAX, bool NHWC, int KS = 1>
 __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, int t0) {
   constexpr int STAGE = rt_stage_bytes(RT, NP, NHWC);
   constexpr int kRtNbuf = KS == 2 ? MTR_RT_KS_NBUF : rt_nbuf(RTMAX, NP, NHWC);
+  constexpr bool kPair = MTR_RT_PAIR && KS == 1 && kRtNbuf == 4;
+  constexpr int LA = kPair ? 2 : kRtNbuf - 1;   // stages in flight behind the one being consumed
   constexpr int NG = 16 * KS;                   // 16-lane groups of the workgroup (decode: one row each)
   constexpr int KR = (RT * 16 + NG - 1) / NG;   // decode rounds
   constexpr int CHUNK = rt_feat_chunk(NHWC);   // LDS bytes of one column block's features per stage
@@ -362,7 +368,7 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
     // prologue: stages 0 .. NBUF-2 in flight
     if (c_tail && n_stages == 1) redirect_tail();
 #pragma unroll
-    for (int p = 0; p < kRtNbuf - 1; ++p)
+    for (int p = 0; p < LA; ++p)
       if (p < n_stages) {
 #pragma unroll
         for (int i = 0; i < JPW; ++i) issue_job(i, p);
@@ -390,10 +396,14 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
 #define RT_BODY(S, P, BUF, MORE, ROLE)                                                            \
   {                                                                                               \
     const bool more = (MORE);                                                                     \
-    if (!more || kRtNbuf == 2) rt_wait_vmcnt<0>();                                                \
-    else if (short_wave) rt_wait_vmcnt<(kRtNbuf - 2) * (JPW - 1)>();                              \
-    else rt_wait_vmcnt<(kRtNbuf - 2) * JPW>();                                                    \
-    __syncthreads();                                                                              \
+    if (kPair) { /* even stages: this wave's copies of stages S and S + 1 have landed, then meet */ \
+      if (((S) & 1) == 0) { rt_wait_vmcnt<0>(); __syncthreads(); }                                \
+    } else {                                                                                      \
+      if (!more || kRtNbuf == 2) rt_wait_vmcnt<0>();                                              \
+      else if (short_wave) rt_wait_vmcnt<(kRtNbuf - 2) * (JPW - 1)>();                            \
+      else rt_wait_vmcnt<(kRtNbuf - 2) * JPW>();                                                  \
+      __syncthreads();                                                                            \
+    }                                                                                             \
     const char* buf = ring + (BUF) * STAGE;                                                       \
     v4f xa[RT], xb[NP];                                                                           \
     rt_read_frags<RT, NP, NHWC>(buf, a_off, b_off, xa, xb);                                       \
@@ -405,7 +415,7 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
     __builtin_amdgcn_sched_barrier(0);                                                            \
     _Pragma("unroll") for (int n = 0; n < 4 * NA; ++n) {                                          \
       rt_mfma_slot<RT, NP>(rg.part[(P) ^ 1], rg.ya, rg.yb, n, false);                             \
-      if (n < JPW && more && !(MTR_RT_ABLATE & 4)) issue_job(n, ((BUF) + kRtNbuf - 1) % kRtNbuf); \
+      if (n < JPW && more && !(MTR_RT_ABLATE & 4)) issue_job(n, ((BUF) + LA) % kRtNbuf);          \
       if (n == JPW && more) stage_issued();                                                       \
       if (ROLE == 1 && n >= 2 * NA) rt_run_add<NA>(rg.run, lr, n - 2 * NA);                       \
       __builtin_amdgcn_sched_barrier(0);                                                          \
@@ -436,7 +446,7 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
     // iteration s; it is emptied into f64 every kRtCarry stages (any point between two iterations
     // is a valid one).
     if constexpr (kRtNbuf == 8) {
-      for (; s + kRtNbuf - 1 + 7 < n_stages; s += 8) {
+      for (; s + LA + 7 < n_stages; s += 8) {
         RT_ITER(s, 0, 0, true)
         if (KS == 1 && s >= kRtCarry && s % kRtCarry == 0) rt_flush<NA>(rg.acc, rg.run);
         RT_ITER(s + 1, 1, 1, true)
@@ -448,7 +458,7 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
         RT_ITER(s + 7, 1, 7, true)
       }
     } else if constexpr (kRtNbuf == 4) {
-      for (; s + kRtNbuf - 1 + 3 < n_stages; s += 4) {
+      for (; s + LA + 3 < n_stages; s += 4) {
         RT_ITER(s, 0, 0, true)
         if (KS == 1 && s >= kRtCarry && s % kRtCarry == 0) rt_flush<NA>(rg.acc, rg.run);
         RT_ITER(s + 1, 1, 1, true)
@@ -456,7 +466,7 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
         RT_ITER(s + 3, 1, 3, true)
       }
     } else {
-      for (; s + kRtNbuf - 1 + 1 < n_stages; s += 2) {
+      for (; s + LA + 1 < n_stages; s += 2) {
         RT_ITER(s, 0, 0, true)
         if (KS == 1 && s >= kRtCarry && s % kRtCarry == 0) rt_flush<NA>(rg.acc, rg.run);
         RT_ITER(s + 1, 1, 1, true)
@@ -465,7 +475,7 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
     // remainder (the last issuing iterations + the NBUF - 1 that only consume)
     for (; s < n_stages; ++s) {
       if (KS == 1 && s >= 2 && (s - 1) % kRtCarry == 0) rt_flush<NA>(rg.acc, rg.run);
-      const bool more_rt = s + kRtNbuf - 1 < n_stages;
+      const bool more_rt = s + LA < n_stages;
       if constexpr (kRtNbuf == 8) {
         switch (s & 7) {
           case 0: RT_ITER(s, 0, 0, more_rt) break;

@@ -20,7 +20,7 @@ VARIANTS = {'full': [], 'exp32': ['-DMTR_RT_EXP32=1'], 'nodecode': ['-DMTR_RT_AB
             'nocarry': ['-DMTR_RT_ABLATE=8'],
             'nofrag': ['-DMTR_RT_ABLATE=16'],
             'nbuf2': ['-DMTR_RT_NBUF=2'], 'nbuf4': ['-DMTR_RT_NBUF=4'], 'nbuf8': ['-DMTR_RT_NBUF=8'], 'a18': ['-DMTR_RT_ABLATE=18'], 'a26': ['-DMTR_RT_ABLATE=26'], 'a27': ['-DMTR_RT_ABLATE=27'],
-            'ks4': ['-DMTR_RT_KS_NBUF=4']}
+            'ks4': ['-DMTR_RT_KS_NBUF=4'], 'pair': ['-DMTR_RT_PAIR=1']}
 if os.environ.get('RT_VARIANTS'):
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ['RT_VARIANTS'].split(',')}
 
@@ -72,10 +72,13 @@ def run_one(name):
                                          vp(packed.data_ptr()), s) == 0
         c2 = torch.empty(B, J, 2, device='cuda'); c3 = torch.empty(B, J, 3, device='cuda')
 
+        # RT_KGROUPS=1|2 in the environment: mtr_head_options.rt_k_groups for every call
+        opts = _lib.HeadOptions(0, 0, -1, 0, int(os.environ.get('RT_KGROUPS', '0')))
+
         def call(stream):
-            rc = lib.mtr_head_fused(vp(feat.data_ptr()), 0, 1 if nhwc else 0, B, C, H, H,
-                                    vp(packed.data_ptr()), J, D, ctypes.byref(hp), vp(c2.data_ptr()),
-                                    vp(c3.data_ptr()), vp(stream))
+            rc = lib.mtr_head_fused_opts(vp(feat.data_ptr()), 0, 1 if nhwc else 0, B, C, H, H,
+                                         vp(packed.data_ptr()), J, D, ctypes.byref(hp), ctypes.byref(opts),
+                                         vp(c2.data_ptr()), vp(c3.data_ptr()), vp(stream))
             assert rc == 0, rc
         for _ in range(5):
             call(torch.cuda.current_stream().cuda_stream)

@@ -47,7 +47,7 @@ def main():
         feat = torch.randn(B, C, H, H, device='cuda', generator=g)
         out = (torch.empty(B, J, 2, device='cuda'), torch.empty(B, J, 3, device='cuda'))
         res = {}
-        for rt, np_, ks in itertools.product((0, 1, 2, 3, 5), (0, 1, 2, 3), (0, 2)):
+        for rt, np_, ks in itertools.product((0, 1, 2, 3, 5), (0, 1, 2, 3), (0, 1, 2)):
             if H == 8 and np_ > 1:
                 continue
             try:
