@@ -31,9 +31,16 @@ class DepthwiseConv2d(nn.Conv2d):
 
     def forward(self, x):
         if x.is_cuda and not DepthwiseConv2d.use_miopen and torch.backends.cudnn.enabled:
-            # scoped, and serialised: another inference thread must neither see MIOpen switched off
-            # for its own convolutions nor switch it back on underneath this call
-            with DepthwiseConv2d._backend_lock, torch.backends.cudnn.flags(enabled=False):
+            # scoped; the lock serialises THESE layers among themselves (two of them must not
+            # interleave their save / restore of the flag).  It does not isolate other threads'
+            # convolutions: a convolution another thread launches while this context is open sees
+            # MIOpen off too (the switch is process-global in torch).  Every other flag is passed
+            # through unchanged -- flags() would otherwise reset benchmark / deterministic /
+            # allow_tf32 to its keyword defaults inside the context.
+            cudnn = torch.backends.cudnn
+            with DepthwiseConv2d._backend_lock, cudnn.flags(
+                    enabled=False, benchmark=cudnn.benchmark, deterministic=cudnn.deterministic,
+                    allow_tf32=cudnn.allow_tf32):
                 return super().forward(x)
         return super().forward(x)
 

@@ -5,6 +5,10 @@
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "../../include/metrabs_hip.h"
 
 namespace mtr {
@@ -19,6 +23,24 @@ constexpr int kWave = 64;
     hipError_t e_ = hipGetLastError();           \
     if (e_ != hipSuccess) return (int)e_;        \
   } while (0)
+
+// More than the default 64 KiB of dynamic LDS: the kernel attribute is set ONCE per (kernel, device)
+// and remembered (it used to be a host call in front of every launch of the launch-latency-bound
+// small-batch paths).  -> MTR_OK or the hipError_t of the failed hipFuncSetAttribute (> 0: the
+// ABI's "hipError_t of a failed launch", mtr_strerror names it).
+inline int allow_dynamic_lds(const void* kern, size_t lds_bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, size_t> granted;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& have = granted[std::make_pair(kern, dev)];
+  if (have >= lds_bytes) return MTR_OK;
+  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) return (int)e;
+  have = lds_bytes;
+  return MTR_OK;
+}
 
 // activations of the backbone epilogues (K10 bias_act.hip, K11 depthwise.hip); codes = the `act`
 // argument of their entry points

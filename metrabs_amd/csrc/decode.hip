@@ -322,13 +322,19 @@ __global__ __launch_bounds__(256) void decode_nhwc_kernel(const T* __restrict__ 
     int h = 0, w = 0;
     for (int p = 0; p < HW; ++p) {
       const float v = to_f32(x[(size_t)p * N + n]);
-      if (v > m) {  // rescale what has been summed under the old maximum
-        const double f = (double)__expf(m - v);  // (m = -inf: exp(-inf) = 0)
-        s *= f; sx *= f; sy *= f;
+      if (v > m) {  // rescale what has been summed under the old maximum -- in f64, as the per-joint
+        // merge below does: a 2-ulp f32 factor at every update of the running maximum would add
+        // ~1e-7 relative per update to the expectation (a few 1e-4 mm of the 1e-3 mm budget)
+        if (m != -INFINITY) {  // (nothing summed yet otherwise)
+          const double f = exp_neg64((double)m - (double)v);
+          s *= f; sx *= f; sy *= f;
+        }
         m = v;
       }
-      const double e = (double)exp_shifted(v, -m * kLog2e);
-      s += e; sx += e * (double)w; sy += e * (double)h;
+      if (v != -INFINITY) {  // a -inf logit weighs nothing (and -inf - -inf is NaN under a -inf maximum)
+        const double e = (double)exp_shifted(v, -m * kLog2e);
+        s += e; sx += e * (double)w; sy += e * (double)h;
+      }
       if (++w == W) { w = 0; ++h; }
     }
     row_m[n] = m;
@@ -366,8 +372,8 @@ static int launch_decode_nhwc(const void* logits, int B, int J, int D, int H, in
   if (lds > 160 * 1024 - 256) return MTR_E_SHAPE;  // > 5,800 channels per position
   auto kern = decode_nhwc_kernel<T>;
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+    const int rc = allow_dynamic_lds((const void*)kern, lds);
+    if (rc != MTR_OK) return rc;
   }
   MTR_CLEAR_STALE();
   hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(256), lds, stream, (const T*)logits, B, J, D, H, W, hs,

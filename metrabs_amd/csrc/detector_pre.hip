@@ -328,9 +328,8 @@ static int launch_detector_pre_t(const uint8_t* images_u8, int N, int H, int W, 
   const size_t lds = (size_t)rows_cap * pitch + (size_t)rows_cap * mtr::kDTX * sizeof(float);
   auto kern = mtr::detector_pre_kernel<KT, TAIL>;
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
-    if (e != hipSuccess) return (int)e;
+    const int rc = mtr::allow_dynamic_lds((const void*)kern, lds);
+    if (rc != MTR_OK) return rc;
   }
   // persistent: every workgroup keeps one column tile; G workgroups share its (plane, row tile)
   // pairs.  The grid is sized to what is RESIDENT at once (a workgroup that has to wait for a slot

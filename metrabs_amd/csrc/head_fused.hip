@@ -692,9 +692,8 @@ static int launch_head16(const void* feat, const float* packed, int B, int C, in
   if (opt.dma != 0 && dma_ok) {
     auto dma = head_fused16dma_kernel<FeatT, CT, GPW, NHWC>;
     if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute((const void*)dma,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return (int)e;
+      const int rc = allow_dynamic_lds((const void*)dma, lds);
+      if (rc != MTR_OK) return rc;
     }
     MTR_CLEAR_STALE();
     hipLaunchKernelGGL(dma, dim3((unsigned)blocks), dim3(256), lds, stream, (const FeatT*)feat,
@@ -704,9 +703,8 @@ static int launch_head16(const void* feat, const float* packed, int B, int C, in
   }
   auto kern = head_fused16_kernel<FeatT, CT, GPW, NHWC>;
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+    const int rc = allow_dynamic_lds((const void*)kern, lds);
+    if (rc != MTR_OK) return rc;
   }
   MTR_CLEAR_STALE();
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, (const FeatT*)feat,

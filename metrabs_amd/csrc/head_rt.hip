@@ -805,8 +805,8 @@ __global__ __launch_bounds__(256, 1) void head_rt_np_kernel(RtArgs a) {
 template <typename Kern>
 static int rt_launch_kernel(Kern kern, int lds, const RtArgs& a, hipStream_t stream, int threads = 256) {
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
+    const int rc = allow_dynamic_lds((const void*)kern, (size_t)lds);
+    if (rc != MTR_OK) return rc;
   }
   const long long blocks = (long long)((a.B + 7) / 8) * 8 * a.n_blocks;
   if (blocks > 0x7fffffffLL) return MTR_E_SHAPE;

@@ -127,9 +127,8 @@ extern "C" int mtr_postprocess_poses(const float* poses_crop, const float* rot,
   const size_t lds = (size_t)A * J * 3 * sizeof(double);
   if (lds > 144 * 1024) return MTR_E_SHAPE;  // A*J <= 6144 (one box's poses live in LDS)
   if (lds > 48 * 1024) {  // e.g. the 555-point multi-skeleton heads with num_aug = 5
-    hipError_t e = hipFuncSetAttribute((const void*)mtr::postprocess_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+    const int rc = mtr::allow_dynamic_lds((const void*)mtr::postprocess_kernel, lds);
+    if (rc != MTR_OK) return rc;
   }
   MTR_CLEAR_STALE();
   hipLaunchKernelGGL(mtr::postprocess_kernel, dim3(n), dim3(256), lds, (hipStream_t)stream,

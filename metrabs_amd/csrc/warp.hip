@@ -842,9 +842,14 @@ static int warp_entry(const void* level0, const float* lut, const float* level1,
   if (!level0 || (!level1 && !l1_empty) || (!level2 && !l2_empty) || !warp_params || !out ||
       (L0U8 && !lut))
     return MTR_E_NULL;
-  if ((long long)N * 3 * Hi * Wi >= 0x7fffffffLL) return MTR_E_SHAPE;  // (32-bit byte offsets in the kernel)
-  // an f32 level 0: the kernels address one image's three planes with 32-bit byte offsets
+  // a uint8 level 0 is ONE buffer descriptor over the whole frame tensor with 32-bit byte offsets:
+  // < 2 GiB per call (the host side, Pose3dEstimator._predict_in_batches, builds the pyramid of the
+  // frames one internal batch references when a call's frames exceed that)
+  if (L0U8 && (long long)N * 3 * Hi * Wi >= 0x7fffffffLL) return MTR_E_SHAPE;
+  // an f32 level 0: the image base is a 64-bit pointer, one image's three planes are addressed with
+  // 32-bit byte offsets
   if (!L0U8 && (long long)Hi * Wi * 12 >= 0x7fffffffLL) return MTR_E_SHAPE;
+  if (Wi >= (1 << 24) || Hi >= (1 << 24)) return MTR_E_SHAPE;  // (row offsets by v_mul_u32_u24)
   // Range of the uint8 descriptor: the tensor's bytes rounded up to a whole dword (a dword
   // straddling num_records reads as zero, and the byte pair of the last texels may sit in the
   // dword that holds the tensor's last byte).  The <= 3 bytes past the tensor are in the SAME

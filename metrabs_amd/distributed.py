@@ -105,6 +105,16 @@ def gather_poses(local_poses, ranges_of_rank, n_boxes, boxes_per_batch, world_si
                                        for r in range(world_size)], n_boxes, group)
 
 
+def exact_mode_needs_allreduce(crop_model):
+    """The single predicate both sides of the exact-monolithic moment all-reduce use
+    (Pose3dEstimator._predict_in_batches for the empty slices, Metrabs.forward for the others): a
+    process group of more than one rank AND a full-perspective model -- the weak-perspective
+    reference point (ptu3d.py:36-49) needs no batch-global scalar, so nothing is exchanged."""
+    cfg = getattr(crop_model, 'config', None)
+    return bool(dist.is_initialized() and dist.get_world_size() > 1
+                and not getattr(cfg, 'weak_perspective', False))
+
+
 def allreduce_moments(moments, group=None):
     """exact-monolithic mode: sum the (sum2d, sumrb, count) f64 triple over ranks."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:

@@ -124,6 +124,10 @@ def _alloc_levels(n, h, w, device, with_level0=True):
     return l0, l1, l2
 
 
+# uint8 frames one sampler call can address (one 32-bit-offset buffer descriptor, csrc/warp.hip)
+MAX_U8_FRAME_BYTES = (1 << 31) - 8
+
+
 def build_pyramid(images_u8, materialize_level0=False):
     """uint8 [N,3,H,W] -> Pyramid: fused gamma decode (u8/255)**2.2 + two 2x2 box levels.  By
     default level 0 is NOT written as f32 (the sampler reads the uint8 frame through the LUT)."""

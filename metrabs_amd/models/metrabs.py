@@ -7,7 +7,7 @@ the fused 1x1-projection GEMM + soft-argmax decode (csrc/head_fused.hip) or, wit
 import numpy as np
 import torch
 
-from metrabs_amd import kernels
+from metrabs_amd import distributed, kernels
 from metrabs_amd.config import MetrabsConfig
 
 
@@ -31,6 +31,7 @@ class MetrabsHeads(torch.nn.Module):
         # path wins for f32 features, the fused kernel for f16 / bf16 at J <= 24).
         self.fused = fused
         self._auto_choice = {}
+        self.last_path = None
         self._packed = None
         self._packed_key = None
 
@@ -57,6 +58,7 @@ class MetrabsHeads(torch.nn.Module):
             c_in, self.n_points, self.config.depth, h, w, kernels._is_channels_last(inp), inp.dtype)
         if use_fused and self.fused == 'auto':
             use_fused = self._auto_pick(inp)
+        self.last_path = 'fused' if use_fused else 'library'  # (bench.py reports which one ran)
         if use_fused:
             return self._forward_fused(inp)
         return self._forward_unfused(inp)
@@ -126,11 +128,9 @@ class Metrabs(torch.nn.Module):
         else:
             features = self.backbone(image)
         coords2d, coords3d = self.heatmap_heads(features)
-        if self.exact_monolithic and torch.distributed.is_initialized() and \
-                torch.distributed.get_world_size() > 1 and not self.config.weak_perspective:
+        if self.exact_monolithic and distributed.exact_mode_needs_allreduce(self):
             # this call holds one rank's slice of a reference internal batch: the batch-global RMS
             # scalars of reconstruct_ref_fullpersp (ptu3d.py:71-74) come from the summed moments
-            from metrabs_amd import distributed
             moments = kernels.reconstruct_moments(coords2d, coords3d, intrinsics)
             distributed.allreduce_moments(moments)
             return kernels.reconstruct_solve(coords2d, coords3d, intrinsics, moments, self.config)

@@ -354,6 +354,10 @@ class Pose3dEstimator(torch.nn.Module):
         if self.shard_across_ranks and torch.distributed.is_initialized():
             rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
         exact = self.shard_across_ranks == 'exact_monolithic' and world > 1
+        # ONE predicate on both sides of the moment all-reduce (Metrabs.forward, models/metrabs.py):
+        # the weak-perspective reference point (ptu3d.py:36-49) has no batch-global scalar, so a
+        # weak-perspective model in exact mode is plain slicing with no collective at all
+        exact_allreduce = exact and distributed.exact_mode_needs_allreduce(self.crop_model)
         if exact:
             ranges_by_rank = distributed.split_internal_batches(n_total, boxes_per_batch, world)
         else:
@@ -368,7 +372,11 @@ class Pose3dEstimator(torch.nn.Module):
                 remap[needed] = torch.arange(len(needed), dtype=image_id_per_box.dtype)
                 image_id_per_box = remap.to(image_id_per_box.device)[image_id_per_box.long()]
                 images = images[torch.tensor(needed, device=images.device)] if needed else images[:0]
-        pyramid = kernels.build_pyramid(images) if len(images) else None
+        # mtr_warp_crops_u8 addresses the uint8 frames of a call through one 32-bit-offset buffer
+        # descriptor (< 2 GiB: 86 4K frames).  Beyond that every internal batch gets the pyramid of
+        # the frames ITS boxes reference (at most boxes_per_batch of them).
+        per_batch_pyramids = images.numel() >= kernels.MAX_U8_FRAME_BYTES
+        pyramid = kernels.build_pyramid(images) if len(images) and not per_batch_pyramids else None
         if exact:
             if not hasattr(self.crop_model, 'exact_monolithic'):
                 raise RuntimeError("shard_across_ranks='exact_monolithic' needs metrabs_amd's Metrabs "
@@ -378,13 +386,17 @@ class Pose3dEstimator(torch.nn.Module):
         try:
             for start, stop in ranges:
                 if start == stop:  # (exact mode) an empty slice still joins the batch's all-reduce
-                    distributed.allreduce_moments(torch.zeros(3, dtype=torch.float64,
-                                                              device=boxes_flat.device))
+                    if exact_allreduce:
+                        distributed.allreduce_moments(torch.zeros(3, dtype=torch.float64,
+                                                                  device=boxes_flat.device))
                     continue
                 s = slice(start, stop)
+                batch_pyramid, batch_ids = pyramid, image_id_per_box[s]
+                if per_batch_pyramids:
+                    batch_pyramid, batch_ids = self._pyramid_of_referenced_frames(images, batch_ids)
                 res = self._predict_single_batch(
-                    pyramid, intrinsic_matrix[s], distortion12[s], camspace_up[s], boxes_flat[s],
-                    image_id_per_box[s], tta, antialias_factor, raw=post is not None)
+                    batch_pyramid, intrinsic_matrix[s], distortion12[s], camspace_up[s], boxes_flat[s],
+                    batch_ids, tta, antialias_factor, raw=post is not None)
                 if post is not None:
                     poses_flat, rot = res
                     p3, p2 = kernels.postprocess_poses(
@@ -405,6 +417,18 @@ class Pose3dEstimator(torch.nn.Module):
         else:
             local = torch.zeros(0, num_aug, self.joint_info.n_joints, 3, device=boxes_flat.device)
         return distributed.gather_ranges(local, ranges_by_rank, n_total)
+
+    @staticmethod
+    def _pyramid_of_referenced_frames(images, image_ids):
+        """-> (pyramid of the frames `image_ids` reference, the ids renumbered into it)."""
+        needed, local_ids = torch.unique(image_ids.long(), sorted=True, return_inverse=True)
+        frames = images[needed.to(images.device)]
+        if frames.numel() >= kernels.MAX_U8_FRAME_BYTES:
+            raise ValueError(
+                f'one internal batch references {len(needed)} frames = {frames.numel()} bytes; the '
+                f'sampler takes < {kernels.MAX_U8_FRAME_BYTES} bytes of uint8 frames per call: lower '
+                f'internal_batch_size')
+        return kernels.build_pyramid(frames), local_ids.to(image_ids.dtype)
 
     def _get_crops(self, pyramid, intrinsic_matrix, distortion12, camspace_up, boxes, image_ids, tta,
                    antialias_factor):

@@ -103,3 +103,93 @@ def test_shard_partition_properties():
                 for r in range(world):
                     seen += [i for a, b in shard_internal_batches(n, per, r, world) for i in range(a, b)]
                 assert sorted(seen) == list(range(n))  # every box exactly once
+
+
+def _exact_worker(rank, world, port, n_boxes, per_batch, weak, q):
+    """The REAL Pose3dEstimator._predict_in_batches in exact-monolithic mode with the GPU stages
+    stubbed: the pyramid is a placeholder and _predict_single_batch is a stand-in crop model that
+    makes exactly the collective calls Metrabs.forward makes (one predicate,
+    distributed.exact_mode_needs_allreduce).  A mismatch between the two sides -- an empty slice
+    all-reducing while the other rank's forward does not -- pairs that all-reduce with the
+    other rank's all-gather: a hang or a corrupted gather."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import types
+    import numpy as np
+    from metrabs_amd import distributed, kernels
+    from metrabs_amd.multiperson.multiperson_model import Pose3dEstimator
+    distributed.init_from_env(backend='gloo')
+
+    class Crop(torch.nn.Module):
+        joint_names = np.array([f'j{i}' for i in range(17)])
+        joint_edges = np.array([[i, i + 1] for i in range(16)])
+        input_resolution = 256
+        exact_monolithic = False
+        config = types.SimpleNamespace(weak_perspective=weak)
+
+    est = Pose3dEstimator(Crop(), {'': dict(indices=list(range(17)), names=list(Crop.joint_names),
+                                            edges=Crop.joint_edges.tolist())}, None)
+    est.shard_across_ranks = 'exact_monolithic'
+    calls = []
+
+    def single_batch(pyramid, K, dist12, up, boxes, image_ids, tta, aa, raw=False):
+        assert est.crop_model.exact_monolithic
+        if distributed.exact_mode_needs_allreduce(est.crop_model):  # == Metrabs.forward
+            m = torch.tensor([1.0, 2.0, float(len(boxes))], dtype=torch.float64)
+            distributed.allreduce_moments(m)
+            calls.append(float(m[2]))
+        return boxes[:, :1].reshape(-1, 1, 1, 1).repeat(1, 1, 17, 3).clone()
+
+    est._predict_single_batch = single_batch
+    orig = kernels.build_pyramid
+    kernels.build_pyramid = lambda images, **kw: None
+    try:
+        boxes = torch.arange(n_boxes, dtype=torch.float32).reshape(-1, 1).repeat(1, 5)
+        tta = dict(gammas=torch.ones(1))
+        out = est._predict_in_batches(
+            torch.zeros(1, 3, 8, 8, dtype=torch.uint8), torch.eye(3).repeat(n_boxes, 1, 1),
+            torch.zeros(n_boxes, 12), torch.zeros(n_boxes, 3), boxes,
+            torch.zeros(n_boxes, dtype=torch.int32), per_batch, tta, 1)
+    finally:
+        kernels.build_pyramid = orig
+    q.put((rank, out.numpy(), calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('weak', [False, True])
+@pytest.mark.parametrize('n_boxes,per_batch', [(1, 4), (5, 2), (3, 1)])
+def test_exact_monolithic_empty_slices_pair_their_collectives(n_boxes, per_batch, weak):
+    """Fewer boxes in an internal batch than ranks: one rank's slice is empty.  Full perspective:
+    the empty slice joins the batch's moment all-reduce.  Weak perspective (ptu3d.py:36-49 has no
+    batch-global scalar): NO all-reduce on either side -- round-2 ADVICE: the empty-slice rank used to
+    all-reduce unconditionally and paired with the other rank's all-gather."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    for attempt in range(3):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_exact_worker, args=(r, world, port, n_boxes, per_batch, weak, q))
+                 for r in range(world)]
+        for p in procs:
+            p.start()
+        try:
+            results = [q.get(timeout=120) for _ in range(world)]
+        except Exception:
+            results = None
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+        if results is not None and all(p.exitcode == 0 for p in procs):
+            break
+    else:
+        pytest.fail('world-size-2 gloo run hung or failed three times (mismatched collectives?)')
+    expected = torch.arange(n_boxes, dtype=torch.float32).reshape(-1, 1, 1, 1).repeat(1, 1, 17, 3)
+    for rank, out, calls in results:
+        assert torch.equal(torch.from_numpy(out), expected), f'rank {rank}: wrong gather'
+        if weak:
+            assert calls == []
+        else:  # every all-reduce this rank's forward joined saw the whole internal batch
+            assert all(c in (float(min(per_batch, n_boxes - b)) for b in range(0, n_boxes, per_batch))
+                       for c in calls)

@@ -81,3 +81,30 @@ def test_public_api_shapes_and_detector(hip_lib):
         est.detector = None
         with pytest.raises(RuntimeError):
             est.detect_poses(case['images'][0])
+
+
+def test_frames_beyond_the_2gib_descriptor_take_per_batch_pyramids(hip_lib, monkeypatch):
+    """mtr_warp_crops_u8 addresses a call's uint8 frames through one 32-bit-offset descriptor
+    (< 2 GiB); beyond that Pose3dEstimator builds, per internal batch, the pyramid of the frames
+    that batch references.  Same kernels on the same texels: bit-equal to the one-pyramid call
+    (the threshold is lowered instead of allocating 2 GiB of frames)."""
+    from metrabs_amd import kernels
+    case = cases.e2e_case('aug5')
+    est = build_estimator(case, True)
+    args = (case['images'], case['boxes'], case['K'], case['dist'], case['extr'], case['world_up'],
+            55, case['ibs'], case['aa'], case['num_aug'], case['average_aug'], '', False)
+    with torch.inference_mode():
+        ref = est._estimate_poses_batched(*args)
+        monkeypatch.setattr(kernels, 'MAX_U8_FRAME_BYTES', 1)
+        calls = []
+        orig = kernels.build_pyramid
+        monkeypatch.setattr(kernels, 'build_pyramid', lambda im, **kw: calls.append(len(im)) or orig(im, **kw))
+        with pytest.raises(ValueError):  # one batch's frames are themselves over the (lowered) limit
+            est._estimate_poses_batched(*args)
+        monkeypatch.setattr(kernels, 'MAX_U8_FRAME_BYTES', case['images'][:1].numel() * 2 + 1)
+        calls.clear()
+        out = est._estimate_poses_batched(*args)
+    if len(case['images']) > 2:
+        assert calls and max(calls) <= 2  # a pyramid per internal batch, only its own frames
+    for k in ('poses3d', 'poses2d'):
+        assert all(torch.equal(a, b) for a, b in zip(ref[k], out[k]))
