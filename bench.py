@@ -151,7 +151,7 @@ def build_model(args, dev):
     ji = JointInfo(names, edges)
     backbone = build_backbone(args.backbone)
     autocast = {'f32': None, 'f16': torch.float16, 'bf16': torch.bfloat16}[args.precision]
-    model = Metrabs(backbone, ji, cfg, in_channels=backbone.out_channels, fused_head=True,
+    model = Metrabs(backbone, ji, cfg, in_channels=backbone.out_channels, fused_head='auto',
                     autocast_dtype=autocast)
     model = model.to(dev)
     calibrate_batchnorm(model.backbone, args.res, dev)
@@ -207,12 +207,13 @@ def depth72_variant(args, dev, im_h, im_w, n_box):
     heads = est72.crop_model.heatmap_heads
     C = est72.crop_model.backbone.out_channels
     hw = args.res // 32
-    fused = bool(heads.fused) and kernels_mod().head_fused_supported(
-        C, args.joints, 72, hw, hw, dtype=torch.float32 if args.precision == 'f32' else torch.float16)
+    fused = heads.last_path == 'fused'
     return dict(crops_per_s_per_gpu=n_box * args.num_aug / ms * 1e3, ms_per_step=ms, steps=n,
                 head=('mtr_head_fused (row-tile core: a joint\'s 72 depth slices + 8 rows of 2D heatmaps '
                       'are one 5-tile atom, 17 atoms)' if fused else
                       '1x1 conv (library GEMM) + mtr_softargmax_decode, D=72'),
+                head_chosen_by=f'MetrabsHeads(fused={heads.fused!r}): both paths timed once on the first eager '
+                               f'call, the faster kept',
                 note='same step as `value` with a 72-bin head; `value` itself uses depth=8 '
                      '(every shipped configuration of the reference)')
 
@@ -245,24 +246,18 @@ def backbone_variant(args, dev, im_h, im_w, n_box, fold_bn, fused_epilogue, note
 
 
 def head_kernel_name(hw, n_crops, J, D, precision='f32', C=1280):
-    """Which kernel mtr_head_fused dispatches to (metrabs_amd/csrc/head_fused.hip:mtr_head_fused)."""
-    if precision == 'f32':  # row-tile core: any map size, D <= 80 (the rules of head_rt.hip:rt_launch)
-        n_tiles, atom = -(-(J * (1 + D)) // 16), 1 if 1 + D <= 16 else -(-(8 + D) // 16)
-        crops8 = -(-n_crops // 8) * 8
-        if atom == 1 and hw > 64 and crops8 * n_tiles <= 256:
-            return 'head_rt_np_kernel'          # one K loop for several column blocks
-        if atom == 1 and crops8 * -(-n_tiles // 3) <= 512:
-            rtg, floor = 3, 2 if C % 64 == 0 else 1
-            while rtg > floor and crops8 * -(-n_tiles // rtg) < 256:
-                rtg -= 1
-            if C % 64 == 0 and rtg >= 2:
-                return 'head_rt_ks_kernel'      # two K groups per workgroup (small launches)
-        return 'head_rt_kernel'
-    if C % 8 == 0:
-        # f16 / bf16 MFMA, a staging loop bounded by the feature bytes; DMA-staged when whole
-        # 16-byte chunks per channel row exist (NCHW: H*W % 8 == 0 and >= 64)
-        return 'head_fused16dma_kernel' if (C % 64 == 0 and hw % 8 == 0 and hw >= 64) else 'head_fused16_kernel'
-    return 'head_fused32_kernel' if 32 < hw <= 128 else 'head_fused_kernel'
+    """Which kernel mtr_head_fused_ws takes for the launch -- asked of the library itself
+    (mtr_head_plan, host-only), not mirrored here."""
+    from metrabs_amd import kernels
+    side = int(round(hw ** 0.5))
+    dt = {'f32': torch.float32, 'f16': torch.float16, 'bf16': torch.bfloat16}[precision]
+    plan = kernels.head_plan(n_crops, C, side, hw // side, J, D, dt)
+    if plan is None:
+        return 'library 1x1 conv (rocBLAS / MIOpen) + decode_nchw_kernel'
+    name = plan['kernel']
+    if plan['split_column_blocks']:
+        name += f' (+ head_rt_merge_kernel: {plan["split_column_blocks"]} column blocks over workgroups)'
+    return name
 
 
 def graph_time(calls, replays):

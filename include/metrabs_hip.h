@@ -125,6 +125,14 @@ typedef struct mtr_head_options {
                                       4..7 and their chains are handed to waves 0..3, which sum in the
                                       one-group order: same bits), 1 = one; 0 = two for blocks of 2-3
                                       tiles (the small-launch configuration)                          */
+  int32_t rt_loader;               /* f32, C % 32 == 0: 2 = four MFMA waves + a LOADER wave per workgroup (320
+                                      threads; the fifth wave issues every global_load_lds and waits for it,
+                                      the MFMA waves only meet it at the stage barrier: same bits), 1 = never;
+                                      0 = for launches of at most one workgroup per CU                 */
+  int32_t rt_split_column_blocks;  /* f32, maps of > 64 positions, mtr_head_fused_ws with a workspace: 2 = deal
+                                      the 64-position column blocks to different workgroups (a second, tiny
+                                      launch merges their softmax statistics in block order: same bits as one
+                                      workgroup walking them), 1 = never; 0 = on small launches        */
 } mtr_head_options;
 
 /* host-only, no GPU work: the row order of the f32 row-tile kernel.  conv_final's J*(1+D) channels
@@ -144,6 +152,36 @@ int mtr_head_fused_opts(const void* features, int feat_dtype, int layout, int B,
                         const void* packed, int J, int D, const mtr_head_params* p,
                         const mtr_head_options* options, float* coords2d, float* coords3d_rel,
                         mtr_stream_t stream);
+/* host-only, no GPU work: which kernel mtr_head_fused_ws takes for a launch (what a profile will show).
+ * kernel: one of MTR_HEAD_KERNEL_*; 0 with return MTR_E_SHAPE = no fused kernel for this shape. */
+enum {
+  MTR_HEAD_KERNEL_RT = 1,        /* head_rt_kernel: 256 threads, every wave copies and multiplies          */
+  MTR_HEAD_KERNEL_RT_LOADER = 2, /* head_rt_ld_kernel: four MFMA waves + a loader wave                     */
+  MTR_HEAD_KERNEL_RT_KS = 3,     /* head_rt_ks_kernel: two K groups                                        */
+  MTR_HEAD_KERNEL_RT_NP = 4,     /* head_rt_np_kernel: row tiles x column blocks per workgroup             */
+  MTR_HEAD_KERNEL_16 = 10,       /* head_fused16_kernel: 16-bit features staged through registers          */
+  MTR_HEAD_KERNEL_16_DMA = 11    /* head_fused16dma_kernel: 16-bit features staged by global_load_lds      */
+};
+typedef struct mtr_head_plan_info {
+  int32_t kernel;
+  int32_t tiles_per_workgroup;    /* f32: row tiles; 16-bit: joint groups                                   */
+  int32_t column_blocks;          /* f32 np kernel: column blocks per workgroup tile, else 1               */
+  int32_t split_column_blocks;    /* f32: column blocks dealt to workgroups (+ the merge launch), else 0   */
+  int64_t workgroups;             /* of the main launch                                                     */
+} mtr_head_plan_info;
+int mtr_head_plan(int feat_dtype, int layout, int B, int C, int H, int W, int J, int D,
+                  const mtr_head_options* options, int have_workspace, mtr_head_plan_info* plan);
+
+/* The same with a caller-provided scratch buffer (8-byte aligned, mtr_head_workspace_bytes(...) bytes,
+ * contents irrelevant before and after; 0 bytes = this shape never uses one): with it, f32 maps of
+ * more than 64 positions may spread their column blocks over workgroups (rt_split_column_blocks).
+ * workspace == NULL is mtr_head_fused_opts.  Still no allocation, no sync, no globals: two launches
+ * on `stream` instead of one when the split is taken. */
+size_t mtr_head_workspace_bytes(int B, int J, int D, int H, int W, int feat_dtype);
+int mtr_head_fused_ws(const void* features, int feat_dtype, int layout, int B, int C, int H, int W,
+                      const void* packed, int J, int D, const mtr_head_params* p,
+                      const mtr_head_options* options, void* workspace, size_t workspace_bytes,
+                      float* coords2d, float* coords3d_rel, mtr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K5: absolute (camera-space) reconstruction.  Replaces

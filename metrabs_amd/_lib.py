@@ -23,7 +23,18 @@ class HeadParams(ctypes.Structure):
 class HeadOptions(ctypes.Structure):
     """mtr_head_options (include/metrabs_hip.h): explicit dispatch choices of mtr_head_fused_opts."""
     _fields_ = [('rt_tiles_per_workgroup', c_int32), ('groups_per_workgroup', c_int32),
-                ('dma_staging', c_int32), ('rt_column_blocks', c_int32), ('rt_k_groups', c_int32)]
+                ('dma_staging', c_int32), ('rt_column_blocks', c_int32), ('rt_k_groups', c_int32),
+                ('rt_loader', c_int32), ('rt_split_column_blocks', c_int32)]
+
+
+class HeadPlanInfo(ctypes.Structure):
+    """mtr_head_plan_info (include/metrabs_hip.h): which kernel mtr_head_fused_ws takes for a launch."""
+    _fields_ = [('kernel', c_int32), ('tiles_per_workgroup', c_int32), ('column_blocks', c_int32),
+                ('split_column_blocks', c_int32), ('workgroups', ctypes.c_int64)]
+
+
+HEAD_KERNEL_NAMES = {1: 'head_rt_kernel', 2: 'head_rt_ld_kernel', 3: 'head_rt_ks_kernel', 4: 'head_rt_np_kernel',
+                     10: 'head_fused16_kernel', 11: 'head_fused16dma_kernel'}
 
 
 class ReconParams(ctypes.Structure):
@@ -65,6 +76,12 @@ SIGNATURES = {
     'mtr_head_fused_opts': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                     c_int, POINTER(HeadParams), POINTER(HeadOptions), c_void_p, c_void_p,
                                     c_void_p]),
+    'mtr_head_plan': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(HeadOptions),
+                              c_int, POINTER(HeadPlanInfo)]),
+    'mtr_head_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    'mtr_head_fused_ws': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                                  c_int, POINTER(HeadParams), POINTER(HeadOptions), c_void_p, c_size_t,
+                                  c_void_p, c_void_p, c_void_p]),
     'mtr_crops_shrink_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'mtr_crops_shrink_antialiased': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                              c_void_p, c_size_t, c_void_p]),

@@ -673,6 +673,8 @@ struct HeadOpts {
   int rt_tiles = 0;          // f32: row tiles per workgroup for one-tile atoms (1..5)
   int rt_np = 0;             // f32: column blocks per workgroup tile (1..4), maps of > 64 positions
   int rt_ks = 0;             // f32: K groups per workgroup (1, 2), blocks of <= 3 tiles
+  int rt_ld = 0;             // f32: loader-wave kernel (1 = never, 2 = whenever possible)
+  int rt_split = 0;          // f32: column blocks over workgroups (1 = never, 2 = whenever possible)
   int groups_per_wg = 0;     // 16-bit: joint groups per workgroup (1..3)
   int dma = -1;              // 16-bit: -1 auto, 0 = stage through registers, 1 = global_load_lds
 };
@@ -713,21 +715,28 @@ static int launch_head16(const void* feat, const float* packed, int B, int C, in
   return MTR_OK;
 }
 
-template <typename FeatT, int CT, bool NHWC>
-static int dispatch_head16(const void* feat, const float* packed, int B, int C, int H, int W, int J,
-                           int D, const HeadGeom& g, const HeadScale& hs, float* c2d, float* c3d,
-                           const HeadOpts& opt, hipStream_t stream) {
+// joint groups per workgroup of the 16-bit kernels (ct = column tiles of 32 positions)
+static int head16_groups_per_wg(int B, int ct, const HeadGeom& g, const HeadOpts& opt) {
   // accumulators: GPW x ceil(CT / 2) tiles of 16 registers per wave
-  constexpr int kMaxGpw = CT <= 2 ? 3 : (CT <= 6 ? 2 : 1);
+  const int max_gpw = ct <= 2 ? 3 : (ct <= 6 ? 2 : 1);
   int gpw = 1;
   const long long crops8 = (long long)((B + 7) / 8) * 8;
-  for (int cand = 2; cand <= kMaxGpw; ++cand) {
+  for (int cand = 2; cand <= max_gpw; ++cand) {
     // several groups per workgroup once the launch still fills the chip (>= 4 workgroups per CU)
     // and the groups divide without an idle remainder worse than the gain
     const int wgs = (g.n_groups + cand - 1) / cand;
     if (crops8 * wgs >= 1024 && wgs * cand - g.n_groups <= (g.n_groups >= 6 ? 1 : 0)) gpw = cand;
   }
-  if (opt.groups_per_wg >= 1) gpw = opt.groups_per_wg < kMaxGpw ? opt.groups_per_wg : kMaxGpw;
+  if (opt.groups_per_wg >= 1) gpw = opt.groups_per_wg < max_gpw ? opt.groups_per_wg : max_gpw;
+  return gpw;
+}
+
+template <typename FeatT, int CT, bool NHWC>
+static int dispatch_head16(const void* feat, const float* packed, int B, int C, int H, int W, int J,
+                           int D, const HeadGeom& g, const HeadScale& hs, float* c2d, float* c3d,
+                           const HeadOpts& opt, hipStream_t stream) {
+  constexpr int kMaxGpw = CT <= 2 ? 3 : (CT <= 6 ? 2 : 1);
+  const int gpw = head16_groups_per_wg(B, CT, g, opt);
   if constexpr (kMaxGpw >= 3)
     if (gpw == 3) return launch_head16<FeatT, CT, 3, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, opt, stream);
   if constexpr (kMaxGpw >= 2)
@@ -829,10 +838,73 @@ extern "C" int mtr_head_pack_weights(const float* weight, const float* bias, int
   return MTR_OK;
 }
 
+static int parse_head_options(const mtr_head_options* options, mtr::HeadOpts& opt) {
+  if (!options) return MTR_OK;
+  if (options->rt_tiles_per_workgroup < 0 || options->rt_tiles_per_workgroup > 5 ||
+      options->groups_per_workgroup < 0 || options->groups_per_workgroup > 3 ||
+      options->dma_staging < -1 || options->dma_staging > 1 ||
+      options->rt_column_blocks < 0 || options->rt_column_blocks > 4 ||
+      options->rt_k_groups < 0 || options->rt_k_groups > 2 ||
+      options->rt_loader < 0 || options->rt_loader > 2 ||
+      options->rt_split_column_blocks < 0 || options->rt_split_column_blocks > 2)
+    return MTR_E_PARAM;
+  opt.rt_tiles = options->rt_tiles_per_workgroup;
+  opt.rt_np = options->rt_column_blocks;
+  opt.rt_ks = options->rt_k_groups;
+  opt.rt_ld = options->rt_loader;
+  opt.rt_split = options->rt_split_column_blocks;
+  opt.groups_per_wg = options->groups_per_workgroup;
+  opt.dma = options->dma_staging;
+  return MTR_OK;
+}
+
+extern "C" int mtr_head_plan(int feat_dtype, int layout, int B, int C, int H, int W, int J, int D,
+                             const mtr_head_options* options, int have_workspace, mtr_head_plan_info* plan) {
+  if (!plan) return MTR_E_NULL;
+  *plan = mtr_head_plan_info{0, 0, 1, 0, 0};
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || J <= 0 || D <= 0 || (H * W) % 4 != 0) return MTR_E_SHAPE;
+  if (layout != MTR_NCHW && layout != MTR_NHWC) return MTR_E_DTYPE;
+  if (layout == MTR_NHWC && C % 4 != 0) return MTR_E_SHAPE;
+  mtr::HeadOpts opt;
+  const int rc = parse_head_options(options, opt);
+  if (rc != MTR_OK) return rc;
+  if (feat_dtype == MTR_F32) {
+    if (!mtr::rt_shape_ok(C, J, D)) return MTR_E_SHAPE;
+    const mtr::RtDispatch d = mtr::rt_dispatch(B, C, H, W, J, D, opt.rt_tiles, opt.rt_np, opt.rt_ks, opt.rt_ld,
+                                               opt.rt_split, have_workspace != 0 && (H * W + 63) / 64 >= 2);
+    *plan = mtr_head_plan_info{d.kernel, d.rtg, d.np, d.split, d.n_wg};
+    return MTR_OK;
+  }
+  if (feat_dtype != MTR_F16 && feat_dtype != MTR_BF16) return MTR_E_DTYPE;
+  if (!mtr::h16_shape_ok(C, J, D) || H * W > 256) return MTR_E_SHAPE;
+  const mtr::HeadGeom g = mtr::head_geom(J, D);
+  int ct = (H * W + 31) / 32;
+  if (ct == 7) ct = 8;
+  const int gpw = mtr::head16_groups_per_wg(B, ct, g, opt);
+  const bool dma_ok = C % mtr::kKH == 0 && (layout == MTR_NHWC || ((H * W) % 8 == 0 && H * W >= 64));
+  plan->kernel = (opt.dma != 0 && dma_ok) ? MTR_HEAD_KERNEL_16_DMA : MTR_HEAD_KERNEL_16;
+  plan->tiles_per_workgroup = gpw;
+  plan->workgroups = (long long)((B + 7) / 8) * 8 * ((g.n_groups + gpw - 1) / gpw);
+  return MTR_OK;
+}
+
+extern "C" size_t mtr_head_workspace_bytes(int B, int J, int D, int H, int W, int feat_dtype) {
+  if (feat_dtype != MTR_F32) return 0;
+  return mtr::rt_workspace_bytes(B, J, D, H, W);
+}
+
 extern "C" int mtr_head_fused_opts(const void* features, int feat_dtype, int layout, int B, int C,
                                    int H, int W, const void* packed, int J, int D,
                                    const mtr_head_params* p, const mtr_head_options* options,
                                    float* coords2d, float* coords3d_rel, mtr_stream_t stream) {
+  return mtr_head_fused_ws(features, feat_dtype, layout, B, C, H, W, packed, J, D, p, options, nullptr, 0,
+                           coords2d, coords3d_rel, stream);
+}
+
+extern "C" int mtr_head_fused_ws(const void* features, int feat_dtype, int layout, int B, int C, int H,
+                                 int W, const void* packed, int J, int D, const mtr_head_params* p,
+                                 const mtr_head_options* options, void* workspace, size_t workspace_bytes,
+                                 float* coords2d, float* coords3d_rel, mtr_stream_t stream) {
   if (!features || !packed || !p || !coords2d || !coords3d_rel) return MTR_E_NULL;
   if (B < 0 || H <= 0 || W <= 0 || C <= 0 || J <= 0 || D <= 0) return MTR_E_SHAPE;
   if (layout != MTR_NCHW && layout != MTR_NHWC) return MTR_E_DTYPE;
@@ -842,26 +914,19 @@ extern "C" int mtr_head_fused_opts(const void* features, int feat_dtype, int lay
   if (p->proc_side <= 0 || p->stride_test <= 0) return MTR_E_PARAM;
   if (((uintptr_t)features % 16) || ((uintptr_t)packed % 16)) return MTR_E_ALIGN;
   mtr::HeadOpts opt;
-  if (options) {
-    if (options->rt_tiles_per_workgroup < 0 || options->rt_tiles_per_workgroup > 5 ||
-        options->groups_per_workgroup < 0 || options->groups_per_workgroup > 3 ||
-        options->dma_staging < -1 || options->dma_staging > 1 ||
-        options->rt_column_blocks < 0 || options->rt_column_blocks > 4 ||
-        options->rt_k_groups < 0 || options->rt_k_groups > 2)
-      return MTR_E_PARAM;
-    opt.rt_tiles = options->rt_tiles_per_workgroup;
-    opt.rt_np = options->rt_column_blocks;
-    opt.rt_ks = options->rt_k_groups;
-    opt.groups_per_wg = options->groups_per_workgroup;
-    opt.dma = options->dma_staging;
+  {
+    const int rc = parse_head_options(options, opt);
+    if (rc != MTR_OK) return rc;
   }
   const mtr::HeadScale hs = mtr::make_head_scale(*p);
   hipStream_t s = (hipStream_t)stream;
   if (feat_dtype == MTR_F32) {  // the row-tile core: any map size, D <= 80
     if (!mtr::rt_shape_ok(C, J, D)) return MTR_E_SHAPE;  // -> 1x1-conv GEMM + mtr_softargmax_decode
     if (B == 0) return MTR_OK;
+    if (workspace && ((uintptr_t)workspace % 8)) return MTR_E_ALIGN;
     return mtr::rt_launch((const float*)features, layout, packed, B, C, H, W, J, D, hs, coords2d,
-                          coords3d_rel, opt.rt_tiles, opt.rt_np, opt.rt_ks, s);
+                          coords3d_rel, opt.rt_tiles, opt.rt_np, opt.rt_ks, opt.rt_ld, opt.rt_split,
+                          workspace, workspace_bytes, s);
   }
   // 16-bit joint-group kernels: a joint's 1 + D rows inside one 64-row tile, maps of <= 256 positions
   if (!mtr::h16_shape_ok(C, J, D) || H * W > 256) return MTR_E_SHAPE;

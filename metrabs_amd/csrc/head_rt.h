@@ -105,8 +105,21 @@ int rt_pack(const float* weight, const float* bias, int C, int J, int D, void* s
 // blocks of 64 positions per workgroup tile for maps of more than 64 positions (0 = pick, 1 = one
 // K loop per column block, 2..4); ks_hint: K groups per workgroup, 0 = pick, 1 = one,
 // 2 = two wherever the kernel can (C % 64 == 0, blocks of <= 3 tiles).
+// ld_hint: loader-wave kernel (four MFMA waves + one wave that issues every copy), 0 = pick, 1 =
+// never, 2 = whenever it can (C % 32 == 0); split_hint: the column blocks of a map of more than 64
+// positions dealt to different workgroups and merged by a second, tiny launch through `workspace`
+// (rt_workspace_bytes; may be NULL: no split), 0 = pick, 1 = never, 2 = whenever possible.
 int rt_launch(const float* feat, int layout, const void* section, int B, int C, int H, int W, int J,
               int D, const HeadScale& hs, float* coords2d, float* coords3d_rel, int rtg_hint, int np_hint,
-              int ks_hint, hipStream_t stream);
+              int ks_hint, int ld_hint, int split_hint, void* workspace, size_t workspace_bytes,
+              hipStream_t stream);
+size_t rt_workspace_bytes(int B, int J, int D, int H, int W);
+
+// which kernel a launch takes: kernel id (MTR_HEAD_KERNEL_* of the header), tiles per workgroup, column
+// blocks per workgroup tile (np kernel), column-block split (0 = none), workgroups of the main launch
+enum { kRtKernelPlain = 1, kRtKernelLoader = 2, kRtKernelTwoKGroups = 3, kRtKernelNp = 4 };
+struct RtDispatch { int kernel, rtg, np, split; long long n_wg; };
+RtDispatch rt_dispatch(int B, int C, int H, int W, int J, int D, int rtg_hint, int np_hint, int ks_hint,
+                       int ld_hint, int split_hint, bool have_workspace);
 
 }  // namespace mtr

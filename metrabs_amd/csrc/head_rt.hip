@@ -48,6 +48,22 @@ using v4f = __attribute__((ext_vector_type(4))) float;
 #ifndef MTR_RT_KS_NBUF
 #define MTR_RT_KS_NBUF 2    // ring depth of each K group of head_rt_ks_kernel
 #endif
+#ifndef MTR_RT_SPREAD_READS
+#define MTR_RT_SPREAD_READS 0   // 1: the fragment reads of a half stage go one per MFMA shadow of the half stage in
+                                // front of it instead of as a burst of RT + NP ds_reads (the four MFMA waves of a
+                                // workgroup run in lock-step: their bursts meet in the LDS queue and no MFMA issues
+                                // behind a queued read)
+#endif
+#ifndef MTR_RT_SCALAR_ADD
+#define MTR_RT_SCALAR_ADD 0
+#endif
+#ifndef MTR_RT_LD_NBUF
+#define MTR_RT_LD_NBUF 4    // ring depth of the loader-wave kernels (head_rt_ld_kernel) for blocks of <= 3 tiles
+#endif
+#ifndef MTR_RT_LD_LA
+#define MTR_RT_LD_LA 3      // ... and the stages its loader runs ahead (<= ring depth - 1; copies per stage x (LA - 1)
+                            // must fit the 6-bit vmcnt)
+#endif
 #ifndef MTR_RT_EXP32
 #define MTR_RT_EXP32 1      // 1: v_exp_f32 in the decode epilogue (f64 sums; measured -0.9 us at B=64, -11 us at
                             // B=1024, parity unchanged: the stand-alone decode does the same); 0: f64 polynomial
@@ -122,7 +138,7 @@ __device__ __forceinline__ unsigned rt_lds_addr(const void* p) {
 __device__ __forceinline__ void rt_dma16(const void* sbase, unsigned voff, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                :
-               : "s"(lds_addr), "v"(voff), "s"(sbase)
+               : "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(sbase)
                : "memory");
 }
 
@@ -142,6 +158,12 @@ struct RtArgs {
   AxisInv inv;           // 1 / (W - 1), 1 / (H - 1), 1 / (D - 1)
   float* c2d;
   float* c3d;
+  // column blocks of a map dealt to different workgroups (maps of more than 64 positions on small
+  // launches): cb_split = their number (0 = every workgroup walks all of its column blocks itself),
+  // ws = [B][cb_split][n_tiles * 16][5] f64: per packed row that starts a softmax unit, the unit's
+  // (max, sum e, sum e x, sum e y, sum e z) over ONE column block, merged by head_rt_merge_kernel
+  double* ws;
+  int cb_split;
 };
 
 constexpr int kRtCarry = 8;  // stages (of 32 channels) summed in f32 before the sum goes into f64
@@ -177,6 +199,28 @@ __device__ __forceinline__ void rt_read_frags(const char* buf, int a_addr, int b
   }
 }
 
+// ... one of them: unit u < RT is the fragment of row tile u, unit RT + p that of column block p
+template <int RT, int NP, bool NHWC>
+__device__ __forceinline__ void rt_read_frag_unit(const char* buf, int a_addr, int b_addr, v4f (&fa)[RT],
+                                                  v4f (&fb)[NP], int u) {
+  if (MTR_RT_ABLATE & 16) {
+    if (u < RT) fa[u] = v4f{(float)a_addr, 1.f, 2.f, (float)u};
+    else fb[u - RT] = v4f{(float)b_addr, 1.f, 2.f, (float)u};
+    return;
+  }
+  if (u < RT) {
+    fa[u] = *reinterpret_cast<const v4f*>(buf + u * 2048 + a_addr);
+  } else {
+    const int p = u - RT;
+    if constexpr (NHWC) {
+      fb[p] = *reinterpret_cast<const v4f*>(buf + RT * 2048 + p * rt_feat_chunk(true) + b_addr);
+    } else {
+      const float* q = reinterpret_cast<const float*>(buf + RT * 2048 + p * rt_feat_chunk(false) + b_addr);
+      fb[p] = v4f{q[0], q[64], q[128], q[192]};
+    }
+  }
+}
+
 // One MFMA slot: slot n of a half stage is accumulator n % (RT NP), k-step n / (RT NP)
 // (accumulator-major inside a k-step, so consecutive MFMAs never share an accumulator).  A stage's
 // chain starts from zero in the first k-step of its first half.
@@ -198,8 +242,18 @@ template <int RT>
 __device__ __forceinline__ void rt_run_add(v4f (&run)[RT], const v4f (&done)[RT], int e2) {
   if (MTR_RT_ABLATE & 8) return;
   const int t = e2 >> 1, r = (e2 & 1) * 2;
+#if MTR_RT_SCALAR_ADD
+  // two v_add_f32 instead of the v_pk_add_f32 the compiler forms from the pair (MI355X_MICROARCH.md:
+  // packed f32 VALU beside MFMAs costs ~+13 cycles per instruction over its issue slot)
+  float x0 = run[t][r], x1 = run[t][r + 1];
+  asm volatile("v_add_f32 %0, %0, %1" : "+v"(x0) : "v"(done[t][r]));
+  asm volatile("v_add_f32 %0, %0, %1" : "+v"(x1) : "v"(done[t][r + 1]));
+  run[t][r] = x0;
+  run[t][r + 1] = x1;
+#else
   run[t][r] += done[t][r];
   run[t][r + 1] += done[t][r + 1];
+#endif
 }
 // the running sums into f64, and restart them
 template <int RT>
@@ -212,6 +266,166 @@ __device__ __forceinline__ void rt_flush(double (&acc)[RT][4], v4f (&run)[RT]) {
   }
 }
 
+// A softmax unit's (max, sums) over column block cb are complete.  One workgroup walking all blocks:
+// merge with the blocks before it like an online softmax -- the running (max, 4 sums) live in LDS
+// (runstat), not in registers that would stay allocated through the K loop -- and write the
+// coordinates behind the last block.  Blocks dealt to different workgroups (a.ws): hand the five
+// numbers to head_rt_merge_kernel, which merges them in the same order with the same arithmetic.
+__device__ __forceinline__ void rt_unit_finish(const RtArgs& a, int crop, int t0, int row, int kind, int j,
+                                               int cb, int n_cb, float umax, double S, double SX, double SY,
+                                               double SZ, double* runstat) {
+  double run_m = (double)umax, run_s = S, run_x = SX, run_y = SY, run_z = SZ;
+  if (a.cb_split) {
+    double* w = a.ws + (((size_t)crop * n_cb + cb) * ((size_t)a.n_tiles * 16) + (size_t)(t0 * 16 + row)) * 5;
+    w[0] = run_m; w[1] = run_s; w[2] = run_x; w[3] = run_y; w[4] = run_z;
+    return;
+  }
+  if (cb > 0) {
+    const double pm = runstat[row * 5];
+    const double mn = fmax(pm, run_m);
+    const double zero = pm - pm;  // 0.0 at run time (the maxima are finite)
+    const double f1 = exp_neg64_late(pm - mn, zero), f2 = exp_neg64_late(run_m - mn, zero);
+    run_s = runstat[row * 5 + 1] * f1 + S * f2;
+    run_x = runstat[row * 5 + 2] * f1 + SX * f2;
+    run_y = runstat[row * 5 + 3] * f1 + SY * f2;
+    run_z = runstat[row * 5 + 4] * f1 + SZ * f2;
+    run_m = mn;
+  }
+  if (cb < n_cb - 1) {
+    runstat[row * 5] = run_m;
+    runstat[row * 5 + 1] = run_s;
+    runstat[row * 5 + 2] = run_x;
+    runstat[row * 5 + 3] = run_y;
+    runstat[row * 5 + 4] = run_z;
+  }
+  if (cb == n_cb - 1) {
+    const size_t o = (size_t)crop * a.J + j;
+    const double inv_s = fast_rcp64(run_s);
+    if (kind == 1) {
+      a.c2d[o * 2 + 0] = heatmap_to_px(axis_coord_rcp(run_x, inv_s, a.inv.w), a.hs);
+      a.c2d[o * 2 + 1] = heatmap_to_px(axis_coord_rcp(run_y, inv_s, a.inv.h), a.hs);
+    } else {
+      a.c3d[o * 3 + 0] = heatmap_to_mm_xy(axis_coord_rcp(run_x, inv_s, a.inv.w), a.hs);
+      a.c3d[o * 3 + 1] = heatmap_to_mm_xy(axis_coord_rcp(run_y, inv_s, a.inv.h), a.hs);
+      a.c3d[o * 3 + 2] = heatmap_to_mm_z(axis_coord_rcp(run_z, inv_s, a.inv.d), a.hs);
+    }
+  }
+}
+
+// Column blocks dealt to different workgroups: one thread per (crop, packed row that starts a
+// unit) merges the blocks' (max, sums) in block order -- the arithmetic of rt_unit_finish's LDS
+// merge, so the coordinates are those of the one-workgroup walk bit for bit.
+__global__ __launch_bounds__(256) void head_rt_merge_kernel(RtArgs a, int n_cb) {
+  const int n_rows = a.n_tiles * 16;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)a.B * n_rows) return;
+  const int crop = (int)(idx / n_rows), row = (int)(idx - (long long)crop * n_rows);
+  const unsigned inf = (unsigned)a.info[row];
+  const int kind = inf & 3, d = (inf >> 2) & 0x3fff, j = (int)(inf >> 16);
+  if (!(kind == 1 || (kind == 2 && d == 0))) return;
+  const double* w = a.ws + ((size_t)crop * n_cb * n_rows + row) * 5;
+  double run_m = w[0], run_s = w[1], run_x = w[2], run_y = w[3], run_z = w[4];
+  for (int cb = 1; cb < n_cb; ++cb) {
+    const double* v = w + (size_t)cb * n_rows * 5;
+    const double mn = fmax(run_m, v[0]);
+    const double f1 = exp_neg64(run_m - mn), f2 = exp_neg64(v[0] - mn);
+    run_s = run_s * f1 + v[1] * f2;
+    run_x = run_x * f1 + v[2] * f2;
+    run_y = run_y * f1 + v[3] * f2;
+    run_z = run_z * f1 + v[4] * f2;
+    run_m = mn;
+  }
+  const size_t o = (size_t)crop * a.J + j;
+  const double inv_s = fast_rcp64(run_s);
+  if (kind == 1) {
+    a.c2d[o * 2 + 0] = heatmap_to_px(axis_coord_rcp(run_x, inv_s, a.inv.w), a.hs);
+    a.c2d[o * 2 + 1] = heatmap_to_px(axis_coord_rcp(run_y, inv_s, a.inv.h), a.hs);
+  } else {
+    a.c3d[o * 3 + 0] = heatmap_to_mm_xy(axis_coord_rcp(run_x, inv_s, a.inv.w), a.hs);
+    a.c3d[o * 3 + 1] = heatmap_to_mm_xy(axis_coord_rcp(run_y, inv_s, a.inv.h), a.hs);
+    a.c3d[o * 3 + 2] = heatmap_to_mm_z(axis_coord_rcp(run_z, inv_s, a.inv.d), a.hs);
+  }
+}
+
+// The loader wave of head_rt_ld_kernel (see rt_block): ALL copies of every stage of one K loop, NBUF - 1
+// stages ahead of the MFMA waves.  Per stage: wait until this wave's copies of stage s have landed
+// (those of s + 1 .. s + NBUF - 2 stay in flight), meet the MFMA waves at barrier B_s -- they have
+// then also left the slot of stage s - 1 --, and refill that slot with stage s + NBUF - 1.  Job j <
+// 2 RT: KiB j of the block's packed weight tiles; the other 8: the 1-KiB chunks of the column
+// block's 64 positions x 32 channels (layouts as in rt_block).  The sources advance by scalar adds.
+__host__ __device__ constexpr int rt_ld_nbuf(int rtmax) { return rtmax <= 3 ? MTR_RT_LD_NBUF : 4; }
+__host__ __device__ constexpr int rt_ld_la(int rtmax) { return rtmax <= 3 ? MTR_RT_LD_LA : 3; }
+
+template <int RT, bool NHWC, int NBUF, int LA>
+__device__ __forceinline__ void rt_loader_loop(const RtArgs& a, unsigned lds0, const char* fcrop, int t0,
+                                               int cb, int n_stages, int lane, int HW) {
+  constexpr int STAGE = rt_stage_bytes(RT, 1, NHWC);
+  constexpr int JOBS = 2 * RT + 8;
+  static_assert(LA >= 1 && LA <= NBUF - 1 && JOBS * (LA - 1) <= 63, "s_waitcnt vmcnt is a 6-bit count");
+  // (the per-lane offsets below are derived HERE: without the empty asm the compiler computes them once
+  //  in front of the column-block loop and keeps JOBS registers alive through the MFMA waves' path)
+  asm volatile("" : "+v"(lane));
+  const char* wsrc = uniform_ptr(a.wt + (size_t)t0 * 2048);
+  const char* fsrc = uniform_ptr(fcrop);
+  const unsigned wstride = (unsigned)a.n_tiles * 2048u;
+  const unsigned fstride = NHWC ? 128u : 32u * (unsigned)HW * 4u;
+  unsigned vo[JOBS];
+#pragma unroll
+  for (int j = 0; j < JOBS; ++j) {
+    if (j < 2 * RT) {
+      vo[j] = (unsigned)lane * 16u + (unsigned)j * 1024u;
+    } else {
+      const int jb = j - 2 * RT;
+      if constexpr (NHWC) {
+        const int pos = jb * 8 + (lane >> 3), slot = (lane & 7) ^ ((pos >> 1) & 7);
+        const int P = cb * 64 + pos;
+        vo[j] = (unsigned)(P < HW ? P : 0) * (unsigned)a.C * 4u + slot * 16;
+      } else {
+        const int ch = jb * 4 + (lane >> 4);
+        const int p = cb * 64 + (lane & 15) * 4;
+        vo[j] = (unsigned)ch * (unsigned)HW * 4u + (unsigned)(p < HW ? p : 0) * 4u;
+      }
+    }
+  }
+  auto issue = [&](int slot) {
+    const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)slot * STAGE));
+#pragma unroll
+    for (int j = 0; j < JOBS; ++j) {
+      if (j < 2 * RT)
+        rt_dma16(wsrc, vo[j], base + j * 1024);
+      else
+        rt_dma16(fsrc, vo[j], base + RT * 2048 + (j - 2 * RT) * (NHWC ? 1024 : kRtChunkNCHW));
+    }
+    wsrc = uniform_ptr(wsrc + wstride);
+    fsrc = uniform_ptr(fsrc + fstride);
+  };
+  int slot = 0;
+  for (int p = 0; p < LA && p < n_stages; ++p) {
+    issue(slot);
+    slot = slot + 1 == NBUF ? 0 : slot + 1;
+  }
+  for (int s = 0; s < n_stages; ++s) {
+    const int rem = n_stages - 1 - s;  // stages behind s; min(rem, LA - 1) of them are in flight
+    if (rem >= LA - 1) {
+      rt_wait_vmcnt<JOBS * (LA - 1)>();
+    } else {
+      bool waited = false;
+      if constexpr (LA - 1 >= 3) {
+        if (rem == 2) { rt_wait_vmcnt<JOBS * 2>(); waited = true; }
+      }
+      if constexpr (LA - 1 >= 2) {
+        if (rem == 1) { rt_wait_vmcnt<JOBS>(); waited = true; }
+      }
+      if (!waited) rt_wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (s + LA < n_stages && !(MTR_RT_ABLATE & 4)) {
+      issue(slot);
+      slot = slot + 1 == NBUF ? 0 : slot + 1;
+    }
+  }
+}
+
 // KS = 2 (head_rt_ks_kernel, 512 threads): waves 4 .. 7 are a second K group -- same tiles, same
 // positions, the ODD 32-channel stages through a ring of their own.  Two waves per SIMD for the
 // launches that give every CU one workgroup: the matrix pipe works for one wave while the other
@@ -220,11 +434,22 @@ __device__ __forceinline__ void rt_flush(double (&acc)[RT][4], v4f (&run)[RT]) {
 // group through LDS (hb: two buffers by iteration parity, a third for the drain); the even group adds the chains to
 // its f32 running sums in stage order c0, c1, c2, ... and carries them into f64 at the same
 // stage boundaries (after c7, c15, ...) as rt_block<KS = 1> does.
-template <int RT, int NP, int RTMAX, bool NHWC, int KS = 1>
-__device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, int t0) {
+//
+// LD (head_rt_ld_kernel, 320 threads): a FIFTH wave is the loader -- it issues every
+// global_load_lds of a stage, waits for its own copies with a counted vmcnt and meets the four
+// MFMA waves at the stage barrier; those never execute a copy or a vmcnt wait: barrier, fragment
+// reads, MFMAs.  A copy costs an MFMA wave 60 - 185 issue cycles beside its MFMAs
+// (MI355X_MICROARCH.md, "LDS-DMA piece issue cost") against ~23 in a wave that does nothing else,
+// and with one MFMA wave per SIMD nothing else fills those gaps.  Same chains, same sums, same bits.
+// cb_first / cb_count: the column blocks this workgroup decodes (all of them, or ONE when the
+// blocks of a map are dealt to different workgroups and merged by head_rt_merge_kernel).
+template <int RT, int NP, int RTMAX, bool NHWC, int KS = 1, bool LD = false>
+__device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, int t0, int cb_first = 0,
+                                         int cb_count = 1 << 30) {
+  static_assert(!LD || (KS == 1 && NP == 1), "the loader wave serves one K group of one column block");
   constexpr int STAGE = rt_stage_bytes(RT, NP, NHWC);
-  constexpr int kRtNbuf = KS == 2 ? MTR_RT_KS_NBUF : rt_nbuf(RTMAX, NP, NHWC);
-  constexpr bool kPair = MTR_RT_PAIR && KS == 1 && kRtNbuf == 4;
+  constexpr int kRtNbuf = LD ? rt_ld_nbuf(RTMAX) : (KS == 2 ? MTR_RT_KS_NBUF : rt_nbuf(RTMAX, NP, NHWC));
+  constexpr bool kPair = MTR_RT_PAIR && KS == 1 && kRtNbuf == 4 && !LD;
   constexpr int LA = kPair ? 2 : kRtNbuf - 1;   // stages in flight behind the one being consumed
   constexpr int NG = 16 * KS;                   // 16-lane groups of the workgroup (decode: one row each)
   constexpr int KR = (RT * 16 + NG - 1) / NG;   // decode rounds
@@ -248,6 +473,7 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wid = wave & 3, kg = KS == 2 ? wave >> 2 : 0;  // position group, K group
+  const bool is_loader = LD && wave == 4;                   // (wave-uniform)
   const int HW = a.H * a.W;
   const int n_stages = KS == 2 ? a.n_stages / 2 : a.n_stages;  // of this K group (KS = 2: C % 64 == 0)
   char* ring = smem + kg * kRtNbuf * STAGE;
@@ -275,7 +501,12 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
   }
 
   const int n_cb = (HW + 63) >> 6;
-  for (int cb0 = 0; cb0 < n_cb; cb0 += NP) {  // groups of NP column blocks: one K loop each
+  const int cb_end = cb_first + cb_count < n_cb ? cb_first + cb_count : n_cb;
+  for (int cb0 = cb_first; cb0 < cb_end; cb0 += NP) {  // groups of NP column blocks: one K loop each
+    if constexpr (LD) {
+      if (is_loader) rt_loader_loop<RT, NHWC, kRtNbuf, rt_ld_la(RTMAX)>(a, lds0, fcrop, t0, cb0, n_stages, lane, HW);
+    }
+    if (!is_loader) {
     // ---- this wave's copies: job j = wid + 4 i (0 .. 2RT-1: weight tiles, then 8 feature chunks).
     // A wave issues JPW copies per stage, or JPW - 1 when its last index falls behind the list
     // (wave-uniform; its counted s_waitcnt is one smaller per stage in flight).  Round 2: such a wave
@@ -366,14 +597,16 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
       }
     }
     // prologue: stages 0 .. NBUF-2 in flight
-    if (c_tail && n_stages == 1) redirect_tail();
+    if constexpr (!LD) {
+      if (c_tail && n_stages == 1) redirect_tail();
 #pragma unroll
-    for (int p = 0; p < LA; ++p)
-      if (p < n_stages) {
+      for (int p = 0; p < LA; ++p)
+        if (p < n_stages) {
 #pragma unroll
-        for (int i = 0; i < JPW; ++i) issue_job(i, p);
-        stage_issued();
-      }
+          for (int i = 0; i < JPW; ++i) issue_job(i, p);
+          stage_issued();
+        }
+    }
 
     // Iteration of stage s with parity P = s & 1 and ring slot BUF = s % NBUF (literals: the chains
     // are registers, the LDS addresses immediates):
@@ -395,8 +628,10 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
     // 2 = odd group: no sums, every finished chain goes to hb[S & 1]
 #define RT_BODY(S, P, BUF, MORE, ROLE)                                                            \
   {                                                                                               \
-    const bool more = (MORE);                                                                     \
-    if (kPair) { /* even stages: this wave's copies of stages S and S + 1 have landed, then meet */ \
+    const bool more = (MORE) && !LD;                                                              \
+    if (LD) { /* the loader wave waited for the copies of stage S; nothing of ours is in flight */ \
+      __syncthreads();                                                                            \
+    } else if (kPair) { /* even stages: this wave's copies of stages S and S + 1 have landed, then meet */ \
       if (((S) & 1) == 0) { rt_wait_vmcnt<0>(); __syncthreads(); }                                \
     } else {                                                                                      \
       if (!more || kRtNbuf == 2) rt_wait_vmcnt<0>();                                              \
@@ -406,7 +641,8 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
     }                                                                                             \
     const char* buf = ring + (BUF) * STAGE;                                                       \
     v4f xa[RT], xb[NP];                                                                           \
-    rt_read_frags<RT, NP, NHWC>(buf, a_off, b_off, xa, xb);                                       \
+    constexpr int R0 = LD ? 0 : JPW;   /* first MFMA slot of block A that takes a fragment read */ \
+    if (!MTR_RT_SPREAD_READS) rt_read_frags<RT, NP, NHWC>(buf, a_off, b_off, xa, xb);             \
     v4f lr[NA];                                                                                   \
     if (ROLE == 1) {                                                                              \
       _Pragma("unroll") for (int q = 0; q < NA; ++q)                                              \
@@ -418,19 +654,31 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
       if (n < JPW && more && !(MTR_RT_ABLATE & 4)) issue_job(n, ((BUF) + LA) % kRtNbuf);          \
       if (n == JPW && more) stage_issued();                                                       \
       if (ROLE == 1 && n >= 2 * NA) rt_run_add<NA>(rg.run, lr, n - 2 * NA);                       \
+      if (MTR_RT_SPREAD_READS && n >= R0 && n - R0 < RT + NP)                                     \
+        rt_read_frag_unit<RT, NP, NHWC>(buf, a_off, b_off, xa, xb, n - R0);                       \
       __builtin_amdgcn_sched_barrier(0);                                                          \
     }                                                                                             \
+    if (MTR_RT_SPREAD_READS) {                                                                    \
+      _Pragma("unroll") for (int u = (4 * NA - R0 > 0 ? 4 * NA - R0 : 0); u < RT + NP; ++u)       \
+        rt_read_frag_unit<RT, NP, NHWC>(buf, a_off, b_off, xa, xb, u);                            \
+    }                                                                                             \
     if (ROLE == 1 && (S) >= 5 && ((S) - 1) % 4 == 0) rt_flush<NA>(rg.acc, rg.run);                \
-    rt_read_frags<RT, NP, NHWC>(buf, a_off ^ 64, b_q1, rg.ya, rg.yb);                             \
+    if (!MTR_RT_SPREAD_READS) rt_read_frags<RT, NP, NHWC>(buf, a_off ^ 64, b_q1, rg.ya, rg.yb);   \
     __builtin_amdgcn_sched_barrier(0);                                                            \
     _Pragma("unroll") for (int n = 0; n < 4 * NA; ++n) {                                          \
       rt_mfma_slot<RT, NP>(rg.part[P], xa, xb, n, true);                                          \
+      if (MTR_RT_SPREAD_READS && n < RT + NP)                                                     \
+        rt_read_frag_unit<RT, NP, NHWC>(buf, a_off ^ 64, b_q1, rg.ya, rg.yb, n);                  \
       if (ROLE != 2) {                                                                            \
         if (n % 2 == 1) rt_run_add<NA>(rg.run, rg.part[(P) ^ 1], n / 2);                          \
       } else if (n % 2 == 1 && n / 2 < NA) {                                                      \
         hb[(((S) & 1) * 4 + wid) * NA * 64 + (n / 2) * 64 + lane] = rg.part[(P) ^ 1][n / 2];      \
       }                                                                                           \
       __builtin_amdgcn_sched_barrier(0);                                                          \
+    }                                                                                             \
+    if (MTR_RT_SPREAD_READS) {                                                                    \
+      _Pragma("unroll") for (int u = 4 * NA; u < RT + NP; ++u)                                    \
+        rt_read_frag_unit<RT, NP, NHWC>(buf, a_off ^ 64, b_q1, rg.ya, rg.yb, u);                  \
     }                                                                                             \
   }
 #define RT_ITER(S, P, BUF, MORE)                                                                  \
@@ -555,6 +803,7 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
           Ls[row * LP + (q / RT) * kRtLP + col] = (float)(rg.acc[q][r] + (double)bias_s[row]);
         }
     }
+    }  // (!is_loader)
     __syncthreads();
 
     if (MTR_RT_ABLATE & 1) {  // no decode: one store per workgroup keeps the GEMM alive
@@ -577,7 +826,7 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
 #pragma unroll
     for (int k = 0; k < KR; ++k) {
       const int row = k * NG + grp;
-      if (KR * NG > R && row >= R) continue;
+      if ((KR * NG > R && row >= R) || is_loader) continue;
       x[k] = *reinterpret_cast<const v4f*>(Lb + row * LP + l16 * 4);
       float m = -INFINITY;
 #pragma unroll
@@ -590,7 +839,7 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
 #pragma unroll
     for (int k = 0; k < KR; ++k) {
       const int row = k * NG + grp;
-      if (KR * NG > R && row >= R) continue;
+      if ((KR * NG > R && row >= R) || is_loader) continue;
       const unsigned inf = (unsigned)info_s[row];
       const int kind = inf & 3, d = (inf >> 2) & 0x3fff;
       const int first = kind == 2 ? row - d : row, n = kind == 2 ? a.D : 1;
@@ -629,7 +878,7 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
   #pragma unroll
       for (int k = 0; k < KR; ++k) {
         const int row = k * NG + grp;
-        if (KR * NG > R && row >= R) continue;
+        if ((KR * NG > R && row >= R) || is_loader) continue;
         const unsigned inf = (unsigned)info_s[row];
         const int kind = inf & 3, d = (inf >> 2) & 0x3fff, j = (int)(inf >> 16);
         if (!(kind == 1 || (kind == 2 && d == 0))) continue;  // (uniform in the group)
@@ -649,39 +898,7 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
           SZ = group_sum<16>(SZ);
         }
         if (l16 != 0) continue;
-        // (max, sums) of the unit across column blocks live in LDS, not in registers that would
-        // stay allocated through the K loop
-        double run_m = (double)unitmax[row], run_s = S, run_x = SX, run_y = SY, run_z = SZ;
-        if (cb > 0) {
-          const double pm = runstat[row * 5];
-          const double mn = fmax(pm, run_m);
-          const double zero = pm - pm;  // 0.0 at run time (the maxima are finite)
-          const double f1 = exp_neg64_late(pm - mn, zero), f2 = exp_neg64_late(run_m - mn, zero);
-          run_s = runstat[row * 5 + 1] * f1 + S * f2;
-          run_x = runstat[row * 5 + 2] * f1 + SX * f2;
-          run_y = runstat[row * 5 + 3] * f1 + SY * f2;
-          run_z = runstat[row * 5 + 4] * f1 + SZ * f2;
-          run_m = mn;
-        }
-        if (cb < n_cb - 1) {
-          runstat[row * 5] = run_m;
-          runstat[row * 5 + 1] = run_s;
-          runstat[row * 5 + 2] = run_x;
-          runstat[row * 5 + 3] = run_y;
-          runstat[row * 5 + 4] = run_z;
-        }
-        if (cb == n_cb - 1) {
-          const size_t o = (size_t)crop * a.J + j;
-          const double inv_s = fast_rcp64(run_s);
-          if (kind == 1) {
-            a.c2d[o * 2 + 0] = heatmap_to_px(axis_coord_rcp(run_x, inv_s, a.inv.w), a.hs);
-            a.c2d[o * 2 + 1] = heatmap_to_px(axis_coord_rcp(run_y, inv_s, a.inv.h), a.hs);
-          } else {
-            a.c3d[o * 3 + 0] = heatmap_to_mm_xy(axis_coord_rcp(run_x, inv_s, a.inv.w), a.hs);
-            a.c3d[o * 3 + 1] = heatmap_to_mm_xy(axis_coord_rcp(run_y, inv_s, a.inv.h), a.hs);
-            a.c3d[o * 3 + 2] = heatmap_to_mm_z(axis_coord_rcp(run_z, inv_s, a.inv.d), a.hs);
-          }
-        }
+        rt_unit_finish(a, crop, t0, row, kind, j, cb, n_cb, unitmax[row], S, SX, SY, SZ, runstat);
       }
     } else {
       int tid_c = tid;
@@ -699,39 +916,7 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
             SY += rowsum[(tid_c + k) * 3 + 2];
             SZ += s * (double)k;
           }
-          // (max, sums) of the unit across column blocks live in LDS, not in registers that would
-          // stay allocated through the K loop
-          double run_m = (double)unitmax[tid_c], run_s = S, run_x = SX, run_y = SY, run_z = SZ;
-          if (cb > 0) {
-            const double pm = runstat[tid_c * 5];
-            const double mn = fmax(pm, run_m);
-            const double zero = pm - pm;  // 0.0 at run time (the maxima are finite)
-            const double f1 = exp_neg64_late(pm - mn, zero), f2 = exp_neg64_late(run_m - mn, zero);
-            run_s = runstat[tid_c * 5 + 1] * f1 + S * f2;
-            run_x = runstat[tid_c * 5 + 2] * f1 + SX * f2;
-            run_y = runstat[tid_c * 5 + 3] * f1 + SY * f2;
-            run_z = runstat[tid_c * 5 + 4] * f1 + SZ * f2;
-            run_m = mn;
-          }
-          if (cb < n_cb - 1) {
-            runstat[tid_c * 5] = run_m;
-            runstat[tid_c * 5 + 1] = run_s;
-            runstat[tid_c * 5 + 2] = run_x;
-            runstat[tid_c * 5 + 3] = run_y;
-            runstat[tid_c * 5 + 4] = run_z;
-          }
-          if (cb == n_cb - 1) {
-            const size_t o = (size_t)crop * a.J + j;
-            const double inv_s = fast_rcp64(run_s);
-            if (kind == 1) {
-              a.c2d[o * 2 + 0] = heatmap_to_px(axis_coord_rcp(run_x, inv_s, a.inv.w), a.hs);
-              a.c2d[o * 2 + 1] = heatmap_to_px(axis_coord_rcp(run_y, inv_s, a.inv.h), a.hs);
-            } else {
-              a.c3d[o * 3 + 0] = heatmap_to_mm_xy(axis_coord_rcp(run_x, inv_s, a.inv.w), a.hs);
-              a.c3d[o * 3 + 1] = heatmap_to_mm_xy(axis_coord_rcp(run_y, inv_s, a.inv.h), a.hs);
-              a.c3d[o * 3 + 2] = heatmap_to_mm_z(axis_coord_rcp(run_z, inv_s, a.inv.d), a.hs);
-            }
-          }
+          rt_unit_finish(a, crop, t0, tid_c, kind, j, cb, n_cb, unitmax[tid_c], S, SX, SY, SZ, runstat);
         }
       }
     }
@@ -742,24 +927,37 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
   }
 }
 
+// Block id -> (crop, block of tiles, column blocks).  XCD-aware (block id b runs on XCD b % 8): the
+// workgroups of a crop -- its tile blocks and, when the column blocks of a map are dealt to
+// different workgroups, those too -- share an XCD, so the crop's features come from HBM once and
+// are re-read from that XCD's L2.
+struct RtWork { int crop, blk, cb_first, cb_count; };
+__device__ __forceinline__ RtWork rt_work(const RtArgs& a) {
+  const int per_crop = a.n_blocks * (a.cb_split ? a.cb_split : 1);
+  const int chunk = 8 * per_crop;
+  const int id = blockIdx.x;
+  RtWork w;
+  w.crop = (id / chunk) * 8 + (id % 8);
+  const int rest = (id % chunk) / 8;
+  w.blk = rest % a.n_blocks;
+  w.cb_first = a.cb_split ? rest / a.n_blocks : 0;
+  w.cb_count = a.cb_split ? 1 : (1 << 30);
+  return w;
+}
+
 template <int RTMAX, bool NHWC>
 __global__ __launch_bounds__(256, RTMAX <= 3 ? 1 : 2) void head_rt_kernel(RtArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // XCD-aware remap (block id b runs on XCD b % 8): the blocks of a crop share an XCD, so its
-  // features come from HBM once and are re-read from that XCD's L2
-  const int chunk = 8 * a.n_blocks;
-  const int id = blockIdx.x;
-  const int crop = (id / chunk) * 8 + (id % 8);
-  const int blk = (id % chunk) / 8;
-  if (crop >= a.B) return;
-  const int t0 = blk * a.rtg;
+  const RtWork w = rt_work(a);
+  if (w.crop >= a.B) return;
+  const int t0 = w.blk * a.rtg;
   const int rt = min(a.rtg, a.n_tiles - t0);
-  if (rt == 1) rt_block<1, 1, RTMAX, NHWC>(a, smem, crop, t0);
-  if (rt == 2) rt_block<2, 1, RTMAX, NHWC>(a, smem, crop, t0);
-  if (rt == 3) rt_block<3, 1, RTMAX, NHWC>(a, smem, crop, t0);
+  if (rt == 1) rt_block<1, 1, RTMAX, NHWC>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
+  if (rt == 2) rt_block<2, 1, RTMAX, NHWC>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
+  if (rt == 3) rt_block<3, 1, RTMAX, NHWC>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
   if constexpr (RTMAX >= 5) {
-    if (rt == 4) rt_block<4, 1, RTMAX, NHWC>(a, smem, crop, t0);
-    if (rt == 5) rt_block<5, 1, RTMAX, NHWC>(a, smem, crop, t0);
+    if (rt == 4) rt_block<4, 1, RTMAX, NHWC>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
+    if (rt == 5) rt_block<5, 1, RTMAX, NHWC>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
   }
 }
 
@@ -767,20 +965,38 @@ __global__ __launch_bounds__(256, RTMAX <= 3 ? 1 : 2) void head_rt_kernel(RtArgs
 template <int RTMAX, bool NHWC>
 __global__ __launch_bounds__(512, 1) void head_rt_ks_kernel(RtArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int chunk = 8 * a.n_blocks;
-  const int id = blockIdx.x;
-  const int crop = (id / chunk) * 8 + (id % 8);
-  const int blk = (id % chunk) / 8;
-  if (crop >= a.B) return;
-  const int t0 = blk * a.rtg;
+  const RtWork w = rt_work(a);
+  if (w.crop >= a.B) return;
+  const int t0 = w.blk * a.rtg;
   const int rt = min(a.rtg, a.n_tiles - t0);
-  if (rt == 1) rt_block<1, 1, RTMAX, NHWC, 2>(a, smem, crop, t0);
-  if (rt == 2) rt_block<2, 1, RTMAX, NHWC, 2>(a, smem, crop, t0);
-  if (rt == 3) rt_block<3, 1, RTMAX, NHWC, 2>(a, smem, crop, t0);
+  if (rt == 1) rt_block<1, 1, RTMAX, NHWC, 2>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
+  if (rt == 2) rt_block<2, 1, RTMAX, NHWC, 2>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
+  if (rt == 3) rt_block<3, 1, RTMAX, NHWC, 2>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
 }
 __host__ __device__ constexpr int rt_ks_lds_bytes(int rtmax, bool nhwc) {
   return 2 * MTR_RT_KS_NBUF * rt_stage_bytes(rtmax, 1, nhwc) + rt_epilogue_bytes(rtmax, 1) +
          3 * 4 * rtmax * 1024;  // + the chain hand-over buffers (two by iteration parity + the drain's)
+}
+
+// Four MFMA waves + a loader wave (see rt_block<..., LD = true>): one workgroup per CU, blocks of
+// <= RTMAX tiles, C a multiple of 32.
+template <int RTMAX, bool NHWC>
+__global__ __launch_bounds__(320, 1) void head_rt_ld_kernel(RtArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const RtWork w = rt_work(a);
+  if (w.crop >= a.B) return;
+  const int t0 = w.blk * a.rtg;
+  const int rt = min(a.rtg, a.n_tiles - t0);
+  if (rt == 1) rt_block<1, 1, RTMAX, NHWC, 1, true>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
+  if (rt == 2) rt_block<2, 1, RTMAX, NHWC, 1, true>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
+  if (rt == 3) rt_block<3, 1, RTMAX, NHWC, 1, true>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
+  if constexpr (RTMAX >= 5) {
+    if (rt == 4) rt_block<4, 1, RTMAX, NHWC, 1, true>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
+    if (rt == 5) rt_block<5, 1, RTMAX, NHWC, 1, true>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
+  }
+}
+__host__ __device__ constexpr int rt_ld_lds_bytes(int rtmax, bool nhwc) {
+  return rt_ld_nbuf(rtmax) * rt_stage_bytes(rtmax, 1, nhwc) + rt_epilogue_bytes(rtmax, 1);
 }
 
 // Tiles of several column blocks (maps of more than 64 positions): RT row tiles x NP column blocks
@@ -789,16 +1005,13 @@ __host__ __device__ constexpr int rt_ks_lds_bytes(int rtmax, bool nhwc) {
 template <int RT, int NP, bool NHWC>
 __global__ __launch_bounds__(256, 1) void head_rt_np_kernel(RtArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int chunk = 8 * a.n_blocks;
-  const int id = blockIdx.x;
-  const int crop = (id / chunk) * 8 + (id % 8);
-  const int blk = (id % chunk) / 8;
-  if (crop >= a.B) return;
-  const int t0 = blk * a.rtg;
+  const RtWork w = rt_work(a);
+  if (w.crop >= a.B) return;
+  const int t0 = w.blk * a.rtg;
   const int rt = min(a.rtg, a.n_tiles - t0);
-  if (rt == RT) rt_block<RT, NP, RT, NHWC>(a, smem, crop, t0);
+  if (rt == RT) rt_block<RT, NP, RT, NHWC>(a, smem, w.crop, t0);
   if constexpr (RT == 2) {
-    if (rt == 1) rt_block<1, NP, RT, NHWC>(a, smem, crop, t0);
+    if (rt == 1) rt_block<1, NP, RT, NHWC>(a, smem, w.crop, t0);
   }
 }
 
@@ -808,11 +1021,17 @@ static int rt_launch_kernel(Kern kern, int lds, const RtArgs& a, hipStream_t str
     const int rc = allow_dynamic_lds((const void*)kern, (size_t)lds);
     if (rc != MTR_OK) return rc;
   }
-  const long long blocks = (long long)((a.B + 7) / 8) * 8 * a.n_blocks;
+  const long long blocks = (long long)((a.B + 7) / 8) * 8 * a.n_blocks * (a.cb_split ? a.cb_split : 1);
   if (blocks > 0x7fffffffLL) return MTR_E_SHAPE;
   MTR_CLEAR_STALE();
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads), lds, stream, a);
   MTR_CHECK_LAUNCH();
+  if (a.cb_split) {  // the column blocks' (max, sums) -> coordinates
+    const long long rows = (long long)a.B * a.n_tiles * 16;
+    hipLaunchKernelGGL(head_rt_merge_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, a,
+                       a.cb_split);
+    MTR_CHECK_LAUNCH();
+  }
   return MTR_OK;
 }
 
@@ -823,6 +1042,17 @@ static int rt_launch_t(const RtArgs& a, hipStream_t stream) {
 template <int RT, int NP, bool NHWC>
 static int rt_launch_np(const RtArgs& a, hipStream_t stream) {
   return rt_launch_kernel(head_rt_np_kernel<RT, NP, NHWC>, rt_lds_bytes(RT, NP, NHWC), a, stream);
+}
+template <int RTMAX, bool NHWC>
+static int rt_launch_ld(const RtArgs& a, hipStream_t stream) {
+  return rt_launch_kernel(head_rt_ld_kernel<RTMAX, NHWC>, rt_ld_lds_bytes(RTMAX, NHWC), a, stream, 320);
+}
+
+size_t rt_workspace_bytes(int B, int J, int D, int H, int W) {
+  if (!rt_shape_ok(1, J, D) || B <= 0 || H <= 0 || W <= 0) return 0;
+  const int n_cb = (H * W + 63) / 64;
+  if (n_cb < 2) return 0;
+  return (size_t)B * n_cb * rt_geom(J, D).n_tiles * 16 * 5 * sizeof(double);
 }
 
 int rt_pack(const float* weight, const float* bias, int C, int J, int D, void* section,
@@ -839,9 +1069,105 @@ int rt_pack(const float* weight, const float* bias, int C, int J, int D, void* s
   return MTR_OK;
 }
 
+// ---- launch plan.  Measured model of a launch (tools/experiments/head_sweep.py, profiles/r03*_head_sweep.jsonl;
+// C = 1280): a workgroup of r tiles alone on its CU takes about 5.5 + 6.3 r us (one K loop of 40
+// stages; the loader-wave kernel 4.7 + 6.1 r); two 256-thread workgroups sharing a CU take 1.65 x that
+// together; workgroups start as CUs free up, one per CU for the loader-wave kernel (320 threads, its
+// ring and registers fill the CU), two for the others.  The plan that minimises the estimate is
+// taken; it reproduces the measured best choice on every shape of the sweep (B = 8 .. 1024 at 8x8,
+// 12x12 / 16x16 / 24x24 with their column blocks dealt to workgroups).
+struct RtPlan { int mode; int rtg; double us; };  // mode 0 = head_rt_kernel, 1 = loader-wave kernel
+static double rt_wg_us(int mode, int r, int k_loops, double stage_scale) {
+  const double fixed = mode == 1 ? 4.7 : 5.5, per_tile = (mode == 1 ? 6.1 : (r <= 3 ? 6.3 : 6.5)) * stage_scale;
+  return fixed + k_loops * per_tile * r + (k_loops - 1) * 3.0;  // (+ a decode per further K loop)
+}
+static double rt_launch_us(int mode, int r, long long crops, int n_tiles, int k_loops, double stage_scale) {
+  const long long n_wg = crops * ((n_tiles + r - 1) / r);
+  const double t = rt_wg_us(mode, r, k_loops, stage_scale);
+  if (mode == 1) return (double)((n_wg + 255) / 256) * t;
+  const long long full = n_wg / 512, rem = n_wg % 512;
+  return full * 1.65 * t + (rem == 0 ? 0.0 : (rem <= 256 ? t : 1.65 * t));
+}
+static RtPlan rt_plan(long long crops, const RtGeom& g, int k_loops, int C, int rtg_hint, int ld_hint) {
+  const double stage_scale = ((C + 31) / 32) / 40.0;
+  const bool ld_ok = C % 32 == 0 && ld_hint != 1;
+  RtPlan best{0, g.a > 1 ? g.a : 3, 1e30};
+  for (int mode = 0; mode <= (ld_ok ? 1 : 0); ++mode) {
+    if (ld_hint == 2 && ld_ok && mode == 0) continue;
+    for (int r = 1; r <= 5; ++r) {
+      if (g.a > 1 && r != g.a) continue;                 // atoms of several tiles are one block
+      if (g.a == 1 && rtg_hint >= 1 && rtg_hint <= 5 && r != rtg_hint) continue;
+      const double us = rt_launch_us(mode, r, crops, g.n_tiles, k_loops, stage_scale);
+      if (us < best.us) best = RtPlan{mode, r, us};
+    }
+  }
+  return best;
+}
+
+// Which kernel a launch takes (shared by rt_launch and the host-only mtr_head_plan)
+RtDispatch rt_dispatch(int B, int C, int H, int W, int J, int D, int rtg_hint, int np_hint, int ks_hint,
+                       int ld_hint, int split_hint, bool have_workspace) {
+  const RtGeom g = rt_geom(J, D);
+  RtDispatch d{kRtKernelPlain, 3, 1, 0, 0};
+  const int n_cb = (H * W + 63) / 64;
+  const long long crops8 = (long long)((B + 7) / 8) * 8;
+  // ---- maps of more than 64 positions: deal the 64-position column blocks to DIFFERENT workgroups
+  // (their (max, sums) per softmax unit go through `workspace` to head_rt_merge_kernel, ~3 us for the
+  // second launch) instead of one workgroup running n_cb K loops back to back: a launch of B crops
+  // then has the shape of a launch of B * n_cb crops of 64 positions.  split_hint: 0 = when the
+  // model says it pays, 1 = never, 2 = whenever a workspace is there.
+  RtPlan plan = rt_plan(crops8, g, n_cb, C, rtg_hint, ld_hint);
+  if (n_cb >= 2 && have_workspace && split_hint != 1) {
+    RtPlan sp = rt_plan(crops8 * n_cb, g, 1, C, rtg_hint, ld_hint);
+    sp.us += 3.0;
+    if (split_hint == 2 || sp.us < plan.us) {
+      plan = sp;
+      d.split = n_cb;
+    }
+  }
+  // ---- maps of several column blocks, one-tile atoms, no split: RT x NP tiles (one K loop for NP column
+  // blocks) -- a workgroup of one row tile that runs n_cb K loops of 8 MFMAs per stage back to back
+  // is bound by its per-stage overhead, not by the matrix pipe.  Such a tile needs 70 - 160 KB of
+  // LDS, i.e. one workgroup per CU, so it only pays while the launch is ONE round of workgroups
+  // (measured, tools/experiments/head_rt_ab.py: B=16 24x24, 160 workgroups: 84 us against 103;
+  // B=32 12x12, 320 workgroups = two rounds on a quarter of the CUs: 57 against 54; B=64 16x16,
+  // 640: 115 against 97).  np_hint: 1 = never, 2..4 = that many column blocks, 0 = this rule.
+  if (g.a == 1 && n_cb >= 2 && np_hint != 1 && !d.split && ld_hint != 2) {
+    int np = np_hint;
+    if (np == 0) {
+      np = n_cb == 2 ? 2 : (n_cb == 3 ? 3 : 4);
+      if (n_cb > 4 && (n_cb + 2) / 3 * 3 - n_cb < (n_cb + 3) / 4 * 4 - n_cb) np = 3;  // less padding
+      if (crops8 * g.n_tiles > 256) np = 1;  // more than one round: two workgroups per CU (below)
+    }
+    if (np >= 2) {
+      d.kernel = kRtKernelNp;
+      d.np = np > 4 ? 4 : np;
+      d.rtg = (d.np == 2 && rtg_hint == 2) ? 2 : 1;
+      d.n_wg = crops8 * ((g.n_tiles + d.rtg - 1) / d.rtg);
+      return d;
+    }
+  }
+  d.rtg = rt_block_tiles(g, plan.rtg);
+  d.n_wg = crops8 * (d.split ? d.split : 1) * ((g.n_tiles + d.rtg - 1) / d.rtg);
+  // ---- four MFMA waves + a loader wave (320 threads, one workgroup per CU; same bits): the MFMA
+  // waves issue no copies and no vmcnt waits.  ld_hint: 0 = the plan, 1 = never, 2 = whenever the
+  // kernel can (C % 32 == 0).
+  if (plan.mode == 1) {
+    d.kernel = kRtKernelLoader;
+    return d;
+  }
+  // two K groups per workgroup (512 threads; same bits as one group, see rt_block): only on request
+  // since the loader-wave kernel exists (round 3: it is as fast or faster on every launch the two K
+  // groups were for -- B = 64: 23.6 against 24.6 us).  ks_hint: 2 = whenever the kernel can (C % 64
+  // == 0, blocks of <= 3 tiles); 0, 1 = one K group.
+  if (C % 64 == 0 && d.rtg <= 3 && ks_hint == 2) d.kernel = kRtKernelTwoKGroups;
+  return d;
+}
+
 int rt_launch(const float* feat, int layout, const void* section, int B, int C, int H, int W, int J,
               int D, const HeadScale& hs, float* coords2d, float* coords3d_rel, int rtg_hint, int np_hint,
-              int ks_hint, hipStream_t stream) {
+              int ks_hint, int ld_hint, int split_hint, void* workspace, size_t workspace_bytes,
+              hipStream_t stream) {
   const RtGeom g = rt_geom(J, D);
   RtArgs a;
   a.feat = feat;
@@ -856,68 +1182,31 @@ int rt_launch(const float* feat, int layout, const void* section, int B, int C, 
   a.c2d = coords2d;
   a.c3d = coords3d_rel;
   const bool nhwc = layout == MTR_NHWC;
-  const long long crops8 = (long long)((B + 7) / 8) * 8;
-  const int n_cb = (H * W + 63) / 64;
-  // ---- maps of several column blocks, one-tile atoms: RT x NP tiles (one K loop for NP column
-  // blocks) -- a workgroup of one row tile that runs n_cb K loops of 8 MFMAs per stage back to back
-  // is bound by its per-stage overhead, not by the matrix pipe.  Such a tile needs 70 - 160 KB of
-  // LDS, i.e. one workgroup per CU, so it only pays while the launch is ONE round of workgroups
-  // (measured, tools/experiments/head_rt_ab.py: B=16 24x24, 160 workgroups: 84 us against 103;
-  // B=32 12x12, 320 workgroups = two rounds on a quarter of the CUs: 57 against 54; B=64 16x16,
-  // 640: 115 against 97).  np_hint: 1 = never, 2..4 = that many column blocks, 0 = this rule.
-  if (g.a == 1 && n_cb >= 2 && np_hint != 1) {
-    int np = np_hint;
-    if (np == 0) {
-      np = n_cb == 2 ? 2 : (n_cb == 3 ? 3 : 4);
-      if (n_cb > 4 && (n_cb + 2) / 3 * 3 - n_cb < (n_cb + 3) / 4 * 4 - n_cb) np = 3;  // less padding
-      if (crops8 * g.n_tiles > 256) np = 1;  // more than one round: two workgroups per CU (below)
-    }
-    if (np >= 2) {
-      if (np > 4) np = 4;
-      a.rtg = (np == 2 && rtg_hint == 2) ? 2 : 1;
-      a.n_blocks = (g.n_tiles + a.rtg - 1) / a.rtg;
+  const bool can_split = workspace != nullptr && ((uintptr_t)workspace % 8) == 0 &&
+                         workspace_bytes >= rt_workspace_bytes(B, J, D, H, W);
+  const RtDispatch d = rt_dispatch(B, C, H, W, J, D, rtg_hint, np_hint, ks_hint, ld_hint, split_hint, can_split);
+  a.cb_split = d.split;
+  a.ws = d.split ? (double*)workspace : nullptr;
+  a.rtg = d.rtg;
+  a.n_blocks = (g.n_tiles + a.rtg - 1) / a.rtg;
+  switch (d.kernel) {
+    case kRtKernelNp:
       if (a.rtg == 2) return nhwc ? rt_launch_np<2, 2, true>(a, stream) : rt_launch_np<2, 2, false>(a, stream);
-      switch (np) {
+      switch (d.np) {
         case 2: return nhwc ? rt_launch_np<1, 2, true>(a, stream) : rt_launch_np<1, 2, false>(a, stream);
         case 3: return nhwc ? rt_launch_np<1, 3, true>(a, stream) : rt_launch_np<1, 3, false>(a, stream);
         default: return nhwc ? rt_launch_np<1, 4, true>(a, stream) : rt_launch_np<1, 4, false>(a, stream);
       }
-    }
+    case kRtKernelLoader:
+      if (a.rtg <= 3) return nhwc ? rt_launch_ld<3, true>(a, stream) : rt_launch_ld<3, false>(a, stream);
+      return nhwc ? rt_launch_ld<5, true>(a, stream) : rt_launch_ld<5, false>(a, stream);
+    case kRtKernelTwoKGroups:
+      return nhwc ? rt_launch_kernel(head_rt_ks_kernel<3, true>, rt_ks_lds_bytes(3, true), a, stream, 512)
+                  : rt_launch_kernel(head_rt_ks_kernel<3, false>, rt_ks_lds_bytes(3, false), a, stream, 512);
+    default:
+      if (a.rtg <= 3) return nhwc ? rt_launch_t<3, true>(a, stream) : rt_launch_t<3, false>(a, stream);
+      return nhwc ? rt_launch_t<5, true>(a, stream) : rt_launch_t<5, false>(a, stream);
   }
-  if (g.a == 1 && rtg_hint == 0) {
-    // one-tile atoms: how many tiles a workgroup takes.
-    if (crops8 * ((g.n_tiles + 2) / 3) <= 512) {
-      // small launches (one round of at most 2 workgroups per CU): 3 tiles per workgroup, fewer
-      // when that would leave CUs without one (few crops, large maps)
-      rtg_hint = 3;
-      // (with two K groups available, 2-tile blocks on fewer CUs beat one-tile blocks on all of them)
-      const int floor_rtg = (C % 64 == 0 && ks_hint != 1) ? 2 : 1;
-      while (rtg_hint > floor_rtg && crops8 * ((g.n_tiles + rtg_hint - 1) / rtg_hint) < 256) --rtg_hint;
-    } else {
-      // several rounds of workgroups: equal blocks first (a crop's 10 tiles as 5 + 5 measured 270 us
-      // at B = 1024 against 315 us as 3 + 3 + 3 + 1), then the larger block (fewer barriers, LDS
-      // reads and feature copies per MFMA)
-      int best_pad = 1 << 30;
-      for (int cand = 5; cand >= 2; --cand) {
-        const int pad = (g.n_tiles + cand - 1) / cand * cand - g.n_tiles;
-        if (pad < best_pad) { best_pad = pad; rtg_hint = cand; }
-      }
-    }
-  }
-  a.rtg = rt_block_tiles(g, rtg_hint);
-  a.n_blocks = (g.n_tiles + a.rtg - 1) / a.rtg;
-  // two K groups per workgroup (512 threads; same bits as one group, see rt_block): blocks of 2 - 3
-  // tiles, i.e. the small-launch configuration, where a CU would otherwise run one wave per SIMD.
-  // Measured (tools/experiments/head_small_launch.py, ablate_rt.py): B = 64 26.8 -> 22.6 us, B = 64
-  // 16x16 98 -> 83, B = 32 12x12 (2-tile blocks) 50 -> 44; one-tile blocks lose (29 -> 32 at B = 64),
-  // 5-tile blocks lose (B = 1024 249 -> 274 in the sum-exchange prototype).  ks_hint: 0 = this rule,
-  // 1 = never, 2 = whenever the kernel can (C % 64 == 0, blocks of <= 3 tiles)
-  if (C % 64 == 0 && a.rtg <= 3 && ks_hint != 1 && (ks_hint == 2 || a.rtg >= 2))
-    return nhwc ? rt_launch_kernel(head_rt_ks_kernel<3, true>, rt_ks_lds_bytes(3, true), a, stream, 512)
-                : rt_launch_kernel(head_rt_ks_kernel<3, false>, rt_ks_lds_bytes(3, false), a, stream, 512);
-  if (a.rtg <= 3)
-    return nhwc ? rt_launch_t<3, true>(a, stream) : rt_launch_t<3, false>(a, stream);
-  return nhwc ? rt_launch_t<5, true>(a, stream) : rt_launch_t<5, false>(a, stream);
 }
 
 }  // namespace mtr

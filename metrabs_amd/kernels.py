@@ -285,11 +285,15 @@ def head_pack_weights(weight2d, bias, n_points, depth, feat_dtype=torch.float32)
 
 
 def head_fused(features, packed, C, n_points, cfg, out=None, rt_tiles=0, groups_per_workgroup=0,
-               dma_staging=-1, rt_column_blocks=0, rt_k_groups=0):
+               dma_staging=-1, rt_column_blocks=0, rt_k_groups=0, rt_loader=0, rt_split=0,
+               workspace=None):
     """features [B,C,H,W] (f32/f16/bf16; NCHW-contiguous or torch channels_last = NHWC memory, which
     is consumed in place) -> (coords2d, coords3d_rel).  rt_tiles / groups_per_workgroup /
-    dma_staging / rt_column_blocks / rt_k_groups: explicit dispatch choices (mtr_head_options;
-    defaults = the library's own)."""
+    dma_staging / rt_column_blocks / rt_k_groups / rt_loader / rt_split: explicit dispatch choices
+    (mtr_head_options; defaults = the library's own).  workspace: None = a scratch tensor of
+    mtr_head_workspace_bytes is allocated when the shape can use one (f32 maps of more than 64
+    positions: column blocks over workgroups); False = none (mtr_head_fused_opts' behaviour); or a
+    uint8 / float64 tensor to use."""
     require_cuda(features, packed)
     lib = _lib.load()
     nhwc = _is_channels_last(features)
@@ -306,19 +310,42 @@ def head_fused(features, packed, C, n_points, cfg, out=None, rt_tiles=0, groups_
         c2d, c3d = out
     hp = cfg.head_params()
     layout = _lib.MTR_NHWC if nhwc else _lib.MTR_NCHW
-    if rt_tiles or groups_per_workgroup or dma_staging != -1 or rt_column_blocks or rt_k_groups:
-        opts = _lib.HeadOptions(int(rt_tiles), int(groups_per_workgroup), int(dma_staging),
-                                int(rt_column_blocks), int(rt_k_groups))
-        check(lib.mtr_head_fused_opts(
-            _ptr(features), dtype_code(features.dtype), layout, B, C, H, W, _ptr(packed), J, D,
-            ctypes.byref(hp), ctypes.byref(opts), _ptr(c2d), _ptr(c3d),
-            current_stream_ptr(features.device)), 'mtr_head_fused_opts')
-    else:
-        check(lib.mtr_head_fused(
-            _ptr(features), dtype_code(features.dtype), layout, B, C, H, W, _ptr(packed), J, D,
-            ctypes.byref(hp), _ptr(c2d), _ptr(c3d), current_stream_ptr(features.device)),
-            'mtr_head_fused')
+    ws_ptr, ws_bytes = None, 0
+    if workspace is not False:
+        need = lib.mtr_head_workspace_bytes(B, J, D, H, W, dtype_code(features.dtype))
+        if need:
+            if workspace is None:
+                workspace = torch.empty(need // 8, device=features.device, dtype=torch.float64)
+            require_cuda(workspace)
+            ws_ptr, ws_bytes = _ptr(workspace), workspace.numel() * workspace.element_size()
+    opts = _lib.HeadOptions(int(rt_tiles), int(groups_per_workgroup), int(dma_staging),
+                            int(rt_column_blocks), int(rt_k_groups), int(rt_loader), int(rt_split))
+    check(lib.mtr_head_fused_ws(
+        _ptr(features), dtype_code(features.dtype), layout, B, C, H, W, _ptr(packed), J, D,
+        ctypes.byref(hp), ctypes.byref(opts), ws_ptr, ws_bytes, _ptr(c2d), _ptr(c3d),
+        current_stream_ptr(features.device)), 'mtr_head_fused_ws')
     return c2d, c3d
+
+
+def head_plan(B, C, H, W, n_points, depth, dtype=torch.float32, channels_last=False, have_workspace=True,
+              **options):
+    """Which kernel mtr_head_fused_ws takes for a launch (host-only; mtr_head_plan) -> dict(kernel=name,
+    tiles_per_workgroup, column_blocks, split_column_blocks, workgroups) or None when the shape has
+    no fused kernel.  options: as head_fused."""
+    lib = _lib.load()
+    opts = _lib.HeadOptions(int(options.get('rt_tiles', 0)), int(options.get('groups_per_workgroup', 0)),
+                            int(options.get('dma_staging', -1)), int(options.get('rt_column_blocks', 0)),
+                            int(options.get('rt_k_groups', 0)), int(options.get('rt_loader', 0)),
+                            int(options.get('rt_split', 0)))
+    info = _lib.HeadPlanInfo()
+    rc = lib.mtr_head_plan(dtype_code(dtype), _lib.MTR_NHWC if channels_last else _lib.MTR_NCHW, int(B), int(C),
+                           int(H), int(W), int(n_points), int(depth), ctypes.byref(opts), int(bool(have_workspace)),
+                           ctypes.byref(info))
+    if rc != 0:
+        return None
+    return dict(kernel=_lib.HEAD_KERNEL_NAMES.get(info.kernel, str(info.kernel)),
+                tiles_per_workgroup=info.tiles_per_workgroup, column_blocks=info.column_blocks,
+                split_column_blocks=info.split_column_blocks, workgroups=int(info.workgroups))
 
 
 def postprocess_poses(poses_crop, rot, should_flip, mirror_mapping, intrinsics, distortion12,

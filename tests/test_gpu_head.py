@@ -420,6 +420,71 @@ def test_two_k_groups_option(shape, hip_lib):
     assert float((a3d - o3d).abs().max()) <= 2e-3 and cpu_ref.mpjpe(a3d, o3d) <= 1e-3
 
 
+@pytest.mark.parametrize('shape', [(64, 1280, 17, 8, 8, 8), (5, 128, 17, 8, 8, 8), (3, 64, 17, 8, 12, 12),
+                                   (2, 192, 6, 16, 10, 10), (2, 64, 17, 72, 8, 8), (4, 96, 17, 8, 8, 8),
+                                   (3, 576, 17, 8, 8, 8), (2, 640, 17, 8, 16, 16), (2, 1088, 5, 8, 8, 8),
+                                   (33, 512, 17, 8, 12, 12), (2, 32, 17, 8, 8, 8), (2, 2048, 24, 8, 8, 8),
+                                   (9, 160, 122, 8, 12, 12), (2, 96, 17, 8, 24, 24)])
+def test_loader_wave_and_split_column_blocks_give_the_same_bits(shape, hip_lib):
+    """mtr_head_options.rt_loader: a fifth wave issues every global_load_lds of the K loop, the four MFMA
+    waves never copy or wait for a copy; rt_split_column_blocks (mtr_head_fused_ws): the 64-position
+    column blocks of a larger map go to different workgroups and a second launch merges their softmax
+    statistics in block order.  Neither changes an MFMA chain, a sum or the merge order -> bit-equal
+    to the one-K-group, no-loader, one-workgroup-walks-its-blocks kernel for every block size, NCHW
+    and NHWC, 1 .. 64 stages, ragged last blocks, D > 16 atoms."""
+    from metrabs_amd import kernels
+    B, C, J, D, H, W = shape
+    cfg = cpu_ref.HeadConfig(depth=D, proc_side=max(H, W) * 8, stride_test=8, stride_train=8)
+    g = cases.gen(8800 + sum(shape))
+    feat = torch.randn(B, C, H, W, generator=g)
+    w, b = cases.default_conv_init(J * (1 + D), C, g)
+    w, b = w * 3, b * 3
+    a2d, a3d = run_fused(feat, w, b, J, cfg, rt_k_groups=1, rt_loader=1, rt_split=1, rt_column_blocks=1,
+                         workspace=False)
+    packed = kernels.head_pack_weights(w.cuda(), b.cuda(), J, D)
+    n_cb = -(-H * W // 64)
+    variants = [dict(), dict(rt_loader=2), dict(rt_loader=2, rt_tiles=1), dict(rt_loader=2, rt_tiles=2),
+                dict(rt_loader=2, rt_tiles=4), dict(rt_loader=2, rt_tiles=5)]
+    if n_cb >= 2:
+        variants += [dict(rt_split=2), dict(rt_split=2, rt_loader=2), dict(rt_split=2, rt_loader=2, rt_tiles=5),
+                     dict(rt_split=2, rt_loader=1, rt_k_groups=2), dict(rt_split=2, rt_loader=1, rt_k_groups=1, rt_tiles=5),
+                     dict(rt_split=1, rt_loader=2, rt_column_blocks=1)]
+    for options in variants:
+        v2d, v3d = run_fused(feat, w, b, J, cfg, **options)
+        assert torch.equal(v3d, a3d) and torch.equal(v2d, a2d), (shape, options, float((v3d - a3d).abs().max()))
+        if C % 4 == 0:
+            l2d, l3d = kernels.head_fused(feat.cuda().contiguous(memory_format=torch.channels_last),
+                                          packed, C, J, mcfg(cfg), **options)
+            assert torch.equal(l3d.cpu(), a3d) and torch.equal(l2d.cpu(), a2d), (shape, options, 'nhwc')
+    with torch.inference_mode():
+        o2d, o3d = cpu_ref.heads_forward(feat, w, b, J, cfg)
+    assert float((a3d - o3d).abs().max()) <= 2e-3 and cpu_ref.mpjpe(a3d, o3d) <= 1e-3
+
+
+def test_head_workspace_contract(hip_lib):
+    """mtr_head_workspace_bytes: 0 for maps of <= 64 positions and for 16-bit features; a too-small or
+    absent workspace silently means "no split" (same bits), a misaligned one is an error."""
+    from metrabs_amd import _lib, kernels
+    from metrabs_amd.config import MetrabsConfig
+    lib = _lib.load()
+    assert lib.mtr_head_workspace_bytes(64, 17, 8, 8, 8, _lib.MTR_F32) == 0
+    assert lib.mtr_head_workspace_bytes(32, 17, 8, 12, 12, _lib.MTR_F16) == 0
+    need = lib.mtr_head_workspace_bytes(32, 17, 8, 12, 12, _lib.MTR_F32)
+    assert need == 32 * 3 * 160 * 5 * 8
+    w, b = cases.default_conv_init(153, 64, cases.gen(2))
+    packed = kernels.head_pack_weights(w.cuda(), b.cuda(), 17, 8)
+    feat = torch.randn(4, 64, 12, 12, device='cuda')
+    cfg = MetrabsConfig(proc_side=384)
+    ref = kernels.head_fused(feat, packed, 64, 17, cfg, workspace=False)
+    small = torch.empty(8, device='cuda', dtype=torch.float64)
+    out = kernels.head_fused(feat, packed, 64, 17, cfg, workspace=small, rt_split=2)
+    assert torch.equal(out[1], ref[1]) and torch.equal(out[0], ref[0])
+    odd = torch.empty(lib.mtr_head_workspace_bytes(4, 17, 8, 12, 12, _lib.MTR_F32) + 8, device='cuda',
+                      dtype=torch.uint8)[4:]
+    with pytest.raises(RuntimeError):
+        kernels.head_fused(feat, packed, 64, 17, cfg, workspace=odd, rt_split=2)
+
+
 def test_head_options_are_validated(hip_lib):
     from metrabs_amd import kernels
     from metrabs_amd.config import MetrabsConfig
@@ -427,6 +492,6 @@ def test_head_options_are_validated(hip_lib):
     packed = kernels.head_pack_weights(w.cuda(), b.cuda(), 17, 8)
     feat = torch.randn(2, 64, 8, 8, device='cuda')
     for bad in (dict(rt_tiles=6), dict(groups_per_workgroup=4), dict(dma_staging=2), dict(rt_column_blocks=5),
-                dict(rt_k_groups=3)):
+                dict(rt_k_groups=3), dict(rt_loader=3), dict(rt_split=3)):
         with pytest.raises(RuntimeError):
             kernels.head_fused(feat, packed, 64, 17, MetrabsConfig(), **bad)

@@ -170,10 +170,33 @@ def test_bench_cli_contract_and_kernel_naming(monkeypatch):
     monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '8', '--steps', '7', '--warmup', '2'])
     a = bench.parse_args()
     assert (a.gpus, a.steps, a.warmup) == (8, 7, 2)
-    assert bench.head_kernel_name(64, 64, 17, 8) == 'head_rt_ks_kernel'              # config 2, f32: 3-tile blocks, two K groups
+    # the roofline entry names the kernel the LIBRARY says it launches (mtr_head_plan, host-only)
+    assert bench.head_kernel_name(64, 64, 17, 8) == 'head_rt_ld_kernel'              # config 2, f32: 3-tile blocks, loader wave
     assert bench.head_kernel_name(64, 1024, 17, 8) == 'head_rt_kernel'               # large launch: 5-tile blocks
-    assert bench.head_kernel_name(64, 64, 17, 8, 'f32', 1283) == 'head_rt_kernel'    # C % 64 != 0
-    assert bench.head_kernel_name(144, 32, 17, 72) == 'head_rt_kernel'               # any map, D <= 80
+    assert bench.head_kernel_name(64, 64, 17, 8, 'f32', 1283) == 'head_rt_kernel'    # C % 32 != 0: no loader kernel
+    assert bench.head_kernel_name(64, 1024, 17, 72) == 'head_rt_kernel'              # D <= 80: 5-tile atoms
+    assert bench.head_kernel_name(144, 32, 17, 8).startswith('head_rt_kernel (+ head_rt_merge_kernel: 3 ')
     assert bench.head_kernel_name(64, 64, 17, 8, 'f16', 1280) == 'head_fused16dma_kernel'
     assert bench.head_kernel_name(36, 64, 17, 8, 'f16', 1280) == 'head_fused16_kernel'   # 6x6: registers
-    assert bench.head_kernel_name(64, 64, 17, 8, 'f16', 1283) == 'head_fused32_kernel'   # C % 8 != 0
+    assert bench.head_kernel_name(64, 64, 17, 8, 'f16', 1283).startswith('library')      # C % 8 != 0
+
+
+def test_head_plan_follows_the_measured_model():
+    """mtr_head_plan (host-only): the launch plan of the f32 head reproduces the measured best choice of
+    the round-3 sweep (profiles/r03a_head_sweep.jsonl) on its shapes."""
+    from metrabs_amd import kernels
+    p = kernels.head_plan(64, 1280, 8, 8, 17, 8)
+    assert (p['kernel'], p['tiles_per_workgroup'], p['workgroups']) == ('head_rt_ld_kernel', 3, 256)
+    p = kernels.head_plan(8, 1280, 8, 8, 17, 8)
+    assert (p['kernel'], p['tiles_per_workgroup']) == ('head_rt_ld_kernel', 1)
+    p = kernels.head_plan(32, 1280, 12, 12, 17, 8)
+    assert (p['kernel'], p['tiles_per_workgroup'], p['split_column_blocks'], p['workgroups']) == \
+        ('head_rt_kernel', 2, 3, 480)
+    assert kernels.head_plan(32, 1280, 12, 12, 17, 8, have_workspace=False)['split_column_blocks'] == 0
+    p = kernels.head_plan(64, 1280, 16, 16, 17, 8)
+    assert (p['kernel'], p['tiles_per_workgroup'], p['split_column_blocks']) == ('head_rt_kernel', 5, 4)
+    p = kernels.head_plan(1024, 1280, 8, 8, 17, 8)
+    assert (p['kernel'], p['tiles_per_workgroup'], p['split_column_blocks']) == ('head_rt_kernel', 5, 0)
+    assert kernels.head_plan(64, 1280, 8, 8, 17, 72)['tiles_per_workgroup'] == 5     # a 72-bin joint = one atom
+    assert kernels.head_plan(64, 1280, 8, 8, 17, 8, rt_k_groups=2, rt_loader=1)['kernel'] == 'head_rt_ks_kernel'
+    assert kernels.head_plan(64, 1280, 7, 7, 17, 8) is None                          # H*W % 4 != 0: library path

@@ -20,7 +20,13 @@ VARIANTS = {'full': [], 'exp32': ['-DMTR_RT_EXP32=1'], 'nodecode': ['-DMTR_RT_AB
             'nocarry': ['-DMTR_RT_ABLATE=8'],
             'nofrag': ['-DMTR_RT_ABLATE=16'],
             'nbuf2': ['-DMTR_RT_NBUF=2'], 'nbuf4': ['-DMTR_RT_NBUF=4'], 'nbuf8': ['-DMTR_RT_NBUF=8'], 'a18': ['-DMTR_RT_ABLATE=18'], 'a26': ['-DMTR_RT_ABLATE=26'], 'a27': ['-DMTR_RT_ABLATE=27'],
-            'ks4': ['-DMTR_RT_KS_NBUF=4'], 'pair': ['-DMTR_RT_PAIR=1']}
+            'ks4': ['-DMTR_RT_KS_NBUF=4'], 'pair': ['-DMTR_RT_PAIR=1'],
+            'nocopy': ['-DMTR_RT_ABLATE=4'], 'a5': ['-DMTR_RT_ABLATE=5'], 'a7': ['-DMTR_RT_ABLATE=7'],
+            'a3': ['-DMTR_RT_ABLATE=3'], 'a21': ['-DMTR_RT_ABLATE=21'], 'a23': ['-DMTR_RT_ABLATE=23'],
+            'sadd': ['-DMTR_RT_SCALAR_ADD=1'], 'spread': ['-DMTR_RT_SPREAD_READS=1'],
+            'spread_nodecode': ['-DMTR_RT_SPREAD_READS=1', '-DMTR_RT_ABLATE=1'],
+            'ld8': ['-DMTR_RT_LD_NBUF=8', '-DMTR_RT_LD_LA=4'], 'ld8la5': ['-DMTR_RT_LD_NBUF=8', '-DMTR_RT_LD_LA=5'],
+            'ld4la2': ['-DMTR_RT_LD_NBUF=4', '-DMTR_RT_LD_LA=2'], 'ld2': ['-DMTR_RT_LD_NBUF=2', '-DMTR_RT_LD_LA=1']}
 if os.environ.get('RT_VARIANTS'):
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ['RT_VARIANTS'].split(',')}
 
@@ -73,7 +79,9 @@ def run_one(name):
         c2 = torch.empty(B, J, 2, device='cuda'); c3 = torch.empty(B, J, 3, device='cuda')
 
         # RT_KGROUPS=1|2 in the environment: mtr_head_options.rt_k_groups for every call
-        opts = _lib.HeadOptions(0, 0, -1, 0, int(os.environ.get('RT_KGROUPS', '0')))
+        # RT_TILES / RT_LOADER / RT_SPLIT likewise
+        opts = _lib.HeadOptions(int(os.environ.get('RT_TILES', '0')), 0, -1, 0, int(os.environ.get('RT_KGROUPS', '0')),
+                                int(os.environ.get('RT_LOADER', '0')), int(os.environ.get('RT_SPLIT', '0')))
 
         def call(stream):
             rc = lib.mtr_head_fused_opts(vp(feat.data_ptr()), 0, 1 if nhwc else 0, B, C, H, H,
