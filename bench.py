@@ -124,6 +124,29 @@ def synth_inputs(pipe, frames, im_h, im_w, n_box, seed):
     pipe.image_ids.copy_((torch.arange(n_box) % frames).int())
 
 
+def synthetic_crops(args, dev, im_h=1080, im_w=1920, seed=99, n_box=32):
+    """Crops as the step's sampler produces them (synthetic frames, boxes and cameras of synth_inputs'
+    kind, another seed): what the backbone's batch norms are calibrated on."""
+    from metrabs_amd import kernels
+    from metrabs_amd.multiperson.multiperson_model import tta_parameters
+    g = torch.Generator().manual_seed(seed)
+    frames = torch.randint(0, 256, (2, 3, im_h, im_w), dtype=torch.uint8, generator=g).to(dev)
+    bw = 60 + 340 * torch.rand(n_box, generator=g)
+    bh = 150 + 750 * torch.rand(n_box, generator=g)
+    bx = torch.rand(n_box, generator=g) * (im_w - bw)
+    by = torch.rand(n_box, generator=g) * (im_h - bh).clamp_min(1.0)
+    boxes = torch.stack([bx, by, bw, bh], dim=1).to(dev)
+    f = max(im_h, im_w) / (np.tan(np.deg2rad(55.0) / 2) * 2)
+    K = torch.tensor([[f, 0, im_w / 2], [0, f, im_h / 2], [0, 0, 1]], dtype=torch.float32).repeat(n_box, 1, 1).to(dev)
+    tta = {k: v.to(dev) for k, v in tta_parameters(args.num_aug).items()}
+    with torch.inference_mode():
+        _, _, wp = kernels.crop_geometry(
+            boxes, K, torch.zeros(n_box, 12, device=dev), torch.tensor([0.0, -1.0, 0.0], device=dev).repeat(n_box, 1),
+            (torch.arange(n_box) % 2).int().to(dev), tta['rotflipmat'], tta['scales'], tta['gammas'], args.res, 1)
+        crops = kernels.warp_crops(kernels.build_pyramid(frames), wp, args.res, 1)
+    return crops[torch.randperm(len(crops), generator=g)[:32].to(dev)].clone()
+
+
 def build_model(args, dev):
     from metrabs_amd.backbones import build_backbone, calibrate_batchnorm, fold_batchnorm
     from metrabs_amd.config import MetrabsConfig
@@ -154,7 +177,7 @@ def build_model(args, dev):
     model = Metrabs(backbone, ji, cfg, in_channels=backbone.out_channels, fused_head='auto',
                     autocast_dtype=autocast)
     model = model.to(dev)
-    calibrate_batchnorm(model.backbone, args.res, dev)
+    calibrate_batchnorm(model.backbone, args.res, dev, samples=synthetic_crops(args, dev))
     model = model.eval()
     reference_backbone = model.backbone  # the unfolded network: what the CPU baseline runs
     if not args.no_fold_bn:

@@ -413,11 +413,15 @@ def fold_batchnorm(backbone, fused_epilogue=False):
     return folded
 
 
-def calibrate_batchnorm(backbone, res, dev, batches=2, batch_size=16, seed=7):
+def calibrate_batchnorm(backbone, res, dev, batches=2, batch_size=16, seed=7, samples=None):
     """Random-weight networks with untouched BatchNorm statistics (mean 0 / var 1) let activations
     grow layer by layer until they overflow.  A few forward passes in training mode on synthetic
     crops set the running statistics (cumulative average), which keeps every layer at unit scale --
-    the regime a trained checkpoint is in.  Weights stay random; the FLOPs are unchanged."""
+    the regime a trained checkpoint is in.  Weights stay random; the FLOPs are unchanged.
+    samples: optional f32 crops [n, 3, res, res] of the kind the network will actually see (the
+    benchmark's sampler output: low-contrast resampled noise with zero padding, whose statistics
+    differ enough from uniform noise for an f16 EfficientNetV2-L to overflow); they are used in
+    chunks of batch_size beside the uniform-noise batches."""
     bns = [m for m in backbone.modules() if isinstance(m, torch.nn.BatchNorm2d)]
     for m in bns:
         m.momentum = None
@@ -427,5 +431,9 @@ def calibrate_batchnorm(backbone, res, dev, batches=2, batch_size=16, seed=7):
     with torch.no_grad():
         for _ in range(batches):
             backbone(torch.rand(batch_size, 3, res, res, device=dev, generator=g))
+        if samples is not None:
+            for chunk in samples.float().split(batch_size):
+                if len(chunk) > 1:
+                    backbone(chunk)
     backbone.eval()
     return backbone
