@@ -160,6 +160,50 @@ def consistent_head_case(B, C, J, hw, proc_side, D, amp, seed, spread=0.18):
     return feat.reshape(B, C, hw, hw).float(), w.float(), b.float(), K
 
 
+# ---- the features -> poses3d parity gates (tests/test_gpu_parity_gates.py, bench.py's parity probe):
+# every BASELINE.json config shape and the metric string's 72 depth bins.
+# name: (B, C, J, map side, proc_side, depth bins, feature dtype)
+PARITY_GATE_SHAPES = {
+    'configs[0] ResNet-18 256 B=1': (1, 512, 17, 8, 256, 8, torch.float32),
+    'configs[1] EffNetV2-S 256 B=64': (64, 1280, 17, 8, 256, 8, torch.float32),
+    'configs[2] EffNetV2-L 384 B=32/GPU': (32, 1280, 17, 12, 384, 8, torch.float32),
+    'configs[2] EffNetV2-L 384 B=256 on one GPU': (256, 1280, 17, 12, 384, 8, torch.float32),
+    'configs[3] MobileNetV3 256, 8 boxes x 5 aug': (40, 1280, 17, 8, 256, 8, torch.float32),
+    'configs[4] EffNetV2-L 384 f16 J=122 B=32/GPU': (32, 1280, 122, 12, 384, 8, torch.float16),
+    'metric string: 72 depth bins, 256 px, B=64': (64, 1280, 17, 8, 256, 72, torch.float32),
+}
+PARITY_GATE_REGIMES = ('consistent_low', 'consistent_peaked', 'random_head')
+
+
+def parity_gate_slug(name, regime):
+    key = {'configs[0] ResNet-18 256 B=1': 'cfg0_r18_b1', 'configs[1] EffNetV2-S 256 B=64': 'cfg1_s_b64',
+           'configs[2] EffNetV2-L 384 B=32/GPU': 'cfg2_l_b32', 'configs[2] EffNetV2-L 384 B=256 on one GPU': 'cfg2_l_b256',
+           'configs[3] MobileNetV3 256, 8 boxes x 5 aug': 'cfg3_mnv3_b40',
+           'configs[4] EffNetV2-L 384 f16 J=122 B=32/GPU': 'cfg4_l_f16_j122_b32',
+           'metric string: 72 depth bins, 256 px, B=64': 'metric_d72_b64'}[name]
+    return f'parity_{key}_{regime}'
+
+
+def parity_gate_inputs(name, regime):
+    """-> (features in the shape's dtype, weight [N,C] f32, bias, K [B,3,3]); seeded, CPU.
+    consistent_low / consistent_peaked: consistent_head_case with bumps of 4 / 25; random_head: N(0,1)
+    features x default-initialised conv_final x 8 (logits +-25) -- what a random-weight network emits."""
+    B, C, J, hw, P, D, dtype = PARITY_GATE_SHAPES[name]
+    seed = 9100 + sum(ord(c) for c in name)
+    if regime == 'random_head':
+        g = gen(seed)
+        feat = torch.randn(B, C, hw, hw, generator=g)
+        w, b = default_conv_init(J * (1 + D), C, g)
+        w, b = w * 8.0, b * 8.0
+        f = (450 + 100 * torch.rand(B, generator=g)) * P / 256
+        K = torch.zeros(B, 3, 3)
+        K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2], K[:, 2, 2] = f, f, P / 2, P / 2, 1
+    else:
+        amp = 4.0 if regime == 'consistent_low' else 25.0
+        feat, w, b, K = consistent_head_case(B, C, J, hw, P, D, amp, seed)
+    return feat.to(dtype), w, b, K
+
+
 # ------------------------------------------------------------------------------------ reconstruct
 
 RECON_CASES = {
@@ -349,6 +393,8 @@ E2E_CASES = {
 }
 
 E2E_C = 24  # tiny backbone channels
+# cases whose backbone outputs are stored too (golden e2efeat_*): the estimator's glue without the sampler
+E2E_FEATURE_CASES = ('aug5', 'aug4_dist12', 'aug1', 'aug5_dist_aa2')
 E2E_SKELETON = [0, 5, 6, 11, 12, 15, 16]
 
 

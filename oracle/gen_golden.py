@@ -89,6 +89,43 @@ def gen_headconv(ref):
              input_sha256=np.array(cases.sha256_of(feat, w, b)))
 
 
+def gen_parity(ref, only=None):
+    """The features -> poses3d gates: the REFERENCE's own MetrabsHeads.forward (models/metrabs.py:75-85)
+    and ptu3d.reconstruct_absolute (ptu3d.py:9-33) on the seeded inputs of cases.parity_gate_inputs, at
+    every BASELINE config shape in three regimes, plus an fp64 evaluation of the same formulas.  The
+    inputs are not stored (up to 190 MB per case): they are regenerated from the seed; their sha256
+    and a float64 checksum ride along.  16-bit features: the reference's arithmetic on them is the
+    f32 conv on the rounded features and the weights rounded to the feature dtype (what autocast does
+    to conv_final; products of two f16 values are exact in f32)."""
+    from oracle import cpu_ref
+    for name, (B, C, J, hw, P, D, dtype) in cases.PARITY_GATE_SHAPES.items():
+        for regime in cases.PARITY_GATE_REGIMES:
+            slug = cases.parity_gate_slug(name, regime)
+            if only and only not in slug:
+                continue
+            feat, w, b, K = cases.parity_gate_inputs(name, regime)
+            wk = cases.head_weights_as_consumed(w, dtype)
+            ocfg = cpu_ref.HeadConfig(proc_side=P, depth=D)
+            with rh.config(**cfg_kwargs(ocfg)), torch.inference_mode():
+                heads = ref.metrabs_model.MetrabsHeads(n_points=J).eval()
+                conv = torch.nn.Conv2d(C, J * (1 + D), 1)
+                conv.weight.copy_(wk[:, :, None, None])
+                conv.bias.copy_(b)
+                heads.conv_final = conv
+                c2d, c3d = heads(feat.float())
+                poses = rh.plain(ref.ptu3d.reconstruct_absolute(
+                    c2d, c3d, K, mix_3d_inside_fov=ocfg.mix_3d_inside_fov, weak_perspective=ocfg.weak_perspective))
+                logits = conv(feat.float())
+                truth = cpu_ref.crop_model_from_features_fp64(feat.float(), wk, b, K, J, ocfg)
+                port = cpu_ref.crop_model_from_features(feat.float(), wk, b, K, J, ocfg)
+            save(slug, poses3d=poses, poses3d_fp64=truth, logits_absmax=np.array(float(logits.abs().max())),
+                 median_depth_mm=np.array(float(truth[..., 2].median())),
+                 reference_vs_fp64_mpjpe_mm=np.array(cpu_ref.mpjpe(poses, truth)),
+                 port_vs_reference_max_mm=np.array(float((port - poses).abs().max())),
+                 features_checksum=np.array(float(feat.double().sum())),
+                 input_sha256=np.array(cases.sha256_of(feat, w, b, K)))
+
+
 def gen_recon(ref, only=None):
     for name in cases.RECON_CASES:
         if only and name != only:
@@ -270,10 +307,26 @@ def gen_e2e(ref, only=None):
                 return r
 
             est._get_crops = rec_get_crops
+            # ... and the backbone's output of every crop-model call: with these injected in place of
+            # its own backbone, an implementation's result depends on everything BUT the sampler
+            # (geometry, head, reconstruction, post-processing): tests/test_gpu_e2e.py gates that
+            # glue at 1e-3 mm against the poses of this same run (golden e2efeat_*)
+            feats = []
+            backbone = est.crop_model.backbone
+            hook = backbone.register_forward_hook(lambda m, i, o: feats.append(o.detach().clone()))
             res = est._estimate_poses_batched(
                 case['images'], case['boxes'], case['K'], case['dist'], case['extr'],
                 case['world_up'], 55, case['ibs'], case['aa'], case['num_aug'],
                 case['average_aug'], '', False)
+            hook.remove()
+        if name in cases.E2E_FEATURE_CASES:
+            save(f'e2efeat_{name}', poses3d=torch.cat(res['poses3d']), poses2d=torch.cat(res['poses2d']),
+                 n_calls=np.array(len(feats)), **{f'features_{i}': f for i, f in enumerate(feats)},
+                 input_sha256=np.array(cases.sha256_of(
+                     case['images'], torch.cat(case['boxes']), case['K'], case['dist'], case['extr'],
+                     case['head_w'], case['head_b'])))
+        if os.environ.get('MTR_GOLDEN_E2EFEAT_ONLY') == '1':
+            continue
         crops0, newk0, rot0 = recorded[0]
         flat = crops0.reshape(-1, *crops0.shape[2:])
         arrays = dict(
@@ -294,7 +347,8 @@ def main():
     torch.manual_seed(0)
     ref = rh.load()
     groups = dict(heads=gen_heads, headconv=gen_headconv, recon=gen_recon, warp=gen_warp,
-                  tta=gen_tta, e2e=gen_e2e, detpre=gen_detpre, filter=gen_filter, backbone=gen_backbone)
+                  tta=gen_tta, e2e=gen_e2e, detpre=gen_detpre, filter=gen_filter, backbone=gen_backbone,
+                  parity=gen_parity)
     for name in (sys.argv[1:] or groups):
         if ':' in name:  # one case of a group (recon, e2e: their lstsq goldens carry run-to-run jitter)
             group, only = name.split(':', 1)
