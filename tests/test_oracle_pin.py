@@ -368,3 +368,30 @@ def test_weak_perspective_known_answer():
 def test_box_consistency_known_answer():
     pose2d, boxes, want = cases.box_consistency_kat()
     assert torch.equal(cpu_ref.is_pose_consistent_with_box(pose2d, boxes), want)
+
+
+@pytest.mark.parametrize('regime', cases.PARITY_GATE_REGIMES)
+@pytest.mark.parametrize('name', ['configs[0] ResNet-18 256 B=1', 'configs[1] EffNetV2-S 256 B=64',
+                                  'configs[3] MobileNetV3 256, 8 boxes x 5 aug'])
+def test_port_reproduces_the_stored_parity_gate_references(name, regime):
+    """The features -> poses3d goldens the GPU gates compare with (tests/golden/parity_*.npz: the
+    reference's own MetrabsHeads.forward + reconstruct_absolute run in the build container) against
+    the CPU port here: bit-equal on the CPU that minted them (the golden records 0.0 mm), within the
+    reference's own run-to-run LAPACK / oneDNN jitter elsewhere; the stored fp64 evaluation is
+    reproduced to 1e-9 relative."""
+    B, C, J, hw, P, D, dtype = cases.PARITY_GATE_SHAPES[name]
+    g = load_golden(cases.parity_gate_slug(name, regime))
+    assert float(g['port_vs_reference_max_mm']) == 0.0
+    feat, w, b, K = cases.parity_gate_inputs(name, regime)
+    ocfg = cpu_ref.HeadConfig(proc_side=P, depth=D)
+    with torch.inference_mode():
+        wk = cases.head_weights_as_consumed(w, dtype)
+        port = cpu_ref.crop_model_from_features(feat.float(), wk, b, K, J, ocfg)
+        truth = cpu_ref.crop_model_from_features_fp64(feat.float(), wk, b, K, J, ocfg)
+    ref = torch.from_numpy(g['poses3d'])
+    if cases.sha256_of(feat, w, b, K) == str(g['input_sha256']) and same_cpu_as_golden(g):
+        # (two consecutive calls of the reference itself differ by up to 2 ulp of z = 9.8e-4 mm: its lstsq)
+        assert float((port - ref).abs().max()) <= 2e-3 and cpu_ref.mpjpe(port, ref) <= 1e-3
+    # whatever the host: the port stays within the reference's distance to fp64 (+ jitter) of it
+    assert cpu_ref.mpjpe(port, ref) <= 2.0 * float(g['reference_vs_fp64_mpjpe_mm']) + 5e-4
+    np.testing.assert_allclose(truth.numpy(), g['poses3d_fp64'], rtol=1e-7, atol=1e-5)
