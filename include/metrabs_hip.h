@@ -107,6 +107,10 @@ int mtr_softargmax_decode(const void* logits, int dtype, int layout, int B, int 
  *   ROUNDED TO THE FEATURE DTYPE (what autocast does to conv_final), f32 accumulation, f32 logits.
  *   (C % 64 == 0, and for NCHW also H*W % 8 == 0 and H*W >= 64: tiles staged by global_load_lds
  *   instead of through registers -- same arithmetic, same results.)
+ *   Beyond those limits (72 depth bins; maps of more than 256 positions), C % 64 == 0, D <= 80: the
+ *   row-tile core on v_mfma_f32_16x16x32_{f16,bf16} (head_rt16_kernel), any map size.  It consumes
+ *   NHWC features; NCHW features are transposed once into the workspace of mtr_head_fused_ws
+ *   (without one: MTR_E_WORKSPACE).
  *
  * mtr_head_fused_opts: the same launch with explicit dispatch choices (A/B measurements, tests of
  * every kernel variant); options == NULL or all-zero fields = the library's own choice.  There are
@@ -160,7 +164,10 @@ enum {
   MTR_HEAD_KERNEL_RT_KS = 3,     /* head_rt_ks_kernel: two K groups                                        */
   MTR_HEAD_KERNEL_RT_NP = 4,     /* head_rt_np_kernel: row tiles x column blocks per workgroup             */
   MTR_HEAD_KERNEL_16 = 10,       /* head_fused16_kernel: 16-bit features staged through registers          */
-  MTR_HEAD_KERNEL_16_DMA = 11    /* head_fused16dma_kernel: 16-bit features staged by global_load_lds      */
+  MTR_HEAD_KERNEL_16_DMA = 11,   /* head_fused16dma_kernel: 16-bit features staged by global_load_lds      */
+  MTR_HEAD_KERNEL_16_RT = 12     /* head_rt16_kernel: 16-bit features on the row-tile core (1 + D > 64 rows per
+                                    joint, or maps of more than 256 positions); NCHW features: needs the
+                                    workspace (one transposing pass in front)                              */
 };
 typedef struct mtr_head_plan_info {
   int32_t kernel;
@@ -177,7 +184,7 @@ int mtr_head_plan(int feat_dtype, int layout, int B, int C, int H, int W, int J,
  * more than 64 positions may spread their column blocks over workgroups (rt_split_column_blocks).
  * workspace == NULL is mtr_head_fused_opts.  Still no allocation, no sync, no globals: two launches
  * on `stream` instead of one when the split is taken. */
-size_t mtr_head_workspace_bytes(int B, int J, int D, int H, int W, int feat_dtype);
+size_t mtr_head_workspace_bytes(int feat_dtype, int layout, int B, int C, int H, int W, int J, int D);
 int mtr_head_fused_ws(const void* features, int feat_dtype, int layout, int B, int C, int H, int W,
                       const void* packed, int J, int D, const mtr_head_params* p,
                       const mtr_head_options* options, void* workspace, size_t workspace_bytes,

@@ -34,7 +34,7 @@ class HeadPlanInfo(ctypes.Structure):
 
 
 HEAD_KERNEL_NAMES = {1: 'head_rt_kernel', 2: 'head_rt_ld_kernel', 3: 'head_rt_ks_kernel', 4: 'head_rt_np_kernel',
-                     10: 'head_fused16_kernel', 11: 'head_fused16dma_kernel'}
+                     10: 'head_fused16_kernel', 11: 'head_fused16dma_kernel', 12: 'head_rt16_kernel'}
 
 
 class ReconParams(ctypes.Structure):
@@ -78,7 +78,7 @@ SIGNATURES = {
                                     c_void_p]),
     'mtr_head_plan': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(HeadOptions),
                               c_int, POINTER(HeadPlanInfo)]),
-    'mtr_head_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    'mtr_head_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'mtr_head_fused_ws': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                   c_int, POINTER(HeadParams), POINTER(HeadOptions), c_void_p, c_size_t,
                                   c_void_p, c_void_p, c_void_p]),

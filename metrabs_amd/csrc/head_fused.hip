@@ -781,6 +781,8 @@ static size_t h16_blob_bytes(int C, int J, int D) {
          (size_t)g.n_groups * ((C + kKH - 1) / kKH) * kRows * kKH * 2;
 }
 
+static size_t h16_blob_padded(int C, int J, int D) { return (h16_blob_bytes(C, J, D) + 15) & ~(size_t)15; }
+
 }  // namespace mtr
 
 // host-only: the row plan of the row-tile core (which conv_final channel each packed row holds)
@@ -806,7 +808,9 @@ extern "C" int mtr_head_row_plan(int J, int D, int32_t* n_tiles, int32_t* tiles_
 extern "C" size_t mtr_head_packed_bytes(int C, int J, int D, int feat_dtype) {
   if (C <= 0 || J <= 0 || D <= 0) return 0;
   if (feat_dtype == MTR_F32) return mtr::rt_section_bytes(C, J, D);
-  if (feat_dtype == MTR_F16 || feat_dtype == MTR_BF16) return mtr::h16_blob_bytes(C, J, D);
+  // 16-bit: [joint-group blob (1 + D <= 64, C % 8 == 0), padded to 16 bytes][row-tile section (C % 64 == 0)]
+  if (feat_dtype == MTR_F16 || feat_dtype == MTR_BF16)
+    return mtr::h16_blob_padded(C, J, D) + mtr::rt16_section_bytes(C, J, D);
   return 0;
 }
 
@@ -817,6 +821,12 @@ extern "C" int mtr_head_pack_weights(const float* weight, const float* bias, int
   if (mtr_head_packed_bytes(C, J, D, feat_dtype) == 0) return MTR_E_SHAPE;
   if ((uintptr_t)packed % 16) return MTR_E_ALIGN;
   if (feat_dtype == MTR_F32) return mtr::rt_pack(weight, bias, C, J, D, packed, (hipStream_t)stream);
+  if (mtr::rt16_section_bytes(C, J, D)) {
+    const int rc = mtr::rt16_pack(weight, bias, C, J, D, feat_dtype, (char*)packed + mtr::h16_blob_padded(C, J, D),
+                                  (hipStream_t)stream);
+    if (rc != MTR_OK) return rc;
+  }
+  if (mtr::h16_blob_bytes(C, J, D) == 0) return MTR_OK;
   const mtr::HeadGeom g = mtr::head_geom(J, D);
   const int n_bias = g.n_groups * mtr::kRows;
   MTR_CLEAR_STALE();
@@ -836,6 +846,11 @@ extern "C" int mtr_head_pack_weights(const float* weight, const float* bias, int
                        0, (hipStream_t)stream, weight, C, J, D, g, n_st, (__hip_bfloat16*)w16);
   MTR_CHECK_LAUNCH();
   return MTR_OK;
+}
+
+// 16-bit features: do the joint-group kernels take the shape, or the row-tile core?
+static bool head16_takes_rt(int C, int J, int D, int H, int W) {
+  return !(mtr::h16_shape_ok(C, J, D) && H * W <= 256) && mtr::rt16_section_bytes(C, J, D) != 0;
 }
 
 static int parse_head_options(const mtr_head_options* options, mtr::HeadOpts& opt) {
@@ -876,6 +891,12 @@ extern "C" int mtr_head_plan(int feat_dtype, int layout, int B, int C, int H, in
     return MTR_OK;
   }
   if (feat_dtype != MTR_F16 && feat_dtype != MTR_BF16) return MTR_E_DTYPE;
+  if (head16_takes_rt(C, J, D, H, W)) {
+    const mtr::RtDispatch d = mtr::rt16_dispatch(B, H, W, J, D, opt.rt_tiles, opt.rt_split,
+                                                 have_workspace != 0 && (H * W + 63) / 64 >= 2);
+    *plan = mtr_head_plan_info{MTR_HEAD_KERNEL_16_RT, d.rtg, 1, d.split, d.n_wg};
+    return (layout == MTR_NCHW && !have_workspace) ? MTR_E_WORKSPACE : MTR_OK;
+  }
   if (!mtr::h16_shape_ok(C, J, D) || H * W > 256) return MTR_E_SHAPE;
   const mtr::HeadGeom g = mtr::head_geom(J, D);
   int ct = (H * W + 31) / 32;
@@ -888,9 +909,12 @@ extern "C" int mtr_head_plan(int feat_dtype, int layout, int B, int C, int H, in
   return MTR_OK;
 }
 
-extern "C" size_t mtr_head_workspace_bytes(int B, int J, int D, int H, int W, int feat_dtype) {
-  if (feat_dtype != MTR_F32) return 0;
-  return mtr::rt_workspace_bytes(B, J, D, H, W);
+extern "C" size_t mtr_head_workspace_bytes(int feat_dtype, int layout, int B, int C, int H, int W, int J, int D) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || J <= 0 || D <= 0) return 0;
+  if (feat_dtype == MTR_F32) return mtr::rt_workspace_bytes(B, J, D, H, W);
+  if ((feat_dtype == MTR_F16 || feat_dtype == MTR_BF16) && head16_takes_rt(C, J, D, H, W))
+    return mtr::rt16_workspace_bytes(B, C, J, D, H, W, layout);
+  return 0;
 }
 
 extern "C" int mtr_head_fused_opts(const void* features, int feat_dtype, int layout, int B, int C,
@@ -927,6 +951,14 @@ extern "C" int mtr_head_fused_ws(const void* features, int feat_dtype, int layou
     return mtr::rt_launch((const float*)features, layout, packed, B, C, H, W, J, D, hs, coords2d,
                           coords3d_rel, opt.rt_tiles, opt.rt_np, opt.rt_ks, opt.rt_ld, opt.rt_split,
                           workspace, workspace_bytes, s);
+  }
+  // 16-bit: the row-tile core beyond the joint-group kernels' limits (1 + D > 64 rows, > 256 positions)
+  if (head16_takes_rt(C, J, D, H, W)) {
+    if (B == 0) return MTR_OK;
+    if (workspace && ((uintptr_t)workspace % 16)) return MTR_E_ALIGN;
+    return mtr::rt16_launch(features, feat_dtype, layout, (const char*)packed + mtr::h16_blob_padded(C, J, D), B, C, H,
+                            W, J, D, hs, coords2d, coords3d_rel, opt.rt_tiles, opt.rt_split, workspace,
+                            workspace_bytes, s);
   }
   // 16-bit joint-group kernels: a joint's 1 + D rows inside one 64-row tile, maps of <= 256 positions
   if (!mtr::h16_shape_ok(C, J, D) || H * W > 256) return MTR_E_SHAPE;

@@ -117,9 +117,20 @@ size_t rt_workspace_bytes(int B, int J, int D, int H, int W);
 
 // which kernel a launch takes: kernel id (MTR_HEAD_KERNEL_* of the header), tiles per workgroup, column
 // blocks per workgroup tile (np kernel), column-block split (0 = none), workgroups of the main launch
-enum { kRtKernelPlain = 1, kRtKernelLoader = 2, kRtKernelTwoKGroups = 3, kRtKernelNp = 4 };
+enum { kRtKernelPlain = 1, kRtKernelLoader = 2, kRtKernelTwoKGroups = 3, kRtKernelNp = 4, kRtKernel16 = 12 };
 struct RtDispatch { int kernel, rtg, np, split; long long n_wg; };
 RtDispatch rt_dispatch(int B, int C, int H, int W, int J, int D, int rtg_hint, int np_hint, int ks_hint,
                        int ld_hint, int split_hint, bool have_workspace);
+
+// ---- 16-bit features on the row-tile core (head_rt16_kernel): C % 64 == 0, D <= 80, any map size; the
+// section of the packed blob: [stage of 64 ch][tile][16 rows][64 ch] in the feature dtype + bias + labels
+size_t rt16_section_bytes(int C, int J, int D);
+int rt16_pack(const float* weight, const float* bias, int C, int J, int D, int feat_dtype, void* section,
+              hipStream_t stream);
+size_t rt16_workspace_bytes(int B, int C, int J, int D, int H, int W, int layout);
+RtDispatch rt16_dispatch(int B, int H, int W, int J, int D, int rtg_hint, int split_hint, bool have_split_ws);
+int rt16_launch(const void* feat, int feat_dtype, int layout, const void* section, int B, int C, int H, int W,
+                int J, int D, const HeadScale& hs, float* coords2d, float* coords3d_rel, int rtg_hint,
+                int split_hint, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
 }  // namespace mtr

@@ -347,6 +347,130 @@ __global__ __launch_bounds__(256) void head_rt_merge_kernel(RtArgs a, int n_cb) 
   }
 }
 
+// The decode of a workgroup's logits tile (rows x NP column blocks of 64 positions, row pitch NP * 68
+// floats in LDS): per row the maximum, per softmax unit (a 2D row; the D depth slices of a joint) the
+// unit maximum, the f64 sums of e, e x, e y per row, the unit's sums and the hand-over to
+// rt_unit_finish.  A 16-lane group per row, NG groups; idle_wave: a wave that only keeps the barrier
+// count (the loader wave).  Shared by the f32 kernels (rt_block) and the 16-bit one (rt16_block).
+template <int RT, int NP, int NG>
+__device__ __forceinline__ void rt_decode_blocks(const RtArgs& a, float* Ls, float* rowmax, float* unitmax,
+                                                 int* info_s, double* rowsum, double* runstat, int tid,
+                                                 bool idle_wave, int HW, int crop, int t0, int cb0, int n_cb) {
+  constexpr int R = RT * 16, KR = (R + NG - 1) / NG, LP = NP * kRtLP;
+#pragma unroll 1
+   for (int np = 0; np < NP; ++np) {  // decode the group's column blocks one after the other
+    const int cb = NP == 1 ? cb0 : cb0 + np;
+    if (NP > 1 && cb >= n_cb) break;
+    const float* Lb = Ls + np * kRtLP;  // this column block's 64 columns (row pitch LP)
+    // ---- decode, a 16-lane group per row (RT rounds of 16 rows)
+    // (the addresses below do not depend on the column block; the empty asm keeps the compiler from
+    //  computing them once in front of the K loop and holding them in registers through it)
+    int tid_d = tid;
+    asm volatile("" : "+v"(tid_d));
+    const int grp = tid_d >> 4, l16 = tid_d & 15;
+    const int pbase = cb * 64 + l16 * 4;  // this lane's 4 positions
+    v4f x[KR];
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+      const int row = k * NG + grp;
+      if ((KR * NG > R && row >= R) || idle_wave) continue;
+      x[k] = *reinterpret_cast<const v4f*>(Lb + row * LP + l16 * 4);
+      float m = -INFINITY;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (pbase + q < HW) m = fmaxf(m, x[k][q]);
+      m = group_max<16>(m);
+      if (l16 == 0) rowmax[row] = m;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+      const int row = k * NG + grp;
+      if ((KR * NG > R && row >= R) || idle_wave) continue;
+      const unsigned inf = (unsigned)info_s[row];
+      const int kind = inf & 3, d = (inf >> 2) & 0x3fff;
+      const int first = kind == 2 ? row - d : row, n = kind == 2 ? a.D : 1;
+      float m = -INFINITY;
+      for (int kk = l16; kk < n; kk += 16) m = fmaxf(m, rowmax[first + kk]);
+      m = group_max<16>(m);
+      const float nm = -m * kLog2e;
+      double s = 0, sx = 0, sy = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int p = pbase + q;
+        if (p < HW && kind != 0) {
+          const double e = MTR_RT_EXP32 ? (double)exp_shifted(x[k][q], nm)
+                                        : exp_neg64((double)x[k][q] - (double)m);
+          const int h = p / a.W, w = p - h * a.W;
+          s += e;
+          sx += e * (double)w;
+          sy += e * (double)h;
+        }
+      }
+      s = group_sum<16>(s);
+      sx = group_sum<16>(sx);
+      sy = group_sum<16>(sy);
+      if (l16 == 0) {
+        rowsum[row * 3 + 0] = s;
+        rowsum[row * 3 + 1] = sx;
+        rowsum[row * 3 + 2] = sy;
+        unitmax[row] = m;
+      }
+    }
+    __syncthreads();
+    if (a.D > 16) {  // (wave-uniform) long units: 72 depth slices
+      // a unit's rows are added by the 16-lane group of its FIRST row (lane l takes rows l, l + 16,
+      // ...: 5 rows per lane instead of a 72-step chain in one thread; measured 170 -> 161 us at
+      // B = 64, D = 72.  Short units keep the one-thread loop below: 8 rows, and 1 - 4 % faster)
+  #pragma unroll
+      for (int k = 0; k < KR; ++k) {
+        const int row = k * NG + grp;
+        if ((KR * NG > R && row >= R) || idle_wave) continue;
+        const unsigned inf = (unsigned)info_s[row];
+        const int kind = inf & 3, d = (inf >> 2) & 0x3fff, j = (int)(inf >> 16);
+        if (!(kind == 1 || (kind == 2 && d == 0))) continue;  // (uniform in the group)
+        const int n = kind == 2 ? a.D : 1;
+        double S = 0, SX = 0, SY = 0, SZ = 0;
+        for (int kk = l16; kk < n; kk += 16) {
+          const double s = rowsum[(row + kk) * 3];
+          S += s;
+          SX += rowsum[(row + kk) * 3 + 1];
+          SY += rowsum[(row + kk) * 3 + 2];
+          SZ += s * (double)kk;
+        }
+        if (n > 1) {
+          S = group_sum<16>(S);
+          SX = group_sum<16>(SX);
+          SY = group_sum<16>(SY);
+          SZ = group_sum<16>(SZ);
+        }
+        if (l16 != 0) continue;
+        rt_unit_finish(a, crop, t0, row, kind, j, cb, n_cb, unitmax[row], S, SX, SY, SZ, runstat);
+      }
+    } else {
+      int tid_c = tid;
+      asm volatile("" : "+v"(tid_c));
+      if (tid_c < R) {
+        const unsigned inf = (unsigned)info_s[tid_c];
+        const int kind = inf & 3, d = (inf >> 2) & 0x3fff, j = (int)(inf >> 16);
+        if (kind == 1 || (kind == 2 && d == 0)) {
+          const int n = kind == 2 ? a.D : 1;
+          double S = 0, SX = 0, SY = 0, SZ = 0;
+          for (int k = 0; k < n; ++k) {
+            const double s = rowsum[(tid_c + k) * 3];
+            S += s;
+            SX += rowsum[(tid_c + k) * 3 + 1];
+            SY += rowsum[(tid_c + k) * 3 + 2];
+            SZ += s * (double)k;
+          }
+          rt_unit_finish(a, crop, t0, tid_c, kind, j, cb, n_cb, unitmax[tid_c], S, SX, SY, SZ, runstat);
+        }
+      }
+    }
+    if (NP > 1) __syncthreads();  // (the next column block re-uses rowmax / rowsum)
+   }
+}
+
 // The loader wave of head_rt_ld_kernel (see rt_block): ALL copies of every stage of one K loop, NBUF - 1
 // stages ahead of the MFMA waves.  Per stage: wait until this wave's copies of stage s have landed
 // (those of s + 1 .. s + NBUF - 2 stay in flight), meet the MFMA waves at barrier B_s -- they have
@@ -356,7 +480,7 @@ __global__ __launch_bounds__(256) void head_rt_merge_kernel(RtArgs a, int n_cb) 
 __host__ __device__ constexpr int rt_ld_nbuf(int rtmax) { return rtmax <= 3 ? MTR_RT_LD_NBUF : 4; }
 __host__ __device__ constexpr int rt_ld_la(int rtmax) { return rtmax <= 3 ? MTR_RT_LD_LA : 3; }
 
-template <int RT, bool NHWC, int NBUF, int LA>
+template <int RT, bool NHWC, int NBUF, int LA, int ESIZE = 4>
 __device__ __forceinline__ void rt_loader_loop(const RtArgs& a, unsigned lds0, const char* fcrop, int t0,
                                                int cb, int n_stages, int lane, int HW) {
   constexpr int STAGE = rt_stage_bytes(RT, 1, NHWC);
@@ -379,7 +503,7 @@ __device__ __forceinline__ void rt_loader_loop(const RtArgs& a, unsigned lds0, c
       if constexpr (NHWC) {
         const int pos = jb * 8 + (lane >> 3), slot = (lane & 7) ^ ((pos >> 1) & 7);
         const int P = cb * 64 + pos;
-        vo[j] = (unsigned)(P < HW ? P : 0) * (unsigned)a.C * 4u + slot * 16;
+        vo[j] = (unsigned)(P < HW ? P : 0) * (unsigned)a.C * (unsigned)ESIZE + slot * 16;
       } else {
         const int ch = jb * 4 + (lane >> 4);
         const int p = cb * 64 + (lane & 15) * 4;
@@ -452,7 +576,6 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
   constexpr bool kPair = MTR_RT_PAIR && KS == 1 && kRtNbuf == 4 && !LD;
   constexpr int LA = kPair ? 2 : kRtNbuf - 1;   // stages in flight behind the one being consumed
   constexpr int NG = 16 * KS;                   // 16-lane groups of the workgroup (decode: one row each)
-  constexpr int KR = (RT * 16 + NG - 1) / NG;   // decode rounds
   constexpr int CHUNK = rt_feat_chunk(NHWC);   // LDS bytes of one column block's features per stage
   constexpr int JOBS = 2 * RT + 8 * NP;  // 1 KiB copies per stage: 2 per weight tile, 8 per column block
   constexpr int JPW = (JOBS + 3) / 4;    // per wave (upper bound)
@@ -810,118 +933,8 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
       if (tid == 0 && cb0 + NP >= n_cb) a.c2d[(size_t)crop * a.J * 2] = Ls[0];
       continue;
     }
-#pragma unroll 1
-   for (int np = 0; np < NP; ++np) {  // decode the group's column blocks one after the other
-    const int cb = NP == 1 ? cb0 : cb0 + np;
-    if (NP > 1 && cb >= n_cb) break;
-    const float* Lb = Ls + np * kRtLP;  // this column block's 64 columns (row pitch LP)
-    // ---- decode, a 16-lane group per row (RT rounds of 16 rows)
-    // (the addresses below do not depend on the column block; the empty asm keeps the compiler from
-    //  computing them once in front of the K loop and holding them in registers through it)
-    int tid_d = tid;
-    asm volatile("" : "+v"(tid_d));
-    const int grp = tid_d >> 4, l16 = tid_d & 15;
-    const int pbase = cb * 64 + l16 * 4;  // this lane's 4 positions
-    v4f x[KR];
-#pragma unroll
-    for (int k = 0; k < KR; ++k) {
-      const int row = k * NG + grp;
-      if ((KR * NG > R && row >= R) || is_loader) continue;
-      x[k] = *reinterpret_cast<const v4f*>(Lb + row * LP + l16 * 4);
-      float m = -INFINITY;
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (pbase + q < HW) m = fmaxf(m, x[k][q]);
-      m = group_max<16>(m);
-      if (l16 == 0) rowmax[row] = m;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < KR; ++k) {
-      const int row = k * NG + grp;
-      if ((KR * NG > R && row >= R) || is_loader) continue;
-      const unsigned inf = (unsigned)info_s[row];
-      const int kind = inf & 3, d = (inf >> 2) & 0x3fff;
-      const int first = kind == 2 ? row - d : row, n = kind == 2 ? a.D : 1;
-      float m = -INFINITY;
-      for (int kk = l16; kk < n; kk += 16) m = fmaxf(m, rowmax[first + kk]);
-      m = group_max<16>(m);
-      const float nm = -m * kLog2e;
-      double s = 0, sx = 0, sy = 0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int p = pbase + q;
-        if (p < HW && kind != 0) {
-          const double e = MTR_RT_EXP32 ? (double)exp_shifted(x[k][q], nm)
-                                        : exp_neg64((double)x[k][q] - (double)m);
-          const int h = p / a.W, w = p - h * a.W;
-          s += e;
-          sx += e * (double)w;
-          sy += e * (double)h;
-        }
-      }
-      s = group_sum<16>(s);
-      sx = group_sum<16>(sx);
-      sy = group_sum<16>(sy);
-      if (l16 == 0) {
-        rowsum[row * 3 + 0] = s;
-        rowsum[row * 3 + 1] = sx;
-        rowsum[row * 3 + 2] = sy;
-        unitmax[row] = m;
-      }
-    }
-    __syncthreads();
-    if (a.D > 16) {  // (wave-uniform) long units: 72 depth slices
-      // a unit's rows are added by the 16-lane group of its FIRST row (lane l takes rows l, l + 16,
-      // ...: 5 rows per lane instead of a 72-step chain in one thread; measured 170 -> 161 us at
-      // B = 64, D = 72.  Short units keep the one-thread loop below: 8 rows, and 1 - 4 % faster)
-  #pragma unroll
-      for (int k = 0; k < KR; ++k) {
-        const int row = k * NG + grp;
-        if ((KR * NG > R && row >= R) || is_loader) continue;
-        const unsigned inf = (unsigned)info_s[row];
-        const int kind = inf & 3, d = (inf >> 2) & 0x3fff, j = (int)(inf >> 16);
-        if (!(kind == 1 || (kind == 2 && d == 0))) continue;  // (uniform in the group)
-        const int n = kind == 2 ? a.D : 1;
-        double S = 0, SX = 0, SY = 0, SZ = 0;
-        for (int kk = l16; kk < n; kk += 16) {
-          const double s = rowsum[(row + kk) * 3];
-          S += s;
-          SX += rowsum[(row + kk) * 3 + 1];
-          SY += rowsum[(row + kk) * 3 + 2];
-          SZ += s * (double)kk;
-        }
-        if (n > 1) {
-          S = group_sum<16>(S);
-          SX = group_sum<16>(SX);
-          SY = group_sum<16>(SY);
-          SZ = group_sum<16>(SZ);
-        }
-        if (l16 != 0) continue;
-        rt_unit_finish(a, crop, t0, row, kind, j, cb, n_cb, unitmax[row], S, SX, SY, SZ, runstat);
-      }
-    } else {
-      int tid_c = tid;
-      asm volatile("" : "+v"(tid_c));
-      if (tid_c < R) {
-        const unsigned inf = (unsigned)info_s[tid_c];
-        const int kind = inf & 3, d = (inf >> 2) & 0x3fff, j = (int)(inf >> 16);
-        if (kind == 1 || (kind == 2 && d == 0)) {
-          const int n = kind == 2 ? a.D : 1;
-          double S = 0, SX = 0, SY = 0, SZ = 0;
-          for (int k = 0; k < n; ++k) {
-            const double s = rowsum[(tid_c + k) * 3];
-            S += s;
-            SX += rowsum[(tid_c + k) * 3 + 1];
-            SY += rowsum[(tid_c + k) * 3 + 2];
-            SZ += s * (double)k;
-          }
-          rt_unit_finish(a, crop, t0, tid_c, kind, j, cb, n_cb, unitmax[tid_c], S, SX, SY, SZ, runstat);
-        }
-      }
-    }
-    if (NP > 1) __syncthreads();  // (the next column block re-uses rowmax / rowsum)
-   }
+    rt_decode_blocks<RT, NP, NG>(a, Ls, rowmax, unitmax, info_s, rowsum, runstat, tid, is_loader, HW, crop, t0,
+                                 cb0, n_cb);
     // (the next group's copies only touch the ring, which every wave left before the barrier behind
     //  the logits store; its logits store is many barriers away)
   }
@@ -1053,6 +1066,273 @@ size_t rt_workspace_bytes(int B, int J, int D, int H, int W) {
   const int n_cb = (H * W + 63) / 64;
   if (n_cb < 2) return 0;
   return (size_t)B * n_cb * rt_geom(J, D).n_tiles * 16 * 5 * sizeof(double);
+}
+
+// =====================================================================================================
+// 16-bit features (f16 / bf16), row-tile core: the shapes the joint-group kernels of head_fused.hip do
+// not take -- more than 63 depth bins (1 + D > 64 rows per joint) or maps of more than 256 positions.
+// Same row plan, same LDS images and the same loader wave as the f32 loader-wave kernel: a row of 64
+// 16-bit channels is the 128 bytes a row of 32 f32 channels is, so a "stage" is 64 channels and the
+// copy job list, the XOR swizzle and the fragment addresses are byte for byte those of the f32 NHWC
+// path.  What differs is the arithmetic, and it is the reference's autocast arithmetic
+// (multiperson_model.py:240-242): v_mfma_f32_16x16x32_{f16,bf16} on the features and on the weights
+// ROUNDED TO THE FEATURE DTYPE, f32 accumulation along all of K in the matrix core (no f64 carry: the
+// products of two 16-bit values are exact in f32), f32 logits on chip.  A lane's 16-byte fragment is 8
+// consecutive channels = one operand of one MFMA: two MFMAs per row tile and stage instead of eight.
+// Features must be NHWC (K-contiguous); NCHW features are transposed once into the caller's workspace
+// (rt16_to_nhwc_kernel) -- these shapes spend 50 - 150 us in the head, the extra pass 3 - 10.
+using h16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+template <typename T>
+__device__ __forceinline__ v4f rt16_mfma(v4f a, v4f b, v4f c) {
+  if constexpr (sizeof(T) == 2 && __is_same(T, __half))
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <typename T>
+__global__ void head_rt16_pack_kernel(const float* __restrict__ w, const float* __restrict__ bias, int C,
+                                      int J, int D, RtGeom g, int n_stages, char* __restrict__ section) {
+  T* wt = reinterpret_cast<T*>(section);
+  const size_t n_w = (size_t)n_stages * g.n_tiles * 1024;  // 16 rows x 64 channels per tile and stage
+  float* bias_p = reinterpret_cast<float*>(section + n_w * 2);
+  int* info = reinterpret_cast<int*>(bias_p + g.n_tiles * 16);
+  const size_t total = n_w + (size_t)g.n_tiles * 16;
+  for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < total;
+       u += (size_t)gridDim.x * blockDim.x) {
+    if (u < n_w) {
+      const int e = (int)(u & 7), slotp = (int)((u >> 3) & 7), row = (int)((u >> 6) & 15);
+      const size_t ts = u >> 10;  // stage * n_tiles + tile
+      const int tile = (int)(ts % g.n_tiles), stage = (int)(ts / g.n_tiles);
+      const int c = stage * 64 + ((slotp ^ ((row >> 1) & 7)) << 3) + e;
+      const RtRow rr = rt_row(g, J, D, tile * 16 + row);
+      float v = 0.0f;
+      if (rr.kind && c < C) v = w[(size_t)(rr.kind == 1 ? rr.joint : J + rr.d * J + rr.joint) * C + c];
+      if constexpr (__is_same(T, __half)) wt[u] = __float2half(v);
+      else wt[u] = __float2bfloat16(v);
+    } else {
+      const int r = (int)(u - n_w);
+      const RtRow rr = rt_row(g, J, D, r);
+      bias_p[r] = rr.kind ? bias[rr.kind == 1 ? rr.joint : J + rr.d * J + rr.joint] : 0.0f;
+      info[r] = rt_encode(rr);
+    }
+  }
+}
+
+// [B][C][HW] -> [B][HW][C], 16-bit elements, 64 x 64 tiles through LDS (C % 64 == 0, HW % 4 == 0)
+template <typename T>
+__global__ __launch_bounds__(256) void rt16_to_nhwc_kernel(const T* __restrict__ in, T* __restrict__ out, int C,
+                                                           int HW) {
+  __shared__ T tile[64][66];
+  const int b = blockIdx.z, c0 = blockIdx.y * 64, p0 = blockIdx.x * 64;
+  const T* src = in + ((size_t)b * C + c0) * HW;
+  T* dst = out + ((size_t)b * HW) * C + c0;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int ch = ty + 4 * i, p = p0 + tx;
+    if (p < HW) tile[ch][tx] = src[(size_t)ch * HW + p];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int pl = ty + 4 * i, p = p0 + pl;
+    if (p < HW) dst[(size_t)p * C + tx] = tile[tx][pl];
+  }
+}
+
+constexpr int kRt16Nbuf = 4, kRt16La = 3;
+__host__ __device__ constexpr int rt16_lds_bytes(int rtmax) {
+  return kRt16Nbuf * rt_stage_bytes(rtmax, 1, true) + rt_epilogue_bytes(rtmax, 1);
+}
+
+template <typename T, int RT, int RTMAX>
+__device__ __forceinline__ void rt16_block(const RtArgs& a, char* smem, int crop, int t0, int cb_first,
+                                           int cb_count) {
+  constexpr int STAGE = rt_stage_bytes(RT, 1, true);
+  constexpr int R = RT * 16, LP = kRtLP;
+  float* Ls = reinterpret_cast<float*>(smem + kRt16Nbuf * rt_stage_bytes(RTMAX, 1, true));
+  float* rowmax = Ls + RTMAX * 16 * LP;
+  float* unitmax = rowmax + RTMAX * 16;
+  float* bias_s = unitmax + RTMAX * 16;
+  int* info_s = reinterpret_cast<int*>(bias_s + RTMAX * 16);
+  double* rowsum = reinterpret_cast<double*>(info_s + RTMAX * 16);
+  double* runstat = rowsum + RTMAX * 16 * 3;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wid = wave & 3;
+  const bool is_loader = wave == 4;
+  const int HW = a.H * a.W;
+  const int n_stages = a.n_stages;
+  const unsigned lds0 = rt_lds_addr(smem);
+  const char* fcrop = reinterpret_cast<const char*>(a.feat) + (size_t)crop * a.C * HW * 2;
+  if (tid < R) {
+    bias_s[tid] = a.bias_p[t0 * 16 + tid];
+    info_s[tid] = a.info[t0 * 16 + tid];
+  }
+  const int i16 = lane & 15, g4 = lane >> 4;
+  const int a_off = i16 * 128 + ((g4 ^ ((i16 >> 1) & 7)) << 4);
+  const int pos = wid * 16 + i16;
+  const int b_off = RT * 2048 + pos * 128 + ((g4 ^ ((pos >> 1) & 7)) << 4);
+  const int n_cb = (HW + 63) >> 6;
+  const int cb_end = cb_first + cb_count < n_cb ? cb_first + cb_count : n_cb;
+  for (int cb0 = cb_first; cb0 < cb_end; ++cb0) {
+    if (is_loader) {
+      rt_loader_loop<RT, true, kRt16Nbuf, kRt16La, 2>(a, lds0, fcrop, t0, cb0, n_stages, lane, HW);
+    } else {
+      v4f acc[RT];
+#pragma unroll
+      for (int t = 0; t < RT; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
+      int slot = 0;
+      for (int s = 0; s < n_stages; ++s) {
+        __syncthreads();  // the loader waited for the copies of stage s; everyone left the slot of s - 1
+        const char* buf = smem + slot * STAGE;
+        slot = slot + 1 == kRt16Nbuf ? 0 : slot + 1;
+        v4f fa0[RT], fa1[RT];
+        const v4f fb0 = *reinterpret_cast<const v4f*>(buf + b_off);
+        const v4f fb1 = *reinterpret_cast<const v4f*>(buf + (b_off ^ 64));
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+          fa0[t] = *reinterpret_cast<const v4f*>(buf + t * 2048 + a_off);
+          fa1[t] = *reinterpret_cast<const v4f*>(buf + t * 2048 + (a_off ^ 64));
+        }
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[t] = rt16_mfma<T>(fa0[t], fb0, acc[t]);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[t] = rt16_mfma<T>(fa1[t], fb1, acc[t]);
+      }
+      // logits (+bias) -> LDS.  C/D layout of the 16x16 accumulators: col = l & 15, row = 4 (l >> 4) + reg
+      const int col = wid * 16 + i16, row0 = g4 * 4;
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = t * 16 + row0 + r;
+          Ls[row * LP + col] = acc[t][r] + bias_s[row];
+        }
+    }
+    __syncthreads();
+    rt_decode_blocks<RT, 1, 16>(a, Ls, rowmax, unitmax, info_s, rowsum, runstat, tid, is_loader, HW, crop, t0, cb0,
+                                n_cb);
+  }
+}
+
+template <typename T, int RTMAX>
+__global__ __launch_bounds__(320, 1) void head_rt16_kernel(RtArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const RtWork w = rt_work(a);
+  if (w.crop >= a.B) return;
+  const int t0 = w.blk * a.rtg;
+  const int rt = min(a.rtg, a.n_tiles - t0);
+  if (rt == 1) rt16_block<T, 1, RTMAX>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
+  if (rt == 2) rt16_block<T, 2, RTMAX>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
+  if (rt == 3) rt16_block<T, 3, RTMAX>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
+  if (rt == 4) rt16_block<T, 4, RTMAX>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
+  if (rt == 5) rt16_block<T, 5, RTMAX>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
+}
+
+size_t rt16_section_bytes(int C, int J, int D) {
+  if (!rt_shape_ok(C, J, D) || C % 64 != 0) return 0;
+  const RtGeom g = rt_geom(J, D);
+  return (size_t)(C / 64) * g.n_tiles * 2048 + (size_t)g.n_tiles * 16 * 8;
+}
+
+int rt16_pack(const float* weight, const float* bias, int C, int J, int D, int feat_dtype, void* section,
+              hipStream_t stream) {
+  const RtGeom g = rt_geom(J, D);
+  const int n_stages = C / 64;
+  const size_t total = (size_t)n_stages * g.n_tiles * 1024 + (size_t)g.n_tiles * 16;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  MTR_CLEAR_STALE();
+  if (feat_dtype == MTR_F16)
+    hipLaunchKernelGGL(head_rt16_pack_kernel<__half>, dim3((unsigned)blocks), dim3(256), 0, stream, weight, bias,
+                       C, J, D, g, n_stages, (char*)section);
+  else
+    hipLaunchKernelGGL(head_rt16_pack_kernel<__hip_bfloat16>, dim3((unsigned)blocks), dim3(256), 0, stream, weight,
+                       bias, C, J, D, g, n_stages, (char*)section);
+  MTR_CHECK_LAUNCH();
+  return MTR_OK;
+}
+
+// workspace: [NHWC copy of NCHW features, 256-byte aligned size][column-block statistics]
+static size_t rt16_nhwc_bytes(int B, int C, int H, int W) {
+  return (((size_t)B * C * H * W * 2) + 255) & ~(size_t)255;
+}
+size_t rt16_workspace_bytes(int B, int C, int J, int D, int H, int W, int layout) {
+  if (!rt_shape_ok(C, J, D) || C % 64 != 0 || B <= 0) return 0;
+  return (layout == MTR_NCHW ? rt16_nhwc_bytes(B, C, H, W) : 0) + rt_workspace_bytes(B, J, D, H, W);
+}
+
+RtDispatch rt16_dispatch(int B, int H, int W, int J, int D, int rtg_hint, int split_hint, bool have_split_ws) {
+  const RtGeom g = rt_geom(J, D);
+  RtDispatch d{kRtKernel16, g.a > 1 ? g.a : 5, 1, 0, 0};
+  const int n_cb = (H * W + 63) / 64;
+  long long crops = (long long)((B + 7) / 8) * 8;
+  // the MFMAs are 1/16 of the f32 kernel's: the launch is bounded by its copies, so the largest block
+  // (fewest re-copies of a crop's features) that still gives every CU a workgroup; column blocks go to
+  // different workgroups while the launch would otherwise leave CUs idle
+  if (n_cb >= 2 && have_split_ws && split_hint != 1 &&
+      (split_hint == 2 || crops * ((g.n_tiles + d.rtg - 1) / d.rtg) < 512)) {
+    d.split = n_cb;
+    crops *= n_cb;
+  }
+  if (g.a == 1) {
+    int r = 5;
+    while (r > 1 && crops * ((g.n_tiles + r - 1) / r) < 256) --r;
+    if (rtg_hint >= 1 && rtg_hint <= 5) r = rtg_hint;
+    d.rtg = r;
+  }
+  d.n_wg = crops * ((g.n_tiles + d.rtg - 1) / d.rtg);
+  return d;
+}
+
+int rt16_launch(const void* feat, int feat_dtype, int layout, const void* section, int B, int C, int H, int W,
+                int J, int D, const HeadScale& hs, float* coords2d, float* coords3d_rel, int rtg_hint,
+                int split_hint, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  const RtGeom g = rt_geom(J, D);
+  RtArgs a;
+  a.n_stages = C / 64;
+  a.wt = (const char*)section;
+  a.bias_p = (const float*)(a.wt + (size_t)a.n_stages * g.n_tiles * 2048);
+  a.info = (const int*)(a.bias_p + g.n_tiles * 16);
+  a.B = B; a.C = C; a.H = H; a.W = W; a.J = J; a.D = D;
+  a.n_tiles = g.n_tiles;
+  a.hs = hs;
+  a.inv = make_axis_inv(W, H, D);
+  a.c2d = coords2d;
+  a.c3d = coords3d_rel;
+  char* ws = (char*)workspace;
+  size_t left = workspace ? workspace_bytes : 0;
+  const void* nhwc = feat;
+  if (layout == MTR_NCHW) {  // K-contiguous operands: one transposing pass into the workspace
+    const size_t need = rt16_nhwc_bytes(B, C, H, W);
+    if (left < need) return MTR_E_WORKSPACE;
+    const dim3 grid((unsigned)((H * W + 63) / 64), (unsigned)(C / 64), (unsigned)B);
+    MTR_CLEAR_STALE();
+    if (feat_dtype == MTR_F16)
+      hipLaunchKernelGGL(rt16_to_nhwc_kernel<__half>, grid, dim3(256), 0, stream, (const __half*)feat, (__half*)ws, C,
+                         H * W);
+    else
+      hipLaunchKernelGGL(rt16_to_nhwc_kernel<__hip_bfloat16>, grid, dim3(256), 0, stream,
+                         (const __hip_bfloat16*)feat, (__hip_bfloat16*)ws, C, H * W);
+    MTR_CHECK_LAUNCH();
+    nhwc = ws;
+    ws += need;
+    left -= need;
+  }
+  a.feat = (const float*)nhwc;
+  const bool can_split = left >= rt_workspace_bytes(B, J, D, H, W) && (H * W + 63) / 64 >= 2;
+  const RtDispatch d = rt16_dispatch(B, H, W, J, D, rtg_hint, split_hint, can_split);
+  a.cb_split = d.split;
+  a.ws = d.split ? (double*)ws : nullptr;
+  a.rtg = d.rtg;
+  a.n_blocks = (g.n_tiles + a.rtg - 1) / a.rtg;
+  if (feat_dtype == MTR_F16)
+    return rt_launch_kernel(head_rt16_kernel<__half, 5>, rt16_lds_bytes(5), a, stream, 320);
+  return rt_launch_kernel(head_rt16_kernel<__hip_bfloat16, 5>, rt16_lds_bytes(5), a, stream, 320);
 }
 
 int rt_pack(const float* weight, const float* bias, int C, int J, int D, void* section,

@@ -251,13 +251,16 @@ def head_fused_supported(C, J, D, H, W, channels_last=False, dtype=torch.float32
     """Shapes the fused projection+decode kernels cover; everything else goes through a library
     GEMM for the 1x1 conv followed by the HIP decode kernel (same results, logits via HBM).
     f32 features run the row-tile kernel: any map size, up to 80 depth bins.  f16 / bf16 features
-    run the joint-group MFMA kernel: a joint's 1 + D rows inside a 64-row tile, maps of <= 256
-    positions."""
+    run the joint-group MFMA kernel (a joint's 1 + D rows inside a 64-row tile, maps of <= 256
+    positions, C % 8 == 0) or, beyond those limits, the 16-bit row-tile kernel (C % 64 == 0, up to 80
+    depth bins, any map size)."""
     if (H * W) % 4 != 0 or (channels_last and C % 4 != 0):
         return False
     if dtype == torch.float32:
         return D <= 80
-    return H * W <= 256 and (1 + D) <= 64 and C % 8 == 0
+    if H * W <= 256 and (1 + D) <= 64 and C % 8 == 0:
+        return True
+    return C % 64 == 0 and D <= 80
 
 
 def _is_channels_last(t):
@@ -312,10 +315,10 @@ def head_fused(features, packed, C, n_points, cfg, out=None, rt_tiles=0, groups_
     layout = _lib.MTR_NHWC if nhwc else _lib.MTR_NCHW
     ws_ptr, ws_bytes = None, 0
     if workspace is not False:
-        need = lib.mtr_head_workspace_bytes(B, J, D, H, W, dtype_code(features.dtype))
+        need = lib.mtr_head_workspace_bytes(dtype_code(features.dtype), layout, B, C, H, W, J, D)
         if need:
             if workspace is None:
-                workspace = torch.empty(need // 8, device=features.device, dtype=torch.float64)
+                workspace = torch.empty((need + 7) // 8, device=features.device, dtype=torch.float64)
             require_cuda(workspace)
             ws_ptr, ws_bytes = _ptr(workspace), workspace.numel() * workspace.element_size()
     opts = _lib.HeadOptions(int(rt_tiles), int(groups_per_workgroup), int(dma_staging),

@@ -61,9 +61,21 @@ def test_version_strerror_and_host_side_argument_checks(lib):
     assert lib.mtr_head_packed_bytes(1280, 17, 72, 0) == 40 * 85 * 2048 + 85 * 16 * 8
     assert lib.mtr_head_packed_bytes(1280, 17, 81, 0) == 0  # > 80 depth bins: library GEMM + decode
     # f16 features: 3 joint groups x 64 rows of bias (f32) + 3 x 20 stages x 64 rows x 64 channels x 2 B
-    assert lib.mtr_head_packed_bytes(1280, 17, 8, 1) == 3 * 64 * 4 + 3 * 20 * 64 * 64 * 2
+    # + the 16-bit row-tile section (C % 64 == 0): 20 stages x 10 tiles x 2 KiB + 160 rows x 8 B
+    joint_groups = 3 * 64 * 4 + 3 * 20 * 64 * 64 * 2
+    assert lib.mtr_head_packed_bytes(1280, 17, 8, 1) == joint_groups + 20 * 10 * 2048 + 160 * 8
     assert lib.mtr_head_packed_bytes(1283, 17, 8, 1) == 0   # C % 8 != 0: no 16-byte operands
-    assert lib.mtr_head_packed_bytes(1280, 17, 72, 2) == 0  # a joint's 73 rows exceed the 64-row group
+    assert lib.mtr_head_packed_bytes(1288, 17, 8, 1) == 3 * 64 * 4 + 3 * 21 * 64 * 64 * 2  # C % 64 != 0: joint groups only
+    # a joint's 73 rows exceed the 64-row group: the row-tile section alone (17 atoms of 5 tiles)
+    assert lib.mtr_head_packed_bytes(1280, 17, 72, 2) == 20 * 85 * 2048 + 85 * 16 * 8
+    assert lib.mtr_head_packed_bytes(1288, 17, 72, 2) == 0
+    # the workspace of mtr_head_fused_ws: f32 maps of > 64 positions (column-block statistics), 16-bit
+    # row-tile shapes (an NHWC copy of NCHW features + the statistics)
+    assert lib.mtr_head_workspace_bytes(0, 0, 64, 1280, 8, 8, 17, 8) == 0
+    assert lib.mtr_head_workspace_bytes(0, 0, 32, 1280, 12, 12, 17, 8) == 32 * 3 * 160 * 5 * 8
+    assert lib.mtr_head_workspace_bytes(1, 0, 64, 1280, 8, 8, 17, 8) == 0
+    assert lib.mtr_head_workspace_bytes(1, 0, 64, 1280, 8, 8, 17, 72) == 64 * 1280 * 64 * 2
+    assert lib.mtr_head_workspace_bytes(1, 1, 64, 1280, 8, 8, 17, 72) == 0
     assert lib.mtr_reconstruct_workspace_bytes(64, 17) == (4 + 2 * 16) * 8
 
 

@@ -71,7 +71,7 @@ def main():
         packed = kernels.head_pack_weights(w, bias, J, D, torch.float32)
         n_cb = -(-side * side // 64)
         out = (torch.empty(B, J, 2, device='cuda'), torch.empty(B, J, 3, device='cuda'))
-        need = kernels._lib.load().mtr_head_workspace_bytes(B, J, D, side, side, 0)
+        need = kernels._lib.load().mtr_head_workspace_bytes(0, 1 if nhwc else 0, B, C, side, side, J, D)
         ws = torch.empty(max(need, 8) // 8, device='cuda', dtype=torch.float64)
         conv = torch.nn.Conv2d(C, J * (1 + D), 1).cuda()
         with torch.no_grad():
