@@ -32,8 +32,22 @@
 #ifndef MTR_WARP_RCP
 #define MTR_WARP_RCP 1  // 1/oz by v_rcp_f32 + one Newton step (<= 1 ulp) instead of the IEEE division sequence
 #endif
+#ifndef MTR_WARP_LEAN
+#define MTR_WARP_LEAN 1  // warp_rows_kernel, round 3: fewer VALU instructions per sample, same taps and the same
+                         // weights bit for bit (checksums of the 64- and 320-crop outputs unchanged) -- tap-pair
+                         // weights by clamps of d = ix - xs instead of selects on (x0 - xs) and the in-range test
+                         // (an out-of-range or non-finite coordinate gives d outside (-1, 2): both weights 0); when
+                         // the row and plane pitches are multiples of 4 the six loads of a sample share ONE address
+                         // register, the plane and row offsets ride in the buffer instruction's scalar offset, and
+                         // the byte window is one v_alignbyte.  64 crops, cache-resident frames: 25.6 -> 24.5 us.
+#endif
 #ifndef MTR_WARP_ABLATE
-#define MTR_WARP_ABLATE 0
+#define MTR_WARP_ABLATE 0   // developer-only timing ablations (tools/experiments/ablate_warp.py); in warp_rows_kernel:
+                            // 1 = no tap loads, 2 = no LUT reads, 4 = no gamma pow, 8 = no stores.  Round 3, 64 crops,
+                            // cache-resident / rotating frames: full 24.5 / 30.3 us, no taps 18.7 / 18.8, no stores
+                            // 17.6 / 20.1, none of the four 11.1 / 11.0 -- arithmetic, taps and stores are nearly
+                            // additive; neither fewer VALU instructions (this macro's LEAN) nor a quarter of the store
+                            // instructions (16-byte stores through an LDS transpose: 24.7 us, not kept) moves the sum
 #endif
 
 namespace mtr {
@@ -666,7 +680,9 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
   const int x = tx * LX + (threadIdx.x & (LX - 1));
   const int v_first = (ty * 4 + (threadIdx.x >> 6)) * ROWS * RI + ((threadIdx.x & 63) / LX);
   if (x >= res || v_first >= res) return;
+#if !MTR_WARP_LEAN
   const float fW = (float)W, fH = (float)H;
+#endif
   const bool same_shift = ((row_bytes | plane_bytes) & 3) == 0;
   // crop stores through a descriptor over this crop: 32-bit offsets, the channel pitch in an SGPR
   const buffer_rsrc_t orsrc = make_rsrc(uniform_ptr(out + (size_t)crop * 3 * res * res),
@@ -696,6 +712,19 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
     }
     const float ix = fmaf(k0, nx, fmaf(k1, ny, k2));
     const float iy = fmaf(k3, nx, fmaf(k4, ny, k5));
+    TapSet t;
+#if MTR_WARP_LEAN
+    // the loaded pair is (xs, xs + 1) with xs clamped into the frame; d = ix - xs.  d in [0, 1): both
+    // taps, weights (1 - d, d) -- the reference's (tx0, tx1), d = ix - floor(ix) exactly; d in [-1, 0):
+    // only the right tap of (x0, x0 + 1) = (-1, 0) exists, weight 1 + d; d in [1, 2): only the left tap
+    // of (W - 1, W), weight 2 - d; anything else (beyond the zero padding, inf, NaN): 0 and 0.
+    // v_cvt_i32_f32 saturates and maps NaN to 0; fmaxf / fminf return the non-NaN operand.
+    const int x0 = (int)floorf(ix), y0 = (int)floorf(iy);
+    const int xs = min(max(x0, 0), W - 2), ys = min(max(y0, 0), H - 2);
+    const float dxf = ix - (float)xs, dyf = iy - (float)ys;
+    const float wl = fmaxf(1.0f - fabsf(dxf), 0.0f), wr = fmaxf(fminf(dxf, 2.0f - dxf), 0.0f);
+    const float wt = fmaxf(1.0f - fabsf(dyf), 0.0f), wb = fmaxf(fminf(dyf, 2.0f - dyf), 0.0f);
+#else
     const bool sane = (ix > -1.0f) && (iy > -1.0f) && (ix < fW) && (iy < fH);
     const float fx0 = floorf(ix), fy0 = floorf(iy);
     const int x0 = sane ? (int)fx0 : 0, y0 = sane ? (int)fy0 : 0;
@@ -708,9 +737,26 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
     float wl = dx == 0 ? tx0 : (dx < 0 ? tx1 : 0.0f), wr = dx == 0 ? tx1 : (dx > 0 ? tx0 : 0.0f);
     const float wt = dy == 0 ? ty0 : (dy < 0 ? ty1 : 0.0f), wb = dy == 0 ? ty1 : (dy > 0 ? ty0 : 0.0f);
     if (!sane) wl = wr = 0.0f;  // (also non-finite coordinates) the sample contributes nothing
-    TapSet t;
+#endif
     t.w00 = wl * wt; t.w01 = wr * wt; t.w10 = wl * wb; t.w11 = wr * wb;
     t.off = ((__mul24(ys, W) + xs) << sh) + img_off;  // (full-rate 24-bit multiply: ys, W < 2^24)
+    if (MTR_WARP_LEAN && same_shift) {
+      // pitches that are multiples of 4: (off + c * plane + r * row) & ~3 = (off & ~3) + c * plane + r * row,
+      // i.e. ONE vector address, the rest in the loads' scalar offset
+      const int base = t.off & ~3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if (MTR_WARP_ABLATE & 1) {  // (timing ablation: no tap loads)
+          t.raw[2 * c] = t.raw[2 * c + 1] = (unsigned long long)(unsigned)base * 0x0101010101ull + c;
+          continue;
+        }
+        t.raw[2 * c] = __builtin_bit_cast(unsigned long long,
+            __builtin_amdgcn_raw_buffer_load_b64(rsrc, base, c * plane_bytes, 0));
+        t.raw[2 * c + 1] = __builtin_bit_cast(unsigned long long,
+            __builtin_amdgcn_raw_buffer_load_b64(rsrc, base, c * plane_bytes + row_bytes, 0));
+      }
+      return t;
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const int ot = t.off + c * plane_bytes, ob = ot + row_bytes;
@@ -729,6 +775,24 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
       for (int c = 0; c < 3; ++c) {
         const F2 tp = __builtin_bit_cast(F2, t.raw[2 * c]), bt = __builtin_bit_cast(F2, t.raw[2 * c + 1]);
         acc[c] += fmaf(bt.b, t.w11, fmaf(bt.a, t.w10, fmaf(tp.b, t.w01, tp.a * t.w00)));
+      }
+    } else if (MTR_WARP_LEAN && same_shift) {
+      // the six byte windows of the sample share one alignment: bytes (off & 3), (off & 3) + 1 of each
+      // 8-byte word = bytes 0, 1 of v_alignbyte(high dword, low dword, off & 3)
+      const unsigned al = (unsigned)t.off & 3u;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const unsigned tw = __builtin_amdgcn_alignbyte((unsigned)(t.raw[2 * c] >> 32), (unsigned)t.raw[2 * c], al);
+        const unsigned bw = __builtin_amdgcn_alignbyte((unsigned)(t.raw[2 * c + 1] >> 32), (unsigned)t.raw[2 * c + 1], al);
+        float ta, tb, ba, bb;
+        if (MTR_WARP_ABLATE & 2) {  // (timing ablation: no LUT reads)
+          ta = (float)(tw & 0xff); tb = (float)((tw >> 8) & 0xff);
+          ba = (float)(bw & 0xff); bb = (float)((bw >> 8) & 0xff);
+        } else {
+          ta = lut[tw & 0xff]; tb = lut[(tw >> 8) & 0xff];
+          ba = lut[bw & 0xff]; bb = lut[(bw >> 8) & 0xff];
+        }
+        acc[c] += fmaf(bb, t.w11, fmaf(ba, t.w10, fmaf(tb, t.w01, ta * t.w00)));
       }
     } else {
 #pragma unroll
@@ -764,9 +828,10 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
       for (int c = 0; c < 3; ++c) {
         float val = acc[c];
         if (AA > 1) val = val * (1.0f / (AA * AA));
-        px[c] = gexp == 1.0f ? val : fast_pow_unit(val, gexp);
+        px[c] = (gexp == 1.0f || (MTR_WARP_ABLATE & 4)) ? val : fast_pow_unit(val, gexp);
         acc[c] = 0.0f;
       }
+      if ((MTR_WARP_ABLATE & 8) && px[0] != 12345.0f) continue;  // (timing ablation: no stores)
       if (v < res) {
         const int pix = v * res + x;
 #pragma unroll

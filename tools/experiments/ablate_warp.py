@@ -22,6 +22,8 @@ VARIANTS.update({'rcp': ['-DMTR_WARP_RCP=1'], 'rcp8': ['-DMTR_WARP_RCP=1', '-DMT
 VARIANTS.update({'px8': ['-DMTR_WARP_PX=8'], 'px8_nostore': ['-DMTR_WARP_PX=8', '-DMTR_WARP_ABLATE=8'],
                  'px16': ['-DMTR_WARP_PX=16'], 'px2': ['-DMTR_WARP_PX=2'], 'px1': ['-DMTR_WARP_PX=1'],
                  'px2_nomem': ['-DMTR_WARP_PX=2', '-DMTR_WARP_ABLATE=15'], 'px8_nomem': ['-DMTR_WARP_PX=8', '-DMTR_WARP_ABLATE=15']})
+VARIANTS.update({f'r{m}': [f'-DMTR_WARP_ABLATE={m}'] for m in (0, 1, 2, 4, 8, 3, 15)})  # the same bits in warp_rows_kernel
+VARIANTS.update({'r0_fat': ['-DMTR_WARP_LEAN=0']})
 if os.environ.get('ABLATE_ONLY'):
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ['ABLATE_ONLY'].split(',')}
 

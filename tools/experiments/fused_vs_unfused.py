@@ -28,7 +28,9 @@ for (B, C, J, D, H, dt) in [(64, 1280, 17, 8, 8, torch.float32), (1024, 1280, 17
                             (64, 1280, 17, 8, 8, torch.float16), (1024, 1280, 17, 8, 8, torch.float16),
                             (64, 1280, 17, 8, 8, torch.bfloat16), (32, 1280, 122, 8, 12, torch.float16),
                             (256, 1280, 122, 8, 12, torch.float16), (256, 2048, 24, 8, 8, torch.float16),
-                            (64, 1280, 17, 72, 8, torch.float32)]:
+                            (64, 1280, 17, 72, 8, torch.float32), (64, 1280, 17, 72, 8, torch.float16),
+                            (1024, 1280, 17, 72, 8, torch.float16), (16, 1280, 17, 8, 24, torch.float16),
+                            (64, 1280, 17, 8, 20, torch.bfloat16)]:
     cfg = MetrabsConfig(depth=D, proc_side=H * 32)
     heads = MetrabsHeads(J, cfg, in_channels=C, fused=True).cuda()
     feat = torch.randn(B, C, H, H, device='cuda').to(dt)
