@@ -305,23 +305,31 @@ static int dispatch_decode(const void* logits, int B, int J, int D, int H, int W
 // sum of e*h (f64).  The rows of a joint -- its 2D row n = j and its depth slices n = J + d*J + j,
 // J channels apart -- then meet in LDS, where one thread per joint merges them like an online
 // softmax over slices.  One workgroup per crop; every logit is read once, coalesced.
+// Round 3: G = blockDim / N position GROUPS per channel run side by side (thread t: channel t % N,
+// group t / N takes positions g, g + G, ...) and their online-softmax states are merged in LDS in
+// group order -- at J = 17, D = 8 (N = 153) a 1024-thread workgroup keeps 918 lanes busy on ~11
+// positions each instead of 153 lanes on 64 (small batches are one workgroup per crop on a quarter
+// of the CUs: the walk over the positions is the critical path).  N > blockDim: one group, channels
+// in rounds, as before.
 template <typename T>
-__global__ __launch_bounds__(256) void decode_nhwc_kernel(const T* __restrict__ logits, int B, int J,
-                                                          int D, int H, int W, HeadScale hs, AxisInv ai,
-                                                          float* __restrict__ coords2d,
-                                                          float* __restrict__ coords3d_rel) {
+__global__ __launch_bounds__(1024) void decode_nhwc_kernel(const T* __restrict__ logits, int B, int J,
+                                                           int D, int H, int W, HeadScale hs, AxisInv ai,
+                                                           float* __restrict__ coords2d,
+                                                           float* __restrict__ coords3d_rel) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int N = J * (1 + D), HW = H * W;
-  float* row_m = reinterpret_cast<float*>(smem_raw);                      // [N]
-  double* row_s = reinterpret_cast<double*>(smem_raw + ((N * 4 + 15) & ~15));  // [N][3]
+  const int G = N <= (int)blockDim.x ? (int)blockDim.x / N : 1;  // position groups per channel
+  float* row_m = reinterpret_cast<float*>(smem_raw);                               // [G][N]
+  double* row_s = reinterpret_cast<double*>(smem_raw + ((G * N * 4 + 15) & ~15));  // [G][N][3]
   const int b = blockIdx.x;
   const T* x = logits + (size_t)b * HW * N;
-  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+  for (int t = threadIdx.x; t < G * N; t += blockDim.x) {
+    const int n = t % N, g = t / N;
     float m = -INFINITY;
     double s = 0.0, sx = 0.0, sy = 0.0;
-    int h = 0, w = 0;
-    for (int p = 0; p < HW; ++p) {
+    for (int p = g; p < HW; p += G) {
       const float v = to_f32(x[(size_t)p * N + n]);
+      const int h = p / W, w = p - h * W;
       if (v > m) {  // rescale what has been summed under the old maximum -- in f64, as the per-joint
         // merge below does: a 2-ulp f32 factor at every update of the running maximum would add
         // ~1e-7 relative per update to the expectation (a few 1e-4 mm of the 1e-3 mm budget)
@@ -335,12 +343,26 @@ __global__ __launch_bounds__(256) void decode_nhwc_kernel(const T* __restrict__ 
         const double e = (double)exp_shifted(v, -m * kLog2e);
         s += e; sx += e * (double)w; sy += e * (double)h;
       }
-      if (++w == W) { w = 0; ++h; }
     }
-    row_m[n] = m;
-    row_s[n * 3 + 0] = s; row_s[n * 3 + 1] = sx; row_s[n * 3 + 2] = sy;
+    row_m[t] = m;
+    row_s[t * 3 + 0] = s; row_s[t * 3 + 1] = sx; row_s[t * 3 + 2] = sy;
   }
   __syncthreads();
+  if (G > 1) {  // the groups of a channel -> group 0's slot, in group order
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+      float M = row_m[n];
+      for (int g = 1; g < G; ++g) M = fmaxf(M, row_m[g * N + n]);
+      double S = 0.0, SX = 0.0, SY = 0.0;
+      for (int g = 0; g < G; ++g) {
+        const int t = g * N + n;
+        const double f = row_m[t] == -INFINITY ? 0.0 : exp_neg64((double)row_m[t] - (double)M);
+        S += row_s[t * 3] * f; SX += row_s[t * 3 + 1] * f; SY += row_s[t * 3 + 2] * f;
+      }
+      row_m[n] = M;
+      row_s[n * 3 + 0] = S; row_s[n * 3 + 1] = SX; row_s[n * 3 + 2] = SY;
+    }
+    __syncthreads();
+  }
   for (int j = threadIdx.x; j < J; j += blockDim.x) {
     const size_t o = (size_t)b * J + j;
     {
@@ -368,7 +390,11 @@ template <typename T>
 static int launch_decode_nhwc(const void* logits, int B, int J, int D, int H, int W, const HeadScale& hs,
                               float* c2d, float* c3d, hipStream_t stream) {
   const long long N = (long long)J * (1 + D);
-  const size_t lds = (size_t)((N * 4 + 15) & ~15LL) + (size_t)N * 24;
+  // 1024 threads (up to 6 position groups per channel at N = 153) while a crop is ONE workgroup and the
+  // batch does not fill the chip; large batches keep 256 threads (4+ workgroups per CU hide the walk)
+  const int threads = B <= 1024 ? 1024 : 256;
+  const long long slots = N <= threads ? (threads / N) * N : N;
+  const size_t lds = (size_t)((slots * 4 + 15) & ~15LL) + (size_t)slots * 24;
   if (lds > 160 * 1024 - 256) return MTR_E_SHAPE;  // > 5,800 channels per position
   auto kern = decode_nhwc_kernel<T>;
   if (lds > 64 * 1024) {
@@ -376,7 +402,7 @@ static int launch_decode_nhwc(const void* logits, int B, int J, int D, int H, in
     if (rc != MTR_OK) return rc;
   }
   MTR_CLEAR_STALE();
-  hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(256), lds, stream, (const T*)logits, B, J, D, H, W, hs,
+  hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(threads), lds, stream, (const T*)logits, B, J, D, H, W, hs,
                      make_axis_inv(W, H, D), c2d, c3d);
   MTR_CHECK_LAUNCH();
   return MTR_OK;
