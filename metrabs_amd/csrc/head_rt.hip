@@ -1143,23 +1143,31 @@ __global__ __launch_bounds__(256) void rt16_to_nhwc_kernel(const T* __restrict__
   }
 }
 
-constexpr int kRt16Nbuf = 4, kRt16La = 3;
-__host__ __device__ constexpr int rt16_lds_bytes(int rtmax) {
-  return kRt16Nbuf * rt_stage_bytes(rtmax, 1, true) + rt_epilogue_bytes(rtmax, 1);
+// Occupancy instead of a deep ring: the MFMAs of a stage are ~1/16 of the f32 kernel's, so a workgroup
+// is latency (barrier, LDS, copy), not matrix, bound.  Two ring slots, the loader one stage ahead, the
+// decode's LDS aliased onto the ring (36 KiB per workgroup at 5 tiles) and <= 96 registers: FOUR
+// workgroups = 20 waves per CU cover each other (first version: one workgroup per CU with a 4-slot
+// ring, 102 KiB: B = 1024, D = 72: 901 us; library pair 455).
+constexpr int kRt16Nbuf = 2, kRt16La = 1;
+// [ring | decode scratch without the running statistics][running (max, 4 sums) per row across column blocks]
+__host__ __device__ constexpr int rt16_scratch_bytes(int rtmax) {
+  return kRt16Nbuf * rt_stage_bytes(rtmax, 1, true) > rt_epilogue_bytes(rtmax, 1) - rtmax * 16 * 40
+             ? kRt16Nbuf * rt_stage_bytes(rtmax, 1, true) : rt_epilogue_bytes(rtmax, 1) - rtmax * 16 * 40;
 }
+__host__ __device__ constexpr int rt16_lds_bytes(int rtmax) { return rt16_scratch_bytes(rtmax) + rtmax * 16 * 40; }
 
 template <typename T, int RT, int RTMAX>
 __device__ __forceinline__ void rt16_block(const RtArgs& a, char* smem, int crop, int t0, int cb_first,
                                            int cb_count) {
   constexpr int STAGE = rt_stage_bytes(RT, 1, true);
   constexpr int R = RT * 16, LP = kRtLP;
-  float* Ls = reinterpret_cast<float*>(smem + kRt16Nbuf * rt_stage_bytes(RTMAX, 1, true));
+  float* Ls = reinterpret_cast<float*>(smem);  // (the decode's arrays alias the ring: barriers around the K loop)
   float* rowmax = Ls + RTMAX * 16 * LP;
   float* unitmax = rowmax + RTMAX * 16;
-  float* bias_s = unitmax + RTMAX * 16;
-  int* info_s = reinterpret_cast<int*>(bias_s + RTMAX * 16);
+  int* info_s = reinterpret_cast<int*>(unitmax + RTMAX * 16 * 2);
   double* rowsum = reinterpret_cast<double*>(info_s + RTMAX * 16);
-  double* runstat = rowsum + RTMAX * 16 * 3;
+  // (the running statistics of a map's column blocks outlive a K loop: behind the ring)
+  double* runstat = reinterpret_cast<double*>(smem + rt16_scratch_bytes(RTMAX));
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wid = wave & 3;
@@ -1168,10 +1176,6 @@ __device__ __forceinline__ void rt16_block(const RtArgs& a, char* smem, int crop
   const int n_stages = a.n_stages;
   const unsigned lds0 = rt_lds_addr(smem);
   const char* fcrop = reinterpret_cast<const char*>(a.feat) + (size_t)crop * a.C * HW * 2;
-  if (tid < R) {
-    bias_s[tid] = a.bias_p[t0 * 16 + tid];
-    info_s[tid] = a.info[t0 * 16 + tid];
-  }
   const int i16 = lane & 15, g4 = lane >> 4;
   const int a_off = i16 * 128 + ((g4 ^ ((i16 >> 1) & 7)) << 4);
   const int pos = wid * 16 + i16;
@@ -1203,6 +1207,7 @@ __device__ __forceinline__ void rt16_block(const RtArgs& a, char* smem, int crop
 #pragma unroll
         for (int t = 0; t < RT; ++t) acc[t] = rt16_mfma<T>(fa1[t], fb1, acc[t]);
       }
+      __syncthreads();  // every wave has read its last fragments: the ring becomes the decode's scratch
       // logits (+bias) -> LDS.  C/D layout of the 16x16 accumulators: col = l & 15, row = 4 (l >> 4) + reg
       const int col = wid * 16 + i16, row0 = g4 * 4;
 #pragma unroll
@@ -1210,17 +1215,20 @@ __device__ __forceinline__ void rt16_block(const RtArgs& a, char* smem, int crop
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = t * 16 + row0 + r;
-          Ls[row * LP + col] = acc[t][r] + bias_s[row];
+          Ls[row * LP + col] = acc[t][r] + a.bias_p[t0 * 16 + row];
         }
+      if (tid < R) info_s[tid] = a.info[t0 * 16 + tid];
     }
+    if (is_loader) __syncthreads();  // (the loader's side of the barrier in front of the logits store)
     __syncthreads();
     rt_decode_blocks<RT, 1, 16>(a, Ls, rowmax, unitmax, info_s, rowsum, runstat, tid, is_loader, HW, crop, t0, cb0,
                                 n_cb);
+    __syncthreads();  // the next column block's copies overwrite the decode's scratch
   }
 }
 
 template <typename T, int RTMAX>
-__global__ __launch_bounds__(320, 1) void head_rt16_kernel(RtArgs a) {
+__global__ __launch_bounds__(320, 5) void head_rt16_kernel(RtArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const RtWork w = rt_work(a);
   if (w.crop >= a.B) return;
