@@ -1052,14 +1052,14 @@ def analysis(args, est, cfg, pipe, dev, step_seconds, im_h, im_w, n_box, world):
     # HBM-side bytes per launch: measured in this run by two rocprofv3 --pmc passes; the stored file
     # of the round's profile set is only a labelled fallback
     tjson, traffic_source = None, None
-    if not args.no_pmc:
+    if not args.no_pmc and world == 1:  # (N > 1: the other ranks wait at the final barrier meanwhile)
         tjson, traffic_source = live_pmc_traffic(args, n_crops, J, D, C)
     if tjson is None:
         live_failure = traffic_source
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         try:
             tjson = json.load(open(tpath))
-            traffic_source = ('STORED, not measured in this run (' + str(live_failure or '--no-pmc') + '): ' +
+            traffic_source = ('STORED, not measured in this run (' + str(live_failure or '--no-pmc / N > 1') + '): ' +
                               str(tjson.get('_source')))
         except (OSError, ValueError):
             tjson, traffic_source = {}, f'none ({live_failure})'

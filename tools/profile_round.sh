@@ -1,9 +1,9 @@
 set -x
 # One round of evidence for profiles/ (run on the GPU box):
-#   gpurun -- 'bash tools/profile_round.sh r02b'
+#   gpurun -- 'bash tools/profile_round.sh r03c'
 # kernel trace of the bench command, the two PMC passes (one counter each, --kernel-trace only) that
 # profiles/traffic.json is reduced from, MFMA counters of the f32 head, micro-benchmarks, bench lines.
-TAG=${1:-r02b}
+TAG=${1:-r03c}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O
@@ -26,9 +26,14 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
 python $R/tools/rocprof_summary.py /tmp/prof_w2 $O/${TAG}_pmc_warp_cycles.md --ours-only
 cd $R
 python tools/microbench.py > $O/${TAG}_microbench.jsonl 2>/dev/null
-timeout 300 python tools/experiments/head_rt_ab.py $TAG > $O/${TAG}_head_rt_ab.jsonl 2>/dev/null
-python tools/experiments/fused_vs_unfused.py > $O/${TAG}_fused_vs_library.txt 2>/dev/null
-cp $O/${TAG}_traffic.json profiles/traffic.json   # the bench line below reports this round's traffic
+timeout 600 python tools/experiments/head_sweep.py > $O/${TAG}_head_sweep.jsonl 2>/dev/null
+python tools/experiments/fused_vs_unfused.py 2>/dev/null | grep fused > $O/${TAG}_fused_vs_library.txt
+python tools/experiments/nhwc_decode_time.py > $O/${TAG}_nhwc_decode.txt 2>/dev/null
+cp $O/${TAG}_traffic.json profiles/traffic.json   # (the labelled fallback of bench.py's live PMC passes)
 python bench.py > $O/${TAG}_bench_f32.json 2> $O/${TAG}_bench.err
 python bench.py --precision f16 --no-cpu-baseline > $O/${TAG}_bench_f16.json 2>> $O/${TAG}_bench.err
+python bench.py --config 2 --no-cpu-baseline --steps 10 > $O/${TAG}_bench_config2.json 2>> $O/${TAG}_bench.err
+python bench.py --config 3 --no-cpu-baseline > $O/${TAG}_bench_config3.json 2>> $O/${TAG}_bench.err
+python bench.py --config 4 --no-cpu-baseline --steps 10 > $O/${TAG}_bench_config4.json 2>> $O/${TAG}_bench.err
+MTR_BENCH_SHARED_DEVICE=1 python bench.py --gpus 2 --steps 10 --quick > $O/${TAG}_bench_gpus2_shared_device.json 2>> $O/${TAG}_bench.err
 tail -3 $O/prof_kt.log; head -c 2500 $O/${TAG}_bench_f32.json; echo; head -c 1200 $O/${TAG}_bench_f16.json
