@@ -101,7 +101,10 @@ int mtr_softargmax_decode(const void* logits, int dtype, int layout, int B, int 
  * f32 features (the reference's CPU arithmetic) -- row-tile kernel, any map size, D <= 80:
  *   v_mfma_f32_16x16x4_f32 on f32 weights, chains of 32 channels summed in f32 over 8 stages and
  *   carried into f64 accumulators; 16-row tiles of whole softmax units (mtr_head_row_plan), a
- *   workgroup = (crop, block of <= 5 tiles), tiles staged by global_load_lds.
+ *   workgroup = (crop, block of <= 5 tiles), tiles staged by global_load_lds -- on launches of at most
+ *   one workgroup per CU by a dedicated loader wave (mtr_head_options.rt_loader); with a workspace
+ *   (mtr_head_fused_ws) the 64-position column blocks of a larger map may go to different workgroups
+ *   (rt_split_column_blocks).  Every dispatch choice gives the same bits.
  * f16 / bf16 features (the reference's autocast GPU arithmetic) -- joint-group kernels, C % 8 == 0,
  *   1 + D <= 64, H*W <= 256: v_mfma_f32_32x32x16_{f16,bf16} on the features and on the weights
  *   ROUNDED TO THE FEATURE DTYPE (what autocast does to conv_final), f32 accumulation, f32 logits.

@@ -26,6 +26,17 @@
 //     blocks' (max, sums) like an online softmax, so any H*W fits the same registers;
 //   * epilogue: logits (+bias) -> LDS, a 16-lane group per row: row max -> unit max -> f64
 //     exp / moment sums per row -> one thread per unit adds its rows and writes the coordinates.
+//
+// Round 3
+//   * head_rt_ld_kernel: a fifth wave (the loader) issues every copy of a stage and waits for it; the
+//     four MFMA waves only meet it at the stage barrier (rt_loader_loop, rt_block<..., LD = true>);
+//   * the column blocks of a map of more than 64 positions can be dealt to different workgroups, their
+//     softmax statistics merged by head_rt_merge_kernel through a caller-provided workspace
+//     (mtr_head_fused_ws) -- bit-identical to one workgroup walking them;
+//   * the launch plan (which kernel, how many tiles per workgroup, split or not) minimises a measured
+//     cost model (rt_plan; host-visible through mtr_head_plan);
+//   * head_rt16_kernel: the same row plan, LDS images, loader wave and decode for f16 / bf16 features on
+//     v_mfma_f32_16x16x32 (the shapes the joint-group kernels of head_fused.hip do not take).
 #include "head_rt.h"
 
 namespace mtr {

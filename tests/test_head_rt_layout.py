@@ -59,8 +59,11 @@ def test_shapes_outside_the_plan_are_rejected():
     assert lib.mtr_head_row_plan(17, 8, ctypes.byref(nt), ctypes.byref(a),
                                  small.ctypes.data_as(ctypes.c_void_p), small.size) == -5
     assert lib.mtr_head_packed_bytes(1280, 17, 72, 0) > 0      # D = 72: row-tile section only
-    assert lib.mtr_head_packed_bytes(1280, 17, 72, 1) == 0     # no 16-bit kernel for 73-row joints
-    assert lib.mtr_head_packed_bytes(1280, 17, 8, 0) > lib.mtr_head_packed_bytes(1280, 17, 8, 1) > 0
+    # 16-bit, 73-row joints: no joint-group blob, the 16-bit row-tile section alone (20 stages of 64 channels)
+    assert lib.mtr_head_packed_bytes(1280, 17, 72, 1) == 20 * 85 * 2048 + 85 * 16 * 8
+    assert lib.mtr_head_packed_bytes(1288, 17, 72, 1) == 0     # ... which needs C % 64 == 0
+    # (the 16-bit blob holds two sections since round 3: joint groups + row tiles)
+    assert lib.mtr_head_packed_bytes(1280, 17, 8, 0) > 0 and lib.mtr_head_packed_bytes(1280, 17, 8, 1) > 0
 
 
 # ---------------------------------------------------------------------------------------------
