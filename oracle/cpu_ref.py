@@ -355,11 +355,17 @@ def undistort_points(points, coeffs):
     return und
 
 
-def warp_single_image(image, intrinsic_matrix, new_invprojmat, distortion_coeffs, output_shape):
-    """warping.py:41-54.  image [3,H,W] linear light; returns [3,oh,ow]."""
+def warp_single_image(image, intrinsic_matrix, new_invprojmat, distortion_coeffs, output_shape,
+                      eval_dtype=None):
+    """warping.py:41-54.  image [3,H,W] linear light; returns [3,oh,ow].
+    eval_dtype=torch.float64: the same formulas on the same (f32) matrices and texels in double --
+    the yardstick for "whose rounding is it" of the sampler gates; the default is the reference's f32."""
     grid = torch.stack(torch.meshgrid(
         torch.arange(output_shape[1]), torch.arange(output_shape[0]), indexing='xy'),
         dim=-1).float()
+    if eval_dtype is not None:
+        image, intrinsic_matrix, new_invprojmat, distortion_coeffs, grid = (
+            t.to(eval_dtype) for t in (image, intrinsic_matrix, new_invprojmat, distortion_coeffs, grid))
     rays = torch.einsum('hwc,Cc->hwC', to_homogeneous(grid), new_invprojmat)
     rays = to_homogeneous(distort_points(project(rays), distortion_coeffs))
     src = torch.einsum('hwc,Cc->hwC', rays, intrinsic_matrix)[..., :2]
@@ -384,7 +390,7 @@ def pyramid_level_index(crop_scales, n_levels=3):
 
 
 def warp_images_with_pyramid(images, intrinsic_matrix, new_invprojmats, distortion_coeffs,
-                             crop_scales, output_shape, image_ids, n_pyramid_levels=3):
+                             crop_scales, output_shape, image_ids, n_pyramid_levels=3, eval_dtype=None):
     """warping.py:6-28."""
     levels = build_pyramid(images, n_pyramid_levels)
     k_levels = [corner_aligned_scale_mat(1 / 2 ** lvl) @ intrinsic_matrix
@@ -393,7 +399,7 @@ def warp_images_with_pyramid(images, intrinsic_matrix, new_invprojmats, distorti
     return torch.stack([
         warp_single_image(
             levels[lvl_idx[i]][image_ids[i]], k_levels[lvl_idx[i]][i], new_invprojmats[i],
-            distortion_coeffs[i], output_shape)
+            distortion_coeffs[i], output_shape, eval_dtype=eval_dtype)
         for i in range(len(image_ids))])
 
 
@@ -444,8 +450,10 @@ def get_new_rotation_and_scale(intrinsic_matrix, distortion_coeffs, camspace_up,
 
 
 def get_crops(images_linear, intrinsic_matrix, distortion_coeffs, camspace_up, boxes, image_ids,
-              aug_rotflipmat, aug_scales, aug_gammas, antialias_factor, res):
-    """multiperson_model.py:264-320.  images_linear: float linear-light [N,3,H,W]."""
+              aug_rotflipmat, aug_scales, aug_gammas, antialias_factor, res, eval_dtype=None):
+    """multiperson_model.py:264-320.  images_linear: float linear-light [N,3,H,W].
+    eval_dtype=torch.float64: the geometry (f32, as the reference computes it) is kept and the sampling
+    itself -- coordinates, distortion, interpolation -- is evaluated in double (see warp_single_image)."""
     r_noaug, box_scales = get_new_rotation_and_scale(
         intrinsic_matrix, distortion_coeffs, camspace_up, boxes, res)
     crop_scales = aug_scales[:, np.newaxis] * box_scales[np.newaxis, :]
@@ -468,7 +476,7 @@ def get_crops(images_linear, intrinsic_matrix, distortion_coeffs, camspace_up, b
         distortion_coeffs=torch.tile(distortion_coeffs, [num_aug, 1]),
         crop_scales=torch.reshape(crop_scales, [-1]) * antialias_factor,
         output_shape=(res * antialias_factor, res * antialias_factor),
-        image_ids=torch.tile(image_ids, [num_aug]))
+        image_ids=torch.tile(image_ids, [num_aug]), eval_dtype=eval_dtype)
     if antialias_factor == 2:
         crops = F.avg_pool2d(crops, 2, 2)
     elif antialias_factor == 4:
@@ -479,7 +487,7 @@ def get_crops(images_linear, intrinsic_matrix, distortion_coeffs, camspace_up, b
         # (transforms/_functional_tensor.py: resize -> torch.nn.functional.interpolate)
         crops = F.interpolate(crops, size=[res, res], mode='bilinear', align_corners=False, antialias=True)
     crops = torch.reshape(crops, [num_aug, num_box, 3, res, res])
-    crops **= torch.reshape(aug_gammas / 2.2, [-1, 1, 1, 1, 1])
+    crops **= torch.reshape(aug_gammas / 2.2, [-1, 1, 1, 1, 1]).to(crops.dtype)
     return crops, new_k, rot
 
 

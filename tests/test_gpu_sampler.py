@@ -207,13 +207,27 @@ def test_warp_full_size_properties(hip_lib):
     sel = [0, 17, 45]
     lin = (imgs.float() / 255) ** 2.2
     with torch.inference_mode():
-        oc, _, _ = cpu_ref.get_crops(lin, K[sel], torch.zeros(3, 5), up[sel], flat[sel], ids[sel],
-                                     tta['rotflipmat'], tta['scales'], tta['gammas'], 1, res)
+        args = (lin, K[sel], torch.zeros(3, 5), up[sel], flat[sel], ids[sel], tta['rotflipmat'], tta['scales'],
+                tta['gammas'], 1, res)
+        oc, _, _ = cpu_ref.get_crops(*args)
+        oc64, _, _ = cpu_ref.get_crops(*args, eval_dtype=torch.float64)  # same matrices and texels, sampling in double
     g = float(tta['gammas'][0] / 2.2)
-    d = (crops[sel].cpu().double().clamp_min(0) ** (1 / g) - oc[0].double().clamp_min(0) ** (1 / g)).abs()
-    print(f'[parity] full-size crops: linear max-abs {float(d.max()):.2e} mean {float(d.mean()):.2e}')
-    # 1080p coordinates (~2000 px) carry ~10x the rounding of the 160 px fixtures
-    assert float(d.max()) <= 1.5e-3 and float(d.mean()) <= 4e-5
+    lin_of = lambda t: t.double().clamp_min(0) ** (1 / g)
+    ours, ref, truth = lin_of(crops[sel].cpu()), lin_of(oc[0]), lin_of(oc64[0])
+    d, d64, r64 = (ours - ref).abs(), (ours - truth).abs(), (ref - truth).abs()
+    print(f'[parity] full-size crops, linear light: ours-vs-reference max {float(d.max()):.2e} mean {float(d.mean()):.2e}; '
+          f'ours-vs-fp64 max {float(d64.max()):.2e} mean {float(d64.mean()):.2e}; '
+          f'reference-vs-fp64 max {float(r64.max()):.2e} mean {float(r64.mean()):.2e}')
+    # Round 3: the bound is derived from the fp64 evaluation of the reference's own formulas on the same
+    # matrices and texels.  At 1080p a sample coordinate (~2000 px) carries 2^-13 px of f32 rounding, so on
+    # noise frames (neighbouring texels differ by up to 1) the reference itself sits ~1e-4 max / ~4e-6 mean
+    # from fp64 (printed above); ours must stay within 4x that floor of the reference and within 3x of fp64.
+    # Measured (round 3): reference-vs-fp64 max 1.30e-4 / mean 1.90e-6 (the floor); ours-vs-reference 2.30e-4 /
+    # 2.90e-6; ours-vs-fp64 1.47e-4 / 2.62e-6.  Fixed bounds at ~4x the floor (round 2: 1.5e-3 / 4e-5, with
+    # no floor stated).
+    assert float(r64.max()) <= 2.5e-4 and float(r64.mean()) <= 4e-6, 'the fixture changed: re-derive the bounds'
+    assert float(d.max()) <= 5e-4 and float(d.mean()) <= 8e-6
+    assert float(d64.max()) <= 4e-4 and float(d64.mean()) <= 6e-6
 
 
 @pytest.mark.parametrize('aa,dtype', [(1, torch.float32), (2, torch.float32), (1, torch.float16), (4, torch.float32)])
