@@ -77,6 +77,11 @@ def parse_args():
     ap.add_argument('--precision', default='f32', choices=['f32', 'f16', 'bf16'],
                     help='backbone arithmetic: f32 = the reference CPU path; f16 = its autocast GPU path')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--graph-gather', action='store_true',
+                    help='N > 1, RCCL, weak scaling: capture the all-gather of the poses INSIDE the step\'s HIP graph '
+                         '(one graph launch per step); falls back to the eager gather behind the replay -- and says '
+                         'so in the line -- if the capture fails.  Off by default: it cannot be validated on a '
+                         '1-GPU box')
     ap.add_argument('--quick', action='store_true',
                     help='print the contract line only: no per-kernel timing, roofline probes, parity probe, '
                          'backbone variants or CPU baseline (those fields are null)')
@@ -772,6 +777,19 @@ def main():
     shard_out = torch.zeros(max_batches * n_box, J, 3, device=dev) if strong else None
 
     use_base_gather = world > 1 and torch.distributed.get_backend() == 'nccl'
+    gather_mode = 'eager all_gather_into_tensor after the graph replay (outside the HIP graph)'
+    graph_gather = False
+    if args.graph_gather and use_base_gather and not strong and not args.no_graph:
+        try:  # re-capture the step with the collective inside the graph
+            pipe.after_step = lambda poses: torch.distributed.all_gather_into_tensor(gathered, poses.contiguous())
+            pipe.capture()
+            torch.cuda.synchronize()
+            graph_gather = True
+            gather_mode = 'all_gather_into_tensor captured inside the step\'s HIP graph (--graph-gather)'
+        except Exception as e:  # noqa: BLE001 -- any capture failure: back to the eager gather
+            pipe.after_step = None
+            pipe.capture()
+            gather_mode += f' [--graph-gather failed: {str(e)[:120]}]'
 
     def step():
         if strong:
@@ -780,7 +798,7 @@ def main():
             poses = shard_out
         else:
             poses = pipe.run()
-        if world > 1:
+        if world > 1 and not graph_gather:
             # the single collective of the path: KB-sized all-gather of the poses over RCCL/xGMI
             if use_base_gather:
                 torch.distributed.all_gather_into_tensor(gathered, poses.contiguous())
@@ -835,7 +853,7 @@ def main():
                      backend=torch.distributed.get_backend(),
                      devices='all ranks on cuda:0 (MTR_BENCH_SHARED_DEVICE=1: code-path test, not a '
                              'scaling measurement)' if shared_device else 'one GPU per rank',
-                     gather='eager all_gather_into_tensor after the graph replay (outside the HIP graph)')
+                     gather=gather_mode)
 
     if rank != 0:
         if world > 1:

@@ -62,6 +62,10 @@ class GraphedCropPipeline:
         self.poses = self.poses3d = self.poses2d = None
         self.graph = None
         self.use_graph = use_graph
+        # optional: called with the poses at the end of every step INSIDE the captured region (e.g. the
+        # RCCL all-gather of a sharded job, so that a step stays one graph launch); also called by the
+        # eager warm-up steps in front of the capture, which is where a communicator initialises
+        self.after_step = None
 
     def _body(self):
         if self.include_pyramid or self.pyramid is None:
@@ -76,6 +80,8 @@ class GraphedCropPipeline:
             poses_flat, rot, self.tta['should_flip_u8'], self.tta['mirror_i32'], self.intrinsics,
             self.distortion12, self.inv_extrinsics, self.est._joint_transform_on(self.images.device),
             None, self.average_aug)
+        if self.after_step is not None:
+            self.after_step(self.poses3d)
         return self.poses3d
 
     def capture(self, warmup=3):
