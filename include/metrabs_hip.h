@@ -328,6 +328,16 @@ int mtr_detector_geometry(int H, int W, int input_size /*416*/, mtr_detector_geo
 /* images_u8 [N,3,H,W] uint8 -> out [N,3,g->out_h,g->out_w] f32 (what the network is fed); g: host */
 int mtr_detector_preprocess(const uint8_t* images_u8, int N, int H, int W, const mtr_detector_geom* g,
                             float* out, mtr_stream_t stream);
+/* The same with the kernel named (tests and timing; the two kernels give identical bits):
+ *   AUTO    the streaming kernel for launches past its measured cross-over (4 frames of 1080p; any
+ *           shrink of 5.5x and more) when the frame tensor is a multiple of 16 bytes and its LDS fits,
+ *           else the tile kernel (what mtr_detector_preprocess does);
+ *   TILE    one 8-row x 64-column output tile at a time, staged through registers;
+ *   STREAM  a 64-column strip walked down the frame, rows loaded global -> LDS two chunks ahead by
+ *           a loading wave (MTR_E_SHAPE when not available for this tensor). */
+enum { MTR_DETECTOR_KERNEL_AUTO = 0, MTR_DETECTOR_KERNEL_TILE = 1, MTR_DETECTOR_KERNEL_STREAM = 2 };
+int mtr_detector_preprocess_kernel(const uint8_t* images_u8, int N, int H, int W, const mtr_detector_geom* g,
+                                   int kernel, float* out, mtr_stream_t stream);
 /* xyxy_conf [n,5] (x1,y1,x2,y2,conf; network frame) -> boxes_out [n,5] (x,y,w,h,conf; image frame) */
 int mtr_detector_scale_boxes(const float* xyxy_conf, int n, const mtr_detector_geom* g,
                              float* boxes_out, mtr_stream_t stream);

@@ -111,6 +111,8 @@ SIGNATURES = {
     'mtr_detector_geometry': (c_int, [c_int, c_int, c_int, POINTER(DetectorGeom)]),
     'mtr_detector_preprocess': (c_int, [c_void_p, c_int, c_int, c_int, POINTER(DetectorGeom), c_void_p,
                                         c_void_p]),
+    'mtr_detector_preprocess_kernel': (c_int, [c_void_p, c_int, c_int, c_int, POINTER(DetectorGeom), c_int,
+                                               c_void_p, c_void_p]),
     'mtr_detector_scale_boxes': (c_int, [c_void_p, c_int, POINTER(DetectorGeom), c_void_p, c_void_p]),
     'mtr_filter_poses_workspace_bytes': (ctypes.c_size_t, [c_int, c_int, c_int]),
     'mtr_filter_poses': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

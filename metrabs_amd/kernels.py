@@ -391,9 +391,13 @@ def detector_geometry(h, w, input_size=416):
     return g
 
 
-def detector_preprocess(images_u8, geom=None, input_size=416, out=None):
+DETECTOR_KERNELS = {'auto': 0, 'tile': 1, 'stream': 2}  # MTR_DETECTOR_KERNEL_*
+
+
+def detector_preprocess(images_u8, geom=None, input_size=416, out=None, kernel='auto'):
     """images_u8 [N,3,H,W] uint8 (cuda) -> ([N,3,out_h,out_w] f32 as fed to the detector network,
-    geometry).  person_detector.py:21-33."""
+    geometry).  person_detector.py:21-33.  `kernel`: 'auto' | 'tile' | 'stream' (identical bits; tests
+    and timing name one)."""
     if images_u8.dtype != torch.uint8 or images_u8.dim() != 4 or images_u8.shape[1] != 3:
         raise ValueError('images must be uint8 [N,3,H,W]')
     require_cuda(images_u8)
@@ -402,9 +406,10 @@ def detector_preprocess(images_u8, geom=None, input_size=416, out=None):
     g = geom if geom is not None else detector_geometry(H, W, input_size)
     if out is None:
         out = torch.empty(N, 3, g.out_h, g.out_w, device=images_u8.device, dtype=torch.float32)
-    check(_lib.load().mtr_detector_preprocess(_ptr(images_u8), N, H, W, ctypes.byref(g), _ptr(out),
-                                              current_stream_ptr(images_u8.device)),
-          'mtr_detector_preprocess')
+    check(_lib.load().mtr_detector_preprocess_kernel(_ptr(images_u8), N, H, W, ctypes.byref(g),
+                                                     DETECTOR_KERNELS[kernel], _ptr(out),
+                                                     current_stream_ptr(images_u8.device)),
+          'mtr_detector_preprocess_kernel')
     return out, g
 
 

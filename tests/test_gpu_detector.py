@@ -39,7 +39,8 @@ def test_detector_preprocess_vs_golden(name, hip_lib):
 
 @pytest.mark.parametrize('shape', [(1, 1080, 1920), (2, 720, 1280), (1, 2160, 3840), (1, 333, 1999),
                                    (1, 64, 416), (2, 8, 8), (1, 417, 200), (1, 200, 6000), (1, 4500, 300)])
-def test_detector_preprocess_vs_oracle_full_tensor(shape, hip_lib):
+@pytest.mark.parametrize('kernel', ['tile', 'stream'])
+def test_detector_preprocess_vs_oracle_full_tensor(shape, kernel, hip_lib):
     """Full-size frames (1080p = BASELINE configs, 4K), extreme aspect ratios (14x shrink: the
     40-tap instantiation), tiny frames, tensor sizes that are not multiples of 16 (byte-wise tail):
     every element against the oracle, and the pad region exactly 0.5."""
@@ -48,22 +49,53 @@ def test_detector_preprocess_vs_oracle_full_tensor(shape, hip_lib):
     img = cases.synth_images(n, h, w, 31)
     with torch.inference_mode():
         ref, m = cpu_ref.detector_preprocess(img)
-    x, g = kernels.detector_preprocess(img.cuda())
+    if kernel == 'stream' and img.numel() % 16:
+        # the streaming kernel loads whole 16-byte vectors: such tensors are the tile kernel's
+        with pytest.raises(RuntimeError):
+            kernels.detector_preprocess(img.cuda(), kernel='stream')
+        x, g = kernels.detector_preprocess(img.cuda())  # ('auto' falls back)
+        assert torch.equal(x, kernels.detector_preprocess(img.cuda(), kernel='tile')[0])
+        return
+    x, g = kernels.detector_preprocess(img.cuda(), kernel=kernel)
     x = x.cpu()
     assert x.shape == ref.shape
     d = (x - ref).abs()
-    print(f'[parity] detector input {shape}: max-abs {float(d.max()):.2e}')
+    print(f'[parity] detector input {shape} ({kernel}): max-abs {float(d.max()):.2e}')
     assert float(d.max()) <= TOL
     inner = torch.zeros(g.out_h, g.out_w, dtype=torch.bool)
     inner[g.pad_top:g.pad_top + g.target_h, g.pad_left:g.pad_left + g.target_w] = True
     assert bool((x[:, :, ~inner] == 0.5).all())
 
 
+@pytest.mark.parametrize('shape', [(8, 1080, 1920), (3, 720, 1280), (1, 2160, 3840), (2, 480, 640), (1, 64, 416),
+                                   (5, 8, 8), (1, 200, 6000), (1, 4500, 300), (2, 1088, 1920), (1, 256, 416),
+                                   (4, 250, 400), (1, 1080, 1928), (7, 360, 648)])
+def test_stream_and_tile_kernels_give_identical_bits(shape, hip_lib):
+    """The streaming kernel (strip walked down the frame, loading wave, ring of filtered rows) and the
+    tile kernel evaluate the same weights and the same fma chains from the same gamma table: every
+    output bit is equal, for shrinking (12 / 24 / 40 tap instantiations), enlarging and 1:1 frames,
+    unit boundaries inside a plane (8 x 1080p: three units per plane; one frame: more) and rows
+    whose staged start is not 16-byte aligned (W = 1928)."""
+    from metrabs_amd import kernels
+    n, h, w = shape
+    img = cases.synth_images(n, h, w, 5).cuda()
+    tile, g = kernels.detector_preprocess(img, kernel='tile')
+    stream, _ = kernels.detector_preprocess(img, kernel='stream')
+    auto, _ = kernels.detector_preprocess(img)  # (whichever of the two the launch size picks)
+    assert torch.equal(tile, stream), float((tile - stream).abs().max())
+    assert torch.equal(auto, stream)
+    # a second call into a poisoned buffer: every element (pad included) is written
+    out = torch.full_like(stream, float('nan'))
+    kernels.detector_preprocess(img, geom=g, out=out, kernel='stream')
+    assert torch.equal(out, stream)
+
+
 def test_binary_frame_isolates_the_final_pow(hip_lib):
     """A frame of only 0 and 255 has LUT values exactly 0.0 / 1.0, so the kernel's linear-light
     resize equals aten's bit for bit (same weights, same fma order) and the only difference left is
-    the last operation, pow(x, 1/2.2): torch's vectorised CPU pow and the device powf round
-    differently on ~10 % of the values, never by more than 1 ulp."""
+    the last operation, pow(x, 1/2.2): the kernel's is correctly rounded (evaluated in double), torch's
+    vectorised CPU pow is for ~98 % of the values and never off by more than 1 ulp (with the device
+    library's powf, the first version, the two agreed on ~90 %)."""
     from metrabs_amd import kernels
     g = cases.gen(77)
     img = (torch.randint(0, 2, (1, 3, 540, 960), generator=g) * 255).to(torch.uint8)
@@ -73,7 +105,7 @@ def test_binary_frame_isolates_the_final_pow(hip_lib):
     x = x.cpu()
     same = float((x == ref).float().mean())
     print(f'[parity] binary frame: {same * 100:.3f} % bit-identical, max {float((x - ref).abs().max()):.2e}')
-    assert same >= 0.8 and float((x - ref).abs().max()) <= 6e-8
+    assert same >= 0.95 and float((x - ref).abs().max()) <= 6e-8
 
 
 def test_shrink_factor_limit_is_reported(hip_lib):

@@ -1,5 +1,6 @@
 """Timing ablations of detector_pre_kernel (developer tool).  build here, run on the GPU box.
-MTR_DET_ABLATE bits: 1 = no staging loads, 2 = no horizontal pass, 4 = no vertical pass."""
+MTR_DET_ABLATE bits: 1 = no staging loads, 2 = no horizontal pass, 4 = no vertical pass, 8 = no final pow
+(streaming kernel only).  DET_KERNEL=tile|stream|auto picks the kernel timed."""
 import json
 import os
 import subprocess
@@ -7,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, 'tools', 'experiments', '_build')
-MASKS = [0, 1, 2, 4, 3, 7]
+MASKS = [int(m) for m in os.environ.get('DET_MASKS', '0,1,2,4,8,6,14,15').split(',')]
 
 
 def build():
@@ -37,12 +38,12 @@ def run_one(mask):
         geom = kernels.detector_geometry(h, w)
         o = torch.empty(n, 3, geom.out_h, geom.out_w, device='cuda')
         for _ in range(5):
-            kernels.detector_preprocess(frames, geom=geom, out=o)
+            kernels.detector_preprocess(frames, geom=geom, out=o, kernel=os.environ.get('DET_KERNEL', 'auto'))
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(30):
-            kernels.detector_preprocess(frames, geom=geom, out=o)
+            kernels.detector_preprocess(frames, geom=geom, out=o, kernel=os.environ.get('DET_KERNEL', 'auto'))
         b.record()
         torch.cuda.synchronize()
         res[name] = round(a.elapsed_time(b) / 30 * 1e3, 1)

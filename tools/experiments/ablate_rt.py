@@ -23,6 +23,7 @@ VARIANTS = {'full': [], 'exp32': ['-DMTR_RT_EXP32=1'], 'nodecode': ['-DMTR_RT_AB
             'ks4': ['-DMTR_RT_KS_NBUF=4'], 'pair': ['-DMTR_RT_PAIR=1'],
             'nocopy': ['-DMTR_RT_ABLATE=4'], 'a5': ['-DMTR_RT_ABLATE=5'], 'a7': ['-DMTR_RT_ABLATE=7'],
             'a3': ['-DMTR_RT_ABLATE=3'], 'a21': ['-DMTR_RT_ABLATE=21'], 'a23': ['-DMTR_RT_ABLATE=23'],
+            'x3': ['-DMTR_RT_X3=1'], 'x3_nodecode': ['-DMTR_RT_X3=1', '-DMTR_RT_ABLATE=1'],
             'sadd': ['-DMTR_RT_SCALAR_ADD=1'], 'spread': ['-DMTR_RT_SPREAD_READS=1'],
             'spread_nodecode': ['-DMTR_RT_SPREAD_READS=1', '-DMTR_RT_ABLATE=1'],
             'ld8': ['-DMTR_RT_LD_NBUF=8', '-DMTR_RT_LD_LA=4'], 'ld8la5': ['-DMTR_RT_LD_NBUF=8', '-DMTR_RT_LD_LA=5'],
@@ -110,6 +111,9 @@ def run_one(name):
         b.record()
         torch.cuda.synchronize()
         res[label] = round(a.elapsed_time(b) / (n * reps) * 1e3, 1)
+        if os.environ.get('RT_DUMP'):  # outputs beside the timings: `run` prints each variant's distance to 'full'
+            os.makedirs(os.environ['RT_DUMP'], exist_ok=True)
+            torch.save((c2.cpu(), c3.cpu()), os.path.join(os.environ['RT_DUMP'], f"{name}_{label.replace(' ', '_')}.pt"))
     print(json.dumps(res), flush=True)
 
 
@@ -119,5 +123,16 @@ if __name__ == '__main__':
     elif sys.argv[1] == 'run':
         for name in VARIANTS:
             subprocess.run([sys.executable, os.path.abspath(__file__), 'one', name], check=False)
+        if os.environ.get('RT_DUMP'):
+            import glob
+            import torch
+            for f in sorted(glob.glob(os.path.join(os.environ['RT_DUMP'], 'full_*.pt'))):
+                ref = torch.load(f)
+                for name in VARIANTS:
+                    g = f.replace('full_', name + '_', 1)
+                    if name != 'full' and os.path.exists(g):
+                        out = torch.load(g)
+                        print(os.path.basename(g), 'max |d coords2d| %.3e  max |d coords3d| %.3e' % (
+                            (out[0] - ref[0]).abs().max(), (out[1] - ref[1]).abs().max()), flush=True)
     else:
         run_one(sys.argv[2])

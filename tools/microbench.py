@@ -173,15 +173,16 @@ def bench_detector_pre():
     once + the f32 network input once."""
     out = []
     g = torch.Generator().manual_seed(0)
-    for name, n, h, w in [('8 x 1080p -> 256x416', 8, 1080, 1920), ('2 x 2160p -> 256x416', 2, 2160, 3840),
-                          ('8 x 480x640 -> 320x416', 8, 480, 640)]:
+    for name, n, h, w in [('8 x 1080p -> 256x416', 8, 1080, 1920), ('1 x 1080p -> 256x416', 1, 1080, 1920),
+                          ('2 x 2160p -> 256x416', 2, 2160, 3840), ('8 x 480x640 -> 320x416', 8, 480, 640)]:
         frames = torch.randint(0, 256, (n, 3, h, w), dtype=torch.uint8, generator=g).cuda()
         geom = kernels.detector_geometry(h, w)
         o = torch.empty(n, 3, geom.out_h, geom.out_w, device='cuda')
-        t = timeit(lambda: kernels.detector_preprocess(frames, geom=geom, out=o))
         nbytes = frames.numel() + o.numel() * 4
-        out.append(dict(kernel='detector_pre', case=name, us=round(t * 1e6, 1),
-                        GBps=round(nbytes / t / 1e9, 1), frac_hbm=round(nbytes / t / HBM, 3)))
+        for kern in ('stream', 'tile'):  # ('auto' = the streaming kernel on these tensors)
+            t = timeit(lambda: kernels.detector_preprocess(frames, geom=geom, out=o, kernel=kern))
+            out.append(dict(kernel='detector_pre', variant=kern, case=name, us=round(t * 1e6, 1),
+                            GBps=round(nbytes / t / 1e9, 1), frac_hbm=round(nbytes / t / HBM, 3)))
     return out
 
 
