@@ -308,76 +308,118 @@ static int dispatch_decode(const void* logits, int B, int J, int D, int H, int W
 // Round 3: G = blockDim / N position GROUPS per channel run side by side (thread t: channel t % N,
 // group t / N takes positions g, g + G, ...) and their online-softmax states are merged in LDS in
 // group order -- at J = 17, D = 8 (N = 153) a 1024-thread workgroup keeps 918 lanes busy on ~11
-// positions each instead of 153 lanes on 64 (small batches are one workgroup per crop on a quarter
-// of the CUs: the walk over the positions is the critical path).  N > blockDim: one group, channels
-// in rounds, as before.
+// positions each instead of 153 lanes on 64.  N > blockDim: one group, channels in rounds.
+// Batches that leave CUs idle (B < 256) deal a crop's JOINTS to `splits` workgroups: a joint's rows
+// (its 2D row and its D depth slices) stay in one workgroup, so nothing is merged across workgroups;
+// workgroup (b, k) walks the channels {j} and {J + d J + j} of its joints j0 <= j < j1 (1 + D runs of
+// j1 - j0 consecutive channels per position) with N = (j1 - j0)(1 + D) local rows.
 template <typename T>
 __global__ __launch_bounds__(1024) void decode_nhwc_kernel(const T* __restrict__ logits, int B, int J,
-                                                           int D, int H, int W, HeadScale hs, AxisInv ai,
-                                                           float* __restrict__ coords2d,
+                                                           int D, int H, int W, int splits, HeadScale hs,
+                                                           AxisInv ai, float* __restrict__ coords2d,
                                                            float* __restrict__ coords3d_rel) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int N = J * (1 + D), HW = H * W;
-  const int G = N <= (int)blockDim.x ? (int)blockDim.x / N : 1;  // position groups per channel
+  const int NC = J * (1 + D), HW = H * W;  // channels per position
+  const int b = blockIdx.x / splits, part = blockIdx.x - b * splits;
+  const int j0 = (int)((long long)part * J / splits), j1 = (int)((long long)(part + 1) * J / splits);
+  const int nj = j1 - j0, N = nj * (1 + D);  // this workgroup's joints / rows
+  // position groups per channel: as many as the threads allow, but a group should have ~8 positions
+  // to walk (one batch of loads) and the groups of a channel are merged one after the other
+  int G = N <= (int)blockDim.x ? (int)blockDim.x / N : 1;
+  G = max(1, min(G, min(16, HW / 8)));
   float* row_m = reinterpret_cast<float*>(smem_raw);                               // [G][N]
   double* row_s = reinterpret_cast<double*>(smem_raw + ((G * N * 4 + 15) & ~15));  // [G][N][3]
-  const int b = blockIdx.x;
-  const T* x = logits + (size_t)b * HW * N;
+  const T* x = logits + (size_t)b * HW * NC;
+  constexpr int U = 8;  // positions per batch: their loads are in flight together (a walk of one
+                        // dependent load per step was the whole 12 us of a 64-crop launch)
   for (int t = threadIdx.x; t < G * N; t += blockDim.x) {
     const int n = t % N, g = t / N;
+    // local row n = (slice, joint): slice 0 is the 2D row, slice 1 + d the depth slice d
+    const int slice = n / nj, jj = n - slice * nj;
+    const int ch = slice == 0 ? j0 + jj : J + (slice - 1) * J + j0 + jj;
     float m = -INFINITY;
     double s = 0.0, sx = 0.0, sy = 0.0;
-    for (int p = g; p < HW; p += G) {
-      const float v = to_f32(x[(size_t)p * N + n]);
-      const int h = p / W, w = p - h * W;
-      if (v > m) {  // rescale what has been summed under the old maximum -- in f64, as the per-joint
-        // merge below does: a 2-ulp f32 factor at every update of the running maximum would add
-        // ~1e-7 relative per update to the expectation (a few 1e-4 mm of the 1e-3 mm budget)
+    for (int p0 = g; p0 < HW; p0 += G * U) {
+      float v[U];
+      float mb = -INFINITY;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int p = p0 + u * G;
+        v[u] = p < HW ? to_f32(x[(size_t)p * NC + ch]) : -INFINITY;
+        mb = fmaxf(mb, v[u]);
+      }
+      if (mb > m) {  // rescale what has been summed under the old maximum, once per batch and in f64
+        // (a 2-ulp f32 factor at every update of the running maximum would add ~1e-7 relative per
+        // update to the expectation: a few 1e-4 mm of the 1e-3 mm budget)
         if (m != -INFINITY) {  // (nothing summed yet otherwise)
-          const double f = exp_neg64((double)m - (double)v);
+          const double f = exp_neg64((double)m - (double)mb);
           s *= f; sx *= f; sy *= f;
         }
-        m = v;
+        m = mb;
       }
-      if (v != -INFINITY) {  // a -inf logit weighs nothing (and -inf - -inf is NaN under a -inf maximum)
-        const double e = (double)exp_shifted(v, -m * kLog2e);
-        s += e; sx += e * (double)w; sy += e * (double)h;
+      const float nm = -m * kLog2e;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int p = p0 + u * G;
+        // a -inf logit (and a position past the map) weighs nothing (-inf - -inf is NaN under a -inf maximum)
+        if (v[u] != -INFINITY) {
+          const int h = p / W, w = p - h * W;
+          const double e = (double)exp_shifted(v[u], nm);
+          s += e; sx += e * (double)w; sy += e * (double)h;
+        }
       }
     }
     row_m[t] = m;
     row_s[t * 3 + 0] = s; row_s[t * 3 + 1] = sx; row_s[t * 3 + 2] = sy;
   }
   __syncthreads();
-  if (G > 1) {  // the groups of a channel -> group 0's slot, in group order
-    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+  // The merges -- the groups of a channel, then the slices of a joint -- are online-softmax merges:
+  // every partial sum is scaled by exp(its max - the common max) in f64 and added in order.  The
+  // factors are evaluated by one thread per PARTIAL (all G N of them side by side, then all N), the
+  // ordered additions by one thread per channel / per joint: the first version looped the f64 exps
+  // inside those (G per channel, D per joint, one after the other: 72 of them for 72 depth slices).
+  const float* chan_m = row_m;  // running maximum of channel n over all its positions
+  if (G > 1) {
+    float* cm = reinterpret_cast<float*>(row_s + (size_t)G * N * 3);  // [N]
+    for (int t = threadIdx.x; t < G * N; t += blockDim.x) {
+      const int n = t % N;
       float M = row_m[n];
       for (int g = 1; g < G; ++g) M = fmaxf(M, row_m[g * N + n]);
-      double S = 0.0, SX = 0.0, SY = 0.0;
-      for (int g = 0; g < G; ++g) {
-        const int t = g * N + n;
-        const double f = row_m[t] == -INFINITY ? 0.0 : exp_neg64((double)row_m[t] - (double)M);
-        S += row_s[t * 3] * f; SX += row_s[t * 3 + 1] * f; SY += row_s[t * 3 + 2] * f;
-      }
-      row_m[n] = M;
-      row_s[n * 3 + 0] = S; row_s[n * 3 + 1] = SX; row_s[n * 3 + 2] = SY;
+      const double f = row_m[t] == -INFINITY ? 0.0 : exp_neg64((double)row_m[t] - (double)M);
+      row_s[t * 3 + 0] *= f; row_s[t * 3 + 1] *= f; row_s[t * 3 + 2] *= f;
+      if (t < N) cm[n] = M;
     }
+    chan_m = cm;
     __syncthreads();
   }
-  for (int j = threadIdx.x; j < J; j += blockDim.x) {
-    const size_t o = (size_t)b * J + j;
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    double S = row_s[n * 3], SX = row_s[n * 3 + 1], SY = row_s[n * 3 + 2];
+    for (int g = 1; g < G; ++g) {  // group order
+      const int t = g * N + n;
+      S += row_s[t * 3]; SX += row_s[t * 3 + 1]; SY += row_s[t * 3 + 2];
+    }
+    const int slice = n / nj, jj = n - slice * nj;
+    if (slice > 0) {  // a depth slice: scaled to the maximum over its joint's slices
+      float M = -INFINITY;
+      for (int d = 0; d < D; ++d) M = fmaxf(M, chan_m[nj + d * nj + jj]);
+      const double f = chan_m[n] == -INFINITY ? 0.0 : exp_neg64((double)chan_m[n] - (double)M);
+      S *= f; SX *= f; SY *= f;
+    }
+    row_s[n * 3 + 0] = S; row_s[n * 3 + 1] = SX; row_s[n * 3 + 2] = SY;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < nj; j += blockDim.x) {
+    const size_t o = (size_t)b * J + j0 + j;
     {
       const double i2 = fast_rcp64(row_s[j * 3]);
       coords2d[o * 2 + 0] = heatmap_to_px(axis_coord_rcp(row_s[j * 3 + 1], i2, ai.w), hs);
       coords2d[o * 2 + 1] = heatmap_to_px(axis_coord_rcp(row_s[j * 3 + 2], i2, ai.h), hs);
     }
-    float M = -INFINITY;
-    for (int d = 0; d < D; ++d) M = fmaxf(M, row_m[J + d * J + j]);
     double S = 0.0, SX = 0.0, SY = 0.0, SZ = 0.0;
-    for (int d = 0; d < D; ++d) {
-      const int n = J + d * J + j;
-      const double f = exp_neg64((double)row_m[n] - (double)M);
-      const double sd = row_s[n * 3] * f;
-      S += sd; SX += row_s[n * 3 + 1] * f; SY += row_s[n * 3 + 2] * f; SZ += sd * (double)d;
+    for (int d = 0; d < D; ++d) {  // slice order
+      const int n = nj + d * nj + j;
+      const double sd = row_s[n * 3];
+      S += sd; SX += row_s[n * 3 + 1]; SY += row_s[n * 3 + 2]; SZ += sd * (double)d;
     }
     const double i3 = fast_rcp64(S);
     coords3d_rel[o * 3 + 0] = heatmap_to_mm_xy(axis_coord_rcp(SX, i3, ai.w), hs);
@@ -392,9 +434,24 @@ static int launch_decode_nhwc(const void* logits, int B, int J, int D, int H, in
   const long long N = (long long)J * (1 + D);
   // 1024 threads (up to 6 position groups per channel at N = 153) while a crop is ONE workgroup and the
   // batch does not fill the chip; large batches keep 256 threads (4+ workgroups per CU hide the walk)
-  const int threads = B <= 1024 ? 1024 : 256;
-  const long long slots = N <= threads ? (threads / N) * N : N;
-  const size_t lds = (size_t)((slots * 4 + 15) & ~15LL) + (size_t)slots * 24;
+  // joints of a crop over `splits` workgroups while the batch leaves CUs idle (B = 64: 4 x 64 workgroups)
+  int splits = B < 256 ? 256 / B : 1;
+  if (splits > J) splits = J;
+  // threads: the rows of the largest part x its position groups (<= 16, ~8 positions each), 256..1024
+  int threads = 256;
+  {
+    const long long rows = (long long)((J + splits - 1) / splits) * (1 + D);
+    long long groups = (long long)H * W / 8;
+    groups = groups < 1 ? 1 : groups > 16 ? 16 : groups;
+    // ... and no more threads than keep every workgroup of the launch resident (2048 per CU)
+    const long long resident = 2048LL * 256 / ((long long)B * splits) / rows;
+    if (groups > resident) groups = resident < 1 ? 1 : resident;
+    const long long want = (rows * groups + 63) / 64 * 64;
+    threads = (int)(want < 256 ? 256 : want > 1024 ? 1024 : want);
+  }
+  // (LDS is sized for the unsplit row count: an upper bound of every part's G * N)
+  const long long slots = N <= threads ? (long long)threads : N;
+  const size_t lds = (size_t)((slots * 4 + 15) & ~15LL) + (size_t)slots * 24 + (size_t)N * 4;
   if (lds > 160 * 1024 - 256) return MTR_E_SHAPE;  // > 5,800 channels per position
   auto kern = decode_nhwc_kernel<T>;
   if (lds > 64 * 1024) {
@@ -402,8 +459,8 @@ static int launch_decode_nhwc(const void* logits, int B, int J, int D, int H, in
     if (rc != MTR_OK) return rc;
   }
   MTR_CLEAR_STALE();
-  hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(threads), lds, stream, (const T*)logits, B, J, D, H, W, hs,
-                     make_axis_inv(W, H, D), c2d, c3d);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(B * splits)), dim3(threads), lds, stream, (const T*)logits, B, J, D,
+                     H, W, splits, hs, make_axis_inv(W, H, D), c2d, c3d);
   MTR_CHECK_LAUNCH();
   return MTR_OK;
 }

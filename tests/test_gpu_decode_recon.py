@@ -140,6 +140,28 @@ def test_decode_channels_last_logits_vs_golden(name, hip_lib):
         assert float((c3d - n3d).abs().max()) <= tol and float((c2d - n2d).abs().max()) <= 4e-4
 
 
+@pytest.mark.parametrize('B,J,D,H', [(1, 17, 8, 8), (3, 17, 8, 8), (64, 17, 8, 8), (100, 24, 8, 8), (255, 17, 8, 8),
+                                     (256, 17, 8, 8), (300, 17, 8, 8), (64, 122, 8, 12), (2, 3, 72, 8), (40, 1, 8, 8)])
+def test_decode_channels_last_joint_splits(B, J, D, H, hip_lib):
+    """Batches under 256 crops deal a crop's joints to 256 // B workgroups (at most J): every split
+    count, joint counts that do not divide, one joint, 72 depth slices and the unsplit launch, against
+    the NCHW kernel on the same logits and against the oracle on a sample."""
+    from metrabs_amd import kernels
+    from metrabs_amd.config import MetrabsConfig
+    cfg = MetrabsConfig(depth=D, proc_side=H * 32)
+    g = torch.Generator(device='cuda').manual_seed(B * 1000 + J)
+    logits = torch.randn(B, J * (1 + D), H, H, generator=g, device='cuda') * 3.0
+    x = logits.contiguous(memory_format=torch.channels_last)
+    c2d, c3d = kernels.softargmax_decode(x, J, cfg)
+    n2d, n3d = kernels.softargmax_decode(logits, J, cfg)
+    assert float((c3d - n3d).abs().max()) <= 5e-4 and float((c2d - n2d).abs().max()) <= 1e-4
+    k = min(B, 4)
+    with torch.inference_mode():
+        o2d, o3d = cpu_ref.heads_from_logits(logits[:k].cpu(), J, cpu_ref.HeadConfig(depth=D, proc_side=H * 32))
+    assert float((c3d[:k].cpu() - o3d).abs().max()) <= 1e-3
+    assert float((c2d[:k].cpu() - o2d).abs().max()) <= 2e-4
+
+
 @pytest.mark.parametrize('name', list(cases.RECON_CASES))
 def test_reconstruct_vs_golden_and_oracle(name, hip_lib):
     """Identical coords -> absolute poses.  The reference solves with fp32 LAPACK lstsq (its own

@@ -9,7 +9,8 @@ from metrabs_amd import kernels  # noqa: E402
 from metrabs_amd.config import MetrabsConfig  # noqa: E402
 from tools.microbench import timeit  # noqa: E402
 
-for B, J, D, side in [(64, 17, 8, 8), (8, 17, 8, 8), (1024, 17, 8, 8), (32, 122, 8, 12), (64, 17, 72, 8)]:
+for B, J, D, side in [(64, 17, 8, 8), (8, 17, 8, 8), (256, 17, 8, 8), (1024, 17, 8, 8), (4096, 17, 8, 8), (32, 122, 8, 12),
+                      (64, 17, 72, 8)]:
     cfg = MetrabsConfig(depth=D, proc_side=side * 32)
     g = torch.Generator(device='cuda').manual_seed(1)
     lg = torch.randn(B, J * (1 + D), side, side, device='cuda', generator=g)
