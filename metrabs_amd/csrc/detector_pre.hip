@@ -601,13 +601,23 @@ __global__ __launch_bounds__(1024) void detector_stream_kernel(DetStreamArgs a, 
             float acc;
             int slot = inf.x;
             if (gy.aa) {
-              acc = __fmul_rn(temp[slot * kDTX + c], wy[rr * KT]);
+              const int slot0 = __builtin_amdgcn_readfirstlane(slot);
+              if (slot0 + KT <= a.ring) {  // (uniform) the window does not wrap: taps at immediate offsets
+                const float* tp = temp + slot0 * kDTX + c;
+                const float* wp = wy + rr * KT;
+                acc = __fmul_rn(tp[0], wp[0]);
 #pragma unroll
-              for (int k = 1; k < KT; ++k)
-                if (k < ys) {
-                  slot = slot + 1 == a.ring ? 0 : slot + 1;
-                  acc = __fmaf_rn(temp[slot * kDTX + c], wy[rr * KT + k], acc);
-                }
+                for (int k = 1; k < KT; ++k)
+                  if (k < ys) acc = __fmaf_rn(tp[k * kDTX], wp[k], acc);
+              } else {
+                acc = __fmul_rn(temp[slot * kDTX + c], wy[rr * KT]);
+#pragma unroll
+                for (int k = 1; k < KT; ++k)
+                  if (k < ys) {
+                    slot = slot + 1 == a.ring ? 0 : slot + 1;
+                    acc = __fmaf_rn(temp[slot * kDTX + c], wy[rr * KT + k], acc);
+                  }
+              }
             } else {
               int s1 = slot + inf.w;
               s1 = s1 >= a.ring ? s1 - a.ring : s1;
@@ -635,15 +645,17 @@ __global__ __launch_bounds__(1024) void detector_stream_kernel(DetStreamArgs a, 
         // minus 3): no test in front of them, so they schedule as one block
         constexpr int kTapsSure = KT == 12 ? 4 : KT == 24 ? 8 : KT == kDTaps ? 20 : KT;
         const size_t base = plane_off + (size_t)y_c * gx.in_size + x_lo;
-        const unsigned lo4 = (unsigned)(base & 15);
+        const unsigned lo4 = (unsigned)(base & 15), w15 = (unsigned)gx.in_size & 15u;
         for (int rb = rg; rb < n_rows; rb += kDSGroups * RU) {
           uint32_t al[RU][NW];
 #pragma unroll
           for (int uu = 0; uu < RU; ++uu) {
             const int r = min(rb + kDSGroups * uu, n_rows - 1);
             // byte offset of tap 0 in the staged row: the row starts at the frame byte (base + r W) & ~15
-            const int off = (int)((lo4 + (unsigned)r * (unsigned)gx.in_size) & 15u) + (xm - x_lo);
-            const uint32_t* wrow = reinterpret_cast<const uint32_t*>(sbuf + (size_t)r * pitch) + (off >> 2);
+            // (r < 64, pitch < 2^16: 24-bit multiplies, full rate; v_mul_lo_u32 is a quarter-rate op)
+            const int off = (int)((lo4 + __builtin_amdgcn_mul_u24((unsigned)r, w15)) & 15u) + (xm - x_lo);
+            const uint32_t* wrow =
+                reinterpret_cast<const uint32_t*>(sbuf + __builtin_amdgcn_mul_u24((unsigned)r, (unsigned)pitch)) + (off >> 2);
             uint32_t raw[NW + 1];
 #pragma unroll
             for (int i = 0; i <= NW; ++i) raw[i] = wrow[i];
