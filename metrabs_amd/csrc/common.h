@@ -1,5 +1,6 @@
 // Shared device/host helpers for libmetrabs_hip.so (gfx950 / CDNA4 only: wave = 64 lanes).
 #pragma once
+#include <cmath>
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <hip/hip_bf16.h>
@@ -23,6 +24,22 @@ constexpr int kWave = 64;
     hipError_t e_ = hipGetLastError();           \
     if (e_ != hipSuccess) return (int)e_;        \
   } while (0)
+
+// (u8 / 255) ** 2.2 (person_detector.py:21, multiperson_model.py:197-198), the 256 values of the
+// gamma decode: fp32 division like torch, the power in double, rounded once.  Made on the host and
+// handed to the kernels by value (1 KiB of kernel arguments): no per-workgroup f64 pow, no global
+// state, graph-safe; the pyramid, the sampler (through the table the pyramid stores) and the
+// detector pre-processing all read the same 256 floats.
+struct GammaLut { float v[256]; };
+inline const GammaLut& gamma_lut_host() {
+  static const GammaLut lut = [] {
+    GammaLut l;
+    for (int i = 0; i < 256; ++i) l.v[i] = (float)std::pow((double)((float)i / 255.0f), (double)2.2f);
+    return l;
+  }();
+  return lut;
+}
+
 
 // More than the default 64 KiB of dynamic LDS: the kernel attribute is set ONCE per (kernel, device)
 // and remembered (it used to be a host call in front of every launch of the launch-latency-bound

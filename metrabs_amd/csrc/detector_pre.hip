@@ -88,10 +88,7 @@ __device__ __forceinline__ float pow_inv_gamma(float xf) {
   return xf > 0.0f ? res : 0.0f;
 }
 
-// (u8 / 255) ** 2.2 of person_detector.py:21, evaluated once on the host in double and rounded to
-// float (the same 256 values the first version derived per workgroup with the device's f64 pow);
-// travels as a kernel argument, so there is no global state and nothing to synchronise
-struct DetLut { float v[256]; };
+using DetLut = GammaLut;  // the host-made gamma table (common.h), a kernel argument
 // dynamic LDS: stage [rows_cap][pitch] uint8, then temp [rows_cap][64] f32
 template <int KT, bool TAIL>
 __global__ __launch_bounds__(256) void detector_pre_kernel(
@@ -653,9 +650,9 @@ __global__ __launch_bounds__(1024) void detector_stream_kernel(DetStreamArgs a, 
             const int r = min(rb + kDSGroups * uu, n_rows - 1);
             // byte offset of tap 0 in the staged row: the row starts at the frame byte (base + r W) & ~15
             // (r < 64, pitch < 2^16: 24-bit multiplies, full rate; v_mul_lo_u32 is a quarter-rate op)
-            const int off = (int)((lo4 + __builtin_amdgcn_mul_u24((unsigned)r, w15)) & 15u) + (xm - x_lo);
+            const int off = (int)((lo4 + __umul24((unsigned)r, w15)) & 15u) + (xm - x_lo);
             const uint32_t* wrow =
-                reinterpret_cast<const uint32_t*>(sbuf + __builtin_amdgcn_mul_u24((unsigned)r, (unsigned)pitch)) + (off >> 2);
+                reinterpret_cast<const uint32_t*>(sbuf + __umul24((unsigned)r, (unsigned)pitch)) + (off >> 2);
             uint32_t raw[NW + 1];
 #pragma unroll
             for (int i = 0; i <= NW; ++i) raw[i] = wrow[i];
@@ -760,14 +757,7 @@ static int device_cu_count() {
   return cache[dev];
 }
 
-static const mtr::DetLut& detector_lut() {
-  static const mtr::DetLut lut = [] {
-    mtr::DetLut l;
-    for (int i = 0; i < 256; ++i) l.v[i] = (float)std::pow((double)((float)i / 255.0f), (double)2.2f);
-    return l;
-  }();
-  return lut;
-}
+static const mtr::DetLut& detector_lut() { return mtr::gamma_lut_host(); }
 
 template <int KT, bool TAIL>
 static int launch_detector_pre_t(const uint8_t* images_u8, int N, int H, int W, const mtr_detector_geom* g,

@@ -60,11 +60,10 @@ namespace mtr {
 template <bool FROM_U8, bool WRITE_L0>
 __global__ __launch_bounds__(256) void build_pyramid_kernel(
     const void* __restrict__ src_any, int planes, int Hi, int Wi, float* __restrict__ l0,
-    float* __restrict__ l1, float* __restrict__ l2, float* __restrict__ lut_out) {
+    float* __restrict__ l1, float* __restrict__ l2, float* __restrict__ lut_out, GammaLut lut_in) {
   __shared__ float lut[256];
   if (FROM_U8) {
-    // (v/255)**2.2: fp32 division like torch, pow evaluated in fp64 and rounded once
-    lut[threadIdx.x] = (float)pow((double)__fdiv_rn((float)threadIdx.x, 255.0f), (double)2.2f);
+    lut[threadIdx.x] = lut_in.v[threadIdx.x];  // (v/255)**2.2, common.h
     if (lut_out != nullptr && blockIdx.x == 0) lut_out[threadIdx.x] = lut[threadIdx.x];
     __syncthreads();
   }
@@ -148,10 +147,10 @@ __global__ __launch_bounds__(256) void build_pyramid_kernel(
 // whatever the pixel values (random pixels averaged ~3.5 ways on the shared 256-entry table).
 __global__ __launch_bounds__(256) void build_pyramid_u8_wide_kernel(
     const uint8_t* __restrict__ src, int planes, int Hi, int Wi, float* __restrict__ l1,
-    float* __restrict__ l2, float* __restrict__ lut_out) {
+    float* __restrict__ l2, float* __restrict__ lut_out, GammaLut lut_in) {
   __shared__ __attribute__((aligned(16))) float lut[256 * 32];
   {
-    const float v = (float)pow((double)__fdiv_rn((float)threadIdx.x, 255.0f), (double)2.2f);
+    const float v = lut_in.v[threadIdx.x];
     if (lut_out != nullptr && blockIdx.x == 0) lut_out[threadIdx.x] = v;
     const float4 v4 = make_float4(v, v, v, v);
 #pragma unroll
@@ -1030,7 +1029,7 @@ extern "C" int mtr_build_pyramid(const uint8_t* images_u8, int N, int Hi, int Wi
   MTR_CLEAR_STALE();
   hipLaunchKernelGGL((mtr::build_pyramid_kernel<true, true>), dim3(pyramid_grid(N, Hi, Wi)), dim3(256),
                      0, (hipStream_t)stream, (const void*)images_u8, N * 3, Hi, Wi, level0, level1,
-                     level2, (float*)nullptr);
+                     level2, (float*)nullptr, mtr::gamma_lut_host());
   MTR_CHECK_LAUNCH();
   return MTR_OK;
 }
@@ -1045,13 +1044,13 @@ extern "C" int mtr_build_pyramid_u8(const uint8_t* images_u8, int N, int Hi, int
   MTR_CLEAR_STALE();
   if (pyramid_wide_ok(images_u8, level1, level2, Hi, Wi)) {
     hipLaunchKernelGGL(mtr::build_pyramid_u8_wide_kernel, dim3(pyramid_wide_grid(N, Hi, Wi)), dim3(256),
-                       0, (hipStream_t)stream, images_u8, N * 3, Hi, Wi, level1, level2, lut);
+                       0, (hipStream_t)stream, images_u8, N * 3, Hi, Wi, level1, level2, lut, mtr::gamma_lut_host());
     MTR_CHECK_LAUNCH();
     return MTR_OK;
   }
   hipLaunchKernelGGL((mtr::build_pyramid_kernel<true, false>), dim3(pyramid_grid(N, Hi, Wi)),
                      dim3(256), 0, (hipStream_t)stream, (const void*)images_u8, N * 3, Hi, Wi,
-                     (float*)nullptr, level1, level2, lut);
+                     (float*)nullptr, level1, level2, lut, mtr::gamma_lut_host());
   MTR_CHECK_LAUNCH();
   return MTR_OK;
 }
@@ -1065,7 +1064,7 @@ extern "C" int mtr_pyramid_from_level0(const float* level0, int N, int Hi, int W
   MTR_CLEAR_STALE();
   hipLaunchKernelGGL((mtr::build_pyramid_kernel<false, false>), dim3(pyramid_grid(N, Hi, Wi)),
                      dim3(256), 0, (hipStream_t)stream, (const void*)level0, N * 3, Hi, Wi,
-                     (float*)nullptr, level1, level2, (float*)nullptr);
+                     (float*)nullptr, level1, level2, (float*)nullptr, mtr::gamma_lut_host());
   MTR_CHECK_LAUNCH();
   return MTR_OK;
 }
