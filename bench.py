@@ -207,6 +207,32 @@ def kernels_mod():
     return kernels
 
 
+def head_by_launch_size(est, args, n_crops):
+    """The f32 fused head at the step's launch size and at one that fills the chip evenly.  At 64 crops
+    of 8x8 maps a crop is 10 row tiles of 16 output channels: 640 tiles on 256 CUs = 3 + 3 + 3 + 1 per
+    crop, i.e. at most 2.5 / 3 of the matrix pipes busy, plus ~5 us outside the K loop; the same kernel
+    family at 1024 crops shows what the K loop itself reaches.  Random features, 20 launches per HIP-graph
+    replay (graph_time)."""
+    heads = est.crop_model.heatmap_heads
+    C = est.crop_model.backbone.out_channels
+    side = args.res // 32
+    J, D = est.joint_info.n_joints, heads.config.depth
+    g = torch.Generator(device='cuda').manual_seed(5)
+    out = {}
+    for B in sorted({n_crops, 1024}):
+        feat = torch.randn(B, C, side, side, device='cuda', generator=g)
+        us = graph_time([lambda: heads._forward_fused(feat)] * 20, 5) * 1e6
+        flops = 2.0 * C * J * (1 + D) * side * side * B
+        plan = kernels_mod().head_plan(B, C, side, side, J, D, torch.float32, False, True)
+        out[str(B)] = dict(us_per_launch=round(us, 2), TFLOPs=round(flops / us / 1e6, 1),
+                           frac_mfma=round(flops / (us * 1e-6) / MFMA_F32_PEAK, 3),
+                           kernel=plan and plan['kernel'], workgroups=plan and plan['workgroups'])
+    tiles = -(-J * (1 + D) // 16)
+    out['note'] = (f'mtr_head_fused alone, f32 features; the step runs {n_crops} crops: {n_crops * tiles} row tiles '
+                   f'of 16 output channels ({tiles} per crop) dealt to workgroups in whole tiles, on 256 CUs')
+    return out
+
+
 def depth72_variant(args, dev, im_h, im_w, n_box):
     """The metric string of BASELINE.json says "72 depth bins"; every shipped configuration of the
     reference uses depth = 8, which is what `value` is measured on.  This is the SAME step with a
@@ -1133,6 +1159,8 @@ def analysis(args, est, cfg, pipe, dev, step_seconds, im_h, im_w, n_box, world):
                           'in front leaves them), over the step time',
         'pcie_inclusive': pcie,
     })
+    if head_is_fused and not h16 and not args.quick:
+        out['head_by_launch_size'] = head_by_launch_size(est, args, n_crops)
     if not args.no_decode_roofline:
         out['decode_roofline'] = decode_roofline()
         out['decode_roofline']['traffic'] = (tjson.get('decode_nchw_kernel') or {}).get('bytes')
