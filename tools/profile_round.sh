@@ -1,9 +1,9 @@
 set -x
 # One round of evidence for profiles/ (run on the GPU box):
-#   gpurun -- 'bash tools/profile_round.sh r03c'
+#   gpurun -- 'bash tools/profile_round.sh r03e'
 # kernel trace of the bench command, the two PMC passes (one counter each, --kernel-trace only) that
 # profiles/traffic.json is reduced from, MFMA counters of the f32 head, micro-benchmarks, bench lines.
-TAG=${1:-r03c}
+TAG=${1:-r03e}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O
@@ -24,9 +24,15 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_
 python $R/tools/rocprof_summary.py /tmp/prof_w1 $O/${TAG}_pmc_warp_insts.md --ours-only
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d /tmp/prof_w2 -o b -- python $R/tools/experiments/pmc_warp.py > /dev/null 2>&1
 python $R/tools/rocprof_summary.py /tmp/prof_w2 $O/${TAG}_pmc_warp_cycles.md --ours-only
+# K9 (detector pre-processing, streaming kernel): issue / wait / LDS counters
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/prof_d1 -o a -- python $R/tools/experiments/pmc_detector.py > /dev/null 2>&1
+python $R/tools/rocprof_summary.py /tmp/prof_d1 $O/${TAG}_pmc_detector_insts.md --ours-only
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d /tmp/prof_d2 -o b -- python $R/tools/experiments/pmc_detector.py > /dev/null 2>&1
+python $R/tools/rocprof_summary.py /tmp/prof_d2 $O/${TAG}_pmc_detector_cycles.md --ours-only
 cd $R
 python tools/microbench.py > $O/${TAG}_microbench.jsonl 2>/dev/null
-timeout 600 python tools/experiments/head_sweep.py > $O/${TAG}_head_sweep.jsonl 2>/dev/null
+python tools/experiments/detector_sizes.py > $O/${TAG}_detector_sizes.jsonl 2>/dev/null
+timeout 400 python tools/experiments/head_sweep.py quick > $O/${TAG}_head_sweep.jsonl 2>/dev/null
 python tools/experiments/fused_vs_unfused.py 2>/dev/null | grep fused > $O/${TAG}_fused_vs_library.txt
 python tools/experiments/nhwc_decode_time.py > $O/${TAG}_nhwc_decode.txt 2>/dev/null
 cp $O/${TAG}_traffic.json profiles/traffic.json   # (the labelled fallback of bench.py's live PMC passes)
