@@ -90,6 +90,36 @@ def test_stream_and_tile_kernels_give_identical_bits(shape, hip_lib):
     assert torch.equal(out, stream)
 
 
+def test_stream_kernel_random_shapes(hip_lib):
+    """60 seeded random frame shapes (8 .. 2600 px a side, 1 - 3 frames; enlarging, shrinking up to the
+    40-tap limit, extreme aspect ratios): wherever the streaming kernel is available its output is
+    bit-identical to the tile kernel's; every fifth shape is also checked against the oracle."""
+    import random
+    from metrabs_amd import kernels
+    rng = random.Random(20260925)
+    n_stream = 0
+    for it in range(60):
+        n = rng.choice([1, 1, 2, 3])
+        h = rng.choice([rng.randint(8, 200), rng.randint(200, 1200), rng.randint(1200, 2600)])
+        w = rng.choice([rng.randint(8, 200), rng.randint(200, 1200), rng.randint(1200, 2600)])
+        if rng.random() < 0.7:
+            w = max(16, w // 16 * 16)  # (a tensor of a multiple of 16 bytes: the streaming kernel's domain)
+        img = cases.synth_images(n, h, w, 100 + it).cuda()
+        try:
+            tile, g = kernels.detector_preprocess(img, kernel='tile')
+        except RuntimeError:
+            continue  # (beyond the 19x shrink limit)
+        if img.numel() % 16 == 0:
+            stream, _ = kernels.detector_preprocess(img, kernel='stream')
+            assert torch.equal(tile, stream), (n, h, w, float((tile - stream).abs().max()))
+            n_stream += 1
+        if it % 5 == 0:
+            with torch.inference_mode():
+                ref, _ = cpu_ref.detector_preprocess(img.cpu())
+            assert float((tile.cpu() - ref).abs().max()) <= TOL, (n, h, w)
+    assert n_stream >= 30
+
+
 def test_binary_frame_isolates_the_final_pow(hip_lib):
     """A frame of only 0 and 255 has LUT values exactly 0.0 / 1.0, so the kernel's linear-light
     resize equals aten's bit for bit (same weights, same fma order) and the only difference left is
