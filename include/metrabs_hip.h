@@ -178,6 +178,8 @@ typedef struct mtr_head_plan_info {
   int32_t column_blocks;          /* f32 np kernel: column blocks per workgroup tile, else 1               */
   int32_t split_column_blocks;    /* f32: column blocks dealt to workgroups (+ the merge launch), else 0   */
   int64_t workgroups;             /* of the main launch                                                     */
+  double model_us;                /* f32 row-tile kernels: the launch plan's own estimate of the launch time
+                                     (its cost model simulates the launch; diagnostic), else 0              */
 } mtr_head_plan_info;
 int mtr_head_plan(int feat_dtype, int layout, int B, int C, int H, int W, int J, int D,
                   const mtr_head_options* options, int have_workspace, mtr_head_plan_info* plan);

@@ -30,7 +30,7 @@ class HeadOptions(ctypes.Structure):
 class HeadPlanInfo(ctypes.Structure):
     """mtr_head_plan_info (include/metrabs_hip.h): which kernel mtr_head_fused_ws takes for a launch."""
     _fields_ = [('kernel', c_int32), ('tiles_per_workgroup', c_int32), ('column_blocks', c_int32),
-                ('split_column_blocks', c_int32), ('workgroups', ctypes.c_int64)]
+                ('split_column_blocks', c_int32), ('workgroups', ctypes.c_int64), ('model_us', ctypes.c_double)]
 
 
 HEAD_KERNEL_NAMES = {1: 'head_rt_kernel', 2: 'head_rt_ld_kernel', 3: 'head_rt_ks_kernel', 4: 'head_rt_np_kernel',

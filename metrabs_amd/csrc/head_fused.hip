@@ -887,14 +887,14 @@ extern "C" int mtr_head_plan(int feat_dtype, int layout, int B, int C, int H, in
     if (!mtr::rt_shape_ok(C, J, D)) return MTR_E_SHAPE;
     const mtr::RtDispatch d = mtr::rt_dispatch(B, C, H, W, J, D, opt.rt_tiles, opt.rt_np, opt.rt_ks, opt.rt_ld,
                                                opt.rt_split, have_workspace != 0 && (H * W + 63) / 64 >= 2);
-    *plan = mtr_head_plan_info{d.kernel, d.rtg, d.np, d.split, d.n_wg};
+    *plan = mtr_head_plan_info{d.kernel, d.rtg, d.np, d.split, d.n_wg, d.model_us};
     return MTR_OK;
   }
   if (feat_dtype != MTR_F16 && feat_dtype != MTR_BF16) return MTR_E_DTYPE;
   if (head16_takes_rt(C, J, D, H, W)) {
     const mtr::RtDispatch d = mtr::rt16_dispatch(B, H, W, J, D, opt.rt_tiles, opt.rt_split,
                                                  have_workspace != 0 && (H * W + 63) / 64 >= 2);
-    *plan = mtr_head_plan_info{MTR_HEAD_KERNEL_16_RT, d.rtg, 1, d.split, d.n_wg};
+    *plan = mtr_head_plan_info{MTR_HEAD_KERNEL_16_RT, d.rtg, 1, d.split, d.n_wg, 0.0};
     return (layout == MTR_NCHW && !have_workspace) ? MTR_E_WORKSPACE : MTR_OK;
   }
   if (!mtr::h16_shape_ok(C, J, D) || H * W > 256) return MTR_E_SHAPE;

@@ -39,6 +39,13 @@
 //     v_mfma_f32_16x16x32 (the shapes the joint-group kernels of head_fused.hip do not take).
 #include "head_rt.h"
 
+#include <array>
+#include <map>
+#include <mutex>
+#include <queue>
+#include <tuple>
+#include <vector>
+
 namespace mtr {
 
 using v4f = __attribute__((ext_vector_type(4))) float;
@@ -1370,22 +1377,92 @@ int rt_pack(const float* weight, const float* bias, int C, int J, int D, void* s
 
 // ---- launch plan.  Measured model of a launch (tools/experiments/head_sweep.py, profiles/r03*_head_sweep.jsonl;
 // C = 1280): a workgroup of r tiles alone on its CU takes about 5.5 + 6.3 r us (one K loop of 40
-// stages; the loader-wave kernel 4.7 + 6.1 r); two 256-thread workgroups sharing a CU take 1.65 x that
-// together; workgroups start as CUs free up, one per CU for the loader-wave kernel (320 threads, its
-// ring and registers fill the CU), two for the others.  The plan that minimises the estimate is
-// taken; it reproduces the measured best choice on every shape of the sweep (B = 8 .. 1024 at 8x8,
-// 12x12 / 16x16 / 24x24 with their column blocks dealt to workgroups).
+// stages; the loader-wave kernel 4.7 + 6.1 r); of two 256-thread workgroups sharing a CU the K loops
+// take 1.75 - 2.4x as long (kRtPairedKLoop; the 5.5 us outside them do not); workgroups start in block order as slots free up, one per CU for the
+// loader-wave kernel (320 threads, its ring and registers fill the CU), two for the others.  A
+// crop's blocks are r, r, ..., (the rest) tiles, so the launch is simulated: an event queue over the
+// CUs (a CU's next completion; only its own completion changes its residents), O(workgroups x log
+// CUs), the result cached per shape by rt_dispatch.  The plan with the smallest estimate is taken.
+// What the closed form of the first version (every block r tiles, whole rounds) missed: 320 crops,
+// r = 5 is 640 equal workgroups on 512 slots = 1.25 rounds (98 us), r = 4 is 960 workgroups of 4, 4, 2
+// tiles that pack the second round (92 us; the library pair: 96).
 struct RtPlan { int mode; int rtg; double us; };  // mode 0 = head_rt_kernel, 1 = loader-wave kernel
-static double rt_wg_us(int mode, int r, int k_loops, double stage_scale) {
-  const double fixed = mode == 1 ? 4.7 : 5.5, per_tile = (mode == 1 ? 6.1 : (r <= 3 ? 6.3 : 6.5)) * stage_scale;
-  return fixed + k_loops * per_tile * r + (k_loops - 1) * 3.0;  // (+ a decode per further K loop)
+constexpr int kRtModelCus = 256;
+// two workgroups on a CU: how much longer their K loops run (the rest of a workgroup is unchanged), by
+// tiles per block of the launch -- measured at 1024 crops (10,240 .. 2,048 workgroups): blocks of 2 and of
+// 5 tiles share a CU well, blocks of 1 and 3 tiles are slower together than one after the other
+constexpr double kRtPairedKLoop[6] = {0.0, 2.4, 1.8, 2.43, 1.8, 1.75};
+struct RtWgTime { double fixed, loop; };  // a workgroup alone on its CU: fixed + loop us
+static RtWgTime rt_wg_us(int mode, int r, int tiles, int k_loops, double stage_scale) {
+  // a block of `tiles` row tiles in the kernel instantiated for blocks of r
+  const double fixed = mode == 1 ? 4.7 : 5.5;
+  const double per_tile = (mode == 1 ? 6.1 : (r <= 3 ? 6.3 : r == 4 ? 6.1 : 6.5)) * stage_scale;  // (measured alone: 30 us at r = 4)
+  return RtWgTime{fixed + (k_loops - 1) * 3.0 /* a decode per further K loop */, k_loops * per_tile * tiles};
 }
 static double rt_launch_us(int mode, int r, long long crops, int n_tiles, int k_loops, double stage_scale) {
-  const long long n_wg = crops * ((n_tiles + r - 1) / r);
-  const double t = rt_wg_us(mode, r, k_loops, stage_scale);
-  if (mode == 1) return (double)((n_wg + 255) / 256) * t;
-  const long long full = n_wg / 512, rem = n_wg % 512;
-  return full * 1.65 * t + (rem == 0 ? 0.0 : (rem <= 256 ? t : 1.65 * t));
+  const int per_crop = (n_tiles + r - 1) / r, last = n_tiles - (per_crop - 1) * r;
+  const long long n_wg = crops * per_crop;
+  const RtWgTime w_full = rt_wg_us(mode, r, r, k_loops, stage_scale), w_last = rt_wg_us(mode, r, last, k_loops, stage_scale);
+  const int slots = mode == 1 ? 1 : 2;
+  // (solo time, paired slowdown) of the two block sizes
+  const double t_full = w_full.fixed + w_full.loop, t_last = w_last.fixed + w_last.loop;
+  const double f_full = (w_full.fixed + kRtPairedKLoop[r] * w_full.loop) / t_full;
+  const double f_last = (w_last.fixed + kRtPairedKLoop[r] * w_last.loop) / t_last;
+  if (n_wg > 32768) {  // far into the steady state: work over throughput
+    const double work = (double)crops * ((per_crop - 1) * t_full * (slots == 2 ? f_full / 2 : 1.0) +
+                                         t_last * (slots == 2 ? f_last / 2 : 1.0));
+    return work / kRtModelCus;
+  }
+  // A CU's residents run at their solo speed (alone) or 1 / their paired slowdown (two).  At equal times
+  // completions come before hand-outs and the emptier CU is served first, and a CU takes ONE waiting
+  // workgroup per event (the dispatcher spreads a second round over the CUs that are free rather than
+  // doubling up on the first one) -- a CU with a second free slot queues again.
+  struct Cu { double rem[2], fac[2]; int n; double at; int ver; };
+  std::vector<Cu> cu(kRtModelCus, Cu{{0.0, 0.0}, {1.0, 1.0}, 0, 0.0, 0});
+  using Ev = std::tuple<double, int, int, int, int>;  // (time, 0 = completion / 1 = take one more, residents, CU, version)
+  std::priority_queue<Ev, std::vector<Ev>, std::greater<Ev>> events;
+  long long next = 0;
+  auto is_last = [&](long long w) { return (int)(w % per_crop) == per_crop - 1; };
+  auto speed = [](const Cu& u, int i) { return u.n <= 1 ? 1.0 : 1.0 / u.fac[i]; };
+  auto advance = [&](Cu& u, double now) {  // progress since the CU's last event; finished residents leave
+    const double dt = now - u.at;
+    int keep = 0;
+    for (int i = 0; i < u.n; ++i) {
+      const double rem = u.rem[i] - dt * speed(u, i);
+      if (rem > 1e-9) { u.rem[keep] = rem; u.fac[keep] = u.fac[i]; ++keep; }
+    }
+    u.n = keep;
+    u.at = now;
+  };
+  auto requeue = [&](int c, double now) {
+    Cu& u = cu[c];
+    ++u.ver;
+    if (u.n < slots && next < n_wg) events.push(Ev(now, 1, u.n, c, u.ver));  // a free slot: take one more
+    else if (u.n > 0) {
+      double first = u.rem[0] / speed(u, 0);
+      if (u.n == 2 && u.rem[1] / speed(u, 1) < first) first = u.rem[1] / speed(u, 1);
+      events.push(Ev(now + first, 0, u.n, c, u.ver));
+    }
+  };
+  for (int c = 0; c < kRtModelCus; ++c) requeue(c, 0.0);
+  double now = 0.0;
+  while (!events.empty()) {
+    const Ev e = events.top();
+    events.pop();
+    const int c = std::get<3>(e);
+    Cu& u = cu[c];
+    if (std::get<4>(e) != u.ver) continue;
+    now = std::get<0>(e);
+    advance(u, now);
+    if (std::get<1>(e) == 1 && u.n < slots && next < n_wg) {
+      const bool l = is_last(next++);
+      u.rem[u.n] = l ? t_last : t_full;
+      u.fac[u.n] = l ? f_last : f_full;
+      ++u.n;
+    }
+    requeue(c, now);
+  }
+  return now;
 }
 static RtPlan rt_plan(long long crops, const RtGeom& g, int k_loops, int C, int rtg_hint, int ld_hint) {
   const double stage_scale = ((C + 31) / 32) / 40.0;
@@ -1404,10 +1481,30 @@ static RtPlan rt_plan(long long crops, const RtGeom& g, int k_loops, int C, int 
 }
 
 // Which kernel a launch takes (shared by rt_launch and the host-only mtr_head_plan)
+static RtDispatch rt_dispatch_uncached(int B, int C, int H, int W, int J, int D, int rtg_hint, int np_hint,
+                                       int ks_hint, int ld_hint, int split_hint, bool have_workspace);
 RtDispatch rt_dispatch(int B, int C, int H, int W, int J, int D, int rtg_hint, int np_hint, int ks_hint,
                        int ld_hint, int split_hint, bool have_workspace) {
+  // (the plan simulates the launch: once per shape and option set)
+  static std::mutex mu;
+  static std::map<std::array<int, 12>, RtDispatch> cache;
+  const std::array<int, 12> key{B, C, H, W, J, D, rtg_hint, np_hint, ks_hint, ld_hint, split_hint, (int)have_workspace};
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    const auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+  }
+  const RtDispatch d = rt_dispatch_uncached(B, C, H, W, J, D, rtg_hint, np_hint, ks_hint, ld_hint, split_hint,
+                                            have_workspace);
+  std::lock_guard<std::mutex> lock(mu);
+  if (cache.size() > 4096) cache.clear();
+  cache[key] = d;
+  return d;
+}
+static RtDispatch rt_dispatch_uncached(int B, int C, int H, int W, int J, int D, int rtg_hint, int np_hint,
+                                       int ks_hint, int ld_hint, int split_hint, bool have_workspace) {
   const RtGeom g = rt_geom(J, D);
-  RtDispatch d{kRtKernelPlain, 3, 1, 0, 0};
+  RtDispatch d{kRtKernelPlain, 3, 1, 0, 0, 0.0};
   const int n_cb = (H * W + 63) / 64;
   const long long crops8 = (long long)((B + 7) / 8) * 8;
   // ---- maps of more than 64 positions: deal the 64-position column blocks to DIFFERENT workgroups
@@ -1448,6 +1545,7 @@ RtDispatch rt_dispatch(int B, int C, int H, int W, int J, int D, int rtg_hint, i
   }
   d.rtg = rt_block_tiles(g, plan.rtg);
   d.n_wg = crops8 * (d.split ? d.split : 1) * ((g.n_tiles + d.rtg - 1) / d.rtg);
+  d.model_us = plan.us;
   // ---- four MFMA waves + a loader wave (320 threads, one workgroup per CU; same bits): the MFMA
   // waves issue no copies and no vmcnt waits.  ld_hint: 0 = the plan, 1 = never, 2 = whenever the
   // kernel can (C % 32 == 0).

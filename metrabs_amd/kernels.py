@@ -333,7 +333,7 @@ def head_fused(features, packed, C, n_points, cfg, out=None, rt_tiles=0, groups_
 def head_plan(B, C, H, W, n_points, depth, dtype=torch.float32, channels_last=False, have_workspace=True,
               **options):
     """Which kernel mtr_head_fused_ws takes for a launch (host-only; mtr_head_plan) -> dict(kernel=name,
-    tiles_per_workgroup, column_blocks, split_column_blocks, workgroups) or None when the shape has
+    tiles_per_workgroup, column_blocks, split_column_blocks, workgroups, model_us) or None when the shape has
     no fused kernel.  options: as head_fused."""
     lib = _lib.load()
     opts = _lib.HeadOptions(int(options.get('rt_tiles', 0)), int(options.get('groups_per_workgroup', 0)),
@@ -348,7 +348,8 @@ def head_plan(B, C, H, W, n_points, depth, dtype=torch.float32, channels_last=Fa
         return None
     return dict(kernel=_lib.HEAD_KERNEL_NAMES.get(info.kernel, str(info.kernel)),
                 tiles_per_workgroup=info.tiles_per_workgroup, column_blocks=info.column_blocks,
-                split_column_blocks=info.split_column_blocks, workgroups=int(info.workgroups))
+                split_column_blocks=info.split_column_blocks, workgroups=int(info.workgroups),
+                model_us=float(info.model_us))
 
 
 def postprocess_poses(poses_crop, rot, should_flip, mirror_mapping, intrinsics, distortion12,

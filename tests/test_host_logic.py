@@ -183,7 +183,7 @@ def test_bench_cli_contract_and_kernel_naming(monkeypatch):
 
 def test_head_plan_follows_the_measured_model():
     """mtr_head_plan (host-only): the launch plan of the f32 head reproduces the measured best choice of
-    the round-3 sweep (profiles/r03a_head_sweep.jsonl) on its shapes."""
+    the round-3 sweeps (profiles/r03*_head_sweep.jsonl, r03f_head_plan_check.jsonl) on their shapes."""
     from metrabs_amd import kernels
     p = kernels.head_plan(64, 1280, 8, 8, 17, 8)
     assert (p['kernel'], p['tiles_per_workgroup'], p['workgroups']) == ('head_rt_ld_kernel', 3, 256)
@@ -197,6 +197,15 @@ def test_head_plan_follows_the_measured_model():
     assert (p['kernel'], p['tiles_per_workgroup'], p['split_column_blocks']) == ('head_rt_kernel', 5, 4)
     p = kernels.head_plan(1024, 1280, 8, 8, 17, 8)
     assert (p['kernel'], p['tiles_per_workgroup'], p['split_column_blocks']) == ('head_rt_kernel', 5, 0)
+    # the launch is simulated (blocks of r, r, ..., rest tiles over the CUs' slots): 320 crops are 960 blocks
+    # of 4, 4, 2 tiles rather than 640 of 5 (1.25 rounds); a 24x24 map's 9 column blocks go to blocks of 2
+    p = kernels.head_plan(320, 1280, 8, 8, 17, 8)
+    assert (p['kernel'], p['tiles_per_workgroup'], p['workgroups']) == ('head_rt_kernel', 4, 960)
+    assert 80.0 < p['model_us'] < 120.0   # (measured: 91 - 95 us)
+    p = kernels.head_plan(16, 1280, 24, 24, 17, 8)
+    assert (p['kernel'], p['tiles_per_workgroup'], p['split_column_blocks']) == ('head_rt_kernel', 2, 9)
+    for b, tiles in ((96, 2), (128, 5), (160, 4), (192, 2), (256, 5), (512, 5), (4096, 5), (40000, 5)):
+        assert kernels.head_plan(b, 1280, 8, 8, 17, 8)['tiles_per_workgroup'] == tiles, b
     assert kernels.head_plan(64, 1280, 8, 8, 17, 72)['tiles_per_workgroup'] == 5     # a 72-bin joint = one atom
     assert kernels.head_plan(64, 1280, 8, 8, 17, 8, rt_k_groups=2, rt_loader=1)['kernel'] == 'head_rt_ks_kernel'
     assert kernels.head_plan(64, 1280, 7, 7, 17, 8) is None                          # H*W % 4 != 0: library path
