@@ -520,15 +520,26 @@ __global__ __launch_bounds__(1024) void detector_stream_kernel(DetStreamArgs a, 
 
   // ================= the 15 computing waves =================
   const int rg = wave - 1;
-  float wreg[KT];
+  // normalised column weights: in registers (2 / 12 taps) or, for the 24- and 40-tap instantiations, in LDS
+  // behind the raw taps (24 / 40 registers on top of the vertical pass and the double-precision pow spilled)
+  constexpr bool kWeightsInLds = KT > 12;
+  constexpr int kWregs = kWeightsInLds ? 1 : KT;
+  float wreg[kWregs];
+  float* wnorm = reinterpret_cast<float*>(xsize + kDTX);  // [KT][64] (sized by the host for KT > 12 only)
   {
     const float total = xtotal[c];
 #pragma unroll
     for (int j = 0; j < KT; ++j) {
       const float raw = j < xs ? wx[j][c] : 0.0f;
-      wreg[j] = (gx.aa && total != 0.0f) ? __fdiv_rn(raw, total) : raw;
+      const float wn = (gx.aa && total != 0.0f) ? __fdiv_rn(raw, total) : raw;
+      if constexpr (kWeightsInLds) {
+        if (wave == 1) wnorm[j * kDTX + c] = wn;  // (visible to the others behind the unit's first barrier)
+      } else {
+        wreg[j] = wn;
+      }
     }
   }
+#define DS_W(j) (kWeightsInLds ? wnorm[(j) * kDTX + c] : wreg[kWeightsInLds ? 0 : (j)])
   const unsigned lane4 = (unsigned)lane * 4u;
   // gamma value of byte K (0..3) of word w: LDS address = byte << 8 | 4 lane, one v_perm_b32.  The
   // table is at LDS address 0 (this kernel has no static LDS; checked once below), so the permuted
@@ -664,13 +675,13 @@ __global__ __launch_bounds__(1024) void detector_stream_kernel(DetStreamArgs a, 
             // taps past a column's own count carry weight 0: fma(v, 0, acc) = acc exactly (v finite), so
             // the taps run without a per-lane branch up to the strip's largest count (a uniform test)
 #pragma unroll
-            for (int uu = 0; uu < RU; ++uu) acc[uu] = __fmul_rn(DS_LUT(al[uu][0], 0u), wreg[0]);
+            for (int uu = 0; uu < RU; ++uu) acc[uu] = __fmul_rn(DS_LUT(al[uu][0], 0u), DS_W(0));
 #pragma unroll
             for (int j = 1; j < KT; ++j)
               if (j < kTapsSure || j < xs_max) {
 #pragma unroll
                 for (int uu = 0; uu < RU; ++uu)
-                  acc[uu] = __fmaf_rn(DS_LUT(al[uu][j >> 2], (unsigned)(j & 3)), wreg[j], acc[uu]);
+                  acc[uu] = __fmaf_rn(DS_LUT(al[uu][j >> 2], (unsigned)(j & 3)), DS_W(j), acc[uu]);
               }
           } else {
             const int j1 = min(xm + 1, gx.in_size - 1) - xm;  // 0 or 1
@@ -678,7 +689,7 @@ __global__ __launch_bounds__(1024) void detector_stream_kernel(DetStreamArgs a, 
             for (int uu = 0; uu < RU; ++uu) {
               const float v0 = DS_LUT(al[uu][0], 0u);
               const float v1 = j1 ? DS_LUT(al[uu][0], 1u) : v0;
-              acc[uu] = __fmaf_rn(v0, wreg[0], __fmul_rn(v1, wreg[1]));
+              acc[uu] = __fmaf_rn(v0, DS_W(0), __fmul_rn(v1, DS_W(1)));
             }
           }
 #pragma unroll
@@ -702,6 +713,7 @@ __global__ __launch_bounds__(1024) void detector_stream_kernel(DetStreamArgs a, 
     ds_barrier();  // D: the row table is free
   }
 #undef DS_LUT
+#undef DS_W
 }
 
 // person_detector.py:47-54.  in: [n,5] (x1, y1, x2, y2, conf) in the padded network frame;
@@ -834,7 +846,7 @@ static int launch_detector_stream(const uint8_t* images_u8, int N, int H, int W,
   if (a.seg_cap > table_rows) return kDetNoStream;
   const size_t lds = (size_t)mtr::kDSLutBytes + (size_t)mtr::kDSNbuf * mtr::kDSCopies * 1024 +
                      (size_t)a.ring * mtr::kDTX * 4 + (size_t)a.seg_cap * (KT * 4 + 16) +
-                     (size_t)(KT + 3) * mtr::kDTX * 4;
+                     (size_t)(KT + 3) * mtr::kDTX * 4 + (KT > 12 ? (size_t)KT * mtr::kDTX * 4 : 0);
   auto kern = mtr::detector_stream_kernel<KT>;
   if (lds > 160 * 1024) return kDetNoStream;
   const int rc = mtr::allow_dynamic_lds((const void*)kern, lds);
