@@ -118,7 +118,7 @@ size_t rt_workspace_bytes(int B, int J, int D, int H, int W);
 // which kernel a launch takes: kernel id (MTR_HEAD_KERNEL_* of the header), tiles per workgroup, column
 // blocks per workgroup tile (np kernel), column-block split (0 = none), workgroups of the main launch
 enum { kRtKernelPlain = 1, kRtKernelLoader = 2, kRtKernelTwoKGroups = 3, kRtKernelNp = 4, kRtKernel16 = 12 };
-struct RtDispatch { int kernel, rtg, np, split; long long n_wg; double model_us; };  // model_us: the plan's estimate (0: none)
+struct RtDispatch { int kernel, rtg, np, split; long long n_wg; double model_us; int pack; };  // model_us: the plan's estimate (0: none); pack: crops per packed last block
 RtDispatch rt_dispatch(int B, int C, int H, int W, int J, int D, int rtg_hint, int np_hint, int ks_hint,
                        int ld_hint, int split_hint, bool have_workspace);
 

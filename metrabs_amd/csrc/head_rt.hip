@@ -182,6 +182,11 @@ struct RtArgs {
   // (max, sum e, sum e x, sum e y, sum e z) over ONE column block, merged by head_rt_merge_kernel
   double* ws;
   int cb_split;
+  // cb_split launches of maps whose last column block holds 16 positions (H W % 64 == 16): the last
+  // blocks of pack_g = 4 consecutive crops share ONE workgroup -- columns 16 s .. 16 s + 15 of its tile
+  // are crop c0 + s's tail -- instead of one workgroup each with 3/4 of its columns padding (12x12
+  // maps: 2.25 instead of 3 blocks per crop).  0 = every block is one crop's.
+  int pack_g;
 };
 
 constexpr int kRtCarry = 8;  // stages (of 32 channels) summed in f32 before the sum goes into f64
@@ -370,11 +375,36 @@ __global__ __launch_bounds__(256) void head_rt_merge_kernel(RtArgs a, int n_cb) 
 // unit maximum, the f64 sums of e, e x, e y per row, the unit's sums and the hand-over to
 // rt_unit_finish.  A 16-lane group per row, NG groups; idle_wave: a wave that only keeps the barrier
 // count (the loader wave).  Shared by the f32 kernels (rt_block) and the 16-bit one (rt16_block).
+// `segs` = 4: a packed last block (RtArgs::pack_g) -- quad s of a row's 16 lanes holds the 16 positions
+// of crop + s, the butterflies stop after their two quad steps and every per-row number exists once
+// per segment ([row * 4 + s]).  The remaining steps of the 16-lane butterflies of an unpacked last
+// block only add zeros (take the maximum with -inf): the segment's numbers are those bit for bit.
+template <typename T>
+__device__ __forceinline__ T rt_seg_sum(T v, bool quads) {
+  v += dpp_move<kDppXor1>(v);
+  v += dpp_move<kDppXor2>(v);
+  if (!quads) {
+    v += dpp_move<kDppRor4>(v);
+    v += dpp_move<kDppRor8>(v);
+  }
+  return v;
+}
+__device__ __forceinline__ float rt_seg_max(float v, bool quads) {
+  v = fmaxf(v, dpp_move<kDppXor1>(v));
+  v = fmaxf(v, dpp_move<kDppXor2>(v));
+  if (!quads) {
+    v = fmaxf(v, dpp_move<kDppRor4>(v));
+    v = fmaxf(v, dpp_move<kDppRor8>(v));
+  }
+  return v;
+}
 template <int RT, int NP, int NG>
 __device__ __forceinline__ void rt_decode_blocks(const RtArgs& a, float* Ls, float* rowmax, float* unitmax,
                                                  int* info_s, double* rowsum, double* runstat, int tid,
-                                                 bool idle_wave, int HW, int crop, int t0, int cb0, int n_cb) {
+                                                 bool idle_wave, int HW, int crop, int t0, int cb0, int n_cb,
+                                                 int segs = 1) {
   constexpr int R = RT * 16, KR = (R + NG - 1) / NG, LP = NP * kRtLP;
+  const bool quads = segs == 4;
 #pragma unroll 1
    for (int np = 0; np < NP; ++np) {  // decode the group's column blocks one after the other
     const int cb = NP == 1 ? cb0 : cb0 + np;
@@ -386,7 +416,8 @@ __device__ __forceinline__ void rt_decode_blocks(const RtArgs& a, float* Ls, flo
     int tid_d = tid;
     asm volatile("" : "+v"(tid_d));
     const int grp = tid_d >> 4, l16 = tid_d & 15;
-    const int pbase = cb * 64 + l16 * 4;  // this lane's 4 positions
+    const int seg = quads ? l16 >> 2 : 0, li = quads ? l16 & 3 : l16, seg_lanes = quads ? 4 : 16;
+    const int pbase = cb * 64 + li * 4;  // this lane's 4 positions (of its segment's crop)
     v4f x[KR];
 #pragma unroll
     for (int k = 0; k < KR; ++k) {
@@ -397,8 +428,8 @@ __device__ __forceinline__ void rt_decode_blocks(const RtArgs& a, float* Ls, flo
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if (pbase + q < HW) m = fmaxf(m, x[k][q]);
-      m = group_max<16>(m);
-      if (l16 == 0) rowmax[row] = m;
+      m = rt_seg_max(m, quads);
+      if (li == 0) rowmax[row * segs + seg] = m;
     }
     __syncthreads();
 #pragma unroll
@@ -409,8 +440,8 @@ __device__ __forceinline__ void rt_decode_blocks(const RtArgs& a, float* Ls, flo
       const int kind = inf & 3, d = (inf >> 2) & 0x3fff;
       const int first = kind == 2 ? row - d : row, n = kind == 2 ? a.D : 1;
       float m = -INFINITY;
-      for (int kk = l16; kk < n; kk += 16) m = fmaxf(m, rowmax[first + kk]);
-      m = group_max<16>(m);
+      for (int kk = li; kk < n; kk += seg_lanes) m = fmaxf(m, rowmax[(first + kk) * segs + seg]);
+      m = rt_seg_max(m, quads);
       const float nm = -m * kLog2e;
       double s = 0, sx = 0, sy = 0;
 #pragma unroll
@@ -425,14 +456,15 @@ __device__ __forceinline__ void rt_decode_blocks(const RtArgs& a, float* Ls, flo
           sy += e * (double)h;
         }
       }
-      s = group_sum<16>(s);
-      sx = group_sum<16>(sx);
-      sy = group_sum<16>(sy);
-      if (l16 == 0) {
-        rowsum[row * 3 + 0] = s;
-        rowsum[row * 3 + 1] = sx;
-        rowsum[row * 3 + 2] = sy;
-        unitmax[row] = m;
+      s = rt_seg_sum(s, quads);
+      sx = rt_seg_sum(sx, quads);
+      sy = rt_seg_sum(sy, quads);
+      if (li == 0) {
+        const int o = row * segs + seg;
+        rowsum[o * 3 + 0] = s;
+        rowsum[o * 3 + 1] = sx;
+        rowsum[o * 3 + 2] = sy;
+        unitmax[o] = m;
       }
     }
     __syncthreads();
@@ -440,53 +472,72 @@ __device__ __forceinline__ void rt_decode_blocks(const RtArgs& a, float* Ls, flo
       // a unit's rows are added by the 16-lane group of its FIRST row (lane l takes rows l, l + 16,
       // ...: 5 rows per lane instead of a 72-step chain in one thread; measured 170 -> 161 us at
       // B = 64, D = 72.  Short units keep the one-thread loop below: 8 rows, and 1 - 4 % faster)
+      for (int sg = 0; sg < segs; ++sg) {  // (a packed block: once per crop)
+        if (crop + sg >= a.B) break;
   #pragma unroll
-      for (int k = 0; k < KR; ++k) {
-        const int row = k * NG + grp;
-        if ((KR * NG > R && row >= R) || idle_wave) continue;
-        const unsigned inf = (unsigned)info_s[row];
-        const int kind = inf & 3, d = (inf >> 2) & 0x3fff, j = (int)(inf >> 16);
-        if (!(kind == 1 || (kind == 2 && d == 0))) continue;  // (uniform in the group)
-        const int n = kind == 2 ? a.D : 1;
-        double S = 0, SX = 0, SY = 0, SZ = 0;
-        for (int kk = l16; kk < n; kk += 16) {
-          const double s = rowsum[(row + kk) * 3];
-          S += s;
-          SX += rowsum[(row + kk) * 3 + 1];
-          SY += rowsum[(row + kk) * 3 + 2];
-          SZ += s * (double)kk;
+        for (int k = 0; k < KR; ++k) {
+          const int row = k * NG + grp;
+          if ((KR * NG > R && row >= R) || idle_wave) continue;
+          const unsigned inf = (unsigned)info_s[row];
+          const int kind = inf & 3, d = (inf >> 2) & 0x3fff, j = (int)(inf >> 16);
+          if (!(kind == 1 || (kind == 2 && d == 0))) continue;  // (uniform in the group)
+          const int n = kind == 2 ? a.D : 1;
+          double S = 0, SX = 0, SY = 0, SZ = 0;
+          for (int kk = l16; kk < n; kk += 16) {
+            const int o = (row + kk) * segs + sg;
+            const double s = rowsum[o * 3];
+            S += s;
+            SX += rowsum[o * 3 + 1];
+            SY += rowsum[o * 3 + 2];
+            SZ += s * (double)kk;
+          }
+          if (n > 1) {
+            S = group_sum<16>(S);
+            SX = group_sum<16>(SX);
+            SY = group_sum<16>(SY);
+            SZ = group_sum<16>(SZ);
+          }
+          if (l16 != 0) continue;
+          rt_unit_finish(a, crop + sg, t0, row, kind, j, cb, n_cb, unitmax[row * segs + sg], S, SX, SY, SZ, runstat);
         }
-        if (n > 1) {
-          S = group_sum<16>(S);
-          SX = group_sum<16>(SX);
-          SY = group_sum<16>(SY);
-          SZ = group_sum<16>(SZ);
-        }
-        if (l16 != 0) continue;
-        rt_unit_finish(a, crop, t0, row, kind, j, cb, n_cb, unitmax[row], S, SX, SY, SZ, runstat);
       }
     } else {
       int tid_c = tid;
       asm volatile("" : "+v"(tid_c));
-      if (tid_c < R) {
-        const unsigned inf = (unsigned)info_s[tid_c];
+      for (int u = tid_c; u < R * segs; u += NG * 16) {  // one thread per (row, segment)
+        const int row = quads ? u >> 2 : u, sg = quads ? u & 3 : 0;
+        if (idle_wave || crop + sg >= a.B) continue;
+        const unsigned inf = (unsigned)info_s[row];
         const int kind = inf & 3, d = (inf >> 2) & 0x3fff, j = (int)(inf >> 16);
         if (kind == 1 || (kind == 2 && d == 0)) {
           const int n = kind == 2 ? a.D : 1;
           double S = 0, SX = 0, SY = 0, SZ = 0;
           for (int k = 0; k < n; ++k) {
-            const double s = rowsum[(tid_c + k) * 3];
+            const int o = (row + k) * segs + sg;
+            const double s = rowsum[o * 3];
             S += s;
-            SX += rowsum[(tid_c + k) * 3 + 1];
-            SY += rowsum[(tid_c + k) * 3 + 2];
+            SX += rowsum[o * 3 + 1];
+            SY += rowsum[o * 3 + 2];
             SZ += s * (double)k;
           }
-          rt_unit_finish(a, crop, t0, tid_c, kind, j, cb, n_cb, unitmax[tid_c], S, SX, SY, SZ, runstat);
+          rt_unit_finish(a, crop + sg, t0, row, kind, j, cb, n_cb, unitmax[row * segs + sg], S, SX, SY, SZ, runstat);
         }
       }
     }
     if (NP > 1) __syncthreads();  // (the next column block re-uses rowmax / rowsum)
    }
+}
+
+// Column `col` (0 .. 63) of a workgroup's tile: in a packed last block (RtArgs::pack_g) segment s = col /
+// (64 / pack) of it is the tail of crop + s -- the column inside that crop's block and the byte offset of
+// that crop's features from the first crop's (a crop past the batch re-reads the last one's; its
+// segment is never decoded).  pack = 0: the column itself.
+struct RtPackedCol { int col; unsigned crop_off; };
+__device__ __forceinline__ RtPackedCol rt_packed_col(const RtArgs& a, int crop, int pack, int col, int esize = 4) {
+  if (pack == 0) return RtPackedCol{col, 0u};
+  const int segw = 64 / pack, seg = col / segw;
+  const int c = min(crop + seg, a.B - 1) - crop;
+  return RtPackedCol{col - seg * segw, (unsigned)c * (unsigned)a.C * (unsigned)(a.H * a.W) * (unsigned)esize};
 }
 
 // The loader wave of head_rt_ld_kernel (see rt_block): ALL copies of every stage of one K loop, NBUF - 1
@@ -500,7 +551,8 @@ __host__ __device__ constexpr int rt_ld_la(int rtmax) { return rtmax <= 3 ? MTR_
 
 template <int RT, bool NHWC, int NBUF, int LA, int ESIZE = 4>
 __device__ __forceinline__ void rt_loader_loop(const RtArgs& a, unsigned lds0, const char* fcrop, int t0,
-                                               int cb, int n_stages, int lane, int HW) {
+                                               int cb, int n_stages, int lane, int HW, int crop = 0,
+                                               int pack = 0) {
   constexpr int STAGE = rt_stage_bytes(RT, 1, NHWC);
   constexpr int JOBS = 2 * RT + 8;
   static_assert(LA >= 1 && LA <= NBUF - 1 && JOBS * (LA - 1) <= 63, "s_waitcnt vmcnt is a 6-bit count");
@@ -520,12 +572,14 @@ __device__ __forceinline__ void rt_loader_loop(const RtArgs& a, unsigned lds0, c
       const int jb = j - 2 * RT;
       if constexpr (NHWC) {
         const int pos = jb * 8 + (lane >> 3), slot = (lane & 7) ^ ((pos >> 1) & 7);
-        const int P = cb * 64 + pos;
-        vo[j] = (unsigned)(P < HW ? P : 0) * (unsigned)a.C * (unsigned)ESIZE + slot * 16;
+        const RtPackedCol pc = rt_packed_col(a, crop, pack, pos, ESIZE);
+        const int P = cb * 64 + pc.col;
+        vo[j] = pc.crop_off + (unsigned)(P < HW ? P : 0) * (unsigned)a.C * (unsigned)ESIZE + slot * 16;
       } else {
         const int ch = jb * 4 + (lane >> 4);
-        const int p = cb * 64 + (lane & 15) * 4;
-        vo[j] = (unsigned)ch * (unsigned)HW * 4u + (unsigned)(p < HW ? p : 0) * 4u;
+        const RtPackedCol pc = rt_packed_col(a, crop, pack, (lane & 15) * 4, ESIZE);
+        const int p = cb * 64 + pc.col;
+        vo[j] = pc.crop_off + (unsigned)ch * (unsigned)HW * 4u + (unsigned)(p < HW ? p : 0) * 4u;
       }
     }
   }
@@ -587,7 +641,7 @@ __device__ __forceinline__ void rt_loader_loop(const RtArgs& a, unsigned lds0, c
 // blocks of a map are dealt to different workgroups and merged by head_rt_merge_kernel).
 template <int RT, int NP, int RTMAX, bool NHWC, int KS = 1, bool LD = false>
 __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, int t0, int cb_first = 0,
-                                         int cb_count = 1 << 30) {
+                                         int cb_count = 1 << 30, int pack = 0) {
   static_assert(!LD || (KS == 1 && NP == 1), "the loader wave serves one K group of one column block");
   constexpr int STAGE = rt_stage_bytes(RT, NP, NHWC);
   constexpr int kRtNbuf = LD ? rt_ld_nbuf(RTMAX) : (KS == 2 ? MTR_RT_KS_NBUF : rt_nbuf(RTMAX, NP, NHWC));
@@ -645,7 +699,8 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
   const int cb_end = cb_first + cb_count < n_cb ? cb_first + cb_count : n_cb;
   for (int cb0 = cb_first; cb0 < cb_end; cb0 += NP) {  // groups of NP column blocks: one K loop each
     if constexpr (LD) {
-      if (is_loader) rt_loader_loop<RT, NHWC, kRtNbuf, rt_ld_la(RTMAX)>(a, lds0, fcrop, t0, cb0, n_stages, lane, HW);
+      if (is_loader)
+        rt_loader_loop<RT, NHWC, kRtNbuf, rt_ld_la(RTMAX)>(a, lds0, fcrop, t0, cb0, n_stages, lane, HW, crop, pack);
     }
     if (!is_loader) {
     // ---- this wave's copies: job j = wid + 4 i (0 .. 2RT-1: weight tiles, then 8 feature chunks).
@@ -669,15 +724,17 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
         gbase[i] = fcrop;
         if constexpr (NHWC) {
           const int pos = jb * 8 + (lane >> 3), slot = (lane & 7) ^ ((pos >> 1) & 7);
-          const int P = (cb0 + np) * 64 + pos;
+          const RtPackedCol pc = rt_packed_col(a, crop, pack, pos);
+          const int P = (cb0 + np) * 64 + pc.col;
           gstride[i] = 128;
-          voff[i] = (unsigned)(P < HW ? P : 0) * (unsigned)a.C * 4u + slot * 16;
+          voff[i] = pc.crop_off + (unsigned)(P < HW ? P : 0) * (unsigned)a.C * 4u + slot * 16;
           ldso[i] = RT * 2048 + np * CHUNK + jb * 1024;
         } else {
           const int ch = jb * 4 + (lane >> 4);
-          const int p = (cb0 + np) * 64 + (lane & 15) * 4;
+          const RtPackedCol pc = rt_packed_col(a, crop, pack, (lane & 15) * 4);
+          const int p = (cb0 + np) * 64 + pc.col;
           gstride[i] = 32u * (unsigned)HW * 4u;
-          voff[i] = (unsigned)ch * (unsigned)HW * 4u + (unsigned)(p < HW ? p : 0) * 4u;
+          voff[i] = pc.crop_off + (unsigned)ch * (unsigned)HW * 4u + (unsigned)(p < HW ? p : 0) * 4u;
           ldso[i] = RT * 2048 + np * CHUNK + jb * kRtChunkNCHW;
         }
       }
@@ -951,8 +1008,20 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
       if (tid == 0 && cb0 + NP >= n_cb) a.c2d[(size_t)crop * a.J * 2] = Ls[0];
       continue;
     }
-    rt_decode_blocks<RT, NP, NG>(a, Ls, rowmax, unitmax, info_s, rowsum, runstat, tid, is_loader, HW, crop, t0,
-                                 cb0, n_cb);
+    if (pack == 0) {
+      rt_decode_blocks<RT, NP, NG>(a, Ls, rowmax, unitmax, info_s, rowsum, runstat, tid, is_loader, HW, crop, t0,
+                                   cb0, n_cb);
+    } else {
+      // a packed last block: per-row numbers once per crop segment -- 4x the arrays, in the ring (this
+      // workgroup's only K loop is over: nothing is copied into it any more, every wave left it
+      // before the barrier above)
+      float* rowmax4 = reinterpret_cast<float*>(smem);  // (the first K group's ring: one set for the workgroup)
+      float* unitmax4 = rowmax4 + R * 4;
+      double* rowsum4 = reinterpret_cast<double*>(unitmax4 + R * 4);
+      static_assert(R * 4 * (4 + 4 + 24) <= 2 * rt_stage_bytes(RT, NP, NHWC), "the segment statistics fit two ring slots");
+      rt_decode_blocks<RT, NP, NG>(a, Ls, rowmax4, unitmax4, info_s, rowsum4, runstat, tid, is_loader, HW, crop, t0,
+                                   cb0, n_cb, 4);
+    }
     // (the next group's copies only touch the ring, which every wave left before the barrier behind
     //  the logits store; its logits store is many barriers away)
   }
@@ -962,17 +1031,31 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
 // workgroups of a crop -- its tile blocks and, when the column blocks of a map are dealt to
 // different workgroups, those too -- share an XCD, so the crop's features come from HBM once and
 // are re-read from that XCD's L2.
-struct RtWork { int crop, blk, cb_first, cb_count; };
+struct RtWork { int crop, blk, cb_first, cb_count, pack; };
+__host__ __device__ inline int rt_wgs_per_8_crops(int n_blocks, int cb_split, int pack_g) {
+  if (pack_g) return 8 * n_blocks * (cb_split - 1) + (8 / pack_g) * n_blocks;
+  return 8 * n_blocks * (cb_split ? cb_split : 1);
+}
 __device__ __forceinline__ RtWork rt_work(const RtArgs& a) {
-  const int per_crop = a.n_blocks * (a.cb_split ? a.cb_split : 1);
-  const int chunk = 8 * per_crop;
-  const int id = blockIdx.x;
+  const int chunk = rt_wgs_per_8_crops(a.n_blocks, a.cb_split, a.pack_g);
+  const int id = blockIdx.x, in = id % chunk;
   RtWork w;
-  w.crop = (id / chunk) * 8 + (id % 8);
-  const int rest = (id % chunk) / 8;
-  w.blk = rest % a.n_blocks;
-  w.cb_first = a.cb_split ? rest / a.n_blocks : 0;
-  w.cb_count = a.cb_split ? 1 : (1 << 30);
+  w.pack = 0;
+  const int full = a.pack_g ? 8 * a.n_blocks * (a.cb_split - 1) : chunk;  // workgroups of whole column blocks
+  if (in < full) {
+    w.crop = (id / chunk) * 8 + (in % 8);
+    const int rest = in / 8;
+    w.blk = rest % a.n_blocks;
+    w.cb_first = a.cb_split ? rest / a.n_blocks : 0;
+    w.cb_count = a.cb_split ? 1 : (1 << 30);
+  } else {  // the packed last blocks of pack_g consecutive crops
+    const int t = in - full, groups = 8 / a.pack_g;
+    w.crop = (id / chunk) * 8 + (t % groups) * a.pack_g;
+    w.blk = t / groups;
+    w.cb_first = a.cb_split - 1;
+    w.cb_count = 1;
+    w.pack = a.pack_g;
+  }
   return w;
 }
 
@@ -983,12 +1066,12 @@ __global__ __launch_bounds__(256, RTMAX <= 3 ? 1 : 2) void head_rt_kernel(RtArgs
   if (w.crop >= a.B) return;
   const int t0 = w.blk * a.rtg;
   const int rt = min(a.rtg, a.n_tiles - t0);
-  if (rt == 1) rt_block<1, 1, RTMAX, NHWC>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
-  if (rt == 2) rt_block<2, 1, RTMAX, NHWC>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
-  if (rt == 3) rt_block<3, 1, RTMAX, NHWC>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
+  if (rt == 1) rt_block<1, 1, RTMAX, NHWC>(a, smem, w.crop, t0, w.cb_first, w.cb_count, w.pack);
+  if (rt == 2) rt_block<2, 1, RTMAX, NHWC>(a, smem, w.crop, t0, w.cb_first, w.cb_count, w.pack);
+  if (rt == 3) rt_block<3, 1, RTMAX, NHWC>(a, smem, w.crop, t0, w.cb_first, w.cb_count, w.pack);
   if constexpr (RTMAX >= 5) {
-    if (rt == 4) rt_block<4, 1, RTMAX, NHWC>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
-    if (rt == 5) rt_block<5, 1, RTMAX, NHWC>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
+    if (rt == 4) rt_block<4, 1, RTMAX, NHWC>(a, smem, w.crop, t0, w.cb_first, w.cb_count, w.pack);
+    if (rt == 5) rt_block<5, 1, RTMAX, NHWC>(a, smem, w.crop, t0, w.cb_first, w.cb_count, w.pack);
   }
 }
 
@@ -1000,9 +1083,9 @@ __global__ __launch_bounds__(512, 1) void head_rt_ks_kernel(RtArgs a) {
   if (w.crop >= a.B) return;
   const int t0 = w.blk * a.rtg;
   const int rt = min(a.rtg, a.n_tiles - t0);
-  if (rt == 1) rt_block<1, 1, RTMAX, NHWC, 2>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
-  if (rt == 2) rt_block<2, 1, RTMAX, NHWC, 2>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
-  if (rt == 3) rt_block<3, 1, RTMAX, NHWC, 2>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
+  if (rt == 1) rt_block<1, 1, RTMAX, NHWC, 2>(a, smem, w.crop, t0, w.cb_first, w.cb_count, w.pack);
+  if (rt == 2) rt_block<2, 1, RTMAX, NHWC, 2>(a, smem, w.crop, t0, w.cb_first, w.cb_count, w.pack);
+  if (rt == 3) rt_block<3, 1, RTMAX, NHWC, 2>(a, smem, w.crop, t0, w.cb_first, w.cb_count, w.pack);
 }
 __host__ __device__ constexpr int rt_ks_lds_bytes(int rtmax, bool nhwc) {
   return 2 * MTR_RT_KS_NBUF * rt_stage_bytes(rtmax, 1, nhwc) + rt_epilogue_bytes(rtmax, 1) +
@@ -1018,12 +1101,12 @@ __global__ __launch_bounds__(320, 1) void head_rt_ld_kernel(RtArgs a) {
   if (w.crop >= a.B) return;
   const int t0 = w.blk * a.rtg;
   const int rt = min(a.rtg, a.n_tiles - t0);
-  if (rt == 1) rt_block<1, 1, RTMAX, NHWC, 1, true>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
-  if (rt == 2) rt_block<2, 1, RTMAX, NHWC, 1, true>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
-  if (rt == 3) rt_block<3, 1, RTMAX, NHWC, 1, true>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
+  if (rt == 1) rt_block<1, 1, RTMAX, NHWC, 1, true>(a, smem, w.crop, t0, w.cb_first, w.cb_count, w.pack);
+  if (rt == 2) rt_block<2, 1, RTMAX, NHWC, 1, true>(a, smem, w.crop, t0, w.cb_first, w.cb_count, w.pack);
+  if (rt == 3) rt_block<3, 1, RTMAX, NHWC, 1, true>(a, smem, w.crop, t0, w.cb_first, w.cb_count, w.pack);
   if constexpr (RTMAX >= 5) {
-    if (rt == 4) rt_block<4, 1, RTMAX, NHWC, 1, true>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
-    if (rt == 5) rt_block<5, 1, RTMAX, NHWC, 1, true>(a, smem, w.crop, t0, w.cb_first, w.cb_count);
+    if (rt == 4) rt_block<4, 1, RTMAX, NHWC, 1, true>(a, smem, w.crop, t0, w.cb_first, w.cb_count, w.pack);
+    if (rt == 5) rt_block<5, 1, RTMAX, NHWC, 1, true>(a, smem, w.crop, t0, w.cb_first, w.cb_count, w.pack);
   }
 }
 __host__ __device__ constexpr int rt_ld_lds_bytes(int rtmax, bool nhwc) {
@@ -1052,7 +1135,7 @@ static int rt_launch_kernel(Kern kern, int lds, const RtArgs& a, hipStream_t str
     const int rc = allow_dynamic_lds((const void*)kern, (size_t)lds);
     if (rc != MTR_OK) return rc;
   }
-  const long long blocks = (long long)((a.B + 7) / 8) * 8 * a.n_blocks * (a.cb_split ? a.cb_split : 1);
+  const long long blocks = (long long)((a.B + 7) / 8) * rt_wgs_per_8_crops(a.n_blocks, a.cb_split, a.pack_g);
   if (blocks > 0x7fffffffLL) return MTR_E_SHAPE;
   MTR_CLEAR_STALE();
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads), lds, stream, a);
@@ -1353,6 +1436,7 @@ int rt16_launch(const void* feat, int feat_dtype, int layout, const void* sectio
   const bool can_split = left >= rt_workspace_bytes(B, J, D, H, W) && (H * W + 63) / 64 >= 2;
   const RtDispatch d = rt16_dispatch(B, H, W, J, D, rtg_hint, split_hint, can_split);
   a.cb_split = d.split;
+  a.pack_g = 0;
   a.ws = d.split ? (double*)ws : nullptr;
   a.rtg = d.rtg;
   a.n_blocks = (g.n_tiles + a.rtg - 1) / a.rtg;
@@ -1504,7 +1588,7 @@ RtDispatch rt_dispatch(int B, int C, int H, int W, int J, int D, int rtg_hint, i
 static RtDispatch rt_dispatch_uncached(int B, int C, int H, int W, int J, int D, int rtg_hint, int np_hint,
                                        int ks_hint, int ld_hint, int split_hint, bool have_workspace) {
   const RtGeom g = rt_geom(J, D);
-  RtDispatch d{kRtKernelPlain, 3, 1, 0, 0, 0.0};
+  RtDispatch d{kRtKernelPlain, 3, 1, 0, 0, 0.0, 0};
   const int n_cb = (H * W + 63) / 64;
   const long long crops8 = (long long)((B + 7) / 8) * 8;
   // ---- maps of more than 64 positions: deal the 64-position column blocks to DIFFERENT workgroups
@@ -1514,11 +1598,16 @@ static RtDispatch rt_dispatch_uncached(int B, int C, int H, int W, int J, int D,
   // model says it pays, 1 = never, 2 = whenever a workspace is there.
   RtPlan plan = rt_plan(crops8, g, n_cb, C, rtg_hint, ld_hint);
   if (n_cb >= 2 && have_workspace && split_hint != 1) {
-    RtPlan sp = rt_plan(crops8 * n_cb, g, 1, C, rtg_hint, ld_hint);
-    sp.us += 3.0;
+    // a last column block of 16 positions (12x12, 20x20, 28x28 maps): those of 4 consecutive crops in one workgroup
+    const int tail = (H * W) % 64;
+    const int pack = tail == 16 ? 4 : 0;
+    const long long units = pack ? crops8 * (n_cb - 1) + crops8 / pack : crops8 * n_cb;  // "crops" of 64 positions
+    RtPlan sp = rt_plan(units, g, 1, C, rtg_hint, ld_hint);
+    sp.us += 3.0;  // the merge launch
     if (split_hint == 2 || sp.us < plan.us) {
       plan = sp;
       d.split = n_cb;
+      d.pack = pack;
     }
   }
   // ---- maps of several column blocks, one-tile atoms, no split: RT x NP tiles (one K loop for NP column
@@ -1544,7 +1633,7 @@ static RtDispatch rt_dispatch_uncached(int B, int C, int H, int W, int J, int D,
     }
   }
   d.rtg = rt_block_tiles(g, plan.rtg);
-  d.n_wg = crops8 * (d.split ? d.split : 1) * ((g.n_tiles + d.rtg - 1) / d.rtg);
+  d.n_wg = crops8 / 8 * rt_wgs_per_8_crops((g.n_tiles + d.rtg - 1) / d.rtg, d.split, d.pack);
   d.model_us = plan.us;
   // ---- four MFMA waves + a loader wave (320 threads, one workgroup per CU; same bits): the MFMA
   // waves issue no copies and no vmcnt waits.  ld_hint: 0 = the plan, 1 = never, 2 = whenever the
@@ -1583,6 +1672,7 @@ int rt_launch(const float* feat, int layout, const void* section, int B, int C, 
                          workspace_bytes >= rt_workspace_bytes(B, J, D, H, W);
   const RtDispatch d = rt_dispatch(B, C, H, W, J, D, rtg_hint, np_hint, ks_hint, ld_hint, split_hint, can_split);
   a.cb_split = d.split;
+  a.pack_g = d.pack;
   a.ws = d.split ? (double*)workspace : nullptr;
   a.rtg = d.rtg;
   a.n_blocks = (g.n_tiles + a.rtg - 1) / a.rtg;

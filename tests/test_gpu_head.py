@@ -474,14 +474,20 @@ def test_two_k_groups_option(shape, hip_lib):
                                    (2, 192, 6, 16, 10, 10), (2, 64, 17, 72, 8, 8), (4, 96, 17, 8, 8, 8),
                                    (3, 576, 17, 8, 8, 8), (2, 640, 17, 8, 16, 16), (2, 1088, 5, 8, 8, 8),
                                    (33, 512, 17, 8, 12, 12), (2, 32, 17, 8, 8, 8), (2, 2048, 24, 8, 8, 8),
-                                   (9, 160, 122, 8, 12, 12), (2, 96, 17, 8, 24, 24)])
+                                   (9, 160, 122, 8, 12, 12), (2, 96, 17, 8, 24, 24),
+                                   # last column block of 16 / 32 positions: packed over 4 / 2 crops when split
+                                   (1, 128, 17, 8, 12, 12), (6, 96, 17, 8, 12, 12), (5, 96, 17, 8, 8, 12),
+                                   (3, 64, 17, 8, 20, 20), (7, 64, 5, 8, 12, 8), (13, 64, 17, 20, 12, 12)])
 def test_loader_wave_and_split_column_blocks_give_the_same_bits(shape, hip_lib):
     """mtr_head_options.rt_loader: a fifth wave issues every global_load_lds of the K loop, the four MFMA
     waves never copy or wait for a copy; rt_split_column_blocks (mtr_head_fused_ws): the 64-position
     column blocks of a larger map go to different workgroups and a second launch merges their softmax
     statistics in block order.  Neither changes an MFMA chain, a sum or the merge order -> bit-equal
     to the one-K-group, no-loader, one-workgroup-walks-its-blocks kernel for every block size, NCHW
-    and NHWC, 1 .. 64 stages, ragged last blocks, D > 16 atoms."""
+    and NHWC, 1 .. 64 stages, ragged last blocks, D > 16 atoms.  Split launches of maps whose last
+    block holds 16 or 32 positions pack those blocks of 4 / 2 consecutive crops into one workgroup
+    (decoded per crop's column segment): the same bits again, batch sizes that do not fill the last
+    group included."""
     from metrabs_amd import kernels
     B, C, J, D, H, W = shape
     cfg = cpu_ref.HeadConfig(depth=D, proc_side=max(H, W) * 8, stride_test=8, stride_train=8)

@@ -189,9 +189,14 @@ def test_head_plan_follows_the_measured_model():
     assert (p['kernel'], p['tiles_per_workgroup'], p['workgroups']) == ('head_rt_ld_kernel', 3, 256)
     p = kernels.head_plan(8, 1280, 8, 8, 17, 8)
     assert (p['kernel'], p['tiles_per_workgroup']) == ('head_rt_ld_kernel', 1)
+    # 12x12 maps = 2 blocks of 64 positions + 16: the last blocks of 4 consecutive crops share a workgroup
+    # (32 crops x 5 blocks of 2 tiles x 2.25 column blocks = 360 workgroups instead of 480)
     p = kernels.head_plan(32, 1280, 12, 12, 17, 8)
     assert (p['kernel'], p['tiles_per_workgroup'], p['split_column_blocks'], p['workgroups']) == \
-        ('head_rt_kernel', 2, 3, 480)
+        ('head_rt_kernel', 2, 3, 360)
+    p = kernels.head_plan(32, 1280, 12, 12, 122, 8)   # configs[4]'s head in f32: 69 row tiles
+    assert (p['kernel'], p['tiles_per_workgroup'], p['split_column_blocks'], p['workgroups']) == \
+        ('head_rt_kernel', 5, 3, 32 * 14 * 2 + 8 * 14)
     assert kernels.head_plan(32, 1280, 12, 12, 17, 8, have_workspace=False)['split_column_blocks'] == 0
     p = kernels.head_plan(64, 1280, 16, 16, 17, 8)
     assert (p['kernel'], p['tiles_per_workgroup'], p['split_column_blocks']) == ('head_rt_kernel', 5, 4)
