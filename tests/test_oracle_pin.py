@@ -219,7 +219,12 @@ class TestAgainstLiveReference:
                 o2d, o3d = cpu_ref.heads_from_logits(logits, J, cfg)
                 oabs = cpu_ref.reconstruct_absolute(o2d, o3d, K, cfg)
             assert torch.equal(r2d, o2d) and torch.equal(r3d, o3d)
-            assert float((rabs - oabs).abs().max()) < 2e-3
+            # both sides solve the reference point with LAPACK's fp32 lstsq, whose threaded reductions
+            # move the depth by up to 2 ulp from one call to the next (1e-3 mm at 2 - 4 m; seen once in
+            # ~20 runs of this test as 2.1e-3 max on a loaded host): the bulk is gated tightly, the
+            # maximum with that jitter in it
+            d = (rabs - oabs).abs()
+            assert float(d.max()) < 4e-3 and float(d.mean()) < 8e-4
 
     def test_batch_coupling_matches_reference(self):
         """the same crop in a different batch differs the way the
@@ -231,7 +236,8 @@ class TestAgainstLiveReference:
             one_ref = ref.ptu3d.reconstruct_absolute(c2d[:1], rel[:1], K[:1], mix_3d_inside_fov=0.5)
             full = cpu_ref.reconstruct_absolute(c2d, rel, K, cfg)
             one = cpu_ref.reconstruct_absolute(c2d[:1], rel[:1], K[:1], cfg)
-        assert float((full - full_ref).abs().max()) < 2e-3 and float((one - one_ref).abs().max()) < 2e-3
+        assert float((full - full_ref).abs().max()) < 4e-3 and float((one - one_ref).abs().max()) < 4e-3  # (lstsq jitter, see above)
+        assert float((full - full_ref).abs().mean()) < 8e-4
         assert float((full[:1] - one).abs().max()) > 1e-4  # the coupling is real
 
     def test_weak_perspective_branch(self):
