@@ -418,6 +418,31 @@ def rotating_sampler_times(pipe, est, args, wp, iters):
     return dict(pyramid=t_pyr, warp=t_warp, n_sets=n_sets)
 
 
+def detector_pre_probe(pipe, iters):
+    """K9 (row f.3 of SURVEY section 8): PersonDetector's pre-processing of the step's own frames --
+    gamma-correct antialiased resize to 416 px + pad -- which `detect_poses` runs in front of the path
+    `value` times (the detector network between them is third party).  Frames rotated over more than
+    the Infinity Cache; algorithmic bytes = the uint8 frames once + the f32 network input once."""
+    from metrabs_amd import kernels
+    n, _, h, w = pipe.images.shape
+    geom = kernels.detector_geometry(h, w)
+    n_sets = max(2, -(-ROTATE_BYTES // pipe.images.numel()))
+    g = torch.Generator(device=pipe.images.device).manual_seed(23)
+    with torch.inference_mode():
+        frames = [torch.randint(0, 256, pipe.images.shape, dtype=torch.uint8, device=pipe.images.device, generator=g)
+                  for _ in range(n_sets)]
+        out = torch.empty(n, 3, geom.out_h, geom.out_w, device=pipe.images.device)
+        t = time_rotating(lambda i: kernels.detector_preprocess(frames[i], geom=geom, out=out), n_sets, iters)
+    nbytes = pipe.images.numel() + out.numel() * 4
+    del frames
+    torch.cuda.empty_cache()
+    return dict(kernel='detector_stream_kernel / detector_pre_kernel (by launch size)', launches=1,
+                us=round(t * 1e6, 2), GBps=round(nbytes / t / 1e9, 1), frac_hbm=round(nbytes / t / HBM_PEAK, 4),
+                frames=list(pipe.images.shape),
+                note='instruction-issue-bound (one LUT lookup + fma per tap, 108 M taps per 8 x 1080p): '
+                     'DESIGN.md section 3, K9')
+
+
 def backbone_epilogue_kernels(est, crops, iters):
     """K10 (bias_act_kernel) and K11 (depthwise3x3_kernel) sit inside the PyTorch backbone of `value`
     (backbones.fold_batchnorm(fused_epilogue=True)).  One eager forward records every launch
@@ -1146,6 +1171,8 @@ def analysis(args, est, cfg, pipe, dev, step_seconds, im_h, im_w, n_box, world):
             per_kernel[k]['traffic_bytes_per_launch'] = tr['bytes']
     for k, v in small.items():
         per_kernel[k] = dict(us_per_step=round(v * 1e6, 2), bound='latency (KB of data)')
+    if not args.quick:
+        per_kernel['K9 detector_pre (in front of the step, not in the timed region)'] = detector_pre_probe(pipe, iters)
     out.update({
         'roofline': roofline,
         'head_path': {'ran': 'mtr_head_fused' if head_is_fused else 'library 1x1 conv + mtr_softargmax_decode',
