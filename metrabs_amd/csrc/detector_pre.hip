@@ -325,10 +325,10 @@ __global__ __launch_bounds__(256) void detector_pre_kernel(
 //     (a "unit") and walks DOWN the frame: every frame row is filtered horizontally exactly once,
 //     into a ring of f32 rows in LDS; an output row is finished (vertical pass, re-gamma, store) as
 //     soon as the ring holds its last tap;
-//   * wave 0 only loads: whole-wave 1 KiB global -> LDS copies (global_load_lds_dwordx4), 16 per
-//     chunk of frame rows, two chunks (32 KiB) ahead of the 15 waves that compute, across unit
-//     boundaries; its vmcnt counts nothing but those copies, so the waits are counted
-//     (vmcnt(16) = "everything but the newest chunk has landed");
+//   * wave 0 only loads: whole-wave 1 KiB global -> LDS copies (global_load_lds_dwordx4), 24 per
+//     chunk of frame rows (60 rows at 1080p: 4 per computing wave), one chunk (24 KiB) ahead of the
+//     15 waves that compute, across unit boundaries; its vmcnt counts nothing but those copies
+//     (16 KiB chunks two ahead with counted waits ran the same at 1080p and 12 % slower at 2160p);
 //   * one barrier per chunk: the horizontal pass of chunk c and the vertical pass of the rows
 //     chunks < c completed run in the same interval (ring >= 2 R + KT rows keeps them apart);
 //   * the gamma table is replicated 64x, one copy per lane ([value][64] floats, 64 KiB): every
@@ -336,8 +336,8 @@ __global__ __launch_bounds__(256) void detector_pre_kernel(
 //     4 x lane in bits 0..7) instead of extract + shift + add.
 // Same weights, same fma order, same table as the tile kernel: the two are bit-identical
 // (tests/test_gpu_detector.py).
-constexpr int kDSCopies = 16;            // wave copies per chunk: a stage buffer is 16 KiB
-constexpr int kDSLa = 2, kDSNbuf = 3;    // chunks in flight / stage buffers
+constexpr int kDSCopies = 24;            // wave copies per chunk: a stage buffer is 24 KiB
+constexpr int kDSLa = 1, kDSNbuf = 2;    // chunks in flight / stage buffers
 constexpr int kDSGroups = 15;            // computing waves = row groups
 constexpr int kDSLutBytes = 256 * 64 * 4;
 constexpr int kDSRowsMax = 60;           // frame rows per chunk (4 per computing wave)
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(1024) void detector_stream_kernel(DetStreamArgs a, 
       // ---- horizontal pass: rows rg, rg + 15, ... of the chunk, RU of them in flight per thread
       if (xs > 0 && !(MTR_DET_ABLATE & 2)) {
         constexpr int NW = (KT + 3) / 4;
-        constexpr int RU = KT <= 12 ? 3 : KT <= 24 ? 2 : 1;
+        constexpr int RU = KT <= 12 ? 4 : KT <= 24 ? 2 : 1;
         // taps every shape of this instantiation has (2 scale + 1 > the next smaller instantiation's bound
         // minus 3): no test in front of them, so they schedule as one block
         constexpr int kTapsSure = KT == 12 ? 4 : KT == 24 ? 8 : KT == kDTaps ? 20 : KT;
