@@ -517,6 +517,49 @@ def test_loader_wave_and_split_column_blocks_give_the_same_bits(shape, hip_lib):
     assert float((a3d - o3d).abs().max()) <= 2e-3 and cpu_ref.mpjpe(a3d, o3d) <= 1e-3
 
 
+def test_random_shapes_planned_launch_equals_the_plain_kernel(hip_lib):
+    """40 seeded random f32 shapes (1 .. 70 crops, 2x2 .. 28x28 maps incl. 12x12 / 20x20 / 28x28 with their
+    packed last blocks, 1 .. 40 joints, 1 .. 24 depth bins, C a multiple of 4 up to 640, both layouts): the
+    launch the plan picks with a workspace (loader wave, split column blocks, packed last blocks, any
+    block size) gives the bits of the plain one-block-at-a-time kernel, and both sit on the oracle."""
+    import random
+    from metrabs_amd import kernels
+    rng = random.Random(4242)
+    sides = [2, 4, 6, 8, 8, 8, 10, 12, 12, 12, 14, 16, 20, 20, 24, 28]
+    seen = set()
+    for it in range(40):
+        B = rng.choice([1, 2, 3, 5, 7, 8, 9, 13, 16, 31, 33, 64, 70])
+        H = rng.choice(sides)
+        W = H if rng.random() < 0.7 else rng.choice(sides)
+        if (H * W) % 4:
+            continue
+        J, D = rng.choice([1, 3, 5, 17, 24, 40]), rng.choice([1, 2, 8, 8, 8, 16, 20, 24])
+        C = 4 * rng.randint(2, 160)
+        if B * H * W * C > 40_000_000:
+            B = max(1, 40_000_000 // (H * W * C))
+        cfg = cpu_ref.HeadConfig(depth=D, proc_side=max(H, W) * 8, stride_test=8, stride_train=8)
+        g = cases.gen(99000 + it)
+        feat = torch.randn(B, C, H, W, generator=g)
+        w, b = cases.default_conv_init(J * (1 + D), C, g)
+        w, b = w * 3, b * 3
+        a2d, a3d = run_fused(feat, w, b, J, cfg, rt_k_groups=1, rt_loader=1, rt_split=1, rt_column_blocks=1,
+                             workspace=False)
+        plan = kernels.head_plan(B, C, H, W, J, D)
+        seen.add((plan['kernel'], plan['split_column_blocks'] > 0, (H * W) % 64 == 16 and plan['split_column_blocks'] > 0))
+        p2d, p3d = run_fused(feat, w, b, J, cfg)
+        assert torch.equal(p3d, a3d) and torch.equal(p2d, a2d), ((B, C, J, D, H, W), plan)
+        packed = kernels.head_pack_weights(w.cuda(), b.cuda(), J, D)
+        l2d, l3d = kernels.head_fused(feat.cuda().contiguous(memory_format=torch.channels_last), packed, C, J, mcfg(cfg))
+        assert torch.equal(l3d.cpu(), a3d) and torch.equal(l2d.cpu(), a2d), ((B, C, J, D, H, W), plan, 'nhwc')
+        if it % 4 == 0:
+            with torch.inference_mode():
+                o2d, o3d = cpu_ref.heads_forward(feat, w, b, J, cfg)
+            assert float((a3d - o3d).abs().max()) <= 2e-3 and cpu_ref.mpjpe(a3d, o3d) <= 1e-3
+    # the draw covers the loader kernel, the plain kernel, split launches and packed last blocks
+    assert {k for k, _, _ in seen} >= {'head_rt_kernel', 'head_rt_ld_kernel'}
+    assert any(split for _, split, _ in seen) and any(packed for _, _, packed in seen)
+
+
 def test_head_workspace_contract(hip_lib):
     """mtr_head_workspace_bytes: 0 for maps of <= 64 positions and for 16-bit features; a too-small or
     absent workspace silently means "no split" (same bits), a misaligned one is an error."""
