@@ -182,10 +182,10 @@ struct RtArgs {
   // (max, sum e, sum e x, sum e y, sum e z) over ONE column block, merged by head_rt_merge_kernel
   double* ws;
   int cb_split;
-  // cb_split launches of maps whose last column block holds 16 positions (H W % 64 == 16): the last
-  // blocks of pack_g = 4 consecutive crops share ONE workgroup -- columns 16 s .. 16 s + 15 of its tile
-  // are crop c0 + s's tail -- instead of one workgroup each with 3/4 of its columns padding (12x12
-  // maps: 2.25 instead of 3 blocks per crop).  0 = every block is one crop's.
+  // cb_split launches of maps whose last column block holds 16 (32) positions (H W % 64): the last
+  // blocks of pack_g = 4 (2) consecutive crops share ONE workgroup -- columns 16 s .. 16 s + 15 (32 s ..)
+  // of its tile are crop c0 + s's tail -- instead of one workgroup each with 3/4 (1/2) of its columns
+  // padding (12x12 maps: 2.25 instead of 3 blocks per crop).  0 = every block is one crop's.
   int pack_g;
 };
 
@@ -375,24 +375,30 @@ __global__ __launch_bounds__(256) void head_rt_merge_kernel(RtArgs a, int n_cb) 
 // unit maximum, the f64 sums of e, e x, e y per row, the unit's sums and the hand-over to
 // rt_unit_finish.  A 16-lane group per row, NG groups; idle_wave: a wave that only keeps the barrier
 // count (the loader wave).  Shared by the f32 kernels (rt_block) and the 16-bit one (rt16_block).
-// `segs` = 4: a packed last block (RtArgs::pack_g) -- quad s of a row's 16 lanes holds the 16 positions
-// of crop + s, the butterflies stop after their two quad steps and every per-row number exists once
+// `segs` = 4 (2): a packed last block (RtArgs::pack_g) -- quad s (half s) of a row's 16 lanes holds the 16 (32)
+// positions of crop + s, the butterflies stop after their two quad steps (+ one pairing step) and every per-row number exists once
 // per segment ([row * 4 + s]).  The remaining steps of the 16-lane butterflies of an unpacked last
 // block only add zeros (take the maximum with -inf): the segment's numbers are those bit for bit.
+// (segs = 2, a last block of 32 positions: two quads per segment, their sums paired by row_half_mirror --
+// one addition, as the two rotate steps of the unpacked block come to once the other two quads are 0.)
 template <typename T>
-__device__ __forceinline__ T rt_seg_sum(T v, bool quads) {
+__device__ __forceinline__ T rt_seg_sum(T v, int segs) {
   v += dpp_move<kDppXor1>(v);
   v += dpp_move<kDppXor2>(v);
-  if (!quads) {
+  if (segs == 2) {
+    v += dpp_move<kDppHalfMirror>(v);
+  } else if (segs == 1) {
     v += dpp_move<kDppRor4>(v);
     v += dpp_move<kDppRor8>(v);
   }
   return v;
 }
-__device__ __forceinline__ float rt_seg_max(float v, bool quads) {
+__device__ __forceinline__ float rt_seg_max(float v, int segs) {
   v = fmaxf(v, dpp_move<kDppXor1>(v));
   v = fmaxf(v, dpp_move<kDppXor2>(v));
-  if (!quads) {
+  if (segs == 2) {
+    v = fmaxf(v, dpp_move<kDppHalfMirror>(v));
+  } else if (segs == 1) {
     v = fmaxf(v, dpp_move<kDppRor4>(v));
     v = fmaxf(v, dpp_move<kDppRor8>(v));
   }
@@ -404,7 +410,6 @@ __device__ __forceinline__ void rt_decode_blocks(const RtArgs& a, float* Ls, flo
                                                  bool idle_wave, int HW, int crop, int t0, int cb0, int n_cb,
                                                  int segs = 1) {
   constexpr int R = RT * 16, KR = (R + NG - 1) / NG, LP = NP * kRtLP;
-  const bool quads = segs == 4;
 #pragma unroll 1
    for (int np = 0; np < NP; ++np) {  // decode the group's column blocks one after the other
     const int cb = NP == 1 ? cb0 : cb0 + np;
@@ -416,7 +421,8 @@ __device__ __forceinline__ void rt_decode_blocks(const RtArgs& a, float* Ls, flo
     int tid_d = tid;
     asm volatile("" : "+v"(tid_d));
     const int grp = tid_d >> 4, l16 = tid_d & 15;
-    const int seg = quads ? l16 >> 2 : 0, li = quads ? l16 & 3 : l16, seg_lanes = quads ? 4 : 16;
+    const int seg_lanes = 16 / segs;  // 16, 8 or 4 lanes of the row's group per segment
+    const int seg = l16 / seg_lanes, li = l16 - seg * seg_lanes;
     const int pbase = cb * 64 + li * 4;  // this lane's 4 positions (of its segment's crop)
     v4f x[KR];
 #pragma unroll
@@ -428,7 +434,7 @@ __device__ __forceinline__ void rt_decode_blocks(const RtArgs& a, float* Ls, flo
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if (pbase + q < HW) m = fmaxf(m, x[k][q]);
-      m = rt_seg_max(m, quads);
+      m = rt_seg_max(m, segs);
       if (li == 0) rowmax[row * segs + seg] = m;
     }
     __syncthreads();
@@ -441,7 +447,7 @@ __device__ __forceinline__ void rt_decode_blocks(const RtArgs& a, float* Ls, flo
       const int first = kind == 2 ? row - d : row, n = kind == 2 ? a.D : 1;
       float m = -INFINITY;
       for (int kk = li; kk < n; kk += seg_lanes) m = fmaxf(m, rowmax[(first + kk) * segs + seg]);
-      m = rt_seg_max(m, quads);
+      m = rt_seg_max(m, segs);
       const float nm = -m * kLog2e;
       double s = 0, sx = 0, sy = 0;
 #pragma unroll
@@ -456,9 +462,9 @@ __device__ __forceinline__ void rt_decode_blocks(const RtArgs& a, float* Ls, flo
           sy += e * (double)h;
         }
       }
-      s = rt_seg_sum(s, quads);
-      sx = rt_seg_sum(sx, quads);
-      sy = rt_seg_sum(sy, quads);
+      s = rt_seg_sum(s, segs);
+      sx = rt_seg_sum(sx, segs);
+      sy = rt_seg_sum(sy, segs);
       if (li == 0) {
         const int o = row * segs + seg;
         rowsum[o * 3 + 0] = s;
@@ -505,7 +511,7 @@ __device__ __forceinline__ void rt_decode_blocks(const RtArgs& a, float* Ls, flo
       int tid_c = tid;
       asm volatile("" : "+v"(tid_c));
       for (int u = tid_c; u < R * segs; u += NG * 16) {  // one thread per (row, segment)
-        const int row = quads ? u >> 2 : u, sg = quads ? u & 3 : 0;
+        const int row = u / segs, sg = u - row * segs;
         if (idle_wave || crop + sg >= a.B) continue;
         const unsigned inf = (unsigned)info_s[row];
         const int kind = inf & 3, d = (inf >> 2) & 0x3fff, j = (int)(inf >> 16);
@@ -1020,7 +1026,7 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
       double* rowsum4 = reinterpret_cast<double*>(unitmax4 + R * 4);
       static_assert(R * 4 * (4 + 4 + 24) <= 2 * rt_stage_bytes(RT, NP, NHWC), "the segment statistics fit two ring slots");
       rt_decode_blocks<RT, NP, NG>(a, Ls, rowmax4, unitmax4, info_s, rowsum4, runstat, tid, is_loader, HW, crop, t0,
-                                   cb0, n_cb, 4);
+                                   cb0, n_cb, pack);
     }
     // (the next group's copies only touch the ring, which every wave left before the barrier behind
     //  the logits store; its logits store is many barriers away)
@@ -1598,9 +1604,10 @@ static RtDispatch rt_dispatch_uncached(int B, int C, int H, int W, int J, int D,
   // model says it pays, 1 = never, 2 = whenever a workspace is there.
   RtPlan plan = rt_plan(crops8, g, n_cb, C, rtg_hint, ld_hint);
   if (n_cb >= 2 && have_workspace && split_hint != 1) {
-    // a last column block of 16 positions (12x12, 20x20, 28x28 maps): those of 4 consecutive crops in one workgroup
+    // a last column block of 16 (32) positions -- 12x12, 20x20, 28x28 (8x12, 16x10) maps: those of 4 (2)
+    // consecutive crops in one workgroup
     const int tail = (H * W) % 64;
-    const int pack = tail == 16 ? 4 : 0;
+    const int pack = tail == 16 ? 4 : tail == 32 ? 2 : 0;
     const long long units = pack ? crops8 * (n_cb - 1) + crops8 / pack : crops8 * n_cb;  // "crops" of 64 positions
     RtPlan sp = rt_plan(units, g, 1, C, rtg_hint, ld_hint);
     sp.us += 3.0;  // the merge launch
