@@ -1,9 +1,9 @@
 set -x
 # One round of evidence for profiles/ (run on the GPU box):
-#   gpurun -- 'bash tools/profile_round.sh r03g'
+#   gpurun -- 'bash tools/profile_round.sh r03h'
 # kernel trace of the bench command, the two PMC passes (one counter each, --kernel-trace only) that
 # profiles/traffic.json is reduced from, MFMA counters of the f32 head, micro-benchmarks, bench lines.
-TAG=${1:-r03g}
+TAG=${1:-r03h}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O
