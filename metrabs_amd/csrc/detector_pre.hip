@@ -521,21 +521,24 @@ __global__ __launch_bounds__(1024) void detector_stream_kernel(DetStreamArgs a, 
   // ================= the 15 computing waves =================
   const int rg = wave - 1;
   // normalised column weights: in registers (2 / 12 taps) or, for the 24- and 40-tap instantiations, in LDS
-  // behind the raw taps (24 / 40 registers on top of the vertical pass and the double-precision pow spilled)
+  // in place of the raw taps (24 / 40 registers on top of the vertical pass and the double-precision pow spilled)
   constexpr bool kWeightsInLds = KT > 12;
   constexpr int kWregs = kWeightsInLds ? 1 : KT;
   float wreg[kWregs];
-  float* wnorm = reinterpret_cast<float*>(xsize + kDTX);  // [KT][64] (sized by the host for KT > 12 only)
+  float* wnorm = &wx[0][0];  // [KT][64]: the raw taps, normalised in place by ONE wave (nobody else reads them any
+                             // more; visible to the others behind the unit's first barrier)
   {
     const float total = xtotal[c];
 #pragma unroll
     for (int j = 0; j < KT; ++j) {
-      const float raw = j < xs ? wx[j][c] : 0.0f;
-      const float wn = (gx.aa && total != 0.0f) ? __fdiv_rn(raw, total) : raw;
       if constexpr (kWeightsInLds) {
-        if (wave == 1) wnorm[j * kDTX + c] = wn;  // (visible to the others behind the unit's first barrier)
+        if (wave == 1) {
+          const float raw = j < xs ? wx[j][c] : 0.0f;
+          wx[j][c] = (gx.aa && total != 0.0f) ? __fdiv_rn(raw, total) : raw;
+        }
       } else {
-        wreg[j] = wn;
+        const float raw = j < xs ? wx[j][c] : 0.0f;
+        wreg[j] = (gx.aa && total != 0.0f) ? __fdiv_rn(raw, total) : raw;
       }
     }
   }
@@ -846,7 +849,7 @@ static int launch_detector_stream(const uint8_t* images_u8, int N, int H, int W,
   if (a.seg_cap > table_rows) return kDetNoStream;
   const size_t lds = (size_t)mtr::kDSLutBytes + (size_t)mtr::kDSNbuf * mtr::kDSCopies * 1024 +
                      (size_t)a.ring * mtr::kDTX * 4 + (size_t)a.seg_cap * (KT * 4 + 16) +
-                     (size_t)(KT + 3) * mtr::kDTX * 4 + (KT > 12 ? (size_t)KT * mtr::kDTX * 4 : 0);
+                     (size_t)(KT + 3) * mtr::kDTX * 4;
   auto kern = mtr::detector_stream_kernel<KT>;
   if (lds > 160 * 1024) return kDetNoStream;
   const int rc = mtr::allow_dynamic_lds((const void*)kern, lds);

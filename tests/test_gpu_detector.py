@@ -110,9 +110,14 @@ def test_stream_kernel_random_shapes(hip_lib):
         except RuntimeError:
             continue  # (beyond the 19x shrink limit)
         if img.numel() % 16 == 0:
-            stream, _ = kernels.detector_preprocess(img, kernel='stream')
-            assert torch.equal(tile, stream), (n, h, w, float((tile - stream).abs().max()))
-            n_stream += 1
+            try:
+                stream, _ = kernels.detector_preprocess(img, kernel='stream')
+            except RuntimeError:
+                stream = None  # (its LDS does not fit this shape: `auto` takes the tile kernel)
+                assert torch.equal(kernels.detector_preprocess(img)[0], tile)
+            if stream is not None:
+                assert torch.equal(tile, stream), (n, h, w, float((tile - stream).abs().max()))
+                n_stream += 1
         if it % 5 == 0:
             with torch.inference_mode():
                 ref, _ = cpu_ref.detector_preprocess(img.cpu())
