@@ -82,6 +82,13 @@ def parse_args():
                          '(one graph launch per step); falls back to the eager gather behind the replay -- and says '
                          'so in the line -- if the capture fails.  Off by default: it cannot be validated on a '
                          '1-GPU box')
+    ap.add_argument('--force-collective', action='store_true',
+                    help='--gpus 1: make a ONE-rank "nccl" (= RCCL) process group anyway and run the path\'s '
+                         'all-gather of the poses in every step on device tensors (eager behind the replay, or '
+                         'inside the graph with --graph-gather): RCCL load, communicator and the collective itself '
+                         'exercised on a 1-GPU box; the line carries `multi_gpu` with backend "nccl"')
+    ap.add_argument('--no-api-path', action='store_true',
+                    help='skip the `api_path` probe (crops/s through Pose3dEstimator.estimate_poses_batched)')
     ap.add_argument('--quick', action='store_true',
                     help='print the contract line only: no per-kernel timing, roofline probes, parity probe, '
                          'backbone variants or CPU baseline (those fields are null)')
@@ -798,8 +805,16 @@ def main():
                          f'{torch.cuda.device_count()} GPU(s)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    force = bool(args.force_collective) and world_env == 1
+    if force:
+        import socket
+        with socket.socket() as sock:
+            sock.bind(('127.0.0.1', 0))
+            os.environ.setdefault('MASTER_PORT', str(sock.getsockname()[1]))
     rank, world, _ = distributed.init_from_env(
-        backend=os.environ.get('MTR_BENCH_BACKEND') or ('gloo' if shared_device and world_env > 1 else None))
+        backend=os.environ.get('MTR_BENCH_BACKEND') or ('gloo' if shared_device and world_env > 1 else None),
+        force_group=force)
+    collective = world > 1 or force   # the step ends in the all-gather of the poses
     from metrabs_amd import _lib
     from metrabs_amd.pipeline import GraphedCropPipeline
     _lib.load()
@@ -824,10 +839,10 @@ def main():
         max_batches = len(distributed.shard_internal_batches(total_boxes, n_box, 0, world))
     else:
         my_batches = max_batches = 1
-    gathered = torch.empty(world * max_batches * n_box, J, 3, device=dev) if world > 1 else None
+    gathered = torch.empty(world * max_batches * n_box, J, 3, device=dev) if collective else None
     shard_out = torch.zeros(max_batches * n_box, J, 3, device=dev) if strong else None
 
-    use_base_gather = world > 1 and torch.distributed.get_backend() == 'nccl'
+    use_base_gather = collective and torch.distributed.get_backend() == 'nccl'
     gather_mode = 'eager all_gather_into_tensor after the graph replay (outside the HIP graph)'
     graph_gather = False
     if args.graph_gather and use_base_gather and not strong and not args.no_graph:
@@ -849,7 +864,7 @@ def main():
             poses = shard_out
         else:
             poses = pipe.run()
-        if world > 1 and not graph_gather:
+        if collective and not graph_gather:
             # the single collective of the path: KB-sized all-gather of the poses over RCCL/xGMI
             if use_base_gather:
                 torch.distributed.all_gather_into_tensor(gathered, poses.contiguous())
@@ -864,19 +879,19 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if collective:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if collective:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     multi = None
-    if world > 1:
+    if collective:
         # every rank's own time for the K steps (one line must be enough to diagnose a flat curve),
         # then the max over ranks = the job's time; the gather alone, timed on its own afterwards
         mine = torch.tensor([elapsed], dtype=torch.float64, device=dev if use_base_gather else 'cpu')
@@ -901,14 +916,20 @@ def main():
         multi = dict(per_rank_ms_per_step=[round(t / args.steps * 1e3, 4) for t in per_rank],
                      gather_us_per_step_alone=round(gather_us, 1),
                      gather_bytes_per_rank=int(poses_now.numel() * 4),
-                     backend=torch.distributed.get_backend(),
+                     backend=torch.distributed.get_backend(), world_size=world,
+                     gathered_equals_poses=bool(torch.equal(
+                         gathered.reshape(world, -1, J, 3)[rank][:poses_now.shape[0]], poses_now)) if use_base_gather
+                     else None,
                      devices='all ranks on cuda:0 (MTR_BENCH_SHARED_DEVICE=1: code-path test, not a '
-                             'scaling measurement)' if shared_device else 'one GPU per rank',
+                             'scaling measurement)' if shared_device else (
+                         'ONE rank (--force-collective: RCCL exercised on a 1-GPU box, not a scaling measurement)'
+                         if force else 'one GPU per rank'),
                      gather=gather_mode)
 
     if rank != 0:
         if world > 1:
             torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
         return
 
     crops_per_step = args.total_crops if strong else world * n_box * args.num_aug
@@ -956,8 +977,9 @@ def main():
         out.update(analysis(args, est, cfg, pipe, dev, elapsed / args.steps, im_h, im_w, n_box, world))
     print(json.dumps(out))
     sys.stdout.flush()
-    if world > 1:
+    if collective:
         torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 def pcie_variants(pipe, args, n_box):
@@ -1005,6 +1027,83 @@ def pcie_variants(pipe, args, n_box):
             'overlapped': {'ms_per_step': pcie_ovl_ms, 'crops_per_s_per_gpu': crops / (pcie_ovl_ms * 1e-3),
                            'note': 'the copy of step i+1 runs on its own HIP stream under '
                                    'the compute of step i (two staging buffers in HBM)'}}
+
+
+def api_path_probe(est, args, im_h, im_w, n_box, value):
+    """crops/s through ``Pose3dEstimator.estimate_poses_batched`` -- the drop-in surface itself
+    (multiperson_model.py:62-74,184-225 of the reference), not the bench's fixed-shape pipeline object:
+    every call builds its cameras and per-box parameters on the host from FRESH host arrays (boxes,
+    intrinsics), uploads them, copies the call's frames into the sampler's buffer, builds the pyramid and
+    runs the internal batch -- eagerly (graph_batches=False) or through the estimator's shape-bucketed
+    HIP-graph cache (graph_cache.py).  Frames: device-resident uint8 tensors as the reference's own demo
+    feeds them (scripts/demo_image.py:34), six different sets in rotation (300 MB, more than the 256 MB
+    Infinity Cache), and pinned host tensors.  `full`: 8 boxes on each of the 8 frames = the step of
+    `value`; `ragged`: 1 - 8 boxes per frame, every call another count (a graph per distinct batch size,
+    all captured before the timed calls)."""
+    frames = args.frames
+    per = max(n_box // frames, 1)
+    g = torch.Generator().manual_seed(7)
+    rng = np.random.default_rng(7)
+    dev_sets = [torch.randint(0, 256, (frames, 3, im_h, im_w), dtype=torch.uint8, generator=g).cuda()
+                for _ in range(6)]
+    host_sets = [d.cpu().pin_memory() for d in dev_sets[:2]]
+    f = max(im_h, im_w) / (np.tan(np.deg2rad(55.0) / 2) * 2)
+    K0 = np.array([[f, 0, im_w / 2], [0, f, im_h / 2], [0, 0, 1]], np.float32)
+
+    def fresh_call(counts):
+        boxes = []
+        for n in counts:
+            bw = 60 + 340 * rng.random(n)
+            bh = 150 + 750 * rng.random(n)
+            bx = rng.random(n) * (im_w - bw)
+            by = rng.random(n) * np.maximum(im_h - bh, 1.0)
+            boxes.append(np.stack([bx, by, bw, bh], axis=1).astype(np.float32))
+        K = np.repeat(K0[None], frames, axis=0) * (1 + 0.01 * rng.standard_normal((frames, 1, 1)).astype(np.float32))
+        K[:, 2, 2] = 1.0
+        return boxes, K
+
+    def timed(mode, image_sets, calls, rounds):
+        est.graph_batches = mode
+        est.graphs.max_graphs = 80
+        inputs = [fresh_call(c) for c in calls]
+        kw = dict(internal_batch_size=n_box * args.num_aug, num_aug=args.num_aug)
+        for _ in range(2):  # every batch size seen (and, graphed, captured) before the timed calls
+            for i, (boxes, K) in enumerate(inputs):
+                est.estimate_poses_batched(image_sets[i % len(image_sets)], boxes, intrinsic_matrix=K, **kw)
+        torch.cuda.synchronize()
+        n_crops, t0 = 0, time.perf_counter()
+        for r in range(rounds):
+            for i, c in enumerate(calls):
+                boxes, K = fresh_call(c)   # (host arrays made inside the timed region: part of a call's cost)
+                res = est.estimate_poses_batched(image_sets[(r + i) % len(image_sets)], boxes, intrinsic_matrix=K, **kw)
+                n_crops += sum(c) * args.num_aug
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert all(torch.isfinite(p).all() for p in res['poses3d'])
+        return dict(crops_per_s=round(n_crops / dt, 1), ms_per_call=round(dt / (rounds * len(calls)) * 1e3, 3),
+                    calls=rounds * len(calls), crops_per_call=round(n_crops / (rounds * len(calls)), 1))
+
+    full = [[per] * frames] * 6
+    ragged = [list(rng.integers(1, per + 1, frames)) for _ in range(16)]
+    rounds = max(2, args.steps // 10)
+    before = (est.graph_batches, est.graphs.max_graphs)
+    out = {}
+    try:
+        with torch.inference_mode():
+            out['full'] = dict(eager=timed(False, dev_sets, full, rounds), graphed=timed(True, dev_sets, full, rounds),
+                               graphed_frames_from_pinned_host=timed(True, host_sets, full, rounds))
+            out['ragged_1_to_%d_boxes_per_frame' % per] = dict(eager=timed(False, dev_sets, ragged, 2),
+                                                               graphed=timed(True, dev_sets, ragged, 2))
+            out['graph_cache'] = dict(est.graphs.stats, graphs=len(est.graphs.graphs))
+    finally:
+        est.graph_batches, est.graphs.max_graphs = before
+        est.graphs.clear()
+        torch.cuda.empty_cache()
+    out['graphed_over_value'] = round(out['full']['graphed']['crops_per_s'] / value, 4)
+    out['note'] = ('Pose3dEstimator.estimate_poses_batched(images, boxes, intrinsic_matrix=...) called back to back with '
+                   'fresh host boxes / cameras per call; `value` is the same internal batch as a bare graph replay on '
+                   'static inputs')
+    return out
 
 
 def live_pmc_traffic(args, n_crops, J, D, C, timeout=240):
@@ -1193,6 +1292,8 @@ def analysis(args, est, cfg, pipe, dev, step_seconds, im_h, im_w, n_box, world):
         out['decode_roofline']['traffic'] = (tjson.get('decode_nchw_kernel') or {}).get('bytes')
         out['decode_roofline']['traffic_source'] = traffic_source
     out['parity'] = parity_probe(est, extras, cfg, args)
+    if world == 1 and not args.no_api_path and not args.strong:
+        out['api_path'] = api_path_probe(est, args, im_h, im_w, n_box, n_box * args.num_aug / step_seconds)
     if world == 1 and args.depth != 72 and not args.no_depth72 and args.config == 1:
         out['depth72'] = depth72_variant(args, dev, im_h, im_w, n_box)
         if not args.no_fold_bn:

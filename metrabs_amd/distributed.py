@@ -18,17 +18,21 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, force_group=False):
     """Initialises torch.distributed from RANK / WORLD_SIZE / MASTER_* (as torchrun sets them).
-    Returns (rank, world_size, local_rank).  World size 1 needs no process group."""
+    Returns (rank, world_size, local_rank).  World size 1 needs no process group (force_group: make
+    one anyway -- a one-rank RCCL communicator on a 1-GPU box)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', str(rank)))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_group) and not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
+        # dmabuf IPC: what RCCL's intra-node transport needs on this driver stack (the legacy IPC
+        # path fails with hipIpcGetMemHandle: invalid argument)
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
 
@@ -71,14 +75,16 @@ def _collective_device(t):
     return 'cpu' if (t.is_cuda and dist.get_backend() == 'gloo') else t.device
 
 
-def gather_ranges(local, ranges_by_rank, n_boxes, group=None):
+def gather_ranges(local, ranges_by_rank, n_boxes, group=None, always=False):
     """One all-gather of the per-rank results, then un-shuffling into global box order.
 
     local: [n_local, ...] results of THIS rank's ranges, concatenated in order;
     ranges_by_rank: for every rank its list of (start, stop) box ranges (host-side knowledge, the
-    same on all ranks).  Every rank returns the full [n_boxes, ...] tensor."""
+    same on all ranks).  Every rank returns the full [n_boxes, ...] tensor.
+    always: run the collective even in a group of ONE rank (how the RCCL path -- library load,
+    communicator, the all-gather itself -- is exercised on a 1-GPU box, tests/test_gpu_rccl.py)."""
     world_size = len(ranges_by_rank)
-    if world_size == 1:
+    if world_size == 1 and not (always and dist.is_initialized()):
         return local
     cap = max(sum(b - a for a, b in rr) for rr in ranges_by_rank)  # equal-sized padded shards
     tail = tuple(local.shape[1:])
@@ -115,9 +121,10 @@ def exact_mode_needs_allreduce(crop_model):
                 and not getattr(cfg, 'weak_perspective', False))
 
 
-def allreduce_moments(moments, group=None):
-    """exact-monolithic mode: sum the (sum2d, sumrb, count) f64 triple over ranks."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+def allreduce_moments(moments, group=None, always=False):
+    """exact-monolithic mode: sum the (sum2d, sumrb, count) f64 triple over ranks (always: also in a
+    group of one rank, see gather_ranges)."""
+    if dist.is_initialized() and (dist.get_world_size(group) > 1 or always):
         dev = _collective_device(moments)
         if dev == 'cpu':
             host = moments.cpu()

@@ -1,0 +1,173 @@
+"""HIP graphs behind Pose3dEstimator's API: shape-bucketed capture of whole internal batches.
+
+At the reference's default internal batch (64 crops, multiperson_model.py:189-220) one batch is ~10
+launches of ours + ~400 of the backbone: the eager path is bound by the host issuing them, not by the
+GPU.  A captured batch is ONE graph launch.  What is captured is exactly the call sequence the eager
+path runs (``Pose3dEstimator._batch_with_postprocess``: crop geometry -> sampler -> crop model -> K7)
+on exactly the same shapes, so a replay returns the eager path's bits.
+
+* ``FrameSet`` -- static uint8 frames + their pyramid for one (n_frames, H, W): the fixed addresses a
+  graph's sampler reads.  A call copies its frames in (host frames: the H2D copy lands there
+  directly) and rebuilds the pyramid with one eager launch.
+* ``BatchGraph`` -- one internal batch of n boxes captured against a FrameSet; static copies of the six
+  per-box parameter arrays, one ``hipGraphLaunch`` per replay, the result cloned out.
+* ``GraphCache`` -- the estimator's cache: key = (frames shape, n boxes, num_aug, antialias factor,
+  crop dtype / layout, average_aug, skeleton, joint transform); a key is captured on its 2nd occurrence
+  ('auto') or its first (True); LRU-bounded; ragged tails and one-off shapes stay eager.
+
+Everything is ordered on the caller's current stream; one estimator serves one stream at a time.
+Weights are read at capture: after changing them call ``estimator.graphs.clear()``.
+"""
+import collections
+import warnings
+
+import torch
+
+from metrabs_amd import kernels
+
+
+class FrameSet:
+    def __init__(self, n, h, w, device):
+        self.key = (n, h, w, str(device))
+        self.images = torch.empty(n, 3, h, w, dtype=torch.uint8, device=device)
+        _, l1, l2 = kernels._alloc_levels(n, h, w, device, with_level0=False)
+        lut = torch.empty(256, device=device, dtype=torch.float32)
+        self.pyramid = kernels.Pyramid([None, l1, l2], images_u8=self.images, lut=lut)
+
+    def load(self, images):
+        """frames (host or device, uint8 [n,3,H,W]) -> the static pyramid (stream-ordered)."""
+        if images.dtype != torch.uint8:
+            raise ValueError('images must be uint8 [N,3,H,W]')
+        self.images.copy_(images, non_blocking=True)
+        return kernels.build_pyramid(self.images, out=self.pyramid)
+
+
+class BatchGraph:
+    """One internal batch captured in a HIP graph.  ``replay(batch_args)`` -> [n, (A,) S, 5]."""
+
+    def __init__(self, est, frames, batch_args, tta, antialias_factor, post, warmup=2):
+        self.frames = frames
+        self.static = [torch.empty_like(a, memory_format=torch.contiguous_format) for a in batch_args]
+        self._load(batch_args)
+        body = lambda: est._batch_with_postprocess(frames.pyramid, *self.static, tta, antialias_factor, post)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):  # lazy initialisation (MIOpen's solver search, weight packing)
+                body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = body()
+        self.replays = 0
+
+    def _load(self, batch_args):
+        for dst, src in zip(self.static, batch_args):
+            dst.copy_(src, non_blocking=True)
+
+    def replay(self, batch_args):
+        self._load(batch_args)
+        self.graph.replay()
+        self.replays += 1
+        return self.out.clone()
+
+
+class _CallPlan:
+    """What GraphCache.plan_call hands to _predict_in_batches for ONE call: the frame set and, per
+    internal batch, whether it replays / captures a graph or runs eagerly."""
+
+    def __init__(self, cache, frames, keys, use, tta, antialias_factor, post):
+        self.cache, self.frames, self.keys, self.use = cache, frames, keys, use
+        self.tta, self.aa, self.post = tta, antialias_factor, post
+
+    def graph_for(self, i_range, batch_args):
+        if not self.use[i_range]:
+            self.cache.stats['eager_batches'] += 1
+            return None
+        return self.cache._get_or_capture(self.keys[i_range], self.frames, batch_args, self.tta, self.aa,
+                                          self.post)
+
+
+class GraphCache:
+    def __init__(self, estimator, max_graphs=16, max_frame_sets=2):
+        self.est = estimator
+        self.max_graphs = max_graphs
+        self.max_frame_sets = max_frame_sets
+        self.graphs = collections.OrderedDict()
+        self.frame_sets = collections.OrderedDict()
+        self.seen = collections.Counter()
+        self.failed = set()
+        self.stats = dict(captures=0, replays=0, eager_batches=0, evictions=0)
+
+    def clear(self):
+        self.graphs.clear()
+        self.frame_sets.clear()
+        self.seen.clear()
+        self.failed.clear()
+
+    def _threshold(self):
+        mode = self.est.graph_batches
+        return 1 if mode is True else 2
+
+    def plan_call(self, images, ranges, tta, antialias_factor, post):
+        """-> _CallPlan when at least one internal batch of this call has, or is now due, a graph; else
+        None (the call runs as before: no frame copy, no static buffers)."""
+        if torch.cuda.is_current_stream_capturing():
+            return None  # (the caller is capturing the whole call itself)
+        est = self.est
+        dev = est._device()
+        n, _, h, w = images.shape
+        fkey = (n, h, w, str(dev))
+        jt = post['joint_transform']
+        base = (fkey, len(tta['gammas']), int(antialias_factor), est.crop_dtype, bool(est.crop_channels_last),
+                bool(post['average_aug']), post['skeleton'].data_ptr(), None if jt is None else jt.data_ptr(),
+                int(est.crop_model.input_resolution))
+        keys = [base + (stop - start,) for start, stop in ranges]
+        threshold = self._threshold()
+        use = []
+        for k, (start, stop) in zip(keys, ranges):
+            if stop == start or k in self.failed:
+                use.append(False)
+                continue
+            self.seen[k] += 1
+            use.append(k in self.graphs or self.seen[k] >= threshold)
+        if len(self.seen) > 4096:
+            self.seen.clear()
+        if not any(use):
+            self.stats['eager_batches'] += len(use)
+            return None
+        frames = self.frame_sets.get(fkey)
+        if frames is None:
+            frames = FrameSet(n, h, w, dev)
+            self.frame_sets[fkey] = frames
+            while len(self.frame_sets) > self.max_frame_sets:
+                old_key, _ = self.frame_sets.popitem(last=False)
+                for k in [k for k in self.graphs if k[0] == old_key]:  # they read the evicted buffers
+                    del self.graphs[k]
+                    self.stats['evictions'] += 1
+        else:
+            self.frame_sets.move_to_end(fkey)
+        return _CallPlan(self, frames, keys, use, tta, antialias_factor, post)
+
+    def _get_or_capture(self, key, frames, batch_args, tta, antialias_factor, post):
+        g = self.graphs.get(key)
+        if g is not None and g.frames is frames:
+            self.graphs.move_to_end(key)
+            self.stats['replays'] += 1
+            return g
+        try:
+            g = BatchGraph(self.est, frames, batch_args, tta, antialias_factor, post)
+        except Exception as e:  # noqa: BLE001 -- whatever a capture can raise: this shape stays eager
+            self.failed.add(key)
+            warnings.warn(f'metrabs_amd: HIP graph capture of an internal batch failed ({str(e)[:200]}); '
+                          f'this shape keeps running eagerly')
+            torch.cuda.synchronize()
+            self.stats['eager_batches'] += 1
+            return None
+        self.graphs[key] = g
+        self.stats['captures'] += 1
+        while len(self.graphs) > self.max_graphs:
+            self.graphs.popitem(last=False)
+            self.stats['evictions'] += 1
+        return g

@@ -128,9 +128,11 @@ def _alloc_levels(n, h, w, device, with_level0=True):
 MAX_U8_FRAME_BYTES = (1 << 31) - 8
 
 
-def build_pyramid(images_u8, materialize_level0=False):
+def build_pyramid(images_u8, materialize_level0=False, out=None):
     """uint8 [N,3,H,W] -> Pyramid: fused gamma decode (u8/255)**2.2 + two 2x2 box levels.  By
-    default level 0 is NOT written as f32 (the sampler reads the uint8 frame through the LUT)."""
+    default level 0 is NOT written as f32 (the sampler reads the uint8 frame through the LUT).
+    out: a Pyramid made by this function over the SAME frame tensor: its levels and LUT are rewritten
+    in place (fixed addresses for captured HIP graphs)."""
     require_cuda(images_u8)
     if images_u8.dtype != torch.uint8 or images_u8.ndim != 4 or images_u8.shape[1] != 3:
         raise ValueError('images must be uint8 [N,3,H,W]')
@@ -143,6 +145,13 @@ def build_pyramid(images_u8, materialize_level0=False):
         check(lib.mtr_build_pyramid(_ptr(images_u8), n, h, w, _ptr(l0), _ptr(l1), _ptr(l2), stream),
               'mtr_build_pyramid')
         return Pyramid([l0, l1, l2])
+    if out is not None:
+        if out.images_u8 is None or out.images_u8.data_ptr() != images_u8.data_ptr() or \
+                (out.n, out.h, out.w) != (n, h, w):
+            raise ValueError('build_pyramid(out=): the pyramid was not built over this frame tensor')
+        check(lib.mtr_build_pyramid_u8(_ptr(images_u8), n, h, w, _ptr(out.lut), _ptr(out.levels[1]),
+                                       _ptr(out.levels[2]), stream), 'mtr_build_pyramid_u8')
+        return out
     _, l1, l2 = _alloc_levels(n, h, w, images_u8.device, with_level0=False)
     lut = torch.empty(256, device=images_u8.device, dtype=torch.float32)
     check(lib.mtr_build_pyramid_u8(_ptr(images_u8), n, h, w, _ptr(lut), _ptr(l1), _ptr(l2), stream),
@@ -261,6 +270,24 @@ def head_fused_supported(C, J, D, H, W, channels_last=False, dtype=torch.float32
     if H * W <= 256 and (1 + D) <= 64 and C % 8 == 0:
         return True
     return C % 64 == 0 and D <= 80
+
+
+def head_auto_choice(C, J, D, H, W, channels_last=False, dtype=torch.float32):
+    """MetrabsHeads(fused='auto'): True = the fused kernel, False = library 1x1 conv + mtr_softargmax_decode.
+    A static table over (dtype, layout, C, H, W, J, D) read off the committed sweeps
+    (profiles/*_fused_vs_library.txt, *_head_sweep.jsonl) -- the batch size is deliberately NOT an input:
+    a slice of a sharded batch, another rank and another process all take the path of the whole batch.
+    The fused kernels are ahead on every shipped configuration (8x8 / 12x12 maps, 8 depth bins, 17 - 122
+    joints, f32 / f16 / bf16); the library pair is kept for
+      * 16-bit features on maps of more than 256 positions (the 16-bit row-tile kernel there is behind
+        rocBLAS: 20x20 bf16 65 vs 39 us, 24x24 f16 37 vs 32 us),
+      * f32 features on maps of >= 576 positions (24x24: 56 vs 50 us)."""
+    if not head_fused_supported(C, J, D, H, W, channels_last, dtype):
+        return False
+    hw = H * W
+    if dtype == torch.float32:
+        return hw < 576
+    return hw <= 256
 
 
 def _is_channels_last(t):

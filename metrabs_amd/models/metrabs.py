@@ -26,10 +26,12 @@ class MetrabsHeads(torch.nn.Module):
         else:
             self.conv_final = torch.nn.Conv2d(in_channels, sum(self.n_outs), kernel_size=1)
         # True: hand-written GEMM + decode in one kernel.  False: library 1x1 conv + the HIP decode
-        # kernel on the materialised logits.  'auto' (Metrabs' default): time both once per (shape,
-        # dtype, layout) on the first eager call and keep the faster -- the fused kernel wins on every
-        # shipped configuration, the library pair on a few others (f32: 72 depth
-        # bins, 122 joints on 12x12 maps, 24x24 maps at B = 16); `last_path` says which one ran.
+        # kernel on the materialised logits.  'auto' (Metrabs' default): a STATIC rule on (dtype,
+        # layout, C, H, W, J, D) -- never on the batch size, never on a clock (kernels.head_auto_choice):
+        # the same deployment runs the same kernel, and therefore gives the same bits, in every
+        # process, on every rank and for every slice of a sharded batch.  'time': the round-3
+        # behaviour, an explicit opt-in -- time both once per shape on the first eager call and keep
+        # the faster (the result can differ from run to run on near ties).  `last_path` says which ran.
         self.fused = fused
         self._auto_choice = {}
         self.last_path = None
@@ -58,7 +60,11 @@ class MetrabsHeads(torch.nn.Module):
         use_fused = bool(self.fused) and kernels.head_fused_supported(
             c_in, self.n_points, self.config.depth, h, w, kernels._is_channels_last(inp), inp.dtype)
         if use_fused and self.fused == 'auto':
-            use_fused = self._auto_pick(inp)
+            use_fused = kernels.head_auto_choice(c_in, self.n_points, self.config.depth, h, w,
+                                                 kernels._is_channels_last(inp), inp.dtype)
+            self._auto_choice[(tuple(inp.shape[1:]), inp.dtype, kernels._is_channels_last(inp))] = use_fused
+        elif use_fused and self.fused == 'time':
+            use_fused = self._timed_pick(inp)
         self.last_path = 'fused' if use_fused else 'library'  # (bench.py reports which one ran)
         if use_fused:
             return self._forward_fused(inp)
@@ -68,7 +74,7 @@ class MetrabsHeads(torch.nn.Module):
         return kernels.head_fused(inp, self._packed_weights(inp.dtype), inp.shape[1], self.n_points,
                                   self.config)
 
-    def _auto_pick(self, inp):
+    def _timed_pick(self, inp):
         key = (tuple(inp.shape), inp.dtype, kernels._is_channels_last(inp))
         if key not in self._auto_choice:
             if torch.cuda.is_current_stream_capturing():

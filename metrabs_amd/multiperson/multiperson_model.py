@@ -15,7 +15,7 @@ Differences to the reference, all documented in DESIGN.md:
 import numpy as np
 import torch
 
-from metrabs_amd import distributed, kernels, pipeline
+from metrabs_amd import distributed, graph_cache, kernels, pipeline
 from metrabs_amd.joint_info import JointInfo
 from metrabs_amd.multiperson import warping
 
@@ -115,6 +115,7 @@ class Pose3dEstimator(torch.nn.Module):
         self.crop_dtype = torch.float32
         self.crop_channels_last = False
         self.shard_across_ranks = False
+        self.force_collective = False   # run the final all-gather even in a process group of one rank
         # K7: one HIP launch for everything after the crop model (False = the torch-op sequence)
         self.fused_postprocess = True
         # Mean bone lengths (mm, one per joint_info.stick_figure_edges entry) switch on the
@@ -125,6 +126,15 @@ class Pose3dEstimator(torch.nn.Module):
         self.mean_bone_lengths = None
         self.filter_unbiased_variance = False  # True: torch.var's default, as the PyTorch port
         self.filter_order = 'index'            # 'score': tf.image.non_max_suppression_overlaps order
+        # HIP graphs behind the API: an internal batch (geometry -> sampler -> crop model -> K7) of a
+        # shape that keeps coming back is captured once and replayed -- at 64 crops the eager path is
+        # launch-bound (~10 launches of ours + ~400 of the backbone per batch).  'auto': a shape is
+        # captured on its 2nd occurrence; True: on its first; False: never.  A replay gives the eager
+        # path's bits (tests/test_gpu_api_graphs.py).  See metrabs_amd/graph_cache.py.
+        self.graph_batches = 'auto'
+        self.graphs = graph_cache.GraphCache(self)
+        self._slabs = []            # two pinned staging buffers of the per-box parameters (one H2D copy
+        self._slab_turn = 0         # per call; the host may run two calls ahead of the GPU)
 
     # ------------------------------------------------------------------ public API (reference names)
 
@@ -226,6 +236,7 @@ class Pose3dEstimator(torch.nn.Module):
             self._tta_cache[key]['mirror_i64'] = self._tta_cache[key]['mirror_i32'].long()
         return self._tta_cache[key]
 
+    @torch.no_grad()
     def _estimate_poses_batched(
             self, images, boxes, intrinsic_matrix, distortion_coeffs, extrinsic_matrix,
             world_up_vector, default_fov_degrees, internal_batch_size, antialias_factor, num_aug,
@@ -239,37 +250,40 @@ class Pose3dEstimator(torch.nn.Module):
             # the reference shrinks only for 2, 4 and > 4 (multiperson_model.py:307-315): at 3 its
             # reshape to [num_aug, n, 3, res, res] fails; > 19 exceeds the shrink filter's 40 taps
             raise ValueError(f'antialias_factor must be 1, 2, 4 or 5..19 (got {antialias_factor})')
-        images = torch.as_tensor(images).to(dev)
+        # frames stay where the caller has them (host or device): they are copied straight into the
+        # buffer the sampler reads (_predict_in_batches)
+        images = torch.as_tensor(images)
         n_images = len(images)
         intrinsic_matrix = _as_f32(intrinsic_matrix)  # (camera set-up happens on the host)
         distortion_coeffs = _as_f32(distortion_coeffs)
         extrinsic_matrix = _as_f32(extrinsic_matrix)
         world_up_vector = _as_f32(world_up_vector)
 
-        # camera set-up on the host (tiny), then one transfer (multiperson_model.py:79-105)
+        # camera set-up on the host (tiny), then ONE transfer (multiperson_model.py:79-105)
         if len(intrinsic_matrix) == 1:
             if torch.all(intrinsic_matrix == -1):
                 intrinsic_matrix = intrinsics_from_fov(default_fov_degrees, images.shape[2:4])
-            intrinsic_matrix = torch.repeat_interleave(intrinsic_matrix, n_images, dim=0)
+            intrinsic_matrix = intrinsic_matrix.expand(n_images, 3, 3)
         if len(distortion_coeffs) == 1:
-            distortion_coeffs = torch.repeat_interleave(distortion_coeffs, n_images, dim=0)
+            distortion_coeffs = distortion_coeffs.expand(n_images, -1)
         if len(extrinsic_matrix) == 1:
-            extrinsic_matrix = torch.repeat_interleave(extrinsic_matrix, n_images, dim=0)
+            extrinsic_matrix = extrinsic_matrix.expand(n_images, 4, 4)
         counts = [len(b) for b in boxes]
-        n_box_per_image = torch.tensor(counts)
+        n_total = sum(counts)
         camspace_up = torch.einsum('c,bCc->bC', world_up_vector, extrinsic_matrix[..., :3, :3])
         inv_extrinsics = torch.linalg.inv(extrinsic_matrix)
-        per_box = lambda x: torch.repeat_interleave(x, n_box_per_image, dim=0).to(dev)
-        intrinsic_matrix_b = per_box(intrinsic_matrix)
-        distortion_b = per_box(warping.pad_axis_to_size(distortion_coeffs, 12))
-        camspace_up_b = per_box(camspace_up)
-        inv_extrinsics_b = per_box(inv_extrinsics)
-        image_id_per_box = per_box(torch.arange(n_images))
         image_id_host = np.repeat(np.arange(n_images), counts)
         boxes_out = boxes
-        boxes_flat = torch.cat([torch.as_tensor(b, dtype=torch.float32).reshape(-1, 5)
-                                for b in boxes if len(b)], dim=0).to(dev) if sum(counts) else \
-            torch.zeros(0, 5, device=dev)
+        boxes_host = (torch.cat([torch.as_tensor(b, dtype=torch.float32).reshape(-1, 5)
+                                 for b in boxes if len(b)], dim=0).cpu().numpy() if n_total
+                      else np.zeros((0, 5), np.float32))
+        per_box = lambda x: np.ascontiguousarray(x, dtype=np.float32).reshape(n_images, -1)[image_id_host]
+        (boxes_flat, intrinsic_matrix_b, distortion_b, camspace_up_b, image_id_per_box,
+         inv_extrinsics_b) = self._upload_per_box(dev, [
+            (boxes_host, (5,)), (per_box(intrinsic_matrix.numpy()), (3, 3)),
+            (per_box(warping.pad_axis_to_size(distortion_coeffs, 12).numpy()), (12,)),
+            (per_box(camspace_up.numpy()), (3,)), (image_id_host.astype(np.int32), ()),
+            (per_box(inv_extrinsics.numpy()), (4, 4))])
 
         tta = self._tta(num_aug, dev)
         n_joints = self.joint_info.n_joints
@@ -332,6 +346,43 @@ class Pose3dEstimator(torch.nn.Module):
         poses2d = list(torch.split(poses2d_flat, counts))
         return dict(boxes=boxes_out, poses3d=poses3d, poses2d=poses2d)
 
+    def _upload_per_box(self, dev, fields):
+        """[(host array [n, ...] f32 or [n] i32, row shape), ...] -> the same as device tensors, through
+        ONE pinned staging buffer and ONE host-to-device copy (field after field: every field, and every
+        box range of it, is a contiguous view of the device copy)."""
+        n = len(fields[0][0])
+        sizes = [int(np.prod(shape, dtype=np.int64)) * n for _, shape in fields]
+        total = max(sum(sizes), 1)
+        if not self._slabs:
+            self._slabs = [[None, None], [None, None]]
+        self._slab_turn ^= 1
+        slot = self._slabs[self._slab_turn]
+        if slot[0] is None or slot[0].numel() < total:
+            slot[0] = torch.empty(max(total, 4096), dtype=torch.float32).pin_memory()
+            slot[1] = torch.cuda.Event()
+        else:
+            slot[1].synchronize()  # (the copy of the call before last has read this staging buffer)
+        stage = slot[0].numpy()
+        off = 0
+        for (arr, _), size in zip(fields, sizes):
+            dst = stage[off:off + size]
+            if arr.dtype == np.int32:
+                dst.view(np.int32)[:] = arr.reshape(-1)
+            else:
+                dst[:] = arr.reshape(-1)
+            off += size
+        slab = torch.empty(total, dtype=torch.float32, device=dev)
+        slab.copy_(slot[0][:total], non_blocking=True)
+        slot[1].record(torch.cuda.current_stream(dev))
+        out, off = [], 0
+        for (arr, shape), size in zip(fields, sizes):
+            t = slab[off:off + size]
+            if arr.dtype == np.int32:
+                t = t.view(torch.int32)
+            out.append(t.reshape(n, *shape))
+            off += size
+        return out
+
     def _predict_in_batches(self, images, intrinsic_matrix, distortion12, camspace_up, boxes_flat,
                             image_id_per_box, internal_batch_size, tta, antialias_factor, post=None,
                             image_id_host=None):
@@ -363,6 +414,20 @@ class Pose3dEstimator(torch.nn.Module):
         else:
             ranges_by_rank = [distributed.shard_internal_batches(n_total, boxes_per_batch, r, world)
                               for r in range(world)]
+        if image_id_host is not None and images.numel() >= kernels.MAX_U8_FRAME_BYTES:
+            # the sampler's limit, checked for EVERY rank's ranges before any kernel or collective runs
+            # (and before the frames are cut down to this rank's), so that all ranks
+            # raise the same error together (one rank raising inside the loop would leave the others
+            # waiting in the moment all-reduce / the final gather)
+            frame_bytes = int(np.prod(images.shape[1:]))
+            for rr in ranges_by_rank:
+                for a_, b_ in rr:
+                    n_ref = len(set(image_id_host[a_:b_].tolist()))
+                    if n_ref * frame_bytes >= kernels.MAX_U8_FRAME_BYTES:
+                        raise ValueError(
+                            f'one internal batch references {n_ref} frames = {n_ref * frame_bytes} bytes; '
+                            f'the sampler takes < {kernels.MAX_U8_FRAME_BYTES} bytes of uint8 frames per '
+                            f'call: lower internal_batch_size')
         ranges = ranges_by_rank[rank]
         # the pyramid of the frames THIS rank's boxes reference (all of them on one rank)
         if world > 1 and image_id_host is not None:
@@ -376,7 +441,19 @@ class Pose3dEstimator(torch.nn.Module):
         # descriptor (< 2 GiB: 86 4K frames).  Beyond that every internal batch gets the pyramid of
         # the frames ITS boxes reference (at most boxes_per_batch of them).
         per_batch_pyramids = images.numel() >= kernels.MAX_U8_FRAME_BYTES
-        pyramid = kernels.build_pyramid(images) if len(images) and not per_batch_pyramids else None
+        dev = boxes_flat.device
+        # HIP graphs (graph_cache.py): the internal batches of this call whose shape has a captured
+        # graph, or is due for one, replay it; the others run the same launches eagerly
+        plan = None
+        if (post is not None and not exact and not per_batch_pyramids and len(images) and dev.type == 'cuda'
+                and self.graph_batches and type(self)._predict_single_batch is Pose3dEstimator._predict_single_batch
+                and '_predict_single_batch' not in self.__dict__):
+            plan = self.graphs.plan_call(images, ranges, tta, antialias_factor, post)
+        if plan is not None:
+            pyramid = plan.frames.load(images)   # static frame + pyramid buffers the graphs read
+        else:
+            images = images.to(dev, non_blocking=True)
+            pyramid = kernels.build_pyramid(images) if len(images) and not per_batch_pyramids else None
         if exact:
             if not hasattr(self.crop_model, 'exact_monolithic'):
                 raise RuntimeError("shard_across_ranks='exact_monolithic' needs metrabs_amd's Metrabs "
@@ -384,7 +461,7 @@ class Pose3dEstimator(torch.nn.Module):
             self.crop_model.exact_monolithic = True
         out = []
         try:
-            for start, stop in ranges:
+            for i_range, (start, stop) in enumerate(ranges):
                 if start == stop:  # (exact mode) an empty slice still joins the batch's all-reduce
                     if exact_allreduce:
                         distributed.allreduce_moments(torch.zeros(3, dtype=torch.float64,
@@ -394,16 +471,18 @@ class Pose3dEstimator(torch.nn.Module):
                 batch_pyramid, batch_ids = pyramid, image_id_per_box[s]
                 if per_batch_pyramids:
                     batch_pyramid, batch_ids = self._pyramid_of_referenced_frames(images, batch_ids)
-                res = self._predict_single_batch(
-                    batch_pyramid, intrinsic_matrix[s], distortion12[s], camspace_up[s], boxes_flat[s],
-                    batch_ids, tta, antialias_factor, raw=post is not None)
                 if post is not None:
-                    poses_flat, rot = res
-                    p3, p2 = kernels.postprocess_poses(
-                        poses_flat, rot, tta['should_flip_u8'], tta['mirror_i32'], intrinsic_matrix[s],
-                        distortion12[s], post['inv_extrinsics'][s], post['joint_transform'],
-                        post['skeleton'], post['average_aug'])
-                    res = torch.cat([p3, p2], dim=-1)
+                    batch_args = (intrinsic_matrix[s], distortion12[s], camspace_up[s], boxes_flat[s], batch_ids,
+                                  post['inv_extrinsics'][s])
+                    graph = plan.graph_for(i_range, batch_args) if plan is not None else None
+                    if graph is not None:
+                        res = graph.replay(batch_args)
+                    else:
+                        res = self._batch_with_postprocess(batch_pyramid, *batch_args, tta, antialias_factor, post)
+                else:
+                    res = self._predict_single_batch(
+                        batch_pyramid, intrinsic_matrix[s], distortion12[s], camspace_up[s], boxes_flat[s],
+                        batch_ids, tta, antialias_factor, raw=False)
                 out.append(res)
         finally:
             if exact:
@@ -416,13 +495,25 @@ class Pose3dEstimator(torch.nn.Module):
             local = torch.zeros(*shape, device=boxes_flat.device)
         else:
             local = torch.zeros(0, num_aug, self.joint_info.n_joints, 3, device=boxes_flat.device)
-        return distributed.gather_ranges(local, ranges_by_rank, n_total)
+        return distributed.gather_ranges(local, ranges_by_rank, n_total, always=self.force_collective)
+
+    def _batch_with_postprocess(self, pyramid, intrinsic_matrix, distortion12, camspace_up, boxes, image_ids,
+                                inv_extrinsics, tta, antialias_factor, post):
+        """One internal batch up to and including K7 -> [n, (A,) S, 5] = poses3d | poses2d.  THE body of
+        the fused path: run eagerly here and captured, call for call, by graph_cache.BatchGraph."""
+        poses_flat, rot = self._predict_single_batch(
+            pyramid, intrinsic_matrix, distortion12, camspace_up, boxes, image_ids, tta, antialias_factor,
+            raw=True)
+        p3, p2 = kernels.postprocess_poses(
+            poses_flat, rot, tta['should_flip_u8'], tta['mirror_i32'], intrinsic_matrix, distortion12,
+            inv_extrinsics, post['joint_transform'], post['skeleton'], post['average_aug'])
+        return torch.cat([p3, p2], dim=-1)
 
     @staticmethod
     def _pyramid_of_referenced_frames(images, image_ids):
         """-> (pyramid of the frames `image_ids` reference, the ids renumbered into it)."""
         needed, local_ids = torch.unique(image_ids.long(), sorted=True, return_inverse=True)
-        frames = images[needed.to(images.device)]
+        frames = images[needed.to(images.device)].to(image_ids.device)
         if frames.numel() >= kernels.MAX_U8_FRAME_BYTES:
             raise ValueError(
                 f'one internal batch references {len(needed)} frames = {frames.numel()} bytes; the '

@@ -1,0 +1,106 @@
+"""HIP graphs behind the drop-in API (metrabs_amd/graph_cache.py): Pose3dEstimator.estimate_poses_batched
+with graph_batches on must return the eager path's bits -- across different frames, boxes and cameras, with
+several internal batches per call, ragged tails, host-resident frames, and frame-set eviction -- and it
+must actually replay graphs (stats), not silently stay eager."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases
+from test_gpu_e2e import build_estimator
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(case, seed, n_images, per_image):
+    """Fresh frames / boxes / cameras of the case's frame size."""
+    g = torch.Generator().manual_seed(seed)
+    _, _, h, w = case['images'].shape
+    images = torch.randint(0, 256, (n_images, 3, h, w), dtype=torch.uint8, generator=g)
+    boxes = []
+    for n in per_image:
+        xy = torch.rand(n, 2, generator=g) * torch.tensor([w * 0.5, h * 0.5])
+        wh = 20 + torch.rand(n, 2, generator=g) * torch.tensor([w * 0.4, h * 0.4])
+        boxes.append(torch.cat([xy, wh], dim=1))
+    K = torch.stack([cases.intrinsics_for(h, w, 50.0 + 5 * i, seed + i) for i in range(n_images)])
+    return images, boxes, K
+
+
+def _call(est, images, boxes, K, case, **kw):
+    args = dict(intrinsic_matrix=K, distortion_coeffs=case['dist'], extrinsic_matrix=case['extr'],
+                world_up_vector=case['world_up'], internal_batch_size=case['ibs'], antialias_factor=case['aa'],
+                num_aug=case['num_aug'], average_aug=case['average_aug'])
+    args.update(kw)
+    r = est.estimate_poses_batched(images, boxes, **args)
+    return torch.cat(r['poses3d']).clone(), torch.cat(r['poses2d']).clone()
+
+
+@pytest.mark.parametrize('name', ['aug5', 'aug4_dist12', 'aug5_dist_aa2'])
+def test_graphed_api_equals_eager_bit_for_bit(name, hip_lib):
+    case = cases.e2e_case(name)
+    eager, graphed = build_estimator(case, 'auto'), build_estimator(case, 'auto')
+    eager.graph_batches = False
+    graphed.graph_batches = True   # capture a shape on its first occurrence
+    per_image = [3, 0, 4, 2]       # 9 boxes: at ibs // num_aug boxes per batch, full batches + a ragged tail
+    for seed in (11, 12, 13):      # three different inputs through the SAME captured graphs
+        images, boxes, K = _inputs(case, seed, 4, per_image)
+        a3, a2 = _call(eager, images.cuda(), boxes, K, case)
+        b3, b2 = _call(graphed, images.cuda(), boxes, K, case)
+        assert torch.isfinite(a3).all() and a3.abs().max() > 0
+        assert torch.equal(a3, b3) and torch.equal(a2, b2), (name, seed, float((a3 - b3).abs().max()))
+    st = graphed.graphs.stats
+    assert st['captures'] >= 1 and st['replays'] >= 2 * st['captures'], st
+    assert eager.graphs.stats['captures'] == 0
+    # host-resident frames land in the static frame buffer directly: same bits again
+    images, boxes, K = _inputs(case, 14, 4, per_image)
+    a3, _ = _call(eager, images, boxes, K, case)
+    b3, _ = _call(graphed, images.numpy(), boxes, K, case)
+    assert torch.equal(a3, b3)
+    # another camera set-up / skeleton-free call with other options: new key, still equal
+    a3, a2 = _call(eager, images.cuda(), boxes, K, case, average_aug=not case['average_aug'])
+    b3, b2 = _call(graphed, images.cuda(), boxes, K, case, average_aug=not case['average_aug'])
+    assert torch.equal(a3, b3) and torch.equal(a2, b2)
+
+
+def test_auto_mode_captures_on_the_second_occurrence_and_results_do_not_alias(hip_lib):
+    case = cases.e2e_case('aug5')
+    est = build_estimator(case, 'auto')
+    assert est.graph_batches == 'auto'
+    images, boxes, K = _inputs(case, 21, 2, [2, 2])   # one internal batch of 4 > ibs // num_aug = 2 -> 2 batches
+    r1 = _call(est, images.cuda(), boxes, K, case, internal_batch_size=20)   # 4 boxes: one batch, first sight
+    assert est.graphs.stats['captures'] == 0
+    r2 = _call(est, images.cuda(), boxes, K, case, internal_batch_size=20)   # second sight: captured + replayed
+    assert est.graphs.stats['captures'] == 1
+    keep = r2[0].clone()
+    images2, boxes2, K2 = _inputs(case, 22, 2, [2, 2])
+    r3 = _call(est, images2.cuda(), boxes2, K2, case, internal_batch_size=20)
+    assert est.graphs.stats['captures'] == 1 and est.graphs.stats['replays'] >= 1
+    assert torch.equal(r1[0], r2[0]) and torch.equal(r2[0], keep), 'a later replay overwrote a returned result'
+    assert not torch.equal(r3[0], r2[0])
+
+
+def test_frame_set_eviction_drops_the_graphs_that_read_it(hip_lib):
+    case = cases.e2e_case('aug5')
+    ref = build_estimator(case, 'auto')
+    ref.graph_batches = False
+    est = build_estimator(case, 'auto')
+    est.graph_batches = True
+    est.graphs.max_frame_sets = 1
+    for n_images in (2, 3, 2):  # the 2-frame set is evicted by the 3-frame one and rebuilt
+        images, boxes, K = _inputs(case, 30 + n_images, n_images, [2] * n_images)
+        a = _call(ref, images.cuda(), boxes, K, case)
+        b = _call(est, images.cuda(), boxes, K, case)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert est.graphs.stats['evictions'] >= 2 and len(est.graphs.frame_sets) == 1
+    assert all(k[0] == next(iter(est.graphs.frame_sets)) for k in est.graphs.graphs)
+
+
+def test_empty_call_and_images_without_boxes(hip_lib):
+    case = cases.e2e_case('aug5')
+    est = build_estimator(case, 'auto')
+    est.graph_batches = True
+    images, _, K = _inputs(case, 40, 2, [0, 0])
+    r = est.estimate_poses_batched(images.cuda(), [torch.zeros(0, 4), torch.zeros(0, 4)], intrinsic_matrix=K,
+                                   num_aug=2)
+    assert [tuple(p.shape) for p in r['poses3d']] == [(0, 17, 3), (0, 17, 3)]
+    assert np.all([tuple(p.shape) == (0, 17, 2) for p in r['poses2d']])

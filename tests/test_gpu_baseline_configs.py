@@ -58,7 +58,9 @@ def test_config3_sampler_tta5_flip_1080p(hip_lib):
                                                   ('effnetv2-l', 384, 2)])
 def test_end_to_end_every_backbone_family(backbone, res, num_aug, hip_lib):
     """The drop-in API runs end to end behind each backbone family of BASELINE.json (random weights):
-    finite poses of the right shape."""
+    finite poses of the right shape -- and the true-shape step is compared with the oracle: the GPU
+    backbone's features (ResNet-18 512 x 8x8, MobileNetV3 960 x 8x8, EffNetV2-L 1280 x 12x12) go through
+    the oracle's head + reconstruction on the CPU and through ours (Metrabs.forward after the backbone)."""
     from metrabs_amd.backbones import build_backbone, calibrate_batchnorm
     from metrabs_amd.config import MetrabsConfig
     from metrabs_amd.joint_info import JointInfo
@@ -79,6 +81,26 @@ def test_end_to_end_every_backbone_family(backbone, res, num_aug, hip_lib):
         assert p2.shape == (len(b), 17, 2)
     # (no bitwise repeatability check here: MIOpen / rocBLAS may change algorithm between calls;
     #  the hand-written kernels' determinism is asserted bitwise in the permutation tests)
+    g = torch.Generator(device='cuda').manual_seed(9)
+    n = 6
+    crops = torch.rand(n, 3, res, res, device='cuda', generator=g)
+    K = torch.stack([cases.intrinsics_for(res, res, 40.0 + 3 * i, 100 + i) for i in range(n)])
+    ocfg = cpu_ref.HeadConfig(proc_side=res)
+    with torch.inference_mode():
+        feat = model.backbone(crops)
+        ours = model((crops, K.cuda())).cpu()
+        w = model.heatmap_heads.conv_final.weight.detach().cpu().reshape(-1, feat.shape[1])
+        b = model.heatmap_heads.conv_final.bias.detach().cpu()
+        ref = cpu_ref.crop_model_from_features(feat.cpu(), w, b, K, 17, ocfg)
+        truth = cpu_ref.crop_model_from_features_fp64(feat.cpu(), w, b, K, 17, ocfg)
+    assert model.heatmap_heads.last_path == 'fused'
+    e_ref, e64, r64 = cpu_ref.mpjpe(ours, ref), cpu_ref.mpjpe(ours, truth), cpu_ref.mpjpe(ref, truth)
+    print(f'[parity] {backbone} {res}px true-shape features {tuple(feat.shape)}: ours-vs-oracle MPJPE {e_ref:.2e} mm '
+          f'max {float((ours - ref).abs().max()):.2e}; ours-vs-fp64 {e64:.2e}; oracle-vs-fp64 {r64:.2e}')
+    # the parity-gate bounds of a random head (tests/test_gpu_parity_gates.py): ours within 1e-3 mm of the
+    # fp64 evaluation; against the oracle run on THIS host's CPU, its own distance to fp64 on top
+    assert e64 <= 1e-3, (e64, r64)
+    assert e_ref <= 1e-3 + r64, (e_ref, r64)
 
 
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])

@@ -3,8 +3,10 @@ _estimate_poses_batched (geometry -> sampler -> backbone -> head -> reconstructi
 
 This is NOT the 1e-3 mm parity claim (that one is on identical crops / features, see
 test_gpu_decode_recon.py and test_gpu_head.py): here crops differ by the sampler's fp32 noise and the
-tiny backbone runs on MIOpen instead of oneDNN, and the head amplifies both.  Bound: 0.05 mm MPJPE,
-0.5 mm max on poses3d; poses2d median 2e-3 px / 95th percentile 0.05 px."""
+tiny backbone runs on MIOpen instead of oneDNN, and the head amplifies both.  Bounds: per case, ~3x what
+was measured on MI355X in round 4 (gpurun_out/r04a_e2e.log; round 3 allowed 0.05 mm MPJPE / 0.5 mm max
+everywhere, 10 - 70x the measured values: a sampler regression of 10x passed); poses2d median 2e-3 px /
+95th percentile 0.05 px."""
 import numpy as np
 import pytest
 import torch
@@ -13,6 +15,14 @@ from conftest import load_golden
 from oracle import cases, cpu_ref
 
 pytestmark = pytest.mark.gpu
+
+# poses3d from IMAGES vs the stored reference output, (MPJPE, max) in mm; measured (fused head) beside each
+E2E_BOUND = {'aug1': (1.5e-2, 6e-2),            # 4.5e-3, 2.0e-2
+             'aug5': (1e-2, 2.5e-2),            # 3.0e-3, 7.6e-3
+             'aug5_dist_aa2': (5e-3, 2e-2),     # 1.4e-3, 6.1e-3
+             'aug4_dist12': (2e-2, 4e-2),       # 6.4e-3, 1.2e-2
+             'aug2_aa8': (3e-3, 1.2e-2),        # 7.8e-4, 3.3e-3
+             'aug2_aa4_bigbox': (6e-3, 1.2e-2)}  # 1.8e-3, 3.6e-3
 
 
 def build_estimator(case, fused_head):
@@ -49,7 +59,8 @@ def test_estimate_poses_vs_golden(name, fused_head, hip_lib):
     assert p3.shape == g3.shape and p2.shape == g2.shape
     print(f'[parity] e2e {name} fused={fused_head}: poses3d MPJPE {cpu_ref.mpjpe(p3, g3):.2e} mm '
           f'max {float((p3 - g3).abs().max()):.2e} mm; poses2d max {float((p2 - g2).abs().max()):.2e} px')
-    assert cpu_ref.mpjpe(p3, g3) <= 0.05 and float((p3 - g3).abs().max()) <= 0.5
+    b_mpjpe, b_max = E2E_BOUND[name]
+    assert cpu_ref.mpjpe(p3, g3) <= b_mpjpe and float((p3 - g3).abs().max()) <= b_max
     # random-weight heads put some joints at near-zero depth where x/z amplifies any difference:
     # bound the bulk of the distribution, not the projection singularities
     d2 = (p2 - g2).abs().flatten()

@@ -213,10 +213,12 @@ def test_fused_equals_unfused_and_module(hip_lib):
     assert set(sd) == {'conv_final.weight', 'conv_final.bias'} and sd['conv_final.weight'].shape == (153, 128, 1, 1)
 
 
-def test_auto_head_path_is_timed_once_and_equivalent(hip_lib):
-    """MetrabsHeads(fused='auto'): both paths are timed on the first eager call of a (shape, dtype,
-    layout) and the faster one is kept; whichever wins, the result stays within the parity bound
-    of the fused path."""
+def test_auto_head_path_is_a_static_rule(hip_lib):
+    """MetrabsHeads(fused='auto') (Metrabs' default): the path is a static function of (dtype, layout, C,
+    H, W, J, D) -- kernels.head_auto_choice -- never of the batch size or of a clock: every batch size
+    (the slices of a sharded batch) takes the path of the whole batch, with the bits of fused=True where
+    the rule says fused.  'time' (explicit opt-in) times both paths once per shape."""
+    from metrabs_amd import kernels
     from metrabs_amd.config import MetrabsConfig
     from metrabs_amd.models.metrabs import MetrabsHeads
     torch.manual_seed(1)
@@ -224,15 +226,24 @@ def test_auto_head_path_is_timed_once_and_equivalent(hip_lib):
     feat = torch.randn(16, 256, 8, 8, device='cuda')
     with torch.inference_mode():
         a2d, a3d = heads(feat)
-        assert list(heads._auto_choice) == [((16, 256, 8, 8), torch.float32, False)]
-        choice = dict(heads._auto_choice)
-        b2d, b3d = heads(feat)
-        assert heads._auto_choice == choice and torch.equal(a3d, b3d)
+        assert heads.last_path == 'fused' and kernels.head_auto_choice(256, 17, 8, 8, 8)
+        assert heads._auto_choice == {((256, 8, 8), torch.float32, False): True}
+        for n in (1, 3, 16):   # a slice takes the whole batch's path
+            heads(feat[:n])
+            assert heads.last_path == 'fused' and len(heads._auto_choice) == 1
         heads(feat.half())
         assert len(heads._auto_choice) == 2
         heads.fused = True
         f2d, f3d = heads(feat)
-    assert float((a3d - f3d).abs().max()) <= 2e-3 and float((a2d - f2d).abs().max()) <= 4e-4
+        assert torch.equal(a3d, f3d) and torch.equal(a2d, f2d)
+        big = torch.randn(2, 256, 24, 24, device='cuda')   # f32 24x24 maps: the library pair by rule
+        heads.fused = 'auto'
+        heads(big)
+        assert heads.last_path == 'library' and not kernels.head_auto_choice(256, 17, 8, 24, 24)
+        heads.fused = 'time'
+        t2d, t3d = heads(feat)
+        assert (tuple(feat.shape), torch.float32, False) in heads._auto_choice
+    assert float((t3d - f3d).abs().max()) <= 2e-3 and float((t2d - f2d).abs().max()) <= 4e-4
 
 
 def test_depth72_runs_in_the_fused_kernel(hip_lib):
