@@ -273,8 +273,8 @@ def depth72_variant(args, dev, im_h, im_w, n_box):
                 head=('mtr_head_fused (row-tile core: a joint\'s 72 depth slices + 8 rows of 2D heatmaps '
                       'are one 5-tile atom, 17 atoms)' if fused else
                       '1x1 conv (library GEMM) + mtr_softargmax_decode, D=72'),
-                head_chosen_by=f'MetrabsHeads(fused={heads.fused!r}): both paths timed once on the first eager '
-                               f'call, the faster kept',
+                head_chosen_by=f'MetrabsHeads(fused={heads.fused!r}): kernels.head_auto_choice, a static rule on '
+                               f'(dtype, layout, C, H, W, J, D) -- no timing, no batch size',
                 note='same step as `value` with a 72-bin head; `value` itself uses depth=8 '
                      '(every shipped configuration of the reference)')
 
@@ -304,6 +304,39 @@ def backbone_variant(args, dev, im_h, im_w, n_box, fold_bn, fused_epilogue, note
     ms = (time.perf_counter() - t0) / n * 1e3
     assert torch.isfinite(pipe.poses).all()
     return dict(crops_per_s_per_gpu=n_box * args.num_aug / ms * 1e3, ms_per_step=ms, steps=n, note=note)
+
+
+def autocast_variant(args, dev, im_h, im_w, n_box, precision='f16'):
+    """The reference's own GPU arithmetic: it runs the crop model under torch.autocast(float16) on a GPU
+    (multiperson_model.py:241).  The SAME step with the backbone under f16 autocast, 16-bit crops from the
+    sampler and the f16-MFMA fused head -- reported beside `value` (which keeps the f32 arithmetic of the
+    reference's CPU path, the parity target)."""
+    import copy
+    from metrabs_amd.pipeline import GraphedCropPipeline
+    a = copy.copy(args)
+    a.precision = precision
+    est, _ = build_model(a, dev)
+    pipe = GraphedCropPipeline(est, args.frames, im_h, im_w, n_box, num_aug=args.num_aug,
+                               use_graph=not args.no_graph)
+    synth_inputs(pipe, args.frames, im_h, im_w, n_box, seed=100)
+    pipe.capture()
+    for _ in range(3):
+        pipe.run()
+    torch.cuda.synchronize()
+    n = max(5, args.steps // 2)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        pipe.run()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    assert torch.isfinite(pipe.poses).all()
+    heads = est.crop_model.heatmap_heads
+    J, C = est.joint_info.n_joints, est.crop_model.backbone.out_channels
+    return dict(crops_per_s_per_gpu=n_box * args.num_aug / ms * 1e3, ms_per_step=ms, steps=n, dtype=precision,
+                head=head_kernel_name((args.res // 32) ** 2, n_box * args.num_aug, J, heads.config.depth, precision, C)
+                if heads.last_path == 'fused' else 'library 1x1 conv + mtr_softargmax_decode',
+                note='same step as `value` with the crop model under torch.autocast(float16) -- the reference\'s '
+                     'GPU arithmetic (multiperson_model.py:241); 16-bit crops, f16-MFMA fused head')
 
 
 def head_kernel_name(hw, n_crops, J, D, precision='f32', C=1280):
@@ -695,6 +728,10 @@ def parity_probe(est, extras, cfg, args):
     out = {'definition': 'poses3d (mm) from identical features: ours = mtr_head_fused + '
                          'mtr_reconstruct_absolute through the C-ABI; ref = oracle/cpu_ref.py (fp32 CPU '
                          'restatement of metrabs_pytorch, pinned to it); fp64 = the same formulas in float64'}
+    try:  # the reference against itself, run to run (oracle/gen_golden.py jitter, build container)
+        jitter = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'parity_reference_jitter.json')))
+    except (OSError, ValueError):
+        jitter = {}
     feats = extras['feats']
     B, C, H, W = feats.shape
     # the bench's shape is one of the parity-gate shapes (configs[1] by default): compare with the
@@ -726,6 +763,10 @@ def parity_probe(est, extras, cfg, args):
             ours = kernels.reconstruct_absolute(c2d, c3d, K.cuda(), model.config).cpu()
         out[regime] = _parity_numbers(ours, ref, truth)
         out[regime]['logits_peak'] = amp
+        if gate is not None and cases.parity_gate_slug(gate, regime) in jitter:
+            jr = jitter[cases.parity_gate_slug(gate, regime)]
+            out[regime]['reference_run_to_run_max_mm'] = jr['run_to_run_max_mm']
+            out[regime]['reference_run_to_run_mpjpe_mm'] = jr['run_to_run_mpjpe_mm']
         out[regime]['ref_is'] = ('stored output of the reference itself (tests/golden/' +
                                  cases.parity_gate_slug(gate, regime) + '.npz)') if stored is not None else \
             'oracle/cpu_ref.py evaluated on this box\'s CPU'
@@ -743,6 +784,10 @@ def parity_probe(est, extras, cfg, args):
     out['bench_batch_random_network'] = dict(_parity_numbers(ours, ref, truth), logits_absmax=logits_absmax)
     out['mpjpe_mm'] = max(out['consistent_low']['mpjpe_mm'], out['consistent_peaked']['mpjpe_mm'])
     out['mpjpe_mm_is'] = 'the larger MPJPE of the two consistent regimes (NOT of the timed batch)'
+    out['max_abs_mm'] = max(out['consistent_low']['max_abs_mm'], out['consistent_peaked']['max_abs_mm'])
+    out['max_abs_mm_is'] = ('the largest |ours - reference| over all coordinates in the two consistent regimes; read it '
+                            'against reference_run_to_run_max_mm, the reference\'s own spread between runs on the same '
+                            'inputs (torch.linalg.lstsq / threaded conv; tests/golden/parity_reference_jitter.json)')
     out['consistent_regimes_within_1e-3_mm'] = bool(out['mpjpe_mm'] <= 1e-3)
     out['timed_batch_mpjpe_mm'] = out['bench_batch_random_network']['mpjpe_mm']
     out['timed_batch_within_1e-3_mm'] = bool(out['timed_batch_mpjpe_mm'] <= 1e-3)
@@ -789,6 +834,12 @@ def main():
         raise SystemExit('bench.py needs a GPU (the hot path has no CPU fallback)')
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and 'RANK' not in os.environ:
         spawn_ranks(args)  # (does not return)
+    # stdout carries ONE JSON line and nothing else: whatever native code writes to file descriptor 1
+    # (RCCL prints its version banner there; MIOpen now and then) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    sys.stdout = os.fdopen(json_fd, 'w')
     # one process per GPU; the device is bound BEFORE the process group exists so that RCCL's
     # communicator and barriers land on it.  MTR_BENCH_SHARED_DEVICE=1 (+ MTR_BENCH_BACKEND=gloo)
     # lets several ranks share cuda:0 -- only to exercise the N>1 code path on a 1-GPU box.
@@ -956,7 +1007,9 @@ def main():
         'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
         'dtype': args.precision, 'data': 'synthetic',
         'config': {'workload': workload + f'num_aug={args.num_aug}, {args.frames} 1080p uint8 frames per internal '
-                                          f'batch, J={J}, D={cfg.depth}, random weights',
+                                          f'batch, J={J}, D={cfg.depth} depth bins (every shipped configuration of the '
+                                          f'reference; the metric string\'s 72-bin reading of the same step is the '
+                                          f'`depth72` object of this line), random weights',
                    'global_batch': crops_per_step, 'parallelism': f'dp{world} (crops sharded, one '
                    f'all-gather of poses)' if world > 1 else 'single GPU',
                    'hip_graph': not args.no_graph,
@@ -1080,8 +1133,17 @@ def api_path_probe(est, args, im_h, im_w, n_box, value):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         assert all(torch.isfinite(p).all() for p in res['poses3d'])
+        lat = []   # one call at a time, the host waiting for its result: what a live camera loop sees
+        for i, c in enumerate(calls[:6]):
+            boxes, K = fresh_call(c)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            res = est.estimate_poses_batched(image_sets[i % len(image_sets)], boxes, intrinsic_matrix=K, **kw)
+            res['poses3d'][0].cpu()
+            lat.append((time.perf_counter() - t1) * 1e3)
         return dict(crops_per_s=round(n_crops / dt, 1), ms_per_call=round(dt / (rounds * len(calls)) * 1e3, 3),
-                    calls=rounds * len(calls), crops_per_call=round(n_crops / (rounds * len(calls)), 1))
+                    calls=rounds * len(calls), crops_per_call=round(n_crops / (rounds * len(calls)), 1),
+                    latency_ms_one_call_synced=round(float(np.median(lat)), 3))
 
     full = [[per] * frames] * 6
     ragged = [list(rng.integers(1, per + 1, frames)) for _ in range(16)]
@@ -1091,6 +1153,7 @@ def api_path_probe(est, args, im_h, im_w, n_box, value):
     try:
         with torch.inference_mode():
             out['full'] = dict(eager=timed(False, dev_sets, full, rounds), graphed=timed(True, dev_sets, full, rounds),
+                               eager_frames_from_pinned_host=timed(False, host_sets, full, rounds),
                                graphed_frames_from_pinned_host=timed(True, host_sets, full, rounds))
             out['ragged_1_to_%d_boxes_per_frame' % per] = dict(eager=timed(False, dev_sets, ragged, 2),
                                                                graphed=timed(True, dev_sets, ragged, 2))
@@ -1296,6 +1359,8 @@ def analysis(args, est, cfg, pipe, dev, step_seconds, im_h, im_w, n_box, world):
         out['api_path'] = api_path_probe(est, args, im_h, im_w, n_box, n_box * args.num_aug / step_seconds)
     if world == 1 and args.depth != 72 and not args.no_depth72 and args.config == 1:
         out['depth72'] = depth72_variant(args, dev, im_h, im_w, n_box)
+        if args.precision == 'f32':
+            out['f16_autocast'] = autocast_variant(args, dev, im_h, im_w, n_box)
         if not args.no_fold_bn:
             out['bn_not_folded'] = backbone_variant(
                 args, dev, im_h, im_w, n_box, False, False,
@@ -1306,6 +1371,16 @@ def analysis(args, est, cfg, pipe, dev, step_seconds, im_h, im_w, n_box, world):
                     args, dev, im_h, im_w, n_box, True, False,
                     'same step as `value` with the batch norms folded but bias / activation / skip / '
                     'mean and the depthwise layers left to PyTorch-ROCm\'s kernels (--no-fused-epilogue)')
+    api = out.get('api_path')
+    out['deployable'] = dict(
+        crops_per_s=(api['full']['graphed_frames_from_pinned_host']['crops_per_s'] if api else
+                     pcie['overlapped']['crops_per_s_per_gpu']),
+        what=('Pose3dEstimator.estimate_poses_batched with the frames of every call arriving from pinned host memory '
+              'over PCIe (copy stream under the previous call\'s compute), fresh boxes / cameras per call: '
+              'api_path.full.graphed_frames_from_pinned_host' if api else
+              'pcie_inclusive.overlapped (frames from pinned host memory every step, copy under compute)'),
+        note='`value` replays one internal batch on inputs resident in HBM, as the bench contract asks (its sampler and '
+             'pyramid find the step\'s own frames partly in the Infinity Cache); this is the figure with nothing resident')
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(est, pipe, args, cfg, args.cpu_seconds)
     else:

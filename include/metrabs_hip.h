@@ -117,9 +117,24 @@ int mtr_softargmax_decode(const void* logits, int dtype, int layout, int B, int 
  *
  * mtr_head_fused_opts: the same launch with explicit dispatch choices (A/B measurements, tests of
  * every kernel variant); options == NULL or all-zero fields = the library's own choice.  There are
- * no environment switches and no other global state behind these entry points.
+ * no environment switches behind these entry points, and no state that changes a result.  What the
+ * library does keep per process is MEMOISATION of pure functions of its arguments: the launch plans of
+ * the f32 head (a mutex-guarded map keyed by the current device's CU count, the shape -- with the batch
+ * size rounded up to a multiple of 8, all the plan reads of it -- and the options), the per-kernel "dynamic LDS allowed" once-flags, and
+ * the detector pre-processing's per-shape kernel choice; all of it is rebuilt identically on a miss.
+ *
+ * mtr_head_fused / mtr_head_fused_opts have no workspace to offer: a shape that needs one (16-bit NCHW
+ * features on the row-tile core) is reported as MTR_E_SHAPE -- "take the library-GEMM path" -- exactly
+ * like any other shape without a fused kernel; only mtr_head_fused_ws returns MTR_E_WORKSPACE.
+ *
+ * mtr_head_options is versioned by its first member: set struct_size = sizeof(mtr_head_options) of the
+ * header you compiled against.  The library reads the fields inside struct_size and takes its own choice
+ * for the ones beyond it (a caller built against an older, shorter struct keeps working); a struct_size
+ * that is not a multiple of 4, below 8 or above 256 is MTR_E_PARAM (a round-3 caller, whose struct began
+ * with rt_tiles_per_workgroup = 0..5, is rejected instead of being misread).
  */
 typedef struct mtr_head_options {
+  uint32_t struct_size;            /* sizeof(mtr_head_options) as the CALLER knows it (see above)            */
   int32_t rt_tiles_per_workgroup;  /* f32: row tiles per workgroup for one-tile atoms, 1..5; 0 = by launch size */
   int32_t groups_per_workgroup;    /* 16-bit: joint groups per workgroup, 1..3; 0 = by launch size        */
   int32_t dma_staging;             /* 16-bit: 1 = global_load_lds where possible, 0 = through registers,

@@ -22,9 +22,17 @@ class HeadParams(ctypes.Structure):
 
 class HeadOptions(ctypes.Structure):
     """mtr_head_options (include/metrabs_hip.h): explicit dispatch choices of mtr_head_fused_opts."""
-    _fields_ = [('rt_tiles_per_workgroup', c_int32), ('groups_per_workgroup', c_int32),
+    _fields_ = [('struct_size', ctypes.c_uint32),
+                ('rt_tiles_per_workgroup', c_int32), ('groups_per_workgroup', c_int32),
                 ('dma_staging', c_int32), ('rt_column_blocks', c_int32), ('rt_k_groups', c_int32),
                 ('rt_loader', c_int32), ('rt_split_column_blocks', c_int32)]
+
+
+def head_options(rt_tiles=0, groups_per_workgroup=0, dma_staging=-1, rt_column_blocks=0, rt_k_groups=0,
+                 rt_loader=0, rt_split=0):
+    """A versioned mtr_head_options (struct_size = this binding's sizeof)."""
+    return HeadOptions(ctypes.sizeof(HeadOptions), int(rt_tiles), int(groups_per_workgroup), int(dma_staging),
+                       int(rt_column_blocks), int(rt_k_groups), int(rt_loader), int(rt_split))
 
 
 class HeadPlanInfo(ctypes.Structure):

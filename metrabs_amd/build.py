@@ -97,16 +97,55 @@ def kernel_resources(src):
         if r.returncode != 0:
             raise RuntimeError(f'hipcc -S failed for {src}:\n{r.stderr}')
         text = open(asm).read()
+    loops = mfma_loop_lane_traffic(text)
     out = []
     meta = text[text.index('amdhsa.kernels:'):] if 'amdhsa.kernels:' in text else ''
     for blk in re.split(r'\n  - ', meta)[1:]:
         if '.vgpr_count:' not in blk:
             continue  # (amdhsa.version's list items)
         get = lambda k: int(re.search(rf'\.{k}:\s+(\d+)', blk).group(1))
-        out.append(dict(name=re.search(r'\.name:\s+(\S+)', blk).group(1),
+        name = re.search(r'\.name:\s+(\S+)', blk).group(1)
+        out.append(dict(name=name, mfma_loops=loops.get(name, []),
                         **{k: get(k) for k in ('vgpr_count', 'agpr_count', 'vgpr_spill_count',
                                                'sgpr_spill_count', 'private_segment_fixed_size',
                                                'group_segment_fixed_size')}))
+    return out
+
+
+def mfma_loop_lane_traffic(asm_text):
+    """Per kernel of an assembly listing: its INNERMOST loops that contain MFMAs (a backward branch whose
+    range holds no other backward branch -- the K loops), each as dict(mfma, lane_moves, barriers, dma):
+    lane_moves = v_readlane + v_writelane instructions inside the loop, i.e. SGPRs the register allocator
+    parked in VGPR lanes and restores on every pass.  The compiler spills dozens of uniform values of the
+    head kernels (kernel arguments, addresses of the decode epilogue); this is how a test pins that none
+    of that traffic sits in a K loop, where it would take VALU slots beside the MFMAs."""
+    import re
+    out = {}
+    for m in re.finditer(r'^(_Z\w+):[^\n]*\n', asm_text, flags=re.M):
+        name = m.group(1)
+        end = asm_text.find('.Lfunc_end', m.end())
+        if end < 0:
+            continue
+        body = asm_text[m.end():end].split('\n')
+        labels = {}
+        for i, line in enumerate(body):
+            lm = re.match(r'^(\.LBB\d+_\d+):', line)
+            if lm:
+                labels[lm.group(1)] = i
+        spans = []
+        for i, line in enumerate(body):
+            bm = re.search(r's_c?branch\S*\s+(\.LBB\d+_\d+)', line)
+            if bm and labels.get(bm.group(1), 1 << 30) <= i:
+                spans.append((labels[bm.group(1)], i))
+        inner = [sp for sp in spans if not any(o != sp and sp[0] <= o[0] and o[1] <= sp[1] for o in spans)]
+        loops = []
+        for a, b in inner:
+            seg = body[a:b + 1]
+            n = lambda key: sum(key in x for x in seg)
+            if n('v_mfma'):
+                loops.append(dict(mfma=n('v_mfma'), lane_moves=n('v_readlane') + n('v_writelane'),
+                                  barriers=n('s_barrier'), dma=n('global_load_lds')))
+        out[name] = loops
     return out
 
 

@@ -29,6 +29,7 @@
 //   4. vertical pass, re-gamma, store; pad pixels are written as 0.5 by the same tile walk.
 // Bound: HBM read of the uint8 frames (6.2 MB per 1080p frame); in practice the LDS pipe (two LDS
 // reads per horizontal tap, ~10 taps per intermediate value at 1080p).
+#include <atomic>
 #include <cmath>
 
 #include "common.h"
@@ -760,16 +761,32 @@ extern "C" int mtr_detector_geometry(int H, int W, int input_size, mtr_detector_
 
 // compute units of the current device (queried once per device and process; read-only)
 static int device_cu_count() {
-  static int cache[64] = {0};
+  static std::atomic<int> cache[64];  // (zero-initialised; racing first calls store the same value)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-  if (cache[dev] == 0) {
-    int n = 0;
+  int n = cache[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
       n = 256;
-    cache[dev] = n;
+    cache[dev].store(n, std::memory_order_relaxed);
   }
-  return cache[dev];
+  return n;
+}
+
+// The streaming kernel addresses its gamma table as "LDS address = permuted word": the dynamic LDS has to
+// start at address 0, i.e. the kernel must own no static LDS.  Asked of the code object once per
+// instantiation (1 = yes, -1 = no: the caller takes the tile kernel); the device-side trap stays as a backstop.
+template <typename Kern>
+static bool stream_kernel_lds_starts_at_zero(Kern kern) {
+  static std::atomic<int> known{0};
+  int k = known.load(std::memory_order_relaxed);
+  if (k == 0) {
+    hipFuncAttributes attr;
+    k = (hipFuncGetAttributes(&attr, (const void*)kern) == hipSuccess && attr.sharedSizeBytes == 0) ? 1 : -1;
+    if (k < 0) (void)hipGetLastError();
+    known.store(k, std::memory_order_relaxed);
+  }
+  return k > 0;
 }
 
 static const mtr::DetLut& detector_lut() { return mtr::gamma_lut_host(); }
@@ -852,6 +869,7 @@ static int launch_detector_stream(const uint8_t* images_u8, int N, int H, int W,
                      (size_t)(KT + 3) * mtr::kDTX * 4;
   auto kern = mtr::detector_stream_kernel<KT>;
   if (lds > 160 * 1024) return kDetNoStream;
+  if (!stream_kernel_lds_starts_at_zero(kern)) return kDetNoStream;
   const int rc = mtr::allow_dynamic_lds((const void*)kern, lds);
   if (rc != MTR_OK) return rc;
   long long per_strip = (long long)a.planes * a.n_seg;

@@ -30,6 +30,7 @@
 // (The first round's f32 joint-group kernels -- 16x16x4 and 32x32x2 cores, 64 padded rows per
 //  group, up to 339 spilled VGPRs on 12x12 and 16x16 maps -- are gone: the row-tile core covers
 //  every shape they did, faster, without scratch.)
+#include <cstring>
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -853,8 +854,17 @@ static bool head16_takes_rt(int C, int J, int D, int H, int W) {
   return !(mtr::h16_shape_ok(C, J, D) && H * W <= 256) && mtr::rt16_section_bytes(C, J, D) != 0;
 }
 
-static int parse_head_options(const mtr_head_options* options, mtr::HeadOpts& opt) {
-  if (!options) return MTR_OK;
+static int parse_head_options(const mtr_head_options* caller, mtr::HeadOpts& opt) {
+  if (!caller) return MTR_OK;
+  // versioned by its first member: the fields inside the caller's struct_size, the library's own choice
+  // (0; dma_staging: -1) for the ones behind it
+  const uint32_t size = caller->struct_size;
+  if (size < 8 || size > 256 || size % 4 != 0) return MTR_E_PARAM;
+  mtr_head_options mine;
+  memset(&mine, 0, sizeof mine);
+  mine.dma_staging = -1;
+  memcpy(&mine, caller, size < sizeof mine ? size : sizeof mine);
+  const mtr_head_options* options = &mine;
   if (options->rt_tiles_per_workgroup < 0 || options->rt_tiles_per_workgroup > 5 ||
       options->groups_per_workgroup < 0 || options->groups_per_workgroup > 3 ||
       options->dma_staging < -1 || options->dma_staging > 1 ||
@@ -921,8 +931,11 @@ extern "C" int mtr_head_fused_opts(const void* features, int feat_dtype, int lay
                                    int H, int W, const void* packed, int J, int D,
                                    const mtr_head_params* p, const mtr_head_options* options,
                                    float* coords2d, float* coords3d_rel, mtr_stream_t stream) {
-  return mtr_head_fused_ws(features, feat_dtype, layout, B, C, H, W, packed, J, D, p, options, nullptr, 0,
-                           coords2d, coords3d_rel, stream);
+  // (no workspace to offer: a shape that needs one has no fused kernel HERE -> MTR_E_SHAPE, the code callers
+  //  fall back to the library GEMM on)
+  const int rc = mtr_head_fused_ws(features, feat_dtype, layout, B, C, H, W, packed, J, D, p, options, nullptr, 0,
+                                   coords2d, coords3d_rel, stream);
+  return rc == MTR_E_WORKSPACE ? MTR_E_SHAPE : rc;
 }
 
 extern "C" int mtr_head_fused_ws(const void* features, int feat_dtype, int layout, int B, int C, int H,

@@ -1477,7 +1477,27 @@ int rt_pack(const float* weight, const float* bias, int C, int J, int D, void* s
 // r = 5 is 640 equal workgroups on 512 slots = 1.25 rounds (98 us), r = 4 is 960 workgroups of 4, 4, 2
 // tiles that pack the second round (92 us; the library pair: 96).
 struct RtPlan { int mode; int rtg; double us; };  // mode 0 = head_rt_kernel, 1 = loader-wave kernel
-constexpr int kRtModelCus = 256;
+constexpr int kRtModelCusDefault = 256;  // MI355X, SPX mode; no device (host-only mtr_head_plan in a CPU process)
+// CUs of the calling thread's current device (what the launch will run on): the plan simulates the launch on
+// that many -- an MI355X partition in CPX mode has 32 -- and its memo is keyed by it.  Cached per device id.
+static int rt_device_cus() {
+  static std::mutex mu;
+  static int cached[64] = {0};
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) {
+    (void)hipGetLastError();
+    return kRtModelCusDefault;
+  }
+  std::lock_guard<std::mutex> lock(mu);
+  if (dev < 64 && cached[dev] > 0) return cached[dev];
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+    (void)hipGetLastError();
+    return kRtModelCusDefault;
+  }
+  if (dev < 64) cached[dev] = cus;
+  return cus;
+}
 // two workgroups on a CU: how much longer their K loops run (the rest of a workgroup is unchanged), by
 // tiles per block of the launch -- measured at 1024 crops (10,240 .. 2,048 workgroups): blocks of 2 and of
 // 5 tiles share a CU well, blocks of 1 and 3 tiles are slower together than one after the other
@@ -1489,7 +1509,8 @@ static RtWgTime rt_wg_us(int mode, int r, int tiles, int k_loops, double stage_s
   const double per_tile = (mode == 1 ? 6.1 : (r <= 3 ? 6.3 : r == 4 ? 6.1 : 6.5)) * stage_scale;  // (measured alone: 30 us at r = 4)
   return RtWgTime{fixed + (k_loops - 1) * 3.0 /* a decode per further K loop */, k_loops * per_tile * tiles};
 }
-static double rt_launch_us(int mode, int r, long long crops, int n_tiles, int k_loops, double stage_scale) {
+static double rt_launch_us(int mode, int r, long long crops, int n_tiles, int k_loops, double stage_scale,
+                           int kRtModelCus) {
   const int per_crop = (n_tiles + r - 1) / r, last = n_tiles - (per_crop - 1) * r;
   const long long n_wg = crops * per_crop;
   const RtWgTime w_full = rt_wg_us(mode, r, r, k_loops, stage_scale), w_last = rt_wg_us(mode, r, last, k_loops, stage_scale);
@@ -1554,7 +1575,7 @@ static double rt_launch_us(int mode, int r, long long crops, int n_tiles, int k_
   }
   return now;
 }
-static RtPlan rt_plan(long long crops, const RtGeom& g, int k_loops, int C, int rtg_hint, int ld_hint) {
+static RtPlan rt_plan(long long crops, const RtGeom& g, int k_loops, int C, int rtg_hint, int ld_hint, int cus) {
   const double stage_scale = ((C + 31) / 32) / 40.0;
   const bool ld_ok = C % 32 == 0 && ld_hint != 1;
   RtPlan best{0, g.a > 1 ? g.a : 3, 1e30};
@@ -1563,7 +1584,7 @@ static RtPlan rt_plan(long long crops, const RtGeom& g, int k_loops, int C, int 
     for (int r = 1; r <= 5; ++r) {
       if (g.a > 1 && r != g.a) continue;                 // atoms of several tiles are one block
       if (g.a == 1 && rtg_hint >= 1 && rtg_hint <= 5 && r != rtg_hint) continue;
-      const double us = rt_launch_us(mode, r, crops, g.n_tiles, k_loops, stage_scale);
+      const double us = rt_launch_us(mode, r, crops, g.n_tiles, k_loops, stage_scale, cus);
       if (us < best.us) best = RtPlan{mode, r, us};
     }
   }
@@ -1572,27 +1593,33 @@ static RtPlan rt_plan(long long crops, const RtGeom& g, int k_loops, int C, int 
 
 // Which kernel a launch takes (shared by rt_launch and the host-only mtr_head_plan)
 static RtDispatch rt_dispatch_uncached(int B, int C, int H, int W, int J, int D, int rtg_hint, int np_hint,
-                                       int ks_hint, int ld_hint, int split_hint, bool have_workspace);
+                                       int ks_hint, int ld_hint, int split_hint, bool have_workspace, int cus);
 RtDispatch rt_dispatch(int B, int C, int H, int W, int J, int D, int rtg_hint, int np_hint, int ks_hint,
                        int ld_hint, int split_hint, bool have_workspace) {
-  // (the plan simulates the launch: once per shape and option set)
+  // The plan simulates the launch (0.5 - 20 ms of host time): memoised per process -- a pure function of
+  // the key, rebuilt identically on a miss.  The key holds the device's CU count and the batch size
+  // ROUNDED UP TO A MULTIPLE OF 8, which is all the plan reads of it (crops are dealt to XCDs in eights):
+  // a server whose box count changes from call to call meets an eighth of the keys.
   static std::mutex mu;
-  static std::map<std::array<int, 12>, RtDispatch> cache;
-  const std::array<int, 12> key{B, C, H, W, J, D, rtg_hint, np_hint, ks_hint, ld_hint, split_hint, (int)have_workspace};
+  static std::map<std::array<int, 13>, RtDispatch> cache;
+  const int cus = rt_device_cus();
+  const int B8 = (B + 7) / 8 * 8;
+  const std::array<int, 13> key{B8, C, H, W, J, D, rtg_hint, np_hint, ks_hint, ld_hint, split_hint,
+                                (int)have_workspace, cus};
   {
     std::lock_guard<std::mutex> lock(mu);
     const auto it = cache.find(key);
     if (it != cache.end()) return it->second;
   }
-  const RtDispatch d = rt_dispatch_uncached(B, C, H, W, J, D, rtg_hint, np_hint, ks_hint, ld_hint, split_hint,
-                                            have_workspace);
+  const RtDispatch d = rt_dispatch_uncached(B8, C, H, W, J, D, rtg_hint, np_hint, ks_hint, ld_hint, split_hint,
+                                            have_workspace, cus);
   std::lock_guard<std::mutex> lock(mu);
   if (cache.size() > 4096) cache.clear();
   cache[key] = d;
   return d;
 }
 static RtDispatch rt_dispatch_uncached(int B, int C, int H, int W, int J, int D, int rtg_hint, int np_hint,
-                                       int ks_hint, int ld_hint, int split_hint, bool have_workspace) {
+                                       int ks_hint, int ld_hint, int split_hint, bool have_workspace, int cus) {
   const RtGeom g = rt_geom(J, D);
   RtDispatch d{kRtKernelPlain, 3, 1, 0, 0, 0.0, 0};
   const int n_cb = (H * W + 63) / 64;
@@ -1602,14 +1629,14 @@ static RtDispatch rt_dispatch_uncached(int B, int C, int H, int W, int J, int D,
   // second launch) instead of one workgroup running n_cb K loops back to back: a launch of B crops
   // then has the shape of a launch of B * n_cb crops of 64 positions.  split_hint: 0 = when the
   // model says it pays, 1 = never, 2 = whenever a workspace is there.
-  RtPlan plan = rt_plan(crops8, g, n_cb, C, rtg_hint, ld_hint);
+  RtPlan plan = rt_plan(crops8, g, n_cb, C, rtg_hint, ld_hint, cus);
   if (n_cb >= 2 && have_workspace && split_hint != 1) {
     // a last column block of 16 (32) positions -- 12x12, 20x20, 28x28 (8x12, 16x10) maps: those of 4 (2)
     // consecutive crops in one workgroup
     const int tail = (H * W) % 64;
     const int pack = tail == 16 ? 4 : tail == 32 ? 2 : 0;
     const long long units = pack ? crops8 * (n_cb - 1) + crops8 / pack : crops8 * n_cb;  // "crops" of 64 positions
-    RtPlan sp = rt_plan(units, g, 1, C, rtg_hint, ld_hint);
+    RtPlan sp = rt_plan(units, g, 1, C, rtg_hint, ld_hint, cus);
     sp.us += 3.0;  // the merge launch
     if (split_hint == 2 || sp.us < plan.us) {
       plan = sp;
@@ -1629,7 +1656,7 @@ static RtDispatch rt_dispatch_uncached(int B, int C, int H, int W, int J, int D,
     if (np == 0) {
       np = n_cb == 2 ? 2 : (n_cb == 3 ? 3 : 4);
       if (n_cb > 4 && (n_cb + 2) / 3 * 3 - n_cb < (n_cb + 3) / 4 * 4 - n_cb) np = 3;  // less padding
-      if (crops8 * g.n_tiles > 256) np = 1;  // more than one round: two workgroups per CU (below)
+      if (crops8 * g.n_tiles > cus) np = 1;  // more than one round: two workgroups per CU (below)
     }
     if (np >= 2) {
       d.kernel = kRtKernelNp;

@@ -348,8 +348,8 @@ def head_fused(features, packed, C, n_points, cfg, out=None, rt_tiles=0, groups_
                 workspace = torch.empty((need + 7) // 8, device=features.device, dtype=torch.float64)
             require_cuda(workspace)
             ws_ptr, ws_bytes = _ptr(workspace), workspace.numel() * workspace.element_size()
-    opts = _lib.HeadOptions(int(rt_tiles), int(groups_per_workgroup), int(dma_staging),
-                            int(rt_column_blocks), int(rt_k_groups), int(rt_loader), int(rt_split))
+    opts = _lib.head_options(rt_tiles, groups_per_workgroup, dma_staging, rt_column_blocks, rt_k_groups,
+                             rt_loader, rt_split)
     check(lib.mtr_head_fused_ws(
         _ptr(features), dtype_code(features.dtype), layout, B, C, H, W, _ptr(packed), J, D,
         ctypes.byref(hp), ctypes.byref(opts), ws_ptr, ws_bytes, _ptr(c2d), _ptr(c3d),
@@ -363,10 +363,9 @@ def head_plan(B, C, H, W, n_points, depth, dtype=torch.float32, channels_last=Fa
     tiles_per_workgroup, column_blocks, split_column_blocks, workgroups, model_us) or None when the shape has
     no fused kernel.  options: as head_fused."""
     lib = _lib.load()
-    opts = _lib.HeadOptions(int(options.get('rt_tiles', 0)), int(options.get('groups_per_workgroup', 0)),
-                            int(options.get('dma_staging', -1)), int(options.get('rt_column_blocks', 0)),
-                            int(options.get('rt_k_groups', 0)), int(options.get('rt_loader', 0)),
-                            int(options.get('rt_split', 0)))
+    opts = _lib.head_options(**{k: options[k] for k in ('rt_tiles', 'groups_per_workgroup', 'dma_staging',
+                                                        'rt_column_blocks', 'rt_k_groups', 'rt_loader', 'rt_split')
+                                if k in options})
     info = _lib.HeadPlanInfo()
     rc = lib.mtr_head_plan(dtype_code(dtype), _lib.MTR_NHWC if channels_last else _lib.MTR_NCHW, int(B), int(C),
                            int(H), int(W), int(n_points), int(depth), ctypes.byref(opts), int(bool(have_workspace)),

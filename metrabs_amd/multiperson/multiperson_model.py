@@ -451,8 +451,12 @@ class Pose3dEstimator(torch.nn.Module):
             plan = self.graphs.plan_call(images, ranges, tta, antialias_factor, post)
         if plan is not None:
             pyramid = plan.frames.load(images)   # static frame + pyramid buffers the graphs read
+        elif (dev.type == 'cuda' and not images.is_cuda and images.is_pinned() and len(images)
+              and not per_batch_pyramids):
+            # pinned host frames: the PCIe copy runs on a copy stream under the previous call's compute
+            pyramid = self.graphs.frame_set(len(images), images.shape[2], images.shape[3], dev).load(images)
         else:
-            images = images.to(dev, non_blocking=True)
+            images = images.to(dev)
             pyramid = kernels.build_pyramid(images) if len(images) and not per_batch_pyramids else None
         if exact:
             if not hasattr(self.crop_model, 'exact_monolithic'):

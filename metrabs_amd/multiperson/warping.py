@@ -47,14 +47,20 @@ def warp_images_with_pyramid(images, intrinsic_matrix, new_invprojmats, distorti
                              crop_scales, output_shape, image_ids, n_pyramid_levels=3):
     """warping.warp_images_with_pyramid (warping.py:6-28).
 
-    images: f32 linear-light [N,3,H,W] on the GPU, or an already built kernels.Pyramid."""
-    if n_pyramid_levels != 3:
-        raise NotImplementedError('the HIP sampler implements the reference default of 3 levels')
-    if output_shape[0] != output_shape[1]:
-        raise NotImplementedError('square crops only (the reference only requests res x res)')
+    images: f32 linear-light [N,3,H,W] on the GPU, or an already built kernels.Pyramid.
+    n_pyramid_levels 1..3: the level of a crop is clipped to n - 1 (warping.py:20-21), so fewer levels are the
+    3-level pyramid with the coarse ones never chosen.  output_shape (h, w): the sampler produces squares; a
+    rectangle is the top-left h x w of the max(h, w) square (an output pixel's source position does not depend
+    on the output size, warping.py:41-54) -- the reference's own callers only ask for res x res."""
+    n_pyramid_levels = int(n_pyramid_levels)
+    if not 1 <= n_pyramid_levels <= 3:
+        raise NotImplementedError('the HIP sampler holds a pyramid of 3 levels (the reference default); '
+                                  f'n_pyramid_levels={n_pyramid_levels}')
+    out_h, out_w = int(output_shape[0]), int(output_shape[1])
     pyr = images if isinstance(images, kernels.Pyramid) else kernels.pyramid_from_level0(images)
     dev = pyr.device
     wp = make_warp_params(
         intrinsic_matrix.to(dev), new_invprojmats.to(dev), distortion_coeffs.to(dev),
         crop_scales.to(dev), image_ids.to(dev), None, n_pyramid_levels)
-    return kernels.warp_crops(pyr, wp, output_shape[0], antialias=1)
+    crops = kernels.warp_crops(pyr, wp, max(out_h, out_w), antialias=1)
+    return crops if out_h == out_w else crops[..., :out_h, :out_w].contiguous()

@@ -126,6 +126,52 @@ def gen_parity(ref, only=None):
                  input_sha256=np.array(cases.sha256_of(feat, w, b, K)))
 
 
+def gen_jitter(ref, only=None, runs=3):
+    """How far the REFERENCE moves against itself: its MetrabsHeads.forward + reconstruct_absolute run
+    `runs` more times on the inputs of every parity-gate golden (torch.linalg.lstsq and the threaded conv
+    are not run-to-run deterministic) -> tests/golden/parity_reference_jitter.json: per case the largest
+    |difference| (mm) and MPJPE between any two of {the stored golden, the new runs}.  The stored goldens
+    are NOT rewritten.  bench.py prints these numbers beside its parity object so that "within 1e-3 mm of
+    the reference" is read against the reference's own spread."""
+    import itertools
+    import json
+    from oracle import cpu_ref
+    path = os.path.join(OUT_DIR, 'parity_reference_jitter.json')
+    out = json.load(open(path)) if os.path.exists(path) else {}
+    for name, (B, C, J, hw, P, D, dtype) in cases.PARITY_GATE_SHAPES.items():
+        for regime in cases.PARITY_GATE_REGIMES:
+            slug = cases.parity_gate_slug(name, regime)
+            if only and only not in slug:
+                continue
+            feat, w, b, K = cases.parity_gate_inputs(name, regime)
+            wk = cases.head_weights_as_consumed(w, dtype)
+            ocfg = cpu_ref.HeadConfig(proc_side=P, depth=D)
+            stored = torch.from_numpy(np.load(os.path.join(OUT_DIR, slug + '.npz'))['poses3d'])
+            results = [stored]
+            with rh.config(**cfg_kwargs(ocfg)), torch.inference_mode():
+                heads = ref.metrabs_model.MetrabsHeads(n_points=J).eval()
+                conv = torch.nn.Conv2d(C, J * (1 + D), 1)
+                conv.weight.copy_(wk[:, :, None, None])
+                conv.bias.copy_(b)
+                heads.conv_final = conv
+                for _ in range(runs):
+                    c2d, c3d = heads(feat.float())
+                    results.append(rh.plain(ref.ptu3d.reconstruct_absolute(
+                        c2d, c3d, K, mix_3d_inside_fov=ocfg.mix_3d_inside_fov,
+                        weak_perspective=ocfg.weak_perspective)).clone())
+            pairs = list(itertools.combinations(range(len(results)), 2))
+            out[slug] = dict(
+                runs=runs, cpu=cpu_tag(),
+                run_to_run_max_mm=max(float((results[i] - results[j]).abs().max()) for i, j in pairs),
+                run_to_run_mpjpe_mm=max(cpu_ref.mpjpe(results[i], results[j]) for i, j in pairs),
+                new_runs_vs_stored_max_mm=max(float((results[i] - stored).abs().max()) for i in range(1, len(results))),
+                new_runs_among_themselves_max_mm=max([float((results[i] - results[j]).abs().max())
+                                                      for i, j in pairs if i and j] or [0.0]))
+            print(slug, out[slug], flush=True)
+            with open(path, 'w') as f:
+                json.dump(out, f, indent=1, sort_keys=True)
+
+
 def gen_recon(ref, only=None):
     for name in cases.RECON_CASES:
         if only and name != only:
@@ -348,8 +394,8 @@ def main():
     ref = rh.load()
     groups = dict(heads=gen_heads, headconv=gen_headconv, recon=gen_recon, warp=gen_warp,
                   tta=gen_tta, e2e=gen_e2e, detpre=gen_detpre, filter=gen_filter, backbone=gen_backbone,
-                  parity=gen_parity)
-    for name in (sys.argv[1:] or groups):
+                  parity=gen_parity, jitter=gen_jitter)
+    for name in (sys.argv[1:] or [g for g in groups if g != 'jitter']):
         if ':' in name:  # one case of a group (recon, e2e: their lstsq goldens carry run-to-run jitter)
             group, only = name.split(':', 1)
             groups[group](ref, only=only)

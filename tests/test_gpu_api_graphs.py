@@ -56,6 +56,17 @@ def test_graphed_api_equals_eager_bit_for_bit(name, hip_lib):
     a3, _ = _call(eager, images, boxes, K, case)
     b3, _ = _call(graphed, images.numpy(), boxes, K, case)
     assert torch.equal(a3, b3)
+    # pinned host frames: copied on the copy stream through two staging buffers (both paths); the caller's
+    # buffer may be overwritten as soon as the call returns
+    pinned = images.clone().pin_memory()
+    for est in (eager, graphed):
+        for seed in (15, 16):
+            fresh, boxes, K = _inputs(case, seed, 4, per_image)
+            pinned.copy_(fresh)
+            want = _call(eager, fresh.cuda(), boxes, K, case)[0]
+            got = _call(est, pinned, boxes, K, case)[0]
+            pinned.zero_()   # (the call has returned: its copy must not see this)
+            assert torch.equal(want, got)
     # another camera set-up / skeleton-free call with other options: new key, still equal
     a3, a2 = _call(eager, images.cuda(), boxes, K, case, average_aug=not case['average_aug'])
     b3, b2 = _call(graphed, images.cuda(), boxes, K, case, average_aug=not case['average_aug'])

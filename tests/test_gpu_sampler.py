@@ -65,6 +65,28 @@ def test_warp_dropin_vs_golden(name, hip_lib):
     assert float(d.max()) <= LIN_MAX and float(d.mean()) <= LIN_MEAN
 
 
+@pytest.mark.parametrize('n_levels,shape', [(1, None), (2, None), (3, 'tall'), (2, 'wide')])
+def test_warp_dropin_pyramid_levels_and_rectangular_output(n_levels, shape, hip_lib):
+    """The rest of the reference signature (warping.py:6-28): n_pyramid_levels 1..3 and a rectangular
+    output_shape, against the oracle's restatement on the same arguments (the reference's own callers use
+    neither; more than 3 levels raise)."""
+    from metrabs_amd.multiperson import warping
+    name = next(iter(cases.WARP_CASES))
+    c = cases.warp_case(name)
+    res = c['res']
+    out_shape = {None: (res, res), 'tall': (res, res - 8), 'wide': (res - 12, res)}[shape]
+    args = (c['K'], c['hinv'], c['dist'], c['crop_scales'])
+    ours = warping.warp_images_with_pyramid(c['images'].cuda(), *[a.cuda() for a in args], out_shape,
+                                            c['image_ids'].cuda(), n_pyramid_levels=n_levels).cpu()
+    ref = cpu_ref.warp_images_with_pyramid(c['images'], *args, out_shape, c['image_ids'], n_pyramid_levels=n_levels)
+    assert ours.shape == ref.shape == (len(c['image_ids']), 3, *out_shape)
+    d = (ours - ref).abs()
+    assert float(d.max()) <= LIN_MAX and float(d.mean()) <= LIN_MEAN
+    with pytest.raises(NotImplementedError):
+        warping.warp_images_with_pyramid(c['images'].cuda(), *[a.cuda() for a in args], out_shape,
+                                         c['image_ids'].cuda(), n_pyramid_levels=4)
+
+
 def test_warp_kat_identity_and_zero_padding(hip_lib):
     """SURVEY 8c KAT 3 on the GPU."""
     from metrabs_amd.multiperson import warping

