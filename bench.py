@@ -87,6 +87,11 @@ def parse_args():
                          'all-gather of the poses in every step on device tensors (eager behind the replay, or '
                          'inside the graph with --graph-gather): RCCL load, communicator and the collective itself '
                          'exercised on a 1-GPU box; the line carries `multi_gpu` with backend "nccl"')
+    ap.add_argument('--step', default='auto', choices=['auto', 'api', 'pipeline'],
+                    help='what a timed step calls.  api (default for the weak-scaling configs 1 and 3): '
+                         'Pose3dEstimator.estimate_poses_batched -- the drop-in surface itself, device-resident frames, '
+                         'host boxes / cameras, the estimator\'s own HIP-graph cache; pipeline (configs 2 and 4, and '
+                         '--graph-gather): a bare replay of the captured internal batch (GraphedCropPipeline)')
     ap.add_argument('--no-api-path', action='store_true',
                     help='skip the `api_path` probe (crops/s through Pose3dEstimator.estimate_poses_batched)')
     ap.add_argument('--quick', action='store_true',
@@ -908,8 +913,41 @@ def main():
             pipe.capture()
             gather_mode += f' [--graph-gather failed: {str(e)[:120]}]'
 
+    # ---- the timed step of the weak-scaling configs goes through the drop-in API itself
+    step_mode = args.step
+    if step_mode == 'auto':
+        step_mode = 'pipeline' if (strong or args.graph_gather or args.no_graph) else 'api'
+    if step_mode == 'api' and strong:
+        raise SystemExit('--step api: the strong-scaling configs replay one captured internal batch per owned batch')
+    api_call = None
+    if step_mode == 'api':
+        per_frame = [int((pipe.image_ids == i).sum()) for i in range(args.frames)]
+        order = torch.argsort(pipe.image_ids.long(), stable=True)   # the API takes boxes frame by frame
+        boxes_sorted = pipe.boxes[order].cpu()
+        api_boxes = [b.numpy().copy() for b in torch.split(boxes_sorted, per_frame)]
+        api_K = pipe.intrinsics[order].cpu()[torch.cumsum(torch.tensor([0] + per_frame[:-1]), 0)].numpy().copy()
+        est.graph_batches = True
+        api_kw = dict(intrinsic_matrix=api_K, internal_batch_size=n_box * args.num_aug, num_aug=args.num_aug)
+
+        def api_call():
+            res = est.estimate_poses_batched(pipe.images, api_boxes, **api_kw)
+            return torch.cat(res['poses3d'])
+
+        with torch.inference_mode():
+            first = api_call()
+            # the API's internal batch is the pipeline's (same kernels, same shapes) with the boxes in frame
+            # order: reported, not required to the bit (another batch order = another order of the f64 sums
+            # of the reconstruction's batch-global RMS)
+            want = pipe.run()[order]
+            api_vs_pipeline_max_mm = float((first - want).abs().max())
+            if not torch.isfinite(first).all() or api_vs_pipeline_max_mm > 0.1:
+                raise SystemExit(f'bench: the API step and the captured pipeline disagree (max {api_vs_pipeline_max_mm} mm)')
+
     def step():
-        if strong:
+        if api_call is not None:
+            with torch.inference_mode():
+                poses = api_call()
+        elif strong:
             for b in range(my_batches):
                 shard_out[b * n_box:(b + 1) * n_box].copy_(pipe.run(), non_blocking=True)
             poses = shard_out
@@ -951,7 +989,7 @@ def main():
         per_rank = [float(t.item()) for t in per_rank]
         elapsed = max(per_rank)
         n_g = max(10, args.steps)
-        poses_now = (shard_out if strong else pipe.poses).contiguous()
+        poses_now = (shard_out if strong else (api_call() if api_call is not None else pipe.poses)).contiguous()
         torch.cuda.synchronize()
         torch.distributed.barrier()
         tg = time.perf_counter()
@@ -1013,6 +1051,14 @@ def main():
                    'global_batch': crops_per_step, 'parallelism': f'dp{world} (crops sharded, one '
                    f'all-gather of poses)' if world > 1 else 'single GPU',
                    'hip_graph': not args.no_graph,
+                   'step_through': ('Pose3dEstimator.estimate_poses_batched(frames on the device, host boxes and '
+                                    'cameras) with the estimator\'s own HIP-graph cache (graph_batches=True): per step '
+                                    'the host camera set-up, one pinned upload of the per-box parameters, the frames '
+                                    'copied into the sampler\'s buffer, the pyramid, one graph launch, the result '
+                                    'cloned out and split per frame' if step_mode == 'api' else
+                                    'a bare replay of the captured internal batch (metrabs_amd.pipeline.'
+                                    'GraphedCropPipeline) on static inputs'),
+                   'api_step_vs_captured_pipeline_max_mm': api_vs_pipeline_max_mm if step_mode == 'api' else None,
                    'backbone': 'PyTorch-ROCm (dense convolutions on rocBLAS / MIOpen' + (
                        '; depthwise layers on PyTorch\'s own kernel' if args.no_fold_bn else
                        '; inference batch norm folded into the convolutions' + (

@@ -505,12 +505,18 @@ __device__ __forceinline__ v4u lds_read_tr16_pair(const char* p0, const char* p1
         dma16_to_lds(b_src[i] + (size_t)(STAGE) * b_stage_elems, (BB) + (i * 4 + wid) * 1024);    \
   }
 
-template <typename FeatT, int CT, int GPW, bool NHWC>
-__global__ __launch_bounds__(256) void head_fused16dma_kernel(
+// LD (round 4): 320 threads -- a FIFTH wave is the loader.  It issues every global_load_lds of a stage (the
+// 4 x (2 GPW + CT) wave-copies the four MFMA waves used to issue between their fragment reads and their
+// MFMAs, 60 - 185 issue cycles each beside MFMAs, MI355X_MICROARCH.md "LDS-DMA piece issue cost"), waits for
+// them and meets the MFMA waves at the stage barrier; those run barrier, fragment reads, MFMAs.  Same
+// stages, same MFMA order, same sums: the bits of the four-wave kernel.
+template <typename FeatT, int CT, int GPW, bool NHWC, bool LD = false>
+__global__ __launch_bounds__(LD ? 320 : 256) void head_fused16dma_kernel(
     const FeatT* __restrict__ feat, const float* __restrict__ packed, int B, int C, int H, int W,
     int J, int D, HeadGeom g, HeadScale hs, float* __restrict__ coords2d,
     float* __restrict__ coords3d_rel) {
   constexpr int TPW = (CT + 1) / 2;
+  constexpr int NT = LD ? 320 : 256;
   constexpr int HWP = hw_pad32<CT>();
   constexpr int A_STAGE = GPW * kRows * 128;  // bytes
   constexpr int B_STAGE = CT * 32 * 128;      // bytes
@@ -527,14 +533,72 @@ __global__ __launch_bounds__(256) void head_fused16dma_kernel(
   const int grp0 = ((id % chunk) / 8) * GPW;
   if (crop >= B) return;
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_loader = LD && wid == 4;  // (wave-uniform)
   const int n_st = C / kKH;
   const float* bias = packed;
   const FeatT* w16 = reinterpret_cast<const FeatT*>(packed + (size_t)g.n_groups * kRows);
   const FeatT* fcrop = feat + (size_t)crop * C * HW;
 
-  for (int v = tid; v < 2 * B_STAGE / 16; v += 256)
+  for (int v = tid; v < 2 * B_STAGE / 16; v += NT)
     reinterpret_cast<v4u*>(Bs)[v] = v4u{0u, 0u, 0u, 0u};
+
+  if constexpr (LD) {
+    if (is_loader) {
+      // every wave-copy of a stage: (i, w) = load i of MFMA wave w in the four-wave kernel
+      const int lr = lane >> 3, ls = lane & 7;
+      const int n_chunks = HW >> 3;
+      const size_t b_stage_elems = NHWC ? (size_t)kKH : (size_t)kKH * HW;
+      const FeatT* a_src[2 * GPW * 4];
+      const FeatT* b_src[CT * 4];
+      bool b_on[CT * 4];
+#pragma unroll
+      for (int iw = 0; iw < 2 * GPW * 4; ++iw) {
+        const int row = iw * 8 + lr;  // (i * 4 + w) * 8 + lr
+        const int grp = min(grp0 + (row >> 6), g.n_groups - 1);
+        a_src[iw] = w16 + (size_t)grp * n_st * (kRows * kKH) + (row & 63) * kKH + ((ls ^ swz(row)) << 3);
+      }
+#pragma unroll
+      for (int iw = 0; iw < CT * 4; ++iw) {
+        if constexpr (NHWC) {
+          const int pos = iw * 8 + lr;
+          b_on[iw] = pos < HW;
+          b_src[iw] = fcrop + (size_t)(b_on[iw] ? pos : 0) * C + ((ls ^ swz(pos)) << 3);
+        } else {
+          const int cid = iw * 64 + lane;
+          b_on[iw] = cid < kKH * n_chunks;
+          const int k = b_on[iw] ? cid / n_chunks : 0, jl = b_on[iw] ? cid - k * n_chunks : 0;
+          const int rot = ((k >> 1) & 1) << 2;
+          const int j = jl >= rot ? jl - rot : jl - rot + n_chunks;
+          b_src[iw] = fcrop + (size_t)k * HW + j * 8;
+        }
+      }
+      auto issue = [&](int stage, char* AB, char* BB) {
+#pragma unroll
+        for (int iw = 0; iw < 2 * GPW * 4; ++iw)
+          dma16_to_lds(a_src[iw] + (size_t)stage * (kRows * kKH), AB + iw * 1024);
+#pragma unroll
+        for (int iw = 0; iw < CT * 4; ++iw)
+          if (b_on[iw]) dma16_to_lds(b_src[iw] + (size_t)stage * b_stage_elems, BB + iw * 1024);
+      };
+      __syncthreads();  // zero fill done
+      issue(0, As, Bs);
+      for (int st = 0; st < n_st; ++st) {
+        __syncthreads();  // (the compiler waits for this wave's copies of stage st in front of the barrier)
+        const int cur = st & 1;
+        if (st + 1 < n_st) issue(st + 1, As + (cur ^ 1) * A_STAGE, Bs + (cur ^ 1) * B_STAGE);
+      }
+      // the epilogue's barriers (two per joint group of the workgroup), nothing to do in between
+#pragma unroll
+      for (int q = 0; q < GPW; ++q) {
+        __syncthreads();
+        if (grp0 + q >= g.n_groups) break;
+        __syncthreads();
+      }
+      return;
+    }
+  }
 
   // per-lane sources of this wave's loads, stage 0.  Load i of the weights covers tile rows
   // (i * 4 + wid) * 8 .. + 7, load i of the features positions (i * 4 + wid) * 8 .. + 7; lane L is
@@ -608,7 +672,7 @@ __global__ __launch_bounds__(256) void head_fused16dma_kernel(
     for (int t = 0; t < TPW; ++t) acc[k][t] = f32x16{0};
 
   __syncthreads();  // zero fill done
-  HEAD16_DMA_ISSUE(0, As, Bs)
+  if constexpr (!LD) HEAD16_DMA_ISSUE(0, As, Bs)
   for (int st = 0; st < n_st; ++st) {
     __syncthreads();  // stage st has landed; every wave finished reading the other buffer
     const int cur = st & 1;
@@ -631,7 +695,8 @@ __global__ __launch_bounds__(256) void head_fused16dma_kernel(
       }
     }
     // (behind the last stage: a repeat into the idle buffer)
-    HEAD16_DMA_ISSUE(min(st + 1, n_st - 1), As + (cur ^ 1) * A_STAGE, Bs + (cur ^ 1) * B_STAGE)
+    if constexpr (!LD)
+      HEAD16_DMA_ISSUE(min(st + 1, n_st - 1), As + (cur ^ 1) * A_STAGE, Bs + (cur ^ 1) * B_STAGE)
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -680,6 +745,14 @@ struct HeadOpts {
   int dma = -1;              // 16-bit: -1 auto, 0 = stage through registers, 1 = global_load_lds
 };
 
+// the loader-wave instantiation of the DMA kernel: dma_staging 2 = always, 1 = never (the four-wave kernel),
+// -1 (auto) = per the measured table below
+static bool head16_loader_wave(const HeadOpts& opt, int ct, int gpw) {
+  if (opt.dma == 2) return true;
+  if (opt.dma == 1) return false;
+  return false;  // (auto: decided after the A/B on MI355X)
+}
+
 template <typename FeatT, int CT, int GPW, bool NHWC>
 static int launch_head16(const void* feat, const float* packed, int B, int C, int H, int W, int J,
                          int D, const HeadGeom& g, const HeadScale& hs, float* c2d, float* c3d,
@@ -692,6 +765,18 @@ static int launch_head16(const void* feat, const float* packed, int B, int C, in
   // stages exist; NHWC: any map; NCHW: whole 16-byte chunks per channel row (H*W % 8 == 0, at
   // least the 8 chunks the bank rotation assumes)
   const bool dma_ok = C % kKH == 0 && (NHWC || ((H * W) % 8 == 0 && H * W >= 64));
+  if (opt.dma != 0 && dma_ok && head16_loader_wave(opt, CT, GPW)) {
+    auto dma = head_fused16dma_kernel<FeatT, CT, GPW, NHWC, true>;
+    if (lds > 64 * 1024) {
+      const int rc = allow_dynamic_lds((const void*)dma, lds);
+      if (rc != MTR_OK) return rc;
+    }
+    MTR_CLEAR_STALE();
+    hipLaunchKernelGGL(dma, dim3((unsigned)blocks), dim3(320), lds, stream, (const FeatT*)feat,
+                       packed, B, C, H, W, J, D, g, hs, c2d, c3d);
+    MTR_CHECK_LAUNCH();
+    return MTR_OK;
+  }
   if (opt.dma != 0 && dma_ok) {
     auto dma = head_fused16dma_kernel<FeatT, CT, GPW, NHWC>;
     if (lds > 64 * 1024) {
@@ -867,7 +952,7 @@ static int parse_head_options(const mtr_head_options* caller, mtr::HeadOpts& opt
   const mtr_head_options* options = &mine;
   if (options->rt_tiles_per_workgroup < 0 || options->rt_tiles_per_workgroup > 5 ||
       options->groups_per_workgroup < 0 || options->groups_per_workgroup > 3 ||
-      options->dma_staging < -1 || options->dma_staging > 1 ||
+      options->dma_staging < -1 || options->dma_staging > 2 ||
       options->rt_column_blocks < 0 || options->rt_column_blocks > 4 ||
       options->rt_k_groups < 0 || options->rt_k_groups > 2 ||
       options->rt_loader < 0 || options->rt_loader > 2 ||

@@ -29,9 +29,13 @@ from metrabs_amd import kernels
 class FrameSet:
     def __init__(self, n, h, w, device):
         self.key = (n, h, w, str(device))
-        self.images = torch.empty(n, 3, h, w, dtype=torch.uint8, device=device)
-        _, l1, l2 = kernels._alloc_levels(n, h, w, device, with_level0=False)
-        lut = torch.empty(256, device=device, dtype=torch.float32)
+        # (buffers that outlive the call and are written in place by later ones: made OUTSIDE inference mode,
+        #  or a first call under torch.inference_mode() would leave inference tensors that a later call under
+        #  plain no_grad may not update)
+        with torch.inference_mode(False):
+            self.images = torch.empty(n, 3, h, w, dtype=torch.uint8, device=device)
+            _, l1, l2 = kernels._alloc_levels(n, h, w, device, with_level0=False)
+            lut = torch.empty(256, device=device, dtype=torch.float32)
         self.pyramid = kernels.Pyramid([None, l1, l2], images_u8=self.images, lut=lut)
         self._copy_stream = None   # pinned host frames: H2D on a stream of its own, two staging buffers
         self._staging, self._staging_free, self._turn = None, None, 0
@@ -50,7 +54,8 @@ class FrameSet:
             cur = torch.cuda.current_stream(dev)
             if self._copy_stream is None:
                 self._copy_stream = torch.cuda.Stream(dev)
-                self._staging = [torch.empty_like(self.images) for _ in range(2)]
+                with torch.inference_mode(False):
+                    self._staging = [torch.empty_like(self.images) for _ in range(2)]
                 self._staging_free = [torch.cuda.Event() for _ in range(2)]
             self._turn ^= 1
             b = self._turn
@@ -73,7 +78,8 @@ class BatchGraph:
 
     def __init__(self, est, frames, batch_args, tta, antialias_factor, post, warmup=2):
         self.frames = frames
-        self.static = [torch.empty_like(a, memory_format=torch.contiguous_format) for a in batch_args]
+        with torch.inference_mode(False):  # (written in place by every later replay, whatever mode it runs under)
+            self.static = [torch.empty(a.shape, dtype=a.dtype, device=a.device) for a in batch_args]
         self._load(batch_args)
         body = lambda: est._batch_with_postprocess(frames.pyramid, *self.static, tta, antialias_factor, post)
         side = torch.cuda.Stream()

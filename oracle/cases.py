@@ -160,6 +160,41 @@ def consistent_head_case(B, C, J, hw, proc_side, D, amp, seed, spread=0.18):
     return feat.reshape(B, C, hw, hw).float(), w.float(), b.float(), K
 
 
+def consistent_head_for_features(features, J, D, proc_side, amp, seed, spread=0.18, ridge=1e-6):
+    """The converse of consistent_head_case for GIVEN features (a real backbone's output, [B,C,h,w] with
+    B*h*w <= C): conv_final parameters under which THESE features describe a plausible pose -- the same
+    Gaussian-bump target logits, W = T F^T (F F^T + ridge * mean diag)^-1 in float64 (a ridge keeps the
+    weights small when the backbone's features are nearly dependent; the logits then equal the targets
+    only approximately, which is all that is asked: peaked heatmaps, a person 2.5 - 4.5 m away), bias 0.
+    -> (weight [N, C] f32, bias [N] f32, K [B,3,3])"""
+    B, C, hw, hw2 = features.shape
+    assert hw == hw2 and B * hw * hw <= C
+    g = gen(seed)
+    f = (450 + 100 * torch.rand(B, generator=g)) * proc_side / 256
+    K = torch.zeros(B, 3, 3)
+    K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2], K[:, 2, 2] = f, f, proc_side / 2, proc_side / 2, 1
+    rel = (torch.randn(B, J, 3, generator=g, dtype=torch.float64) *
+           torch.tensor([0.13, 0.17, 0.12], dtype=torch.float64)).clamp(-0.3, 0.3)
+    u3 = 0.5 + rel
+    u2 = 0.5 + rel[..., :2] / (1.0 + 0.5 * rel[..., 2:])
+    gx = torch.linspace(0, 1, hw, dtype=torch.float64)
+    gz = torch.linspace(0, 1, D, dtype=torch.float64)
+    d2 = ((gx[None, None, None, :] - u2[..., 0, None, None]) ** 2 +
+          (gx[None, None, :, None] - u2[..., 1, None, None]) ** 2)
+    l2 = amp * torch.exp(-d2 / (2 * spread * spread))
+    d3 = ((gx[None, None, None, None, :] - u3[..., 0, None, None, None]) ** 2 +
+          (gx[None, None, None, :, None] - u3[..., 1, None, None, None]) ** 2 +
+          (gz[None, None, :, None, None] - u3[..., 2, None, None, None]) ** 2)
+    l3 = amp * torch.exp(-d3 / (2 * spread * spread))
+    target = torch.cat([l2, l3.permute(0, 2, 1, 3, 4).reshape(B, D * J, hw, hw)], dim=1)   # [B, N, h, w]
+    T = target.permute(1, 0, 2, 3).reshape(J * (1 + D), B * hw * hw)                        # [N, B*HW]
+    F = features.double().permute(1, 0, 2, 3).reshape(C, B * hw * hw)                        # [C, B*HW]
+    gram = F.T @ F                                                                           # [BHW, BHW]
+    gram = gram + ridge * gram.diagonal().mean() * torch.eye(gram.shape[0], dtype=torch.float64)
+    w = torch.linalg.solve(gram, T.T).T @ F.T                                                # [N, C]
+    return w.float(), torch.zeros(J * (1 + D)), K
+
+
 # ---- the features -> poses3d parity gates (tests/test_gpu_parity_gates.py, bench.py's parity probe):
 # every BASELINE.json config shape and the metric string's 72 depth bins.
 # name: (B, C, J, map side, proc_side, depth bins, feature dtype)

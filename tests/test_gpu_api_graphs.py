@@ -90,6 +90,29 @@ def test_auto_mode_captures_on_the_second_occurrence_and_results_do_not_alias(hi
     assert not torch.equal(r3[0], r2[0])
 
 
+def test_calls_under_inference_mode_and_plain_no_grad_share_the_cache(hip_lib):
+    """The static buffers of the cache outlive the call that made them: a first call under
+    torch.inference_mode() must not leave inference tensors that a later call outside it cannot update (and
+    the other way round) -- device frames, pinned host frames, captured batches."""
+    case = cases.e2e_case('aug5')
+    ref = build_estimator(case, 'auto')
+    ref.graph_batches = False
+    for first_inference in (True, False):
+        est = build_estimator(case, 'auto')
+        est.graph_batches = True
+        for i, seed in enumerate((51, 52, 53, 54)):
+            images, boxes, K = _inputs(case, seed, 2, [2, 2])
+            frames = images.pin_memory() if i >= 2 else images.cuda()
+            want = _call(ref, images.cuda(), boxes, K, case)[0]
+            if (i % 2 == 0) == first_inference:
+                with torch.inference_mode():
+                    got = _call(est, frames, boxes, K, case)[0]
+            else:
+                got = _call(est, frames, boxes, K, case)[0]
+            assert torch.equal(want, got), (first_inference, i)
+        assert est.graphs.stats['replays'] >= 2
+
+
 def test_frame_set_eviction_drops_the_graphs_that_read_it(hip_lib):
     case = cases.e2e_case('aug5')
     ref = build_estimator(case, 'auto')

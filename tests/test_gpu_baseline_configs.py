@@ -82,25 +82,42 @@ def test_end_to_end_every_backbone_family(backbone, res, num_aug, hip_lib):
     # (no bitwise repeatability check here: MIOpen / rocBLAS may change algorithm between calls;
     #  the hand-written kernels' determinism is asserted bitwise in the permutation tests)
     g = torch.Generator(device='cuda').manual_seed(9)
-    n = 6
+    n = 4
     crops = torch.rand(n, 3, res, res, device='cuda', generator=g)
-    K = torch.stack([cases.intrinsics_for(res, res, 40.0 + 3 * i, 100 + i) for i in range(n)])
     ocfg = cpu_ref.HeadConfig(proc_side=res)
     with torch.inference_mode():
         feat = model.backbone(crops)
+    # conv_final parameters under which THESE features describe a plausible pose (a default-initialised
+    # conv_final on real features is the ill-conditioned "random head" regime of test_gpu_parity_gates.py:
+    # nearly uniform heatmaps, reference-point depth ~0, where the fp32 reference itself is up to 4.5e-3 mm
+    # from an fp64 evaluation and no bound holds from run to run)
+    w, b, K = cases.consistent_head_for_features(feat.cpu(), 17, 8, res, amp=8.0, seed=1000 + res)
+    with torch.no_grad():   # (not inference mode: the packed copy of the weights follows their version counter)
+        model.heatmap_heads.conv_final.weight.copy_(w.reshape(w.shape[0], -1, 1, 1))
+        model.heatmap_heads.conv_final.bias.copy_(b)
+    with torch.inference_mode():
         ours = model((crops, K.cuda())).cpu()
-        w = model.heatmap_heads.conv_final.weight.detach().cpu().reshape(-1, feat.shape[1])
-        b = model.heatmap_heads.conv_final.bias.detach().cpu()
-        ref = cpu_ref.crop_model_from_features(feat.cpu(), w, b, K, 17, ocfg)
-        truth = cpu_ref.crop_model_from_features_fp64(feat.cpu(), w, b, K, 17, ocfg)
+        feat2 = model.backbone(crops)   # (what the model's own forward saw: MIOpen may pick another algorithm)
+        ref = cpu_ref.crop_model_from_features(feat2.cpu(), w, b, K, 17, ocfg)
+        truth = cpu_ref.crop_model_from_features_fp64(feat2.cpu(), w, b, K, 17, ocfg)
+        c2d, c3d = model.heatmap_heads(feat2)
+        same_feat = kernels_recon(c2d, c3d, K.cuda(), model.config).cpu()
     assert model.heatmap_heads.last_path == 'fused'
-    e_ref, e64, r64 = cpu_ref.mpjpe(ours, ref), cpu_ref.mpjpe(ours, truth), cpu_ref.mpjpe(ref, truth)
-    print(f'[parity] {backbone} {res}px true-shape features {tuple(feat.shape)}: ours-vs-oracle MPJPE {e_ref:.2e} mm '
-          f'max {float((ours - ref).abs().max()):.2e}; ours-vs-fp64 {e64:.2e}; oracle-vs-fp64 {r64:.2e}')
-    # the parity-gate bounds of a random head (tests/test_gpu_parity_gates.py): ours within 1e-3 mm of the
-    # fp64 evaluation; against the oracle run on THIS host's CPU, its own distance to fp64 on top
-    assert e64 <= 1e-3, (e64, r64)
-    assert e_ref <= 1e-3 + r64, (e_ref, r64)
+    e_ref, e64, r64 = cpu_ref.mpjpe(same_feat, ref), cpu_ref.mpjpe(same_feat, truth), cpu_ref.mpjpe(ref, truth)
+    print(f'[parity] {backbone} {res}px true-shape features {tuple(feat.shape)}, plausible-pose head: ours-vs-oracle '
+          f'MPJPE {e_ref:.2e} mm max {float((same_feat - ref).abs().max()):.2e}; ours-vs-fp64 {e64:.2e}; '
+          f'oracle-vs-fp64 {r64:.2e}; median depth {float(truth[..., 2].median()):.0f} mm; '
+          f'model forward vs same-features {float((ours - same_feat).abs().max()):.2e} mm')
+    assert float(truth[..., 2].median()) > 1000   # a person in front of the camera, not a degenerate solve
+    # the parity-gate bounds of the consistent regimes (tests/test_gpu_parity_gates.py)
+    assert e64 <= 5e-4, (e64, r64)
+    assert e_ref <= 1e-3 or e_ref <= r64 + 3e-4, (e_ref, r64)
+    assert float((ours - same_feat).abs().max()) <= 0.05   # (two backbone passes: MIOpen's run-to-run noise x head gain)
+
+
+def kernels_recon(c2d, c3d, K, cfg):
+    from metrabs_amd import kernels
+    return kernels.reconstruct_absolute(c2d, c3d, K, cfg)
 
 
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
