@@ -750,7 +750,8 @@ struct HeadOpts {
 static bool head16_loader_wave(const HeadOpts& opt, int ct, int gpw) {
   if (opt.dma == 2) return true;
   if (opt.dma == 1) return false;
-  return false;  // (auto: decided after the A/B on MI355X)
+  return false;  // (auto: never -- measured slower on every shape, profiles/r04c_head16_ab.jsonl: at two workgroups
+                 //  per CU one wave issuing all 36 copies of a stage, one stage ahead, is the bottleneck)
 }
 
 template <typename FeatT, int CT, int GPW, bool NHWC>
@@ -998,7 +999,9 @@ extern "C" int mtr_head_plan(int feat_dtype, int layout, int B, int C, int H, in
   if (ct == 7) ct = 8;
   const int gpw = mtr::head16_groups_per_wg(B, ct, g, opt);
   const bool dma_ok = C % mtr::kKH == 0 && (layout == MTR_NHWC || ((H * W) % 8 == 0 && H * W >= 64));
-  plan->kernel = (opt.dma != 0 && dma_ok) ? MTR_HEAD_KERNEL_16_DMA : MTR_HEAD_KERNEL_16;
+  plan->kernel = (opt.dma != 0 && dma_ok) ? (mtr::head16_loader_wave(opt, ct, gpw) ? MTR_HEAD_KERNEL_16_DMA_LOADER
+                                                                                    : MTR_HEAD_KERNEL_16_DMA)
+                                          : MTR_HEAD_KERNEL_16;
   plan->tiles_per_workgroup = gpw;
   plan->workgroups = (long long)((B + 7) / 8) * 8 * ((g.n_groups + gpw - 1) / gpw);
   return MTR_OK;

@@ -81,8 +81,10 @@ def run_one(name):
 
         # RT_KGROUPS=1|2 in the environment: mtr_head_options.rt_k_groups for every call
         # RT_TILES / RT_LOADER / RT_SPLIT likewise
-        opts = _lib.HeadOptions(int(os.environ.get('RT_TILES', '0')), 0, -1, 0, int(os.environ.get('RT_KGROUPS', '0')),
-                                int(os.environ.get('RT_LOADER', '0')), int(os.environ.get('RT_SPLIT', '0')))
+        opts = _lib.head_options(rt_tiles=int(os.environ.get('RT_TILES', '0')),
+                                 rt_k_groups=int(os.environ.get('RT_KGROUPS', '0')),
+                                 rt_loader=int(os.environ.get('RT_LOADER', '0')),
+                                 rt_split=int(os.environ.get('RT_SPLIT', '0')))
 
         def call(stream):
             rc = lib.mtr_head_fused_opts(vp(feat.data_ptr()), 0, 1 if nhwc else 0, B, C, H, H,

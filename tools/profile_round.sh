@@ -3,7 +3,7 @@ set -x
 #   gpurun -- 'bash tools/profile_round.sh r03h'
 # kernel trace of the bench command, the two PMC passes (one counter each, --kernel-trace only) that
 # profiles/traffic.json is reduced from, MFMA counters of the f32 head, micro-benchmarks, bench lines.
-TAG=${1:-r03h}
+TAG=${1:-r04e}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O
@@ -43,3 +43,8 @@ python bench.py --config 3 --no-cpu-baseline > $O/${TAG}_bench_config3.json 2>> 
 python bench.py --config 4 --no-cpu-baseline --steps 10 > $O/${TAG}_bench_config4.json 2>> $O/${TAG}_bench.err
 MTR_BENCH_SHARED_DEVICE=1 python bench.py --gpus 2 --steps 10 --quick > $O/${TAG}_bench_gpus2_shared_device.json 2>> $O/${TAG}_bench.err
 tail -3 $O/prof_kt.log; head -c 2500 $O/${TAG}_bench_f32.json; echo; head -c 1200 $O/${TAG}_bench_f16.json
+# one-rank RCCL: the all-gather eager behind the step and captured inside the step's graph
+python bench.py --quick --force-collective --step pipeline > $O/${TAG}_bench_rccl_one_rank.json 2>> $O/${TAG}_bench.err
+python bench.py --quick --force-collective --graph-gather > $O/${TAG}_bench_rccl_one_rank_graph_gather.json 2>> $O/${TAG}_bench.err
+python bench.py --quick --force-collective > $O/${TAG}_bench_rccl_one_rank_api_step.json 2>> $O/${TAG}_bench.err
+python tools/head16_ab.py > $O/${TAG}_head16_ab.jsonl 2>/dev/null
