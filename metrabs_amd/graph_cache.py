@@ -1,9 +1,11 @@
 """HIP graphs behind Pose3dEstimator's API: shape-bucketed capture of whole internal batches.
 
-At the reference's default internal batch (64 crops, multiperson_model.py:189-220) one batch is ~10
-launches of ours + ~400 of the backbone: the eager path is bound by the host issuing them, not by the
-GPU.  A captured batch is ONE graph launch.  What is captured is exactly the call sequence the eager
-path runs (``Pose3dEstimator._batch_with_postprocess``: crop geometry -> sampler -> crop model -> K7)
+One internal batch (multiperson_model.py:189-220) is ~10 launches of ours + ~400 of the backbone.  At the
+reference's default of 64 crops the host issues them faster than the GPU runs them (back-to-back calls
+run at the GPU's rate either way, measured: DESIGN.md section 9); with fewer boxes per call the eager
+path is bound by the host (37 crops per call: +18 % with graphs), and a single synchronous call always
+pays the issue time.  A captured batch is ONE graph launch.  What is captured is exactly the call sequence
+the eager path runs (``Pose3dEstimator._batch_with_postprocess``: crop geometry -> sampler -> crop model -> K7)
 on exactly the same shapes, so a replay returns the eager path's bits.
 
 * ``FrameSet`` -- static uint8 frames + their pyramid for one (n_frames, H, W): the fixed addresses a

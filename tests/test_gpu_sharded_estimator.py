@@ -40,7 +40,7 @@ def _worker(rank, world, port, q):
         if name not in cases.E2E_CASES:
             continue
         case = cases.e2e_case(name)
-        est = build_estimator(case, True)
+        est = build_estimator(case, 'auto')   # the default head dispatch: a static rule, the same on every rank and slice
         args = (case['images'], case['boxes'], case['K'], case['dist'], case['extr'], case['world_up'],
                 55, case['ibs'], case['aa'], case['num_aug'], case['average_aug'], '', False)
         with torch.inference_mode():
