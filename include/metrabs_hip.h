@@ -141,7 +141,9 @@ typedef struct mtr_head_options {
                                       2 = global_load_lds issued by a fifth, LOADER wave (320 threads; same
                                       bits; measured 10 - 25 % SLOWER than 1 on every shape of
                                       profiles/r04c_head16_ab.jsonl -- kept for A/B runs, never the library's
-                                      choice), -1 = library's choice (NB: a zeroed struct selects registers) */
+                                      choice), 3 = global_load_lds with the copies of stage s + 1 issued first in
+                                      stage s and the fragments read per 16-channel step (round 4; same bits),
+                                      -1 = library's choice (NB: a zeroed struct selects registers) */
   int32_t rt_column_blocks;        /* f32, maps of > 64 positions: 64-position column blocks per workgroup
                                       tile, 2..4 (one K loop for all of them); 1 = one K loop per column
                                       block; 0 = by launch size                                         */
@@ -186,6 +188,7 @@ enum {
   MTR_HEAD_KERNEL_RT_NP = 4,     /* head_rt_np_kernel: row tiles x column blocks per workgroup             */
   MTR_HEAD_KERNEL_16 = 10,       /* head_fused16_kernel: 16-bit features staged through registers          */
   MTR_HEAD_KERNEL_16_DMA = 11,   /* head_fused16dma_kernel: 16-bit features staged by global_load_lds      */
+  MTR_HEAD_KERNEL_16_DMA_EARLY = 14,  /* head_fused16dma_kernel<..., EARLY>: copies of stage s + 1 issued first in stage s */
   MTR_HEAD_KERNEL_16_DMA_LOADER = 13, /* head_fused16dma_kernel<..., LD>: the same with a loader wave (dma_staging 2) */
   MTR_HEAD_KERNEL_16_RT = 12     /* head_rt16_kernel: 16-bit features on the row-tile core (1 + D > 64 rows per
                                     joint, or maps of more than 256 positions); NCHW features: needs the

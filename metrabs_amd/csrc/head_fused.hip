@@ -92,12 +92,12 @@ __host__ __device__ constexpr int hw_pad32() { return CT * 32 + 4; }
 // PV = positions per lane and step: 4 for maps of more than 64 positions, 2 below (an 8x8 map
 // then keeps all 32 lanes of the half-wave busy instead of 16).
 template <bool ACC64, int PV>
-__device__ __forceinline__ void decode_group_from_lds(const float* Ls, int HWP, int grp,
-                                                      const HeadGeom& g, int crop, int J, int D,
-                                                      int H, int W, const HeadScale& hs,
-                                                      float* __restrict__ coords2d,
-                                                      float* __restrict__ coords3d_rel, int wid,
-                                                      int lane) {
+__device__ __forceinline__ void decode_group_from_lds_pv(const float* Ls, int HWP, int grp,
+                                                         const HeadGeom& g, int crop, int J, int D,
+                                                         int H, int W, const HeadScale& hs,
+                                                         float* __restrict__ coords2d,
+                                                         float* __restrict__ coords3d_rel, int wid,
+                                                         int lane) {
   using vecf = __attribute__((ext_vector_type(PV))) float;
   const int HW = H * W;
   const int per = 1 + D;
@@ -120,29 +120,51 @@ __device__ __forceinline__ void decode_group_from_lds(const float* Ls, int HWP, 
     }
     m2 = group_max<32>(m2);
     m3 = group_max<32>(m3);
-    double s2 = 0, sx2 = 0, sy2 = 0, s3 = 0, sx3 = 0, sy3 = 0, sz3 = 0;
+    // exp(x - m) as ONE v_exp_f32 of fma(x, log2 e, -m log2 e) (round 4; was libm's expf: ~12 instructions
+    // per logit of a VALU-bound epilogue) -- what the f32 row-tile kernel and the stand-alone decode do
+    // (common.h: exp_shifted; the sums stay f64)
+    const float nm2 = -m2 * kLog2e, nm3 = -m3 * kLog2e;
+    double s2 = 0, sx2 = 0, sy2 = 0, s3 = 0, sx3 = 0, sy3 = 0, sz3 = 0, sz3b = 0;
     for (int p = li * PV; p < HW; p += 32 * PV) {
       const vecf v2 = *reinterpret_cast<const vecf*>(row2d + p);
-      double col[PV];
+      // two depth slices per pass, each with its own f64 chains (even / odd slices): the epilogue runs at
+      // two waves per SIMD, where one dependent chain of f64 adds per lane is latency, not throughput
+      double col[PV], colb[PV];
 #pragma unroll
-      for (int q = 0; q < PV; ++q) col[q] = 0;
-      for (int d = 0; d < D; ++d) {
-        const vecf u3 = *reinterpret_cast<const vecf*>(row3d + (size_t)d * HWP + p);
+      for (int q = 0; q < PV; ++q) col[q] = colb[q] = 0;
+      int d = 0;
+      for (; d + 1 < D; d += 2) {
+        const vecf ua = *reinterpret_cast<const vecf*>(row3d + (size_t)d * HWP + p);
+        const vecf ub = *reinterpret_cast<const vecf*>(row3d + (size_t)(d + 1) * HWP + p);
 #pragma unroll
         for (int q = 0; q < PV; ++q) {
-          const double e = ACC64 ? exp_neg64((double)u3[q] - (double)m3) : (double)expf(u3[q] - m3);
-          col[q] += e;
-          sz3 += e * (double)d;
+          const double ea = ACC64 ? exp_neg64((double)ua[q] - (double)m3) : (double)exp_shifted(ua[q], nm3);
+          const double eb = ACC64 ? exp_neg64((double)ub[q] - (double)m3) : (double)exp_shifted(ub[q], nm3);
+          col[q] += ea;
+          colb[q] += eb;
+          sz3 += ea * (double)d;
+          sz3b += eb * (double)(d + 1);
+        }
+      }
+      if (d < D) {
+        const vecf ua = *reinterpret_cast<const vecf*>(row3d + (size_t)d * HWP + p);
+#pragma unroll
+        for (int q = 0; q < PV; ++q) {
+          const double ea = ACC64 ? exp_neg64((double)ua[q] - (double)m3) : (double)exp_shifted(ua[q], nm3);
+          col[q] += ea;
+          sz3 += ea * (double)d;
         }
       }
 #pragma unroll
       for (int q = 0; q < PV; ++q) {
         const int h = (p + q) / W, w = (p + q) - h * W;  // narrow maps wrap more than once
-        const double e2 = ACC64 ? exp_neg64((double)v2[q] - (double)m2) : (double)expf(v2[q] - m2);
+        const double e2 = ACC64 ? exp_neg64((double)v2[q] - (double)m2) : (double)exp_shifted(v2[q], nm2);
+        const double c = col[q] + colb[q];
         s2 += e2; sx2 += e2 * w; sy2 += e2 * h;
-        s3 += col[q]; sx3 += col[q] * w; sy3 += col[q] * h;
+        s3 += c; sx3 += c * w; sy3 += c * h;
       }
     }
+    sz3 += sz3b;
     s2 = group_sum<32>(s2); sx2 = group_sum<32>(sx2); sy2 = group_sum<32>(sy2);
     s3 = group_sum<32>(s3); sx3 = group_sum<32>(sx3); sy3 = group_sum<32>(sy3);
     sz3 = group_sum<32>(sz3);
@@ -155,6 +177,28 @@ __device__ __forceinline__ void decode_group_from_lds(const float* Ls, int HWP, 
       coords3d_rel[o * 3 + 2] = heatmap_to_mm_z(axis_coord(sz3, s3, D), hs);
     }
   }
+}
+
+// Positions per lane and step of the half-wave that decodes a joint: the choice that leaves the fewest idle
+// lane-slots, ceil(HW / (32 PV)) * PV minimal (ties: the wider read).  Round 4: a 12x12 map (144 positions)
+// ran PV = 4, i.e. two steps of 128 positions with 112 of the second step's 128 slots idle -- 44 % of the
+// epilogue's lane-slots; at PV = 1 it is five steps of 32 with 16 idle.  The epilogue was 44 - 52 % of
+// the 16-bit kernels' time (tools/experiments/head_fixed_vs_stage.py: the same launch at C = 64 ... 1280).
+template <bool ACC64, int PVMAX>
+__device__ __forceinline__ void decode_group_from_lds(const float* Ls, int HWP, int grp,
+                                                      const HeadGeom& g, int crop, int J, int D,
+                                                      int H, int W, const HeadScale& hs,
+                                                      float* __restrict__ coords2d,
+                                                      float* __restrict__ coords3d_rel, int wid,
+                                                      int lane) {
+  const int HW = H * W;
+  const int c1 = (HW + 31) / 32, c2 = (HW + 63) / 64 * 2, c4 = (HW + 127) / 128 * 4;  // lane-slots per row
+  if (PVMAX >= 4 && c4 <= c2 && c4 <= c1)
+    decode_group_from_lds_pv<ACC64, 4>(Ls, HWP, grp, g, crop, J, D, H, W, hs, coords2d, coords3d_rel, wid, lane);
+  else if (c2 <= c1)
+    decode_group_from_lds_pv<ACC64, 2>(Ls, HWP, grp, g, crop, J, D, H, W, hs, coords2d, coords3d_rel, wid, lane);
+  else
+    decode_group_from_lds_pv<ACC64, 1>(Ls, HWP, grp, g, crop, J, D, H, W, hs, coords2d, coords3d_rel, wid, lane);
 }
 
 // LDS (40-90 KiB per workgroup) already caps residency at <= 4 waves per SIMD; asking for 2 lets the
@@ -487,6 +531,20 @@ __device__ __forceinline__ void dma16_to_lds(const void* src, char* lds_wave_bas
   __builtin_amdgcn_global_load_lds(src, lds_wave_base, 16, 0, 0);  // lane L -> base + 16 L
 }
 
+// The same copy issued from inline asm: the compiler does not know that LDS is written, so it neither
+// waits for vmcnt(0) in front of every later ds_read (what it does behind the builtin: prefetch distance
+// zero for anything issued before the reads) nor orders anything for us -- the kernel waits for its own
+// copies (s_waitcnt vmcnt) in front of the stage barrier.  LDS address = M0 + 16 * lane.
+__device__ __forceinline__ void dma16_to_lds_asm(const void* src, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+               :
+               : "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(src)
+               : "memory");
+}
+__device__ __forceinline__ unsigned lds_byte_addr(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+
 // two transposing 8-byte LDS reads = one 8-channel MFMA operand (semantics: see the kernel)
 __device__ __forceinline__ v4u lds_read_tr16_pair(const char* p0, const char* p1) {
   using trv = __attribute__((ext_vector_type(4))) short;
@@ -496,6 +554,14 @@ __device__ __forceinline__ v4u lds_read_tr16_pair(const char* p0, const char* p1
                                      __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_trv*)p1)});
 }
 
+#ifndef MTR_H16_EARLY_DEFAULT
+#define MTR_H16_EARLY_DEFAULT -1  // -1: the library's rule (head16_early_copies); 0 / 1: force (ablation builds)
+#endif
+#ifndef MTR_H16_DMA_ABLATE
+#define MTR_H16_DMA_ABLATE 0   // developer-only timing ablations of head_fused16dma_kernel (tools/experiments/
+                               // ablate_head16dma.py): 1 = no decode, 2 = no logits store + no decode, 4 = no MFMA,
+                               // 8 = no copies inside the K loop, 16 = no fragment reads
+#endif
 #define HEAD16_DMA_ISSUE(STAGE, AB, BB)                                                           \
   {                                                                                               \
     _Pragma("unroll") for (int i = 0; i < 2 * GPW; ++i)                                           \
@@ -510,8 +576,15 @@ __device__ __forceinline__ v4u lds_read_tr16_pair(const char* p0, const char* p1
 // MFMAs, 60 - 185 issue cycles each beside MFMAs, MI355X_MICROARCH.md "LDS-DMA piece issue cost"), waits for
 // them and meets the MFMA waves at the stage barrier; those run barrier, fragment reads, MFMAs.  Same
 // stages, same MFMA order, same sums: the bits of the four-wave kernel.
-template <typename FeatT, int CT, int GPW, bool NHWC, bool LD = false>
-__global__ __launch_bounds__(LD ? 320 : 256) void head_fused16dma_kernel(
+// EARLY (round 4, the default since): the copies of stage s + 1 are issued FIRST in iteration s, right behind
+// the barrier (inline asm: see dma16_to_lds_asm), and the fragments are read one 16-channel step at a time in
+// front of that step's MFMAs instead of all 20 up front: the copies get the whole stage to land (they are
+// what bounds the loop: L2 -> LDS at ~14 TB/s chip-wide, tools/experiments/ablate_head16dma.py), and the
+// kernel drops from 228 + 96 registers (one workgroup per CU at 12x12, GPW 2: every phase of the workgroup
+// serialised, the ablations' parts added up to the whole) to two workgroups per CU.  Same stages, same MFMA
+// order per accumulator, same sums: the bits of the other variants.
+template <typename FeatT, int CT, int GPW, bool NHWC, bool LD = false, bool EARLY = false>
+__global__ __launch_bounds__(LD ? 320 : 256, EARLY ? 2 : 1) void head_fused16dma_kernel(
     const FeatT* __restrict__ feat, const float* __restrict__ packed, int B, int C, int H, int W,
     int J, int D, HeadGeom g, HeadScale hs, float* __restrict__ coords2d,
     float* __restrict__ coords3d_rel) {
@@ -671,6 +744,54 @@ __global__ __launch_bounds__(LD ? 320 : 256) void head_fused16dma_kernel(
 #pragma unroll
     for (int t = 0; t < TPW; ++t) acc[k][t] = f32x16{0};
 
+  if constexpr (EARLY) {
+    const unsigned As_a = lds_byte_addr(As), Bs_a = lds_byte_addr(Bs);
+    auto issue_early = [&](int stage, int buf) {
+#pragma unroll
+      for (int i = 0; i < 2 * GPW; ++i)
+        dma16_to_lds_asm(a_src[i] + (size_t)stage * (kRows * kKH), As_a + buf * A_STAGE + (i * 4 + wid) * 1024);
+#pragma unroll
+      for (int i = 0; i < CT; ++i)
+        if (b_on[i])
+          dma16_to_lds_asm(b_src[i] + (size_t)stage * b_stage_elems, Bs_a + buf * B_STAGE + (i * 4 + wid) * 1024);
+    };
+    __syncthreads();  // zero fill done
+    issue_early(0, 0);
+    for (int st = 0; st < n_st; ++st) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's copies of stage st have landed
+      __syncthreads();  // ... everyone's; and every wave has consumed the fragments of stage st - 1
+      const int cur = st & 1;
+      if (st + 1 < n_st && !(MTR_H16_DMA_ABLATE & 8)) issue_early(st + 1, cur ^ 1);
+      const char* Ab = As + cur * A_STAGE;
+      const char* Bb = Bs + cur * B_STAGE;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v4u af[GPW], bf[TPW];
+#pragma unroll
+        for (int q = 0; q < GPW; ++q)
+          af[q] = (MTR_H16_DMA_ABLATE & 16) ? v4u{(unsigned)a_off[q], 1u, 2u, (unsigned)st}
+                                            : *reinterpret_cast<const v4u*>(Ab + (a_off[q] ^ (u << 5)));
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+          if (MTR_H16_DMA_ABLATE & 16) {
+            bf[t] = v4u{(unsigned)b_off[t], 1u, 2u, (unsigned)st};
+          } else if constexpr (NHWC) {
+            bf[t] = *reinterpret_cast<const v4u*>(Bb + (b_off[t] ^ (u << 5)));
+          } else {
+            const char* p = Bb + b_off[t] + u * (4 * tr_pitch4);
+            bf[t] = lds_read_tr16_pair(p, p + tr_pitch4);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+          for (int q = 0; q < GPW; ++q) {
+            if (MTR_H16_DMA_ABLATE & 4) acc[q][t][0] += __builtin_bit_cast(float, af[q][0] ^ bf[t][0]);
+            else acc[q][t] = Mfma16<FeatT>::run(af[q], bf[t], acc[q][t]);
+          }
+      }
+    }
+  } else {
   __syncthreads();  // zero fill done
   if constexpr (!LD) HEAD16_DMA_ISSUE(0, As, Bs)
   for (int st = 0; st < n_st; ++st) {
@@ -683,10 +804,13 @@ __global__ __launch_bounds__(LD ? 320 : 256) void head_fused16dma_kernel(
     for (int u = 0; u < 4; ++u) {
 #pragma unroll
       for (int q = 0; q < GPW; ++q)
-        af[q][u] = *reinterpret_cast<const v4u*>(Ab + (a_off[q] ^ (u << 5)));
+        af[q][u] = (MTR_H16_DMA_ABLATE & 16) ? v4u{(unsigned)a_off[q], 1u, 2u, (unsigned)st}
+                                             : *reinterpret_cast<const v4u*>(Ab + (a_off[q] ^ (u << 5)));
 #pragma unroll
       for (int t = 0; t < TPW; ++t) {
-        if constexpr (NHWC) {
+        if (MTR_H16_DMA_ABLATE & 16) {
+          bf[t][u] = v4u{(unsigned)b_off[t], 1u, 2u, (unsigned)st};
+        } else if constexpr (NHWC) {
           bf[t][u] = *reinterpret_cast<const v4u*>(Bb + (b_off[t] ^ (u << 5)));
         } else {
           const char* p = Bb + b_off[t] + u * (4 * tr_pitch4);
@@ -695,16 +819,22 @@ __global__ __launch_bounds__(LD ? 320 : 256) void head_fused16dma_kernel(
       }
     }
     // (behind the last stage: a repeat into the idle buffer)
-    if constexpr (!LD)
-      HEAD16_DMA_ISSUE(min(st + 1, n_st - 1), As + (cur ^ 1) * A_STAGE, Bs + (cur ^ 1) * B_STAGE)
+    if constexpr (!LD) {
+      if (!(MTR_H16_DMA_ABLATE & 8))
+        HEAD16_DMA_ISSUE(min(st + 1, n_st - 1), As + (cur ^ 1) * A_STAGE, Bs + (cur ^ 1) * B_STAGE)
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int t = 0; t < TPW; ++t)
 #pragma unroll
-        for (int q = 0; q < GPW; ++q)
-          acc[q][t] = Mfma16<FeatT>::run(af[q][u], bf[t][u], acc[q][t]);
+        for (int q = 0; q < GPW; ++q) {
+          if (MTR_H16_DMA_ABLATE & 4) acc[q][t][0] += __builtin_bit_cast(float, af[q][u][0] ^ bf[t][u][0]);
+          else acc[q][t] = Mfma16<FeatT>::run(af[q][u], bf[t][u], acc[q][t]);
+        }
   }
+
+  }  // (!EARLY)
 
 #pragma unroll
   for (int q = 0; q < GPW; ++q) {
@@ -713,7 +843,7 @@ __global__ __launch_bounds__(LD ? 320 : 256) void head_fused16dma_kernel(
     const float* bgrp = bias + (size_t)(grp0 + q) * kRows;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-      if (!on[t]) continue;
+      if (!on[t] || (MTR_H16_DMA_ABLATE & 2)) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = rp * 32 + 8 * (r >> 2) + 4 * fg + (r & 3);
@@ -721,6 +851,10 @@ __global__ __launch_bounds__(LD ? 320 : 256) void head_fused16dma_kernel(
       }
     }
     __syncthreads();
+    if (MTR_H16_DMA_ABLATE & 3) {  // no decode: one store per workgroup keeps the GEMM alive
+      if (tid == 0) coords2d[(size_t)crop * J * 2 + (grp0 + q)] = acc[q][0][0] + Ls[0];
+      continue;
+    }
     decode_group_from_lds<false, (CT > 2 ? 4 : 2)>(Ls, HWP, grp0 + q, g, crop, J, D, H, W, hs,
                                                    coords2d, coords3d_rel, wid, lane);
   }
@@ -754,6 +888,18 @@ static bool head16_loader_wave(const HeadOpts& opt, int ct, int gpw) {
                  //  per CU one wave issuing all 36 copies of a stage, one stage ahead, is the bottleneck)
 }
 
+// the early-copies instantiation (dma_staging 3).  The library's own choice (-1), from the A/B of nine shapes x
+// two layouts on MI355X (profiles/r04i_head16_ab.jsonl): NCHW features -- the transposing fragment reads are
+// the longer phase there -- always (0 ... +14 %); NHWC features only when the launch puts at least two
+// workgroups on every CU (J = 122: +3 ... +8 %; a launch of fewer, longer-lived workgroups prefers the
+// 228-register instantiation's deeper read-ahead: -1 ... -7 %).
+static bool head16_early_copies(const HeadOpts& opt, bool nhwc, long long workgroups) {
+  if (opt.dma == 3) return true;
+  if (opt.dma == 1 || opt.dma == 2) return false;
+  if (MTR_H16_EARLY_DEFAULT >= 0) return MTR_H16_EARLY_DEFAULT != 0;  // (developer builds: ablate_head16dma.py)
+  return !nhwc || workgroups >= 512;
+}
+
 template <typename FeatT, int CT, int GPW, bool NHWC>
 static int launch_head16(const void* feat, const float* packed, int B, int C, int H, int W, int J,
                          int D, const HeadGeom& g, const HeadScale& hs, float* c2d, float* c3d,
@@ -766,6 +912,18 @@ static int launch_head16(const void* feat, const float* packed, int B, int C, in
   // stages exist; NHWC: any map; NCHW: whole 16-byte chunks per channel row (H*W % 8 == 0, at
   // least the 8 chunks the bank rotation assumes)
   const bool dma_ok = C % kKH == 0 && (NHWC || ((H * W) % 8 == 0 && H * W >= 64));
+  if (opt.dma != 0 && dma_ok && head16_early_copies(opt, NHWC, blocks)) {
+    auto dma = head_fused16dma_kernel<FeatT, CT, GPW, NHWC, false, true>;
+    if (lds > 64 * 1024) {
+      const int rc = allow_dynamic_lds((const void*)dma, lds);
+      if (rc != MTR_OK) return rc;
+    }
+    MTR_CLEAR_STALE();
+    hipLaunchKernelGGL(dma, dim3((unsigned)blocks), dim3(256), lds, stream, (const FeatT*)feat,
+                       packed, B, C, H, W, J, D, g, hs, c2d, c3d);
+    MTR_CHECK_LAUNCH();
+    return MTR_OK;
+  }
   if (opt.dma != 0 && dma_ok && head16_loader_wave(opt, CT, GPW)) {
     auto dma = head_fused16dma_kernel<FeatT, CT, GPW, NHWC, true>;
     if (lds > 64 * 1024) {
@@ -813,6 +971,9 @@ static int head16_groups_per_wg(int B, int ct, const HeadGeom& g, const HeadOpts
     // and the groups divide without an idle remainder worse than the gain
     const int wgs = (g.n_groups + cand - 1) / cand;
     if (crops8 * wgs >= 1024 && wgs * cand - g.n_groups <= (g.n_groups >= 6 ? 1 : 0)) gpw = cand;
+    // many joint groups per crop (J = 122: 18) on a small launch: two groups per workgroup as soon as every
+    // CU still gets one (B = 32: 288 workgroups, 45 -> 40 us; round 4)
+    if (cand == 2 && g.n_groups >= 6 && crops8 * wgs >= 256 && wgs * cand - g.n_groups <= 1) gpw = cand;
   }
   if (opt.groups_per_wg >= 1) gpw = opt.groups_per_wg < max_gpw ? opt.groups_per_wg : max_gpw;
   return gpw;
@@ -953,7 +1114,7 @@ static int parse_head_options(const mtr_head_options* caller, mtr::HeadOpts& opt
   const mtr_head_options* options = &mine;
   if (options->rt_tiles_per_workgroup < 0 || options->rt_tiles_per_workgroup > 5 ||
       options->groups_per_workgroup < 0 || options->groups_per_workgroup > 3 ||
-      options->dma_staging < -1 || options->dma_staging > 2 ||
+      options->dma_staging < -1 || options->dma_staging > 3 ||
       options->rt_column_blocks < 0 || options->rt_column_blocks > 4 ||
       options->rt_k_groups < 0 || options->rt_k_groups > 2 ||
       options->rt_loader < 0 || options->rt_loader > 2 ||
@@ -999,9 +1160,11 @@ extern "C" int mtr_head_plan(int feat_dtype, int layout, int B, int C, int H, in
   if (ct == 7) ct = 8;
   const int gpw = mtr::head16_groups_per_wg(B, ct, g, opt);
   const bool dma_ok = C % mtr::kKH == 0 && (layout == MTR_NHWC || ((H * W) % 8 == 0 && H * W >= 64));
-  plan->kernel = (opt.dma != 0 && dma_ok) ? (mtr::head16_loader_wave(opt, ct, gpw) ? MTR_HEAD_KERNEL_16_DMA_LOADER
-                                                                                    : MTR_HEAD_KERNEL_16_DMA)
-                                          : MTR_HEAD_KERNEL_16;
+  plan->kernel = !(opt.dma != 0 && dma_ok) ? MTR_HEAD_KERNEL_16
+                 : mtr::head16_early_copies(opt, layout == MTR_NHWC, (long long)((B + 7) / 8) * 8 * ((g.n_groups + gpw - 1) / gpw))
+                     ? MTR_HEAD_KERNEL_16_DMA_EARLY
+                 : mtr::head16_loader_wave(opt, ct, gpw) ? MTR_HEAD_KERNEL_16_DMA_LOADER
+                                                         : MTR_HEAD_KERNEL_16_DMA;
   plan->tiles_per_workgroup = gpw;
   plan->workgroups = (long long)((B + 7) / 8) * 8 * ((g.n_groups + gpw - 1) / gpw);
   return MTR_OK;

@@ -84,16 +84,23 @@ class BatchGraph:
             self.static = [torch.empty(a.shape, dtype=a.dtype, device=a.device) for a in batch_args]
         self._load(batch_args)
         body = lambda: est._batch_with_postprocess(frames.pyramid, *self.static, tta, antialias_factor, post)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):  # lazy initialisation (MIOpen's solver search, weight packing)
-                body()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = body()
+        # ALWAYS captured under inference mode, whatever the caller runs under: torch creates the CUDA
+        # generator's graph-state tensors at the process's first capture and updates them in place at every
+        # later capture_begin -- a first capture under inference_mode (ours, the bench's pipeline, a test's)
+        # followed by one under plain no_grad fails with "inplace update to inference tensor"; in-place updates
+        # of normal tensors under inference mode are fine, so this order-independent rule works both ways.
+        # (The captured output is cloned on every replay: callers get normal tensors outside inference mode.)
+        with torch.inference_mode():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):  # lazy initialisation (MIOpen's solver search, weight packing)
+                    body()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = body()
         self.replays = 0
 
     def _load(self, batch_args):
@@ -133,6 +140,7 @@ class GraphCache:
         self.seen = collections.Counter()
         self.failed = set()
         self.stats = dict(captures=0, replays=0, eager_batches=0, evictions=0)
+        self.last_capture_error = None
 
     def clear(self):
         self.graphs.clear()
@@ -200,9 +208,11 @@ class GraphCache:
         try:
             g = BatchGraph(self.est, frames, batch_args, tta, antialias_factor, post)
         except Exception as e:  # noqa: BLE001 -- whatever a capture can raise: this shape stays eager
+            import traceback
             self.failed.add(key)
+            self.last_capture_error = traceback.format_exc()
             warnings.warn(f'metrabs_amd: HIP graph capture of an internal batch failed ({str(e)[:200]}); '
-                          f'this shape keeps running eagerly')
+                          f'this shape keeps running eagerly (estimator.graphs.last_capture_error has the traceback)')
             torch.cuda.synchronize()
             self.stats['eager_batches'] += 1
             return None

@@ -110,7 +110,7 @@ def test_calls_under_inference_mode_and_plain_no_grad_share_the_cache(hip_lib):
             else:
                 got = _call(est, frames, boxes, K, case)[0]
             assert torch.equal(want, got), (first_inference, i)
-        assert est.graphs.stats['replays'] >= 2
+        assert est.graphs.stats['replays'] >= 2, est.graphs.last_capture_error
 
 
 def test_frame_set_eviction_drops_the_graphs_that_read_it(hip_lib):

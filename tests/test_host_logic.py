@@ -176,7 +176,7 @@ def test_bench_cli_contract_and_kernel_naming(monkeypatch):
     assert bench.head_kernel_name(64, 64, 17, 8, 'f32', 1283) == 'head_rt_kernel'    # C % 32 != 0: no loader kernel
     assert bench.head_kernel_name(64, 1024, 17, 72) == 'head_rt_kernel'              # D <= 80: 5-tile atoms
     assert bench.head_kernel_name(144, 32, 17, 8).startswith('head_rt_kernel (+ head_rt_merge_kernel: 3 ')
-    assert bench.head_kernel_name(64, 64, 17, 8, 'f16', 1280) == 'head_fused16dma_kernel'
+    assert bench.head_kernel_name(64, 64, 17, 8, 'f16', 1280) == 'head_fused16dma_kernel (early copies)'
     assert bench.head_kernel_name(36, 64, 17, 8, 'f16', 1280) == 'head_fused16_kernel'   # 6x6: registers
     assert bench.head_kernel_name(64, 64, 17, 8, 'f16', 1283).startswith('library')      # C % 8 != 0
 

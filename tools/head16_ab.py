@@ -35,7 +35,7 @@ def main():
             base = kernels.head_fused(feat, packed, C, J, cfg)
             plan = kernels.head_plan(B, C, H, W, J, D, dt, nhwc)
             flops = 2.0 * C * J * (1 + D) * H * W * B
-            for opts in ([dict()] + [dict(dma_staging=s, groups_per_workgroup=gp) for s in (1, 2) for gp in (0, 1, 2, 3)]):
+            for opts in ([dict()] + [dict(dma_staging=s, groups_per_workgroup=gp) for s in (1, 3) for gp in (0, 1, 2, 3)]):
                 try:
                     out = kernels.head_fused(feat, packed, C, J, cfg, **opts)
                 except RuntimeError as e:
