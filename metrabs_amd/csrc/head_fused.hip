@@ -889,15 +889,15 @@ static bool head16_loader_wave(const HeadOpts& opt, int ct, int gpw) {
 }
 
 // the early-copies instantiation (dma_staging 3).  The library's own choice (-1), from the A/B of nine shapes x
-// two layouts on MI355X (profiles/r04i_head16_ab.jsonl): NCHW features -- the transposing fragment reads are
-// the longer phase there -- always (0 ... +14 %); NHWC features only when the launch puts at least two
-// workgroups on every CU (J = 122: +3 ... +8 %; a launch of fewer, longer-lived workgroups prefers the
-// 228-register instantiation's deeper read-ahead: -1 ... -7 %).
-static bool head16_early_copies(const HeadOpts& opt, bool nhwc, long long workgroups) {
+// two layouts on MI355X (profiles/r04i_head16_ab.jsonl, r04k_): NCHW features -- the transposing fragment reads
+// are the longer phase there -- always (0 ... +14 %); NHWC features on the wide tiles only: six or more column
+// tiles (16x16: +9 %), or three or more with at least six joint groups per crop (J = 122 on 12x12: +3 ... +8 %);
+// the 8x8 tiles and J = 17 on 12x12 prefer the 228-register instantiation's deeper read-ahead (-1 ... -7 %).
+static bool head16_early_copies(const HeadOpts& opt, bool nhwc, int ct, int n_groups) {
   if (opt.dma == 3) return true;
   if (opt.dma == 1 || opt.dma == 2) return false;
   if (MTR_H16_EARLY_DEFAULT >= 0) return MTR_H16_EARLY_DEFAULT != 0;  // (developer builds: ablate_head16dma.py)
-  return !nhwc || workgroups >= 512;
+  return !nhwc || ct >= 6 || (ct >= 3 && n_groups >= 6);
 }
 
 template <typename FeatT, int CT, int GPW, bool NHWC>
@@ -912,7 +912,7 @@ static int launch_head16(const void* feat, const float* packed, int B, int C, in
   // stages exist; NHWC: any map; NCHW: whole 16-byte chunks per channel row (H*W % 8 == 0, at
   // least the 8 chunks the bank rotation assumes)
   const bool dma_ok = C % kKH == 0 && (NHWC || ((H * W) % 8 == 0 && H * W >= 64));
-  if (opt.dma != 0 && dma_ok && head16_early_copies(opt, NHWC, blocks)) {
+  if (opt.dma != 0 && dma_ok && head16_early_copies(opt, NHWC, CT, g.n_groups)) {
     auto dma = head_fused16dma_kernel<FeatT, CT, GPW, NHWC, false, true>;
     if (lds > 64 * 1024) {
       const int rc = allow_dynamic_lds((const void*)dma, lds);
@@ -1161,8 +1161,7 @@ extern "C" int mtr_head_plan(int feat_dtype, int layout, int B, int C, int H, in
   const int gpw = mtr::head16_groups_per_wg(B, ct, g, opt);
   const bool dma_ok = C % mtr::kKH == 0 && (layout == MTR_NHWC || ((H * W) % 8 == 0 && H * W >= 64));
   plan->kernel = !(opt.dma != 0 && dma_ok) ? MTR_HEAD_KERNEL_16
-                 : mtr::head16_early_copies(opt, layout == MTR_NHWC, (long long)((B + 7) / 8) * 8 * ((g.n_groups + gpw - 1) / gpw))
-                     ? MTR_HEAD_KERNEL_16_DMA_EARLY
+                 : mtr::head16_early_copies(opt, layout == MTR_NHWC, ct, g.n_groups) ? MTR_HEAD_KERNEL_16_DMA_EARLY
                  : mtr::head16_loader_wave(opt, ct, gpw) ? MTR_HEAD_KERNEL_16_DMA_LOADER
                                                          : MTR_HEAD_KERNEL_16_DMA;
   plan->tiles_per_workgroup = gpw;
