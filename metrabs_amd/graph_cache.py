@@ -131,10 +131,18 @@ class _CallPlan:
 
 
 class GraphCache:
-    def __init__(self, estimator, max_graphs=16, max_frame_sets=2):
+    def __init__(self, estimator, max_graphs=32, max_frame_sets=2, min_batches_between_evictions=128):
         self.est = estimator
         self.max_graphs = max_graphs
         self.max_frame_sets = max_frame_sets
+        # A capture costs a few eager batches (warm-up + the capture itself).  While the cache has room a
+        # shape is captured on its 2nd (True: 1st) occurrence; once it is FULL, a new shape may push out the
+        # least recently used graph only every `min_batches_between_evictions` batches -- a server whose box
+        # count wanders over more shapes than the cache holds keeps replaying what it has and runs the rest
+        # eagerly instead of capturing on every call.
+        self.min_batches_between_evictions = min_batches_between_evictions
+        self._batches = 0
+        self._last_eviction_at = -(1 << 60)
         self.graphs = collections.OrderedDict()
         self.frame_sets = collections.OrderedDict()
         self.seen = collections.Counter()
@@ -173,7 +181,13 @@ class GraphCache:
                 use.append(False)
                 continue
             self.seen[k] += 1
-            use.append(k in self.graphs or self.seen[k] >= threshold)
+            self._batches += 1
+            due = self.seen[k] >= threshold
+            if due and k not in self.graphs and len(self.graphs) >= self.max_graphs:
+                due = self._batches - self._last_eviction_at >= self.min_batches_between_evictions
+                if due:
+                    self._last_eviction_at = self._batches
+            use.append(k in self.graphs or due)
         if len(self.seen) > 4096:
             self.seen.clear()
         if not any(use):

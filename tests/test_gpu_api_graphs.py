@@ -129,6 +129,27 @@ def test_frame_set_eviction_drops_the_graphs_that_read_it(hip_lib):
     assert all(k[0] == next(iter(est.graphs.frame_sets)) for k in est.graphs.graphs)
 
 
+def test_a_full_cache_does_not_capture_on_every_call(hip_lib):
+    """More shapes than the cache holds: once full, the cache keeps replaying what it has and runs the other
+    shapes eagerly -- at most one eviction per `min_batches_between_evictions` batches."""
+    case = cases.e2e_case('aug5')
+    ref = build_estimator(case, 'auto')
+    ref.graph_batches = False
+    est = build_estimator(case, 'auto')
+    est.graph_batches = True
+    est.graphs.max_graphs = 2
+    est.graphs.min_batches_between_evictions = 1000
+    for rnd in range(3):
+        for n in (1, 2, 3, 4):   # four batch sizes (one internal batch each), a cache of two
+            images, boxes, K = _inputs(case, 60 + 10 * rnd + n, 2, [n, 0])
+            a = _call(ref, images.cuda(), boxes, K, case, internal_batch_size=100)
+            b = _call(est, images.cuda(), boxes, K, case, internal_batch_size=100)
+            assert torch.equal(a[0], b[0])
+    st = est.graphs.stats
+    # the first eviction is allowed at once (the counter starts "long ago"), then none for 1000 batches
+    assert st['captures'] <= 3 and len(est.graphs.graphs) == 2 and st['eager_batches'] >= 4, st
+
+
 def test_empty_call_and_images_without_boxes(hip_lib):
     case = cases.e2e_case('aug5')
     est = build_estimator(case, 'auto')
