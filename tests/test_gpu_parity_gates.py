@@ -117,6 +117,18 @@ def test_plausible_poses_are_within_1e3_mm_of_the_reference(name, regime, hip_li
     assert (r['logits_absmax'] <= 5.5) if regime == 'consistent_low' else (r['logits_absmax'] >= 20)
     assert r['mpjpe_ours_vs_ref'] <= REF_BOUND.get((name, regime), 1e-3), r
     assert r['mpjpe_ours_vs_fp64'] <= FP64_BOUND.get((name, regime), 5e-4), r
+    # max-abs over all coordinates (round 4; the gates above are means): ours within 1.2e-3 mm of the fp64
+    # evaluation everywhere (measured 2.3e-4 ... 1.0e-3; the two peaked cells below: 1.5e-3 / 1.7e-3), and from
+    # the stored reference by no more than the reference's OWN largest distance to fp64 plus that -- the
+    # reference is 6e-4 ... 6.4e-3 mm from fp64 at its worst coordinate and moves by up to 9.8e-4 mm between
+    # two runs on the same inputs (tests/golden/parity_reference_jitter.json)
+    own = MAX_FP64_BOUND.get((name, regime), 1.2e-3)
+    assert r['max_ours_vs_fp64'] <= own, r
+    assert r['max_ours_vs_ref'] <= r['max_ref_vs_fp64'] + own, r
+
+
+MAX_FP64_BOUND = {('metric string: 72 depth bins, 256 px, B=64', 'consistent_peaked'): 2.2e-3,
+                  ('configs[4] EffNetV2-L 384 f16 J=122 B=32/GPU', 'consistent_peaked'): 2.0e-3}
 
 
 @pytest.mark.parametrize('name', list(SHAPES))
