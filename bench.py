@@ -373,7 +373,7 @@ def graph_time(calls, replays):
             c()
         st.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=st):
+        with torch.cuda.graph(g, stream=st, capture_error_mode='thread_local'):  # (see metrabs_amd/pipeline.py)
             for c in calls:
                 c()
         g.replay()
@@ -1214,6 +1214,31 @@ def api_path_probe(est, args, im_h, im_w, n_box, value):
                                graphed_frames_from_pinned_host=timed(True, host_sets, full, rounds))
             out['ragged_1_to_%d_boxes_per_frame' % per] = dict(eager=timed(False, dev_sets, ragged, 2),
                                                                graphed=timed(True, dev_sets, ragged, 2))
+            # the live-camera case: ONE 1080p frame with one / four boxes per call, the host waiting for every result
+            # (launch-bound when eager: ~400 launches for a batch the GPU finishes in a fraction of their issue time)
+            small = {}
+            for n_b in (1, 4):
+                one_frame = [d[:1] for d in dev_sets]
+                res_mode = {}
+                for mode in (False, True):
+                    est.graph_batches = mode
+                    lat = []
+                    for i in range(12):
+                        bw = 60 + 340 * rng.random(n_b)
+                        bh = 150 + 750 * rng.random(n_b)
+                        bx = rng.random(n_b) * (im_w - bw)
+                        by = rng.random(n_b) * np.maximum(im_h - bh, 1.0)
+                        boxes = [np.stack([bx, by, bw, bh], axis=1).astype(np.float32)]
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        res = est.estimate_poses_batched(one_frame[i % len(one_frame)], boxes, intrinsic_matrix=K0[None],
+                                                         internal_batch_size=n_box * args.num_aug, num_aug=args.num_aug)
+                        res['poses3d'][0].cpu()
+                        lat.append((time.perf_counter() - t1) * 1e3)
+                    res_mode['graphed' if mode else 'eager'] = round(float(np.median(lat[4:])), 3)
+                small[f'{n_b}_box'] = dict(latency_ms_one_call_synced=res_mode,
+                                           speedup=round(res_mode['eager'] / res_mode['graphed'], 2))
+            out['one_frame_per_call'] = small
             out['graph_cache'] = dict(est.graphs.stats, graphs=len(est.graphs.graphs))
     finally:
         est.graph_batches, est.graphs.max_graphs = before

@@ -26,6 +26,7 @@ import warnings
 import torch
 
 from metrabs_amd import kernels
+from metrabs_amd.pipeline import CAPTURE_ERROR_MODE
 
 
 class FrameSet:
@@ -99,7 +100,7 @@ class BatchGraph:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_ERROR_MODE):
                 self.out = body()
         self.replays = 0
 

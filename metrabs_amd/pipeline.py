@@ -7,6 +7,14 @@ import torch
 
 from metrabs_amd import kernels
 
+# hipStreamCaptureModeThreadLocal for every capture of this package.  The default ("global") turns a HIP call
+# of ANY other thread during the capture into an error -- and once a process group exists, ProcessGroupNCCL's
+# watchdog thread polls its events all the time: a capture that overlaps one of its hipEventQuery calls fails
+# with "operation not permitted when stream is capturing" INSIDE the watchdog thread, which takes the whole
+# process down (seen once in four one-rank RCCL runs of bench.py --graph-gather, round 4).  Thread-local mode
+# only polices the capturing thread, which is the one that has to behave.
+CAPTURE_ERROR_MODE = 'thread_local'
+
 
 def predict_single_batch(crop_model, mirror_mapping, should_flip, any_flip, pyramid, intrinsic_matrix,
                          distortion12, camspace_up, boxes, image_ids, rotflipmat, aug_scales,
@@ -95,7 +103,7 @@ class GraphedCropPipeline:
             torch.cuda.synchronize()
             if self.use_graph:
                 self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph):
+                with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_ERROR_MODE):
                     self.poses = self._body()
         return self
 

@@ -52,7 +52,7 @@ dist.all_gather_into_tensor(dst, src)   # warm-up outside the capture (communica
 torch.cuda.synchronize()
 g = torch.cuda.CUDAGraph()
 try:
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, capture_error_mode='thread_local'):  # (the watchdog thread polls events meanwhile)
         dist.all_gather_into_tensor(dst, src)
     src.normal_()
     dst.zero_()

@@ -39,7 +39,7 @@ def timeit(fn, iters=50, warm=10, graph=True):
             fn()
         st.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=st):
+        with torch.cuda.graph(g, stream=st, capture_error_mode='thread_local'):
             for _ in range(iters):
                 fn()
         g.replay()
