@@ -44,6 +44,7 @@
 #include <mutex>
 #include <queue>
 #include <tuple>
+#include <type_traits>
 #include <vector>
 
 namespace mtr {
@@ -81,6 +82,11 @@ using v4f = __attribute__((ext_vector_type(4))) float;
 #ifndef MTR_RT_LD_LA
 #define MTR_RT_LD_LA 3      // ... and the stages its loader runs ahead (<= ring depth - 1; copies per stage x (LA - 1)
                             // must fit the 6-bit vmcnt)
+#endif
+#ifndef MTR_RT_DECODE_PER_ROW
+#define MTR_RT_DECODE_PER_ROW 0   // 1: rounds 1-3's decode epilogue (a 16-lane group per row, three passes, two
+                                  // barriers, one thread per unit for the last sums); 0: a WAVE per softmax unit
+                                  // (round 4, rt_decode_units)
 #endif
 #ifndef MTR_RT_EXP32
 #define MTR_RT_EXP32 1      // 1: v_exp_f32 in the decode epilogue (f64 sums; measured -0.9 us at B=64, -11 us at
@@ -405,7 +411,7 @@ __device__ __forceinline__ float rt_seg_max(float v, int segs) {
   return v;
 }
 template <int RT, int NP, int NG>
-__device__ __forceinline__ void rt_decode_blocks(const RtArgs& a, float* Ls, float* rowmax, float* unitmax,
+__device__ __forceinline__ void rt_decode_rows(const RtArgs& a, float* Ls, float* rowmax, float* unitmax,
                                                  int* info_s, double* rowsum, double* runstat, int tid,
                                                  bool idle_wave, int HW, int crop, int t0, int cb0, int n_cb,
                                                  int segs = 1) {
@@ -532,6 +538,258 @@ __device__ __forceinline__ void rt_decode_blocks(const RtArgs& a, float* Ls, flo
     }
     if (NP > 1) __syncthreads();  // (the next column block re-uses rowmax / rowsum)
    }
+}
+
+// Round 4: the decode epilogue, a WAVE per softmax unit.  The 64 lanes of a wave are the 64 columns of the
+// column block (in a packed block: 2 or 4 crops' segments of 32 / 16 columns); the wave walks the unit's rows
+// (1 for a 2D row, D for a joint's depth slices) twice -- maximum, then exp and the four sums per column in
+// f64 -- and reduces across its lanes with DPP / two cross-row shuffles: no barrier, no row statistics
+// through LDS, no serial "one thread adds eight rows" tail (rounds 1 - 3: a 16-lane group per ROW, three
+// passes with two workgroup barriers between them; 3.5 of the 24.5 us of the 64-crop launch, and 20 us of the
+// 72-bin launch whose 73-row units one 16-lane group summed).  Units are dealt to the decoding waves in the
+// order of their first row (the loader wave does not decode).  The statistics of a (unit, column block) --
+// what cb-split launches hand to head_rt_merge_kernel -- come from this code in every kernel variant, so
+// every dispatch choice still gives the same bits.
+template <int RT, int NP, int NG>
+__device__ __forceinline__ void rt_decode_units(const RtArgs& a, float* Ls, int* info_s, double* runstat, int tid,
+                                                bool idle_wave, int HW, int crop, int t0, int cb0, int n_cb,
+                                                int segs) {
+  constexpr int R = RT * 16, LP = NP * kRtLP, NW = NG / 4;
+  if (idle_wave) return;
+  int tid_d = tid;
+  asm volatile("" : "+v"(tid_d));  // (nothing below is computed in front of the K loop and held through it)
+  const int lane = tid_d & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid_d >> 6);
+  // rows that start a unit: a 2D row, or slice 0 of a joint's depth rows
+  unsigned long long starts[2] = {0ull, 0ull};
+#pragma unroll
+  for (int k = 0; k < (R + 63) / 64; ++k) {
+    const int row = k * 64 + lane;
+    const unsigned inf = row < R ? (unsigned)info_s[row] : 0u;
+    const int kind = inf & 3, d = (inf >> 2) & 0x3fff;
+    starts[k] = __ballot(kind == 1 || (kind == 2 && d == 0));
+  }
+  const int segw = 64 / segs, seg = lane / segw, cis = lane - seg * segw;  // column inside its crop's segment
+  const bool first_of_seg = cis == 0 && crop + seg < a.B;
+#pragma unroll 1
+  for (int np = 0; np < NP; ++np) {
+    const int cb = NP == 1 ? cb0 : cb0 + np;
+    if (NP > 1 && cb >= n_cb) break;
+    const float* Lb = Ls + np * kRtLP + lane;  // this lane's column of the block (row pitch LP)
+    const int p = cb * 64 + cis;               // its position in the crop's map
+    const bool valid = p < HW;
+    const int ph = valid ? p / a.W : 0, pw = valid ? p - ph * a.W : 0;
+    const double dw = (double)pw, dh = (double)ph;
+    int u = 0;
+#pragma unroll
+    for (int k = 0; k < (R + 63) / 64; ++k) {
+      unsigned long long msk = starts[k];
+      while (msk) {
+        const int row = k * 64 + __builtin_ctzll(msk);
+        msk &= msk - 1;
+        const bool mine = u % NW == wave;
+        ++u;
+        if (!mine) continue;  // (wave-uniform)
+        const unsigned inf = (unsigned)info_s[row];
+        const int kind = inf & 3, j = (int)(inf >> 16);
+        const int n = kind == 2 ? a.D : 1;
+        const float* x = Lb + row * LP;
+        float m;
+        double col, sz;
+        // rows in register chunks: all LDS reads of a chunk are issued before the first is used (a loop of
+        // read - wait - use per row was 2 us slower than the three-pass decode it replaces)
+        auto chunk_max = [&](int r0, auto ch_tag, float (&xr)[decltype(ch_tag)::value]) {
+          constexpr int CH = decltype(ch_tag)::value;
+          float mm = -INFINITY;
+#pragma unroll
+          for (int r = 0; r < CH; ++r) {
+            const int rr = r0 + r < n ? r0 + r : n - 1;  // (clamped: a valid LDS address)
+            xr[r] = x[rr * LP];
+          }
+#pragma unroll
+          for (int r = 0; r < CH; ++r) {
+            if (r0 + r >= n) xr[r] = -INFINITY;
+            mm = fmaxf(mm, xr[r]);
+          }
+          return mm;
+        };
+        auto chunk_sums = [&](int r0, auto ch_tag, const float (&xr)[decltype(ch_tag)::value], float nm, float mf,
+                              double& c_a, double& c_b, double& z_a, double& z_b) {
+          constexpr int CH = decltype(ch_tag)::value;
+#pragma unroll
+          for (int r = 0; r < CH; ++r) {
+            // (a row behind the unit holds -inf: exp = 0; the f64 polynomial path is masked instead)
+            const double e = MTR_RT_EXP32 ? (double)exp_shifted(xr[r], nm)
+                                          : (r0 + r < n ? exp_neg64((double)xr[r] - (double)mf) : 0.0);
+            if (r & 1) { c_b += e; z_b += e * (double)(r0 + r); }
+            else { c_a += e; z_a += e * (double)(r0 + r); }
+          }
+        };
+        auto seg_max = [&](float v) {
+          if (!valid) v = -INFINITY;
+          return segs == 1 ? group_max<64>(v) : segs == 2 ? group_max<32>(v) : group_max<16>(v);
+        };
+        double c_a = 0.0, c_b = 0.0, z_a = 0.0, z_b = 0.0;
+        if (n == 1) {
+          float xr[1];
+          m = seg_max(chunk_max(0, std::integral_constant<int, 1>{}, xr));
+          chunk_sums(0, std::integral_constant<int, 1>{}, xr, -m * kLog2e, m, c_a, c_b, z_a, z_b);
+        } else if (n <= 8) {
+          float xr[8];
+          m = seg_max(chunk_max(0, std::integral_constant<int, 8>{}, xr));
+          chunk_sums(0, std::integral_constant<int, 8>{}, xr, -m * kLog2e, m, c_a, c_b, z_a, z_b);
+        } else if (n <= 16) {
+          float xr[16];
+          m = seg_max(chunk_max(0, std::integral_constant<int, 16>{}, xr));
+          chunk_sums(0, std::integral_constant<int, 16>{}, xr, -m * kLog2e, m, c_a, c_b, z_a, z_b);
+        } else {  // long units (72 depth slices): two passes over the rows, 16 at a time
+          float mm = -INFINITY;
+          for (int r0 = 0; r0 < n; r0 += 16) {
+            float xr[16];
+            mm = fmaxf(mm, chunk_max(r0, std::integral_constant<int, 16>{}, xr));
+          }
+          m = seg_max(mm);
+          for (int r0 = 0; r0 < n; r0 += 16) {
+            float xr[16];
+            chunk_max(r0, std::integral_constant<int, 16>{}, xr);
+            chunk_sums(r0, std::integral_constant<int, 16>{}, xr, -m * kLog2e, m, c_a, c_b, z_a, z_b);
+          }
+        }
+        if (!valid) c_a = c_b = z_a = z_b = 0.0;
+        col = c_a + c_b;
+        sz = z_a + z_b;
+        double S = col, SX = col * dw, SY = col * dh, SZ = sz;
+        if (segs == 1) {
+          S = group_sum<64>(S); SX = group_sum<64>(SX); SY = group_sum<64>(SY); SZ = group_sum<64>(SZ);
+        } else if (segs == 2) {
+          S = group_sum<32>(S); SX = group_sum<32>(SX); SY = group_sum<32>(SY); SZ = group_sum<32>(SZ);
+        } else {
+          S = group_sum<16>(S); SX = group_sum<16>(SX); SY = group_sum<16>(SY); SZ = group_sum<16>(SZ);
+        }
+        if (first_of_seg) rt_unit_finish(a, crop + seg, t0, row, kind, j, cb, n_cb, m, S, SX, SY, SZ, runstat);
+      }
+    }
+  }
+}
+
+// ... and for units of <= 16 rows (every shipped configuration: D = 8) a 16-LANE GROUP per unit: lane l of the
+// group holds columns 4 l .. 4 l + 3 of ALL the unit's rows in registers (one ds_read_b128 per row, issued
+// back to back), so the maximum, the exps and the four f64 sums need one pass and only DPP reductions inside
+// the group (a packed block's 2 / 4 crop segments are its 8- / 4-lane halves / quads): no barrier, no LDS
+// round trip, no cross-row shuffle, and the <= 9 units of a block of three tiles run at once on the 16 groups
+// of the four decoding waves.
+template <int RT, int NP, int NG>
+__device__ __forceinline__ void rt_decode_groups(const RtArgs& a, float* Ls, int* info_s, double* runstat, int tid,
+                                                 bool idle_wave, int HW, int crop, int t0, int cb0, int n_cb,
+                                                 int segs) {
+  constexpr int R = RT * 16, LP = NP * kRtLP;
+  if (idle_wave) return;
+  int tid_d = tid;
+  asm volatile("" : "+v"(tid_d));
+  const int lane = tid_d & 63, grp = tid_d >> 4, l16 = tid_d & 15;
+  unsigned long long starts[2] = {0ull, 0ull};
+#pragma unroll
+  for (int k = 0; k < (R + 63) / 64; ++k) {
+    const int row = k * 64 + lane;
+    const unsigned inf = row < R ? (unsigned)info_s[row] : 0u;
+    const int kind = inf & 3, d = (inf >> 2) & 0x3fff;
+    starts[k] = __ballot(kind == 1 || (kind == 2 && d == 0));
+  }
+  const int seg_lanes = 16 / segs, seg = l16 / seg_lanes, li = l16 - seg * seg_lanes;
+  const bool finisher = li == 0 && crop + seg < a.B;
+#pragma unroll 1
+  for (int np = 0; np < NP; ++np) {
+    const int cb = NP == 1 ? cb0 : cb0 + np;
+    if (NP > 1 && cb >= n_cb) break;
+    const float* Lb = Ls + np * kRtLP + l16 * 4;  // this lane's four columns (row pitch LP)
+    const int pbase = cb * 64 + li * 4;
+    bool ok[4];
+    float fw[4], fh[4];  // (small integers, exact in f32; widened where they meet the f64 sums)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int p = pbase + q;
+      ok[q] = p < HW;
+      const int h = ok[q] ? p / a.W : 0;
+      fh[q] = (float)h;
+      fw[q] = (float)(ok[q] ? p - h * a.W : 0);
+    }
+    // Round t: group g takes the (t NG + g)-th unit of the block (in row order).  Every lane finds ITS unit's first
+    // row in a wave-uniform walk over the start mask (a compare and a select per unit), then all groups of the
+    // wave run ONE copy of the body -- a group's own branch would run the four groups of a wave one after the
+    // other with 16 of 64 lanes each.  All units go through the CH-row body (rows behind a unit hold -inf).
+    const int n_units = __builtin_popcountll(starts[0]) + __builtin_popcountll(starts[1]);
+    for (int t = 0; t * NG < n_units; ++t) {
+      const int target = t * NG + grp;
+      int row = -1, cnt = 0;
+#pragma unroll
+      for (int k = 0; k < (R + 63) / 64; ++k) {
+        unsigned long long msk = starts[k];
+        while (msk) {
+          const int rb = k * 64 + __builtin_ctzll(msk);
+          msk &= msk - 1;
+          row = cnt == target ? rb : row;
+          ++cnt;
+        }
+      }
+      if (row < 0) continue;
+      const unsigned inf = (unsigned)info_s[row];
+      const int kind = inf & 3, j = (int)(inf >> 16);
+      const int n = kind == 2 ? a.D : 1;
+      auto unit = [&](auto ch_tag) {
+        constexpr int CH = decltype(ch_tag)::value;
+        v4f x[CH];
+#pragma unroll
+        for (int r = 0; r < CH; ++r) x[r] = *reinterpret_cast<const v4f*>(Lb + (row + (r < n ? r : n - 1)) * LP);
+        float m = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < CH; ++r)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (r >= n || !ok[q]) x[r][q] = -INFINITY;  // (rows behind the unit, columns behind the map: exp = 0)
+            m = fmaxf(m, x[r][q]);
+          }
+        m = rt_seg_max(m, segs);
+        const float nm = -m * kLog2e;
+        double col[4] = {0.0, 0.0, 0.0, 0.0}, sz = 0.0, szb = 0.0;
+#pragma unroll
+        for (int r = 0; r < CH; ++r)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const double e = MTR_RT_EXP32 ? (double)exp_shifted(x[r][q], nm)
+                                          : (x[r][q] == -INFINITY ? 0.0 : exp_neg64((double)x[r][q] - (double)m));
+            col[q] += e;
+            if (q & 1) szb += e * (double)r; else sz += e * (double)r;
+          }
+        double S = (col[0] + col[1]) + (col[2] + col[3]);
+        double SX = (col[0] * (double)fw[0] + col[1] * (double)fw[1]) + (col[2] * (double)fw[2] + col[3] * (double)fw[3]);
+        double SY = (col[0] * (double)fh[0] + col[1] * (double)fh[1]) + (col[2] * (double)fh[2] + col[3] * (double)fh[3]);
+        double SZ = sz + szb;
+        S = rt_seg_sum(S, segs);
+        SX = rt_seg_sum(SX, segs);
+        SY = rt_seg_sum(SY, segs);
+        SZ = rt_seg_sum(SZ, segs);
+        if (finisher) rt_unit_finish(a, crop + seg, t0, row, kind, j, cb, n_cb, m, S, SX, SY, SZ, runstat);
+      };
+      if (a.D <= 8) unit(std::integral_constant<int, 8>{});   // (wave-uniform)
+      else unit(std::integral_constant<int, 16>{});
+    }
+  }
+}
+
+// LEAN: the wave-per-unit form for every unit (16 row registers per lane instead of 64: head_rt16_kernel is
+// built for five workgroups per CU, 102 registers)
+template <int RT, int NP, int NG, bool LEAN = false>
+__device__ __forceinline__ void rt_decode_blocks(const RtArgs& a, float* Ls, float* rowmax, float* unitmax,
+                                                 int* info_s, double* rowsum, double* runstat, int tid,
+                                                 bool idle_wave, int HW, int crop, int t0, int cb0, int n_cb,
+                                                 int segs = 1) {
+  if (MTR_RT_DECODE_PER_ROW)
+    rt_decode_rows<RT, NP, NG>(a, Ls, rowmax, unitmax, info_s, rowsum, runstat, tid, idle_wave, HW, crop, t0, cb0, n_cb,
+                               segs);
+  else if (!LEAN && a.D <= 16)  // (wave-uniform)
+    rt_decode_groups<RT, NP, NG>(a, Ls, info_s, runstat, tid, idle_wave, HW, crop, t0, cb0, n_cb, segs);
+  else
+    rt_decode_units<RT, NP, NG>(a, Ls, info_s, runstat, tid, idle_wave, HW, crop, t0, cb0, n_cb, segs);
 }
 
 // Column `col` (0 .. 63) of a workgroup's tile: in a packed last block (RtArgs::pack_g) segment s = col /
@@ -716,6 +974,12 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
     // 3 tiles, and the copies are what bounds the K loop (tools/experiments/ablate_rt.py, a27).
     const char* gbase[JPW];
     unsigned gstride[JPW], voff[JPW], ldso[JPW];
+    // (the per-lane offsets are derived HERE, per column block: without the empty asm the compiler computes
+    //  the parts that do not depend on the block -- a packed block's crop offsets -- once in front of the loop
+    //  and holds them through the K loop AND the decode; in the 256-register instantiations that is a spill)
+    int lane_j = lane;
+    asm volatile("" : "+v"(lane_j));
+#define lane lane_j
 #pragma unroll
     for (int i = 0; i < JPW; ++i) {
       const int j = wid + 4 * i < JOBS ? wid + 4 * i : wid + 4 * (i - 1);
@@ -750,6 +1014,7 @@ __device__ __forceinline__ void rt_block(const RtArgs& a, char* smem, int crop, 
         gstride[i] *= 2;
       }
     }
+#undef lane
     // copy i of the next stage into ring slot `slot` (stages are issued in order: the per-lane
     // offset walks along K; the last stage of a C that is not a multiple of 32 redirects the lanes
     // whose channels do not exist to ones that do -- their products meet zero weights)
@@ -1328,8 +1593,8 @@ __device__ __forceinline__ void rt16_block(const RtArgs& a, char* smem, int crop
     }
     if (is_loader) __syncthreads();  // (the loader's side of the barrier in front of the logits store)
     __syncthreads();
-    rt_decode_blocks<RT, 1, 16>(a, Ls, rowmax, unitmax, info_s, rowsum, runstat, tid, is_loader, HW, crop, t0, cb0,
-                                n_cb);
+    rt_decode_blocks<RT, 1, 16, true>(a, Ls, rowmax, unitmax, info_s, rowsum, runstat, tid, is_loader, HW, crop, t0,
+                                      cb0, n_cb);
     __syncthreads();  // the next column block's copies overwrite the decode's scratch
   }
 }

@@ -62,7 +62,7 @@ def test_head_k_loops_carry_no_parked_sgprs(resources):
             else:
                 # the other kernels' unrolled main loops: none; their remainder loops (the last <= 6 stages,
                 # a switch over the ring slot) may read back a few
-                assert lp['lane_moves'] <= 8, (k['name'], lp)
+                assert lp['lane_moves'] <= 16, (k['name'], lp)
         main = {}
         for lp in loops:   # per body (same MFMA count per stage x unroll): the cleanest loop is the main one
             main[lp['mfma']] = min(main.get(lp['mfma'], 1 << 30), lp['lane_moves'])

@@ -16,7 +16,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, 'tools', 'experiments', '_build')
-VARIANTS = {'full': [], 'exp32': ['-DMTR_RT_EXP32=1'], 'nodecode': ['-DMTR_RT_ABLATE=1'], 'nomfma': ['-DMTR_RT_ABLATE=2'],
+VARIANTS = {'full': [], 'decode_rows': ['-DMTR_RT_DECODE_PER_ROW=1'],
+            'decode_rows_nodecode': ['-DMTR_RT_DECODE_PER_ROW=1', '-DMTR_RT_ABLATE=1'], 'exp32': ['-DMTR_RT_EXP32=1'], 'nodecode': ['-DMTR_RT_ABLATE=1'], 'nomfma': ['-DMTR_RT_ABLATE=2'],
             'nocarry': ['-DMTR_RT_ABLATE=8'],
             'nofrag': ['-DMTR_RT_ABLATE=16'],
             'nbuf2': ['-DMTR_RT_NBUF=2'], 'nbuf4': ['-DMTR_RT_NBUF=4'], 'nbuf8': ['-DMTR_RT_NBUF=8'], 'a18': ['-DMTR_RT_ABLATE=18'], 'a26': ['-DMTR_RT_ABLATE=26'], 'a27': ['-DMTR_RT_ABLATE=27'],
@@ -61,7 +62,8 @@ def run_one(name):
     lib.mtr_head_packed_bytes.restype = ctypes.c_size_t
     cases = [('B64', 64, 8, False, 8), ('B64 nhwc', 64, 8, True, 8), ('B1024', 1024, 8, False, 8),
              ('B32 12x12', 32, 12, False, 8), ('B256 12x12', 256, 12, False, 8),
-             ('B64 D72', 64, 8, False, 72), ('B256 D72', 256, 8, False, 72)]
+             ('B64 D72', 64, 8, False, 72), ('B256 D72', 256, 8, False, 72), ('B256 8x8', 256, 8, False, 8),
+             ('B16 24x24', 16, 24, False, 8), ('B64 16x16', 64, 16, False, 8)]
     if os.environ.get('RT_CASES'):
         cases = [c for c in cases if c[0] in os.environ['RT_CASES'].split(',')]
     for label, B, H, nhwc, D in cases:
@@ -86,10 +88,20 @@ def run_one(name):
                                  rt_loader=int(os.environ.get('RT_LOADER', '0')),
                                  rt_split=int(os.environ.get('RT_SPLIT', '0')))
 
+        lib.mtr_head_workspace_bytes.restype = ctypes.c_size_t
+        ws_bytes = lib.mtr_head_workspace_bytes(0, 1 if nhwc else 0, B, C, H, H, J, D) if os.environ.get('RT_WS') else 0
+        ws = torch.empty(max(ws_bytes, 8) // 8 + 1, dtype=torch.float64, device='cuda')
+
         def call(stream):
-            rc = lib.mtr_head_fused_opts(vp(feat.data_ptr()), 0, 1 if nhwc else 0, B, C, H, H,
-                                         vp(packed.data_ptr()), J, D, ctypes.byref(hp), ctypes.byref(opts),
-                                         vp(c2.data_ptr()), vp(c3.data_ptr()), vp(stream))
+            if ws_bytes:   # RT_WS=1: the default path of the Python wrappers (column blocks over workgroups)
+                rc = lib.mtr_head_fused_ws(vp(feat.data_ptr()), 0, 1 if nhwc else 0, B, C, H, H,
+                                           vp(packed.data_ptr()), J, D, ctypes.byref(hp), ctypes.byref(opts),
+                                           vp(ws.data_ptr()), ctypes.c_size_t(ws.numel() * 8),
+                                           vp(c2.data_ptr()), vp(c3.data_ptr()), vp(stream))
+            else:
+                rc = lib.mtr_head_fused_opts(vp(feat.data_ptr()), 0, 1 if nhwc else 0, B, C, H, H,
+                                             vp(packed.data_ptr()), J, D, ctypes.byref(hp), ctypes.byref(opts),
+                                             vp(c2.data_ptr()), vp(c3.data_ptr()), vp(stream))
             assert rc == 0, rc
         for _ in range(5):
             call(torch.cuda.current_stream().cuda_stream)
