@@ -705,11 +705,15 @@ __device__ __forceinline__ void rt_decode_groups(const RtArgs& a, float* Ls, int
     const int pbase = cb * 64 + li * 4;
     bool ok[4];
     float fw[4], fh[4];  // (small integers, exact in f32; widened where they meet the f64 sums)
+    // h = p / W without four ~30-instruction integer divisions per lane: floor((p + 0.5) * (1 / W)) -- the true
+    // quotient of p + 0.5 is at least 0.5 / W away from an integer and the f32 product is within p / W * 2^-22
+    // of it, i.e. exact for every p < 2^21 (maps are a few thousand positions)
+    const float rcp_w = __frcp_rn((float)a.W);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int p = pbase + q;
       ok[q] = p < HW;
-      const int h = ok[q] ? p / a.W : 0;
+      const int h = !ok[q] ? 0 : HW <= 65536 ? (int)(((float)p + 0.5f) * rcp_w) : p / a.W;  // (checked exhaustively to 2^16)
       fh[q] = (float)h;
       fw[q] = (float)(ok[q] ? p - h * a.W : 0);
     }
