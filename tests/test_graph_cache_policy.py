@@ -1,0 +1,96 @@
+"""CPU: the policy of the estimator's HIP-graph cache (metrabs_amd/graph_cache.py) with the GPU objects
+stubbed -- when a shape is captured ('auto': 2nd occurrence, True: 1st), LRU order, the eviction rate limit of
+a full cache, graphs dropped with the frame set they read, a failed capture leaving its shape eager."""
+import types
+
+import pytest
+import torch
+
+from metrabs_amd import graph_cache
+
+
+class FakeFrames:
+    def __init__(self, n, h, w, device):
+        self.key = (n, h, w, str(device))
+
+
+class FakeGraph:
+    fail = False
+
+    def __init__(self, est, frames, batch_args, tta, aa, post):
+        if FakeGraph.fail:
+            raise RuntimeError('capture failed')
+        self.frames = frames
+
+
+@pytest.fixture
+def cache(monkeypatch):
+    monkeypatch.setattr(graph_cache, 'FrameSet', FakeFrames)
+    monkeypatch.setattr(graph_cache, 'BatchGraph', FakeGraph)
+    monkeypatch.setattr(torch.cuda, 'is_current_stream_capturing', lambda: False)
+    monkeypatch.setattr(torch.cuda, 'synchronize', lambda *a, **k: None)
+    FakeGraph.fail = False
+    est = types.SimpleNamespace(graph_batches='auto', crop_dtype=torch.float32, crop_channels_last=False,
+                                crop_model=types.SimpleNamespace(input_resolution=256),
+                                _device=lambda: torch.device('cpu'))
+    return graph_cache.GraphCache(est, max_graphs=2, max_frame_sets=1, min_batches_between_evictions=5)
+
+
+TTA = dict(gammas=torch.ones(1))
+POST = dict(joint_transform=None, average_aug=True, skeleton=torch.arange(17))
+
+
+def call(cache, n_boxes, n_frames=2):
+    """One call with a single internal batch of n_boxes -> 'replay' | 'capture' | 'eager'."""
+    images = torch.zeros(n_frames, 3, 8, 8, dtype=torch.uint8)
+    before = dict(cache.stats)
+    plan = cache.plan_call(images, [(0, n_boxes)], TTA, 1, POST)
+    if plan is None:
+        return 'eager'
+    g = plan.graph_for(0, ())
+    if g is None:
+        return 'eager'
+    return 'capture' if cache.stats['captures'] > before['captures'] else 'replay'
+
+
+def test_auto_captures_on_the_second_occurrence_and_true_on_the_first(cache):
+    assert [call(cache, 4) for _ in range(3)] == ['eager', 'capture', 'replay']
+    cache.est.graph_batches = True
+    assert [call(cache, 5) for _ in range(2)] == ['capture', 'replay']
+    assert cache.stats['captures'] == 2 and cache.stats['replays'] == 2
+
+
+def test_full_cache_evicts_at_most_once_per_interval(cache):
+    cache.est.graph_batches = True
+    assert call(cache, 1) == 'capture' and call(cache, 2) == 'capture'   # full (2 graphs)
+    assert call(cache, 3) == 'capture'            # the first eviction is free (LRU = the 1-box graph)
+    assert call(cache, 1) == 'eager'              # evicted, and no second eviction within 5 batches
+    assert call(cache, 2) == 'replay' and call(cache, 3) == 'replay'
+    assert call(cache, 4) == 'eager'
+    outcomes = [call(cache, 4) for _ in range(3)]  # batches 8, 9, 10 of the cache: the interval has passed
+    assert 'capture' in outcomes and cache.stats['evictions'] == 2
+    assert len(cache.graphs) == 2
+
+
+def test_graphs_go_with_their_frame_set(cache):
+    cache.est.graph_batches = True
+    assert call(cache, 4, n_frames=2) == 'capture'
+    assert call(cache, 4, n_frames=3) == 'capture'     # another frame shape: the 2-frame set is evicted ...
+    assert len(cache.frame_sets) == 1 and all(k[0][0] == 3 for k in cache.graphs)   # ... and its graph with it
+    assert call(cache, 4, n_frames=2) == 'capture'     # rebuilt
+
+
+def test_a_failed_capture_leaves_the_shape_eager(cache):
+    cache.est.graph_batches = True
+    FakeGraph.fail = True
+    with pytest.warns(UserWarning):
+        assert call(cache, 4) == 'eager'
+    FakeGraph.fail = False
+    assert call(cache, 4) == 'eager' and cache.last_capture_error   # not retried
+    assert call(cache, 5) == 'capture'                               # other shapes are
+
+
+def test_empty_ranges_and_disabled_cache(cache):
+    images = torch.zeros(2, 3, 8, 8, dtype=torch.uint8)
+    assert cache.plan_call(images, [(3, 3)], TTA, 1, POST) is None    # an empty slice is never a graph
+    assert cache.stats['captures'] == 0
