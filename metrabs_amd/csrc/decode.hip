@@ -332,6 +332,7 @@ __global__ __launch_bounds__(1024) void decode_nhwc_kernel(const T* __restrict__
   const T* x = logits + (size_t)b * HW * NC;
   constexpr int U = 8;  // positions per batch: their loads are in flight together (a walk of one
                         // dependent load per step was the whole 12 us of a 64-crop launch)
+  const float rcp_w = __frcp_rn((float)W);
   for (int t = threadIdx.x; t < G * N; t += blockDim.x) {
     const int n = t % N, g = t / N;
     // local row n = (slice, joint): slice 0 is the 2D row, slice 1 + d the depth slice d
@@ -363,7 +364,9 @@ __global__ __launch_bounds__(1024) void decode_nhwc_kernel(const T* __restrict__
         const int p = p0 + u * G;
         // a -inf logit (and a position past the map) weighs nothing (-inf - -inf is NaN under a -inf maximum)
         if (v[u] != -INFINITY) {
-          const int h = p / W, w = p - h * W;
+          // (row / column of the position without an integer division per logit: exact for p < 2^16, see
+          //  head_rt.hip rt_decode_groups; the division was most of this VALU-bound loop)
+          const int h = HW <= 65536 ? (int)(((float)p + 0.5f) * rcp_w) : p / W, w = p - h * W;
           const double e = (double)exp_shifted(v[u], nm);
           s += e; sx += e * (double)w; sy += e * (double)h;
         }

@@ -102,6 +102,7 @@ __device__ __forceinline__ void decode_group_from_lds_pv(const float* Ls, int HW
   const int HW = H * W;
   const int per = 1 + D;
   const int li = lane & 31;
+  const float rcp_w = __frcp_rn((float)W);
   for (int jl = wid * 2 + (lane >> 5); jl < g.jg; jl += 8) {
     const int j = grp * g.jg + jl;
     if (j >= J) continue;
@@ -157,7 +158,8 @@ __device__ __forceinline__ void decode_group_from_lds_pv(const float* Ls, int HW
       }
 #pragma unroll
       for (int q = 0; q < PV; ++q) {
-        const int h = (p + q) / W, w = (p + q) - h * W;  // narrow maps wrap more than once
+        // (narrow maps wrap more than once; no integer division: exact for positions < 2^16, head_rt.hip)
+        const int h = HW <= 65536 ? (int)(((float)(p + q) + 0.5f) * rcp_w) : (p + q) / W, w = (p + q) - h * W;
         const double e2 = ACC64 ? exp_neg64((double)v2[q] - (double)m2) : (double)exp_shifted(v2[q], nm2);
         const double c = col[q] + colb[q];
         s2 += e2; sx2 += e2 * w; sy2 += e2 * h;
