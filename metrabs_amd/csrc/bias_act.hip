@@ -14,16 +14,46 @@ namespace mtr {
 
 template <typename T> struct Vec16 { static constexpr int n = 16 / sizeof(T); };
 
-template <typename T, int ACT, bool RES>
+// Unsigned 32-bit division by a launch-time constant as a multiply-high and two shifts (Granlund &
+// Montgomery; exact for every 32-bit dividend): the channel of a vector used to cost a 64-bit division and a
+// 64-bit modulo -- ~150 VALU instructions per 32 bytes of traffic, as many issue cycles as the HBM time of
+// the bytes (round 4; found through the same per-logit division in the NHWC decode).
+struct FastDiv {
+  unsigned m, s1, s2, d;
+};
+inline FastDiv make_fastdiv(unsigned d) {
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;  // ceil(log2 d)
+  FastDiv f;
+  f.m = (unsigned)((((1ull << 32) * ((1ull << l) - d)) / d) + 1);
+  f.s1 = l < 1 ? l : 1;
+  f.s2 = l > 1 ? l - 1 : 0;
+  f.d = d;
+  return f;
+}
+__device__ __forceinline__ unsigned fastdiv(unsigned n, const FastDiv& f) {
+  const unsigned t = __umulhi(f.m, n);
+  return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+
+// WIDE: more than 2^32 - 1 vectors (64-bit index arithmetic, the round-1 form)
+template <typename T, int ACT, bool RES, bool WIDE>
 __global__ __launch_bounds__(256) void bias_act_kernel(T* __restrict__ y,
                                                        const float* __restrict__ bias,
                                                        const T* __restrict__ residual,
-                                                       long long n_vec, int C, int hw_vec) {
+                                                       long long n_vec, int C, int hw_vec, FastDiv by_hw,
+                                                       FastDiv by_c) {
   constexpr int VEC = Vec16<T>::n;
   struct alignas(16) Pack { T v[VEC]; };
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec;
        i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)((i / hw_vec) % C);
+    int c;
+    if constexpr (WIDE) {
+      c = (int)((i / hw_vec) % C);
+    } else {
+      const unsigned row = fastdiv((unsigned)i, by_hw);   // (b, c) row of the vector
+      c = (int)(row - fastdiv(row, by_c) * by_c.d);
+    }
     const float b = bias[c];
     Pack p = *reinterpret_cast<const Pack*>(y + i * VEC);
     Pack q;
@@ -112,14 +142,24 @@ static int launch_bias_act(void* y, const float* bias, const void* residual, int
   long long blocks = (n_vec + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride beyond 32 workgroups per CU
   const dim3 grid((unsigned)blocks), block(256);
+  const bool wide = n_vec > 0xffffffffLL;
+  const FastDiv by_hw = make_fastdiv((unsigned)(HW / VEC)), by_c = make_fastdiv((unsigned)C);
   MTR_CLEAR_STALE();
+#define MTR_BIAS_ACT_LAUNCH(ACT)                                                                                 \
+  if (wide)                                                                                                      \
+    hipLaunchKernelGGL((bias_act_kernel<T, ACT, RES, true>), grid, block, 0, stream, (T*)y, bias,                \
+                       (const T*)residual, n_vec, C, HW / VEC, by_hw, by_c);                                    \
+  else                                                                                                           \
+    hipLaunchKernelGGL((bias_act_kernel<T, ACT, RES, false>), grid, block, 0, stream, (T*)y, bias,               \
+                       (const T*)residual, n_vec, C, HW / VEC, by_hw, by_c);
   switch (act) {
-    case kActNone: hipLaunchKernelGGL((bias_act_kernel<T, kActNone, RES>), grid, block, 0, stream, (T*)y, bias, (const T*)residual, n_vec, C, HW / VEC); break;
-    case kActRelu: hipLaunchKernelGGL((bias_act_kernel<T, kActRelu, RES>), grid, block, 0, stream, (T*)y, bias, (const T*)residual, n_vec, C, HW / VEC); break;
-    case kActSilu: hipLaunchKernelGGL((bias_act_kernel<T, kActSilu, RES>), grid, block, 0, stream, (T*)y, bias, (const T*)residual, n_vec, C, HW / VEC); break;
-    case kActHardswish: hipLaunchKernelGGL((bias_act_kernel<T, kActHardswish, RES>), grid, block, 0, stream, (T*)y, bias, (const T*)residual, n_vec, C, HW / VEC); break;
+    case kActNone: MTR_BIAS_ACT_LAUNCH(kActNone) break;
+    case kActRelu: MTR_BIAS_ACT_LAUNCH(kActRelu) break;
+    case kActSilu: MTR_BIAS_ACT_LAUNCH(kActSilu) break;
+    case kActHardswish: MTR_BIAS_ACT_LAUNCH(kActHardswish) break;
     default: return MTR_E_PARAM;
   }
+#undef MTR_BIAS_ACT_LAUNCH
   MTR_CHECK_LAUNCH();
   return MTR_OK;
 }
