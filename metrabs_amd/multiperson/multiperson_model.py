@@ -133,8 +133,20 @@ class Pose3dEstimator(torch.nn.Module):
         # path's bits (tests/test_gpu_api_graphs.py).  See metrabs_amd/graph_cache.py.
         self.graph_batches = 'auto'
         self.graphs = graph_cache.GraphCache(self)
+        # captured graphs read the weights at capture: loading a state dict (into the estimator or the crop
+        # model) and moving / casting the module (.to, .cuda, .half: nn.Module._apply) drop them.  In-place
+        # edits of single parameters do not: call self.graphs.clear() after those.
+        drop = lambda *a, **k: self.graphs.clear()
+        for m in (self, self.crop_model):
+            if hasattr(m, 'register_load_state_dict_post_hook'):
+                m.register_load_state_dict_post_hook(drop)
         self._slabs = []            # two pinned staging buffers of the per-box parameters (one H2D copy
         self._slab_turn = 0         # per call; the host may run two calls ahead of the GPU)
+
+    def _apply(self, fn, *args, **kwargs):
+        if hasattr(self, 'graphs'):
+            self.graphs.clear()   # (the static buffers and captured graphs belong to the old device / dtype)
+        return super()._apply(fn, *args, **kwargs)
 
     # ------------------------------------------------------------------ public API (reference names)
 

@@ -129,6 +129,23 @@ def test_frame_set_eviction_drops_the_graphs_that_read_it(hip_lib):
     assert all(k[0] == next(iter(est.graphs.frame_sets)) for k in est.graphs.graphs)
 
 
+def test_loading_weights_drops_the_captured_graphs(hip_lib):
+    case = cases.e2e_case('aug5')
+    est = build_estimator(case, 'auto')
+    est.graph_batches = True
+    images, boxes, K = _inputs(case, 70, 2, [2, 2])
+    a = _call(est, images.cuda(), boxes, K, case)[0]
+    assert len(est.graphs.graphs) >= 1
+    sd = {k: v.clone() for k, v in est.crop_model.state_dict().items()}
+    sd['heatmap_heads.conv_final.bias'] += 0.5
+    est.crop_model.load_state_dict(sd)
+    assert len(est.graphs.graphs) == 0            # a replay would still see the old bias
+    b = _call(est, images.cuda(), boxes, K, case)[0]
+    assert not torch.equal(a, b)
+    est.cuda()                                     # nn.Module._apply: dropped as well
+    assert len(est.graphs.graphs) == 0
+
+
 def test_a_full_cache_does_not_capture_on_every_call(hip_lib):
     """More shapes than the cache holds: once full, the cache keeps replaying what it has and runs the other
     shapes eagerly -- at most one eviction per `min_batches_between_evictions` batches."""
