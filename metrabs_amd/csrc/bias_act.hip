@@ -14,28 +14,6 @@ namespace mtr {
 
 template <typename T> struct Vec16 { static constexpr int n = 16 / sizeof(T); };
 
-// Unsigned 32-bit division by a launch-time constant as a multiply-high and two shifts (Granlund &
-// Montgomery; exact for every 32-bit dividend): the channel of a vector used to cost a 64-bit division and a
-// 64-bit modulo -- ~150 VALU instructions per 32 bytes of traffic, as many issue cycles as the HBM time of
-// the bytes (round 4; found through the same per-logit division in the NHWC decode).
-struct FastDiv {
-  unsigned m, s1, s2, d;
-};
-inline FastDiv make_fastdiv(unsigned d) {
-  unsigned l = 0;
-  while ((1ull << l) < d) ++l;  // ceil(log2 d)
-  FastDiv f;
-  f.m = (unsigned)((((1ull << 32) * ((1ull << l) - d)) / d) + 1);
-  f.s1 = l < 1 ? l : 1;
-  f.s2 = l > 1 ? l - 1 : 0;
-  f.d = d;
-  return f;
-}
-__device__ __forceinline__ unsigned fastdiv(unsigned n, const FastDiv& f) {
-  const unsigned t = __umulhi(f.m, n);
-  return (t + ((n - t) >> f.s1)) >> f.s2;
-}
-
 // WIDE: more than 2^32 - 1 vectors (64-bit index arithmetic, the round-1 form)
 template <typename T, int ACT, bool RES, bool WIDE>
 __global__ __launch_bounds__(256) void bias_act_kernel(T* __restrict__ y,

@@ -95,6 +95,29 @@ __device__ __forceinline__ void load_vec(const T* __restrict__ p, float (&out)[V
   }
 }
 
+// Unsigned 32-bit division by a launch-time constant as a multiply-high and two shifts (Granlund &
+// Montgomery; exact for every 32-bit dividend): round 4 -- the grid-stride kernels derived
+// (plane, row, column) of a work item with two or three 64-BIT divisions and modulos, ~150 VALU instructions
+// each: in the pyramid kernel twice the instructions of the tile's own work.
+struct FastDiv {
+  unsigned m, s1, s2, d;
+};
+inline FastDiv make_fastdiv(unsigned d) {
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;  // ceil(log2 d)
+  FastDiv f;
+  f.m = (unsigned)((((1ull << 32) * ((1ull << l) - d)) / d) + 1);
+  f.s1 = l < 1 ? l : 1;
+  f.s2 = l > 1 ? l - 1 : 0;
+  f.d = d;
+  return f;
+}
+__device__ __forceinline__ unsigned fastdiv(unsigned n, const FastDiv& f) {
+  const unsigned t = __umulhi(f.m, n);
+  return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+
+
 // ---- cross-lane butterflies.  Inside a 16-lane DPP row the partner exchange is a VALU-rate DPP
 // move (quad_perm xor-1, xor-2, then row_ror 4 and 8), not an LDS-crossbar ds_bpermute; only the
 // two row-crossing steps of a 64-lane reduction go through __shfl_xor.

@@ -60,7 +60,8 @@ namespace mtr {
 template <bool FROM_U8, bool WRITE_L0>
 __global__ __launch_bounds__(256) void build_pyramid_kernel(
     const void* __restrict__ src_any, int planes, int Hi, int Wi, float* __restrict__ l0,
-    float* __restrict__ l1, float* __restrict__ l2, float* __restrict__ lut_out, GammaLut lut_in) {
+    float* __restrict__ l1, float* __restrict__ l2, float* __restrict__ lut_out, GammaLut lut_in,
+    FastDiv by_bw, FastDiv by_bh) {
   __shared__ float lut[256];
   if (FROM_U8) {
     lut[threadIdx.x] = lut_in.v[threadIdx.x];  // (v/255)**2.2, common.h
@@ -75,9 +76,17 @@ __global__ __launch_bounds__(256) void build_pyramid_kernel(
   const long long total = (long long)planes * bh * bw;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
        t += (long long)gridDim.x * blockDim.x) {
-    const int bx = (int)(t % bw);
-    const int by = (int)((t / bw) % bh);
-    const int pl = (int)(t / ((long long)bw * bh));
+    int bx, by, pl;
+    if (total <= 0xffffffffLL) {  // (wave-uniform) no 64-bit division per block: common.h FastDiv
+      const unsigned rowi = fastdiv((unsigned)t, by_bw);
+      bx = (int)((unsigned)t - rowi * (unsigned)bw);
+      pl = (int)fastdiv(rowi, by_bh);
+      by = (int)(rowi - (unsigned)pl * (unsigned)bh);
+    } else {
+      bx = (int)(t % bw);
+      by = (int)((t / bw) % bh);
+      pl = (int)(t / ((long long)bw * bh));
+    }
     const int x0 = bx * 4, y0 = by * 4;
     const uint8_t* sp = src + (size_t)pl * Hi * Wi;
     const float* spf = srcf + (size_t)pl * Hi * Wi;
@@ -147,7 +156,7 @@ __global__ __launch_bounds__(256) void build_pyramid_kernel(
 // whatever the pixel values (random pixels averaged ~3.5 ways on the shared 256-entry table).
 __global__ __launch_bounds__(256) void build_pyramid_u8_wide_kernel(
     const uint8_t* __restrict__ src, int planes, int Hi, int Wi, float* __restrict__ l1,
-    float* __restrict__ l2, float* __restrict__ lut_out, GammaLut lut_in) {
+    float* __restrict__ l2, float* __restrict__ lut_out, GammaLut lut_in, FastDiv by_tw, FastDiv by_th) {
   __shared__ __attribute__((aligned(16))) float lut[256 * 32];
   {
     const float v = lut_in.v[threadIdx.x];
@@ -163,9 +172,18 @@ __global__ __launch_bounds__(256) void build_pyramid_u8_wide_kernel(
   const long long total = (long long)planes * th * tw;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
        t += (long long)gridDim.x * blockDim.x) {
-    const int tx = (int)(t % tw);
-    const int ty = (int)((t / tw) % th);
-    const int pl = (int)(t / ((long long)tw * th));
+    int tx, ty, pl;
+    if (total <= 0xffffffffLL) {  // (wave-uniform) round 4: three 64-bit divisions per tile were ~450 of the
+      // thread's ~700 VALU instructions (common.h FastDiv)
+      const unsigned rowi = fastdiv((unsigned)t, by_tw);
+      tx = (int)((unsigned)t - rowi * (unsigned)tw);
+      pl = (int)fastdiv(rowi, by_th);
+      ty = (int)(rowi - (unsigned)pl * (unsigned)th);
+    } else {
+      tx = (int)(t % tw);
+      ty = (int)((t / tw) % th);
+      pl = (int)(t / ((long long)tw * th));
+    }
     const uint8_t* sp = src + ((size_t)pl * Hi + (size_t)ty * 8) * Wi + (size_t)tx * 8;
     uint2 raw[8];
 #pragma unroll
@@ -1029,7 +1047,8 @@ extern "C" int mtr_build_pyramid(const uint8_t* images_u8, int N, int Hi, int Wi
   MTR_CLEAR_STALE();
   hipLaunchKernelGGL((mtr::build_pyramid_kernel<true, true>), dim3(pyramid_grid(N, Hi, Wi)), dim3(256),
                      0, (hipStream_t)stream, (const void*)images_u8, N * 3, Hi, Wi, level0, level1,
-                     level2, (float*)nullptr, mtr::gamma_lut_host());
+                     level2, (float*)nullptr, mtr::gamma_lut_host(), mtr::make_fastdiv((unsigned)((Wi + 3) / 4)),
+                     mtr::make_fastdiv((unsigned)((Hi + 3) / 4)));
   MTR_CHECK_LAUNCH();
   return MTR_OK;
 }
@@ -1044,13 +1063,15 @@ extern "C" int mtr_build_pyramid_u8(const uint8_t* images_u8, int N, int Hi, int
   MTR_CLEAR_STALE();
   if (pyramid_wide_ok(images_u8, level1, level2, Hi, Wi)) {
     hipLaunchKernelGGL(mtr::build_pyramid_u8_wide_kernel, dim3(pyramid_wide_grid(N, Hi, Wi)), dim3(256),
-                       0, (hipStream_t)stream, images_u8, N * 3, Hi, Wi, level1, level2, lut, mtr::gamma_lut_host());
+                       0, (hipStream_t)stream, images_u8, N * 3, Hi, Wi, level1, level2, lut, mtr::gamma_lut_host(),
+                       mtr::make_fastdiv((unsigned)(Wi / 8)), mtr::make_fastdiv((unsigned)(Hi / 8)));
     MTR_CHECK_LAUNCH();
     return MTR_OK;
   }
   hipLaunchKernelGGL((mtr::build_pyramid_kernel<true, false>), dim3(pyramid_grid(N, Hi, Wi)),
                      dim3(256), 0, (hipStream_t)stream, (const void*)images_u8, N * 3, Hi, Wi,
-                     (float*)nullptr, level1, level2, lut, mtr::gamma_lut_host());
+                     (float*)nullptr, level1, level2, lut, mtr::gamma_lut_host(), mtr::make_fastdiv((unsigned)((Wi + 3) / 4)),
+                     mtr::make_fastdiv((unsigned)((Hi + 3) / 4)));
   MTR_CHECK_LAUNCH();
   return MTR_OK;
 }
@@ -1064,7 +1085,8 @@ extern "C" int mtr_pyramid_from_level0(const float* level0, int N, int Hi, int W
   MTR_CLEAR_STALE();
   hipLaunchKernelGGL((mtr::build_pyramid_kernel<false, false>), dim3(pyramid_grid(N, Hi, Wi)),
                      dim3(256), 0, (hipStream_t)stream, (const void*)level0, N * 3, Hi, Wi,
-                     (float*)nullptr, level1, level2, (float*)nullptr, mtr::gamma_lut_host());
+                     (float*)nullptr, level1, level2, (float*)nullptr, mtr::gamma_lut_host(),
+                     mtr::make_fastdiv((unsigned)((Wi + 3) / 4)), mtr::make_fastdiv((unsigned)((Hi + 3) / 4)));
   MTR_CHECK_LAUNCH();
   return MTR_OK;
 }
