@@ -329,6 +329,16 @@ int mtr_postprocess_poses(const float* poses_crop, const float* rot, const uint8
                           const float* distortion, const float* inv_extrinsics, int A, int n, int J,
                           int average_aug, float* poses3d, float* poses2d, mtr_stream_t stream);
 
+/* Row a11: Metrabs.latent_points_to_joints (metrabs_tf/models/metrabs.py:80-81 ->
+ * tfu3d.linear_combine_points tfu3d.py:48-49, einsum 'bjc,jJ->bJc'), the step Metrabs.forward runs
+ * behind reconstruct_absolute when transform_coords / predict_all_and_latents is set
+ * (metrabs_pytorch/models/metrabs.py:61-62, metrabs_tf/models/metrabs.py:61-62).
+ *   points [B, J_in, 3] f32 (the reconstructed latent points), weights [J_in, J_out] f32 row-major
+ *   (`w2` of the affine-weights file = recombination_weights) -> out [B, J_out, 3] f32.
+ * f64 sums, one rounding per output.  J_in <= 4096. */
+int mtr_linear_combine_points(const float* points, const float* weights, int B, int J_in, int J_out,
+                              float* out, mtr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K9: detector pre-processing, the step in front of the hot path.
  * Replaces PersonDetector.forward minus the network (metrabs_pytorch/multiperson/person_detector.py):

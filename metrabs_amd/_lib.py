@@ -115,6 +115,7 @@ SIGNATURES = {
     'mtr_postprocess_poses': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                       c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                       c_void_p, c_void_p, c_void_p]),
+    'mtr_linear_combine_points': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'mtr_warp_crops': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
                                c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'mtr_detector_geometry': (c_int, [c_int, c_int, c_int, POINTER(DetectorGeom)]),

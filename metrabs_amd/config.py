@@ -6,7 +6,7 @@ explicit object and cross the C-ABI as POD structs (include/metrabs_hip.h), so n
 read inside a kernel launch.
 """
 import dataclasses
-from typing import Optional
+from typing import Any, Optional
 
 from metrabs_amd import _lib
 
@@ -22,6 +22,11 @@ class MetrabsConfig:
     box_size_mm: float = 2200.0
     weak_perspective: bool = False
     mix_3d_inside_fov: Optional[float] = 0.5
+    # the affine-latent options of the crop model (config.yaml; models/metrabs.py:23-44,52-62)
+    affine_weights: Any = None          # path / name of the .npz with w1, w2 -- or a dict holding them
+    transform_coords: bool = False
+    predict_all_and_latents: bool = False
+    regularize_to_manifold: bool = False
 
     def head_params(self):
         return _lib.HeadParams(

@@ -366,7 +366,7 @@ __device__ __forceinline__ void ds_dma16(const void* sbase, unsigned voff, unsig
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                :
                : "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(su)
-               : "memory");
+               : "memory", "m0");  // (M0 is overwritten: the register allocator must know)
 }
 // Workgroup barrier without the fence __syncthreads() carries (s_waitcnt vmcnt(0) would drain the
 // loading wave's copies and make every computing wave wait for its output stores): LDS traffic of

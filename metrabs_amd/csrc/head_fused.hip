@@ -541,7 +541,7 @@ __device__ __forceinline__ void dma16_to_lds_asm(const void* src, unsigned lds_a
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
                :
                : "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(src)
-               : "memory");
+               : "memory", "m0");  // (M0 is overwritten: the register allocator must know)
 }
 __device__ __forceinline__ unsigned lds_byte_addr(const void* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;

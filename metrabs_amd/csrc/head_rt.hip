@@ -163,7 +163,7 @@ __device__ __forceinline__ void rt_dma16(const void* sbase, unsigned voff, unsig
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                :
                : "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(sbase)
-               : "memory");
+               : "memory", "m0");  // (M0 is overwritten: the register allocator must know)
 }
 
 template <int N>

@@ -101,7 +101,45 @@ __global__ __launch_bounds__(256) void postprocess_kernel(
   }
 }
 
+// Metrabs.latent_points_to_joints (metrabs_tf/models/metrabs.py:80-81 -> tfu3d.linear_combine_points
+// tfu3d.py:48-49, einsum 'bjc,jJ->bJc'; called by Metrabs.forward behind reconstruct_absolute when
+// transform_coords / predict_all_and_latents, metrabs_pytorch/models/metrabs.py:61-62): every output
+// joint is an affine combination of the crop's latent points.  One workgroup per crop, the crop's
+// points in LDS, one thread per (output joint, coordinate); the weight column of a joint is read
+// with lanes along J_out (coalesced), sums in f64, one rounding.
+__global__ __launch_bounds__(256) void linear_combine_kernel(
+    const float* __restrict__ points, const float* __restrict__ weights, int Jin, int Jout,
+    float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float pts[];  // [Jin][3]
+  const int b = blockIdx.x;
+  for (int t = threadIdx.x; t < Jin * 3; t += blockDim.x) pts[t] = points[(size_t)b * Jin * 3 + t];
+  __syncthreads();
+  for (int jo = threadIdx.x; jo < Jout; jo += blockDim.x) {
+    double x = 0.0, y = 0.0, z = 0.0;
+    for (int j = 0; j < Jin; ++j) {
+      const double w = weights[(size_t)j * Jout + jo];
+      x += w * pts[j * 3]; y += w * pts[j * 3 + 1]; z += w * pts[j * 3 + 2];
+    }
+    float* o = out + ((size_t)b * Jout + jo) * 3;
+    o[0] = (float)x; o[1] = (float)y; o[2] = (float)z;
+  }
+}
+
 }  // namespace mtr
+
+extern "C" int mtr_linear_combine_points(const float* points, const float* weights, int B, int J_in,
+                                         int J_out, float* out, mtr_stream_t stream) {
+  if (!points || !weights || !out) return MTR_E_NULL;
+  if (B < 0 || J_in <= 0 || J_out <= 0) return MTR_E_SHAPE;
+  const size_t lds = (size_t)J_in * 3 * sizeof(float);
+  if (lds > 48 * 1024) return MTR_E_SHAPE;  // <= 4096 latent points
+  if (B == 0) return MTR_OK;
+  MTR_CLEAR_STALE();
+  hipLaunchKernelGGL(mtr::linear_combine_kernel, dim3(B), dim3(J_out > 128 ? 256 : (J_out > 64 ? 128 : 64)),
+                     lds, (hipStream_t)stream, points, weights, J_in, J_out, out);
+  MTR_CHECK_LAUNCH();
+  return MTR_OK;
+}
 
 extern "C" int mtr_postprocess_poses(const float* poses_crop, const float* rot,
                                      const uint8_t* should_flip, const int32_t* mirror_mapping,

@@ -75,6 +75,43 @@ def _collective_device(t):
     return 'cpu' if (t.is_cuda and dist.get_backend() == 'gloo') else t.device
 
 
+def unshuffle_index(ranges_by_rank, cap, n_boxes):
+    """Host side of gather_ranges: for every global box its row in the gathered [world * cap, ...] buffer
+    (rank r's k-th local row sits at r * cap + k).  int64 numpy [n_boxes]; vectorised per rank -- a
+    thousand internal batches cost a few numpy calls, not a thousand tensor slice copies."""
+    import numpy as np
+    idx = np.full(n_boxes, -1, np.int64)
+    for r, rr in enumerate(ranges_by_rank):
+        if not rr:
+            continue
+        a = np.asarray(rr, np.int64).reshape(-1, 2)
+        lens = a[:, 1] - a[:, 0]
+        total = int(lens.sum())
+        if total == 0:
+            continue
+        within = np.arange(total) - np.repeat(np.cumsum(lens) - lens, lens)   # offset inside its range
+        idx[np.repeat(a[:, 0], lens) + within] = r * cap + np.arange(total)
+    if n_boxes and idx.min() < 0:
+        raise ValueError('the ranks\' ranges do not cover every box')
+    return idx
+
+
+_INDEX_CACHE = {}   # (ranges signature, device) -> device index tensor: a serving loop repeats its shapes
+
+
+def _device_index(ranges_by_rank, cap, n_boxes, device):
+    key = (tuple(tuple(rr) for rr in ranges_by_rank), n_boxes, str(device))
+    hit = _INDEX_CACHE.get(key)
+    if hit is None:
+        if device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            return None   # (no host-to-device copy inside a capture: the caller copies slices instead)
+        if len(_INDEX_CACHE) >= 64:
+            _INDEX_CACHE.clear()
+        hit = torch.from_numpy(unshuffle_index(ranges_by_rank, cap, n_boxes)).to(device)
+        _INDEX_CACHE[key] = hit
+    return hit
+
+
 def gather_ranges(local, ranges_by_rank, n_boxes, group=None, always=False):
     """One all-gather of the per-rank results, then un-shuffling into global box order.
 
@@ -93,7 +130,12 @@ def gather_ranges(local, ranges_by_rank, n_boxes, group=None, always=False):
     padded[:local.shape[0]] = local.to(dev)
     gathered = torch.empty((world_size * cap,) + tail, dtype=local.dtype, device=dev)
     dist.all_gather_into_tensor(gathered, padded, group=group)
-    gathered = gathered.reshape((world_size, cap) + tail).to(local.device)
+    gathered = gathered.to(local.device)
+    # un-shuffle: ONE gather by a host-built index (cached per shape of the call)
+    index = _device_index(ranges_by_rank, cap, n_boxes, local.device)
+    if index is not None:
+        return gathered.index_select(0, index)
+    gathered = gathered.reshape((world_size, cap) + tail)
     out = local.new_empty((n_boxes,) + tail)
     for r, rr in enumerate(ranges_by_rank):
         offset = 0

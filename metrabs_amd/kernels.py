@@ -407,6 +407,25 @@ def postprocess_poses(poses_crop, rot, should_flip, mirror_mapping, intrinsics, 
     return p3, p2
 
 
+def linear_combine_points(points, weights, out=None):
+    """points [B, J_in, 3], weights [J_in, J_out] -> [B, J_out, 3]: einsum 'bjc,jJ->bJc'
+    (tfu3d.linear_combine_points, metrabs_tf/tfu3d.py:48-49; Metrabs.latent_points_to_joints,
+    metrabs_tf/models/metrabs.py:80-81)."""
+    require_cuda(points, weights)
+    points = points.contiguous().float()
+    weights = weights.contiguous().float()
+    B, j_in = points.shape[:2]
+    if points.shape[2] != 3 or weights.dim() != 2 or weights.shape[0] != j_in:
+        raise ValueError(f'points {tuple(points.shape)} and weights {tuple(weights.shape)} do not match')
+    j_out = weights.shape[1]
+    if out is None:
+        out = torch.empty(B, j_out, 3, device=points.device, dtype=torch.float32)
+    check(_lib.load().mtr_linear_combine_points(_ptr(points), _ptr(weights), B, j_in, j_out, _ptr(out),
+                                                current_stream_ptr(points.device)),
+          'mtr_linear_combine_points')
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # K9: detector pre-processing (person_detector.py:14-54 minus the network)
 

@@ -4,6 +4,8 @@ Same constructor roles and forward signatures as the reference; the head runs in
 the fused 1x1-projection GEMM + soft-argmax decode (csrc/head_fused.hip) or, with
 ``fused=False``, a library GEMM for the 1x1 conv followed by the HIP decode kernel
 (csrc/decode.hip).  There is no CPU path."""
+import os
+
 import numpy as np
 import torch
 
@@ -35,51 +37,107 @@ class MetrabsHeads(torch.nn.Module):
         self.fused = fused
         self._auto_choice = {}
         self.last_path = None
-        self._packed = None
-        self._packed_key = None
+        # derived weight tensors, one slot per (what, feature dtype, number of leading points kept):
+        # slot -> (version key of conv_final's parameters, tensor(s)).  Several slots live side by side
+        # (an f32 and an f16 pack; the full head and its latent prefix): a HIP graph captured over one
+        # of them reads it by address (graph_cache.BatchGraph keeps `packed_snapshot()` alive and
+        # re-checks it before every replay).
+        self._derived = {}
 
-    def _packed_weights(self, feat_dtype):
+    def _version_key(self):
         w, b = self.conv_final.weight, self.conv_final.bias
-        # in-place parameter updates are seen through the version counters; inference tensors
-        # (parameters created under torch.inference_mode) have none, so they are re-packed per
-        # call (one tiny launch)
-        trackable = not (w.is_inference() or b.is_inference())
-        key = (w.data_ptr(), w._version, b.data_ptr(), b._version, feat_dtype, w.device)
-        if not trackable or self._packed_key != key:
-            self._packed = kernels.head_pack_weights(
-                w.detach().reshape(w.shape[0], -1), b.detach(), self.n_points, self.config.depth,
-                feat_dtype)
-            self._packed_key = key
-        return self._packed
+        return (w.data_ptr(), w._version, b.data_ptr(), b._version, w.device)
 
-    def forward(self, inp):
+    def _trackable(self):
+        # in-place parameter updates are seen through the version counters; inference tensors
+        # (parameters created under torch.inference_mode) have none, so what derives from them is
+        # rebuilt per call (one or two tiny launches; inside a capture: part of the graph)
+        return not (self.conv_final.weight.is_inference() or self.conv_final.bias.is_inference())
+
+    def _point_rows(self, n_keep, device):
+        """Output channels of the first n_keep points: [j < n_keep] of the 2D block and of every depth
+        slice of the 3D block (channel J + d*J + j, models/metrabs.py:79)."""
+        J, D = self.n_points, self.config.depth
+        j = torch.arange(n_keep, device=device)
+        return torch.cat([j] + [J + d * J + j for d in range(D)])
+
+    def _weights(self, n_keep=None):
+        """(weight [n_out, C], bias [n_out]) of the whole head, or of its first n_keep points."""
+        w, b = self.conv_final.weight, self.conv_final.bias
+        w2 = w.detach().reshape(w.shape[0], -1)
+        if n_keep is None or n_keep == self.n_points:
+            return w2, b.detach()
+        slot = ('rows', None, n_keep)
+        key = self._version_key()
+        hit = self._derived.get(slot)
+        if not self._trackable() or hit is None or hit[0] != key:
+            rows = self._point_rows(n_keep, w.device)
+            hit = (key, (w2.index_select(0, rows).contiguous(), b.detach().index_select(0, rows).contiguous()))
+            self._derived[slot] = hit
+        return hit[1]
+
+    def _packed_weights(self, feat_dtype, n_keep=None):
+        n_keep = self.n_points if n_keep is None else int(n_keep)
+        slot = ('packed', feat_dtype, n_keep)
+        key = self._version_key()
+        hit = self._derived.get(slot)
+        if not self._trackable() or hit is None or hit[0] != key:
+            w2, b = self._weights(n_keep)
+            hit = (key, kernels.head_pack_weights(w2, b, n_keep, self.config.depth, feat_dtype))
+            self._derived[slot] = hit
+        return hit[1]
+
+    def packed_snapshot(self):
+        """What a captured graph may have read by address: {slot: (version key, tensors)} (references
+        keep the memory from being handed out again while the graph lives)."""
+        return dict(self._derived)
+
+    def snapshot_is_current(self, snapshot):
+        """False once conv_final's parameters were edited in place, replaced or moved after `snapshot`
+        was taken, or a slot of it was rebuilt (its tensor is no longer the one the graph reads)."""
+        key = self._version_key()
+        for slot, (k, tensors) in snapshot.items():
+            cur = self._derived.get(slot)
+            if k != key or cur is None or cur[1] is not tensors:
+                return False
+        return True
+
+    def forward(self, inp, first_points=None):
+        """first_points = k: only the first k points are computed (their weight rows are selected once
+        per weight version; every point's soft-argmax is independent of the others, so the result is
+        what `forward(inp)[...][:, :k]` gives -- Metrabs' predict_all_and_latents slicing,
+        models/metrabs.py:52-54 -- without computing or storing the rest)."""
         if isinstance(self.conv_final, torch.nn.modules.lazy.LazyModuleMixin) and \
                 self.conv_final.has_uninitialized_params():
             self.conv_final(inp[:1])  # materialise the lazy conv exactly like the reference would
+        n_keep = self.n_points if first_points is None else int(first_points)
+        if not 0 < n_keep <= self.n_points:
+            raise ValueError(f'first_points = {first_points} of {self.n_points} points')
         _, c_in, h, w = inp.shape
         use_fused = bool(self.fused) and kernels.head_fused_supported(
-            c_in, self.n_points, self.config.depth, h, w, kernels._is_channels_last(inp), inp.dtype)
+            c_in, n_keep, self.config.depth, h, w, kernels._is_channels_last(inp), inp.dtype)
         if use_fused and self.fused == 'auto':
-            use_fused = kernels.head_auto_choice(c_in, self.n_points, self.config.depth, h, w,
+            use_fused = kernels.head_auto_choice(c_in, n_keep, self.config.depth, h, w,
                                                  kernels._is_channels_last(inp), inp.dtype)
             self._auto_choice[(tuple(inp.shape[1:]), inp.dtype, kernels._is_channels_last(inp))] = use_fused
         elif use_fused and self.fused == 'time':
-            use_fused = self._timed_pick(inp)
+            use_fused = self._timed_pick(inp, n_keep)
         self.last_path = 'fused' if use_fused else 'library'  # (bench.py reports which one ran)
         if use_fused:
-            return self._forward_fused(inp)
-        return self._forward_unfused(inp)
+            return self._forward_fused(inp, n_keep)
+        return self._forward_unfused(inp, n_keep)
 
-    def _forward_fused(self, inp):
-        return kernels.head_fused(inp, self._packed_weights(inp.dtype), inp.shape[1], self.n_points,
+    def _forward_fused(self, inp, n_keep=None):
+        n_keep = self.n_points if n_keep is None else n_keep
+        return kernels.head_fused(inp, self._packed_weights(inp.dtype, n_keep), inp.shape[1], n_keep,
                                   self.config)
 
-    def _timed_pick(self, inp):
-        key = (tuple(inp.shape), inp.dtype, kernels._is_channels_last(inp))
+    def _timed_pick(self, inp, n_keep=None):
+        key = (tuple(inp.shape), inp.dtype, kernels._is_channels_last(inp), n_keep)
         if key not in self._auto_choice:
             if torch.cuda.is_current_stream_capturing():
                 return True  # nothing can be timed inside a capture; decided on an eager call
-            fns = (self._forward_fused, self._forward_unfused)
+            fns = (lambda x: self._forward_fused(x, n_keep), lambda x: self._forward_unfused(x, n_keep))
             for fn in fns:  # lazy initialisation (weight packing, MIOpen's solver search)
                 for _ in range(3):
                     fn(inp)
@@ -96,24 +154,51 @@ class MetrabsHeads(torch.nn.Module):
             self._auto_choice[key] = best[0] <= best[1]
         return self._auto_choice[key]
 
-    def _forward_unfused(self, inp):
+    def _forward_unfused(self, inp, n_keep=None):
         # 1x1 conv as a library GEMM (rocBLAS / MIOpen).  16-bit features (the autocast backbone's
         # output) meet f32 parameters here: run the conv as autocast would (multiperson_model.py:241)
+        n_keep = self.n_points if n_keep is None else n_keep
+        if n_keep == self.n_points:
+            conv = self.conv_final
+        else:
+            w2, b = self._weights(n_keep)
+            conv = lambda x: torch.nn.functional.conv2d(x, w2[:, :, None, None], b)
         if inp.dtype != self.conv_final.weight.dtype and inp.dtype in (torch.float16, torch.bfloat16):
             with torch.autocast(device_type=inp.device.type, dtype=inp.dtype):
-                logits = self.conv_final(inp)
+                logits = conv(inp)
         else:
-            logits = self.conv_final(inp)
-        return kernels.softargmax_decode(logits, self.n_points, self.config)
+            logits = conv(inp)
+        return kernels.softargmax_decode(logits, n_keep, self.config)
+
+
+def load_affine_weights(spec):
+    """FLAGS.affine_weights (models/metrabs.py:23-32): a path to an .npz holding `w1` [J, n_latents]
+    (joints -> latent points) and `w2` [n_latents, J] (latent points -> joints), or a bare name looked
+    up as $DATA_ROOT/skeleton_conversion/<name>.npz (posepile.paths.DATA_ROOT is the DATA_ROOT
+    environment variable); a dict / npz object with those two arrays is taken as is."""
+    if isinstance(spec, (str, os.PathLike)):
+        path = os.fspath(spec)
+        if not os.path.exists(path):
+            path = os.path.join(os.environ.get('DATA_ROOT', ''), 'skeleton_conversion', f'{path}.npz')
+        spec = np.load(path)
+    w1 = torch.as_tensor(np.asarray(spec['w1']), dtype=torch.float32)
+    w2 = torch.as_tensor(np.asarray(spec['w2']), dtype=torch.float32)
+    if w1.dim() != 2 or w2.dim() != 2 or w1.shape != (w2.shape[1], w2.shape[0]):
+        raise ValueError(f'affine weights: w1 {tuple(w1.shape)} and w2 {tuple(w2.shape)} are not a '
+                         f'[J, n_latents] / [n_latents, J] pair')
+    return w1, w2
 
 
 class Metrabs(torch.nn.Module):
-    """models/metrabs.py:15-64 without the affine-latent options (transform_coords /
-    predict_all_and_latents call an undefined latent_points_to_joints in the reference,
-    models/metrabs.py:61-62, and are not part of the default configs)."""
+    """models/metrabs.py:15-64 (TF twin metrabs_tf/models/metrabs.py:16-87), the affine-latent options
+    included: with ``affine_weights`` the head predicts ``n_latents`` latent points
+    (``transform_coords``), the latent points followed by the joints (``predict_all_and_latents``), or
+    the joints alone (``regularize_to_manifold``, a training-time loss only); forward reconstructs the
+    latent points and maps them to the joints with `recombination_weights` (latent_points_to_joints --
+    the PyTorch file calls it at :62 without defining it; the TF file's :80-81 is the definition)."""
 
     def __init__(self, backbone, joint_info, config=None, in_channels=None, fused_head='auto',
-                 autocast_dtype=None):
+                 autocast_dtype=None, affine_weights=None):
         super().__init__()
         # The reference runs the crop model under torch.autocast(float16) on the GPU
         # (multiperson_model.py:241); None keeps the fp32 arithmetic of its CPU path.
@@ -124,11 +209,63 @@ class Metrabs(torch.nn.Module):
         self.joint_edges = np.array([[i, j] for i, j in joint_info.stick_figure_edges])
         self.input_resolution = np.int32(self.config.proc_side)
         self.joint_info = joint_info
+        cfg = self.config
+        affine = affine_weights if affine_weights is not None else cfg.affine_weights
+        self.n_latents = None
+        self.latent_output = False   # forward ends with latent_points_to_joints
+        self.latent_prefix = None    # forward keeps the first n_latents raw points
+        if affine is not None and not (isinstance(affine, str) and not affine):
+            w1, w2 = load_affine_weights(affine)
+            if w2.shape[1] != joint_info.n_joints:
+                raise ValueError(f'affine weights map to {w2.shape[1]} joints, the model has '
+                                 f'{joint_info.n_joints}')
+            self.n_latents = int(w2.shape[0])
+            # (plain attributes in the reference: not part of its state_dict -> non-persistent buffers)
+            self.register_buffer('recombination_weights', w2, persistent=False)
+            self.register_buffer('encoder_weights', w1, persistent=False)
+            self.register_buffer('reconstruction_weights', w1 @ w2, persistent=False)
+            if cfg.transform_coords:
+                n_raw_points = self.n_latents
+            elif cfg.predict_all_and_latents:
+                n_raw_points = self.n_latents + joint_info.n_joints
+            elif cfg.regularize_to_manifold:
+                n_raw_points = joint_info.n_joints
+            else:
+                raise ValueError('affine weights not used')  # (models/metrabs.py:41)
+            self.latent_output = bool(cfg.transform_coords or cfg.predict_all_and_latents)
+            # models/metrabs.py:52-54 slices under predict_all_and_latents alone; under transform_coords
+            # every raw point is a latent point already
+            if cfg.predict_all_and_latents:
+                self.latent_prefix = self.n_latents
+        else:
+            if cfg.transform_coords or cfg.predict_all_and_latents:
+                # the reference would fail at forward time (no recombination_weights); fail at construction
+                raise ValueError('transform_coords / predict_all_and_latents need affine_weights')
+            n_raw_points = joint_info.n_joints
+        self.n_raw_points = n_raw_points
         self.heatmap_heads = MetrabsHeads(
-            n_points=joint_info.n_joints, config=self.config, in_channels=in_channels,
-            fused=fused_head)
+            n_points=n_raw_points, config=self.config, in_channels=in_channels, fused=fused_head)
         # set by Pose3dEstimator(shard_across_ranks='exact_monolithic') around its calls
         self.exact_monolithic = False
+        # bumped whenever the module's tensors are moved / cast (nn.Module._apply): graphs captured over
+        # the old storage are dropped by their owner (graph_cache.GraphCache.plan_call)
+        self.storage_generation = 0
+
+    def _apply(self, fn, *args, **kwargs):
+        self.storage_generation = getattr(self, 'storage_generation', 0) + 1
+        return super()._apply(fn, *args, **kwargs)
+
+    def latent_points_to_joints(self, points):
+        """metrabs_tf/models/metrabs.py:80-81 (tfu3d.linear_combine_points, tfu3d.py:48-49)."""
+        return kernels.linear_combine_points(points, self.recombination_weights)
+
+    def joints_to_latent_points(self, points):
+        """metrabs_tf/models/metrabs.py:83-84."""
+        return kernels.linear_combine_points(points, self.encoder_weights)
+
+    def joints_to_joints(self, points):
+        """metrabs_tf/models/metrabs.py:86-87."""
+        return kernels.linear_combine_points(points, self.reconstruction_weights)
 
     def forward(self, inp):
         image, intrinsics = inp
@@ -137,11 +274,17 @@ class Metrabs(torch.nn.Module):
                 features = self.backbone(image)
         else:
             features = self.backbone(image)
-        coords2d, coords3d = self.heatmap_heads(features)
+        # predict_all_and_latents: coords[:, :n_latents] (models/metrabs.py:52-54) -- the head computes
+        # just those points
+        coords2d, coords3d = self.heatmap_heads(features, first_points=self.latent_prefix)
         if self.exact_monolithic and distributed.exact_mode_needs_allreduce(self):
             # this call holds one rank's slice of a reference internal batch: the batch-global RMS
             # scalars of reconstruct_ref_fullpersp (ptu3d.py:71-74) come from the summed moments
             moments = kernels.reconstruct_moments(coords2d, coords3d, intrinsics)
             distributed.allreduce_moments(moments)
-            return kernels.reconstruct_solve(coords2d, coords3d, intrinsics, moments, self.config)
-        return kernels.reconstruct_absolute(coords2d, coords3d, intrinsics, self.config)
+            coords3d_abs = kernels.reconstruct_solve(coords2d, coords3d, intrinsics, moments, self.config)
+        else:
+            coords3d_abs = kernels.reconstruct_absolute(coords2d, coords3d, intrinsics, self.config)
+        if self.latent_output:  # models/metrabs.py:61-62
+            coords3d_abs = self.latent_points_to_joints(coords3d_abs)
+        return coords3d_abs

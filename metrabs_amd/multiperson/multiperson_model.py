@@ -134,8 +134,9 @@ class Pose3dEstimator(torch.nn.Module):
         self.graph_batches = 'auto'
         self.graphs = graph_cache.GraphCache(self)
         # captured graphs read the weights at capture: loading a state dict (into the estimator or the crop
-        # model) and moving / casting the module (.to, .cuda, .half: nn.Module._apply) drop them.  In-place
-        # edits of single parameters do not: call self.graphs.clear() after those.
+        # model) and moving / casting the module (.to, .cuda, .half: nn.Module._apply) drop them; so do
+        # .to / .half on the crop model alone and edits of the head's parameters (graph_cache.BatchGraph.
+        # is_current).  In-place edits of single BACKBONE parameters do not: self.graphs.clear() after those.
         drop = lambda *a, **k: self.graphs.clear()
         for m in (self, self.crop_model):
             if hasattr(m, 'register_load_state_dict_post_hook'):
@@ -289,7 +290,8 @@ class Pose3dEstimator(torch.nn.Module):
         boxes_host = (torch.cat([torch.as_tensor(b, dtype=torch.float32).reshape(-1, 5)
                                  for b in boxes if len(b)], dim=0).cpu().numpy() if n_total
                       else np.zeros((0, 5), np.float32))
-        per_box = lambda x: np.ascontiguousarray(x, dtype=np.float32).reshape(n_images, -1)[image_id_host]
+        per_box = lambda x: np.ascontiguousarray(x, dtype=np.float32).reshape(
+            n_images, int(np.prod(x.shape[1:])))[image_id_host]   # (-1 cannot be inferred for 0 frames)
         (boxes_flat, intrinsic_matrix_b, distortion_b, camspace_up_b, image_id_per_box,
          inv_extrinsics_b) = self._upload_per_box(dev, [
             (boxes_host, (5,)), (per_box(intrinsic_matrix.numpy()), (3, 3)),
@@ -461,12 +463,16 @@ class Pose3dEstimator(torch.nn.Module):
                 and self.graph_batches and type(self)._predict_single_batch is Pose3dEstimator._predict_single_batch
                 and '_predict_single_batch' not in self.__dict__):
             plan = self.graphs.plan_call(images, ranges, tta, antialias_factor, post)
+        staging = None
+        if (plan is None and dev.type == 'cuda' and not images.is_cuda and images.is_pinned() and len(images)
+                and not per_batch_pyramids):
+            # pinned host frames: the PCIe copy runs on a copy stream under the previous call's compute
+            # (None: no frame set free for this frame size right now -- the plain blocking upload below)
+            staging = self.graphs.frame_set(len(images), images.shape[2], images.shape[3], dev, optional=True)
         if plan is not None:
             pyramid = plan.frames.load(images)   # static frame + pyramid buffers the graphs read
-        elif (dev.type == 'cuda' and not images.is_cuda and images.is_pinned() and len(images)
-              and not per_batch_pyramids):
-            # pinned host frames: the PCIe copy runs on a copy stream under the previous call's compute
-            pyramid = self.graphs.frame_set(len(images), images.shape[2], images.shape[3], dev).load(images)
+        elif staging is not None:
+            pyramid = staging.load(images)
         else:
             images = images.to(dev)
             pyramid = kernels.build_pyramid(images) if len(images) and not per_batch_pyramids else None

@@ -239,6 +239,40 @@ def parity_gate_inputs(name, regime):
     return feat.to(dtype), w, b, K
 
 
+# ---- row a11: the affine-latent options of Metrabs (models/metrabs.py:23-44,52-62)
+# name: (mode, B, C, n_joints, n_latents, map side, proc_side, depth bins, bump height, seed)
+LATENT_CASES = {
+    'transform_b8': ('transform_coords', 8, 256, 17, 12, 8, 256, 8, 4.0, 9501),
+    'all_and_latents_b8': ('predict_all_and_latents', 8, 512, 17, 12, 8, 256, 8, 25.0, 9502),
+    'all_and_latents_j60_384': ('predict_all_and_latents', 4, 1280, 60, 32, 12, 384, 8, 4.0, 9503),
+    'regularize_b4': ('regularize_to_manifold', 4, 256, 17, 12, 8, 256, 8, 4.0, 9504),
+}
+
+
+def affine_weights_case(n_joints, n_latents, seed):
+    """A synthetic affine-weights file: w1 [J, n_latents] (every latent point an affine combination of
+    the joints: its column sums to 1) and w2 [n_latents, J] (every joint an affine combination of the
+    latent points, negative weights included) -- what the reference's skeleton_conversion/*.npz hold."""
+    g = gen(seed)
+    w1 = torch.softmax(2.0 * torch.randn(n_joints, n_latents, generator=g), dim=0)
+    r = 0.3 * torch.randn(n_latents, n_joints, generator=g)
+    w2 = r - r.mean(dim=0, keepdim=True) + 1.0 / n_latents
+    return w1.float().contiguous(), w2.float().contiguous()
+
+
+def latent_case(name):
+    """-> dict(cfg, features [B,C,h,w], weight [N,C], bias [N], K [B,3,3], w1, w2, n_joints, n_latents,
+    n_raw): a plausible-pose head (consistent_head_case) over the model's RAW points."""
+    mode, B, C, J, n_lat, hw, P, D, amp, seed = LATENT_CASES[name]
+    cfg = HeadConfig(proc_side=P, depth=D, **{mode: True})
+    n_raw = {'transform_coords': n_lat, 'predict_all_and_latents': n_lat + J,
+             'regularize_to_manifold': J}[mode]
+    feat, w, b, K = consistent_head_case(B, C, n_raw, hw, P, D, amp, seed)
+    w1, w2 = affine_weights_case(J, n_lat, seed + 50)
+    return dict(cfg=cfg, features=feat, weight=w, bias=b, K=K, w1=w1, w2=w2, n_joints=J, n_latents=n_lat,
+                n_raw=n_raw)
+
+
 # ------------------------------------------------------------------------------------ reconstruct
 
 RECON_CASES = {

@@ -37,6 +37,11 @@ class HeadConfig:
     box_size_mm: float = 2200.0
     weak_perspective: bool = False
     mix_3d_inside_fov: float = 0.5
+    # the affine-latent options of Metrabs (models/metrabs.py:23-44,52-62); the weights themselves
+    # (FLAGS.affine_weights names a file) travel beside the config
+    transform_coords: bool = False
+    predict_all_and_latents: bool = False
+    regularize_to_manifold: bool = False
 
     def as_dict(self):
         return dataclasses.asdict(self)
@@ -265,10 +270,39 @@ def reconstruct_absolute(coords2d, coords3d_rel, intrinsics, cfg, mix_3d_inside_
     return torch.where(in_fov[..., np.newaxis], abs_2d_based, abs_3d_based)
 
 
-def crop_model_from_features(features, weight, bias, intrinsics, n_points, cfg):
-    """Metrabs.forward after the backbone, models/metrabs.py:50-59."""
+def linear_combine_points(coords, weights):
+    """tfu3d.linear_combine_points, metrabs_tf/tfu3d.py:48-49 (the PyTorch port calls
+    Metrabs.latent_points_to_joints at models/metrabs.py:62 without defining it; the TF twin's
+    definition, metrabs_tf/models/metrabs.py:80-81, is the specification)."""
+    return torch.einsum('bjc,jJ->bJc', coords, weights)
+
+
+def n_raw_points(n_joints, n_latents, cfg):
+    """Metrabs.__init__, models/metrabs.py:34-44: how many points the head predicts."""
+    if n_latents is None:
+        return n_joints
+    if cfg.transform_coords:
+        return n_latents
+    if cfg.predict_all_and_latents:
+        return n_latents + n_joints
+    if cfg.regularize_to_manifold:
+        return n_joints
+    raise Exception('affine weights not used')
+
+
+def crop_model_from_features(features, weight, bias, intrinsics, n_points, cfg, recombination_weights=None):
+    """Metrabs.forward after the backbone, models/metrabs.py:50-64.  n_points = the head's raw point
+    count; recombination_weights [n_latents, J] (`w2` of the affine-weights file) when the model was
+    built with affine weights."""
     coords2d, coords3d_rel = heads_forward(features, weight, bias, n_points, cfg)
-    return reconstruct_absolute(coords2d, coords3d_rel, intrinsics, cfg)
+    if cfg.predict_all_and_latents:  # :52-54
+        n_latents = recombination_weights.shape[0]
+        coords2d = coords2d[:, :n_latents]
+        coords3d_rel = coords3d_rel[:, :n_latents]
+    coords3d_abs = reconstruct_absolute(coords2d, coords3d_rel, intrinsics, cfg)
+    if cfg.transform_coords or cfg.predict_all_and_latents:  # :61-62
+        coords3d_abs = linear_combine_points(coords3d_abs, recombination_weights)
+    return coords3d_abs
 
 
 def lookat_matrix(forward_vector, up_vector):
@@ -590,13 +624,19 @@ def mpjpe(a, b):
     return float(torch.linalg.norm(a.double() - b.double(), dim=-1).mean())
 
 
-def crop_model_from_features_fp64(features, weight, bias, intrinsics, n_points, cfg):
+def crop_model_from_features_fp64(features, weight, bias, intrinsics, n_points, cfg,
+                                  recombination_weights=None):
     """The same head + reconstruction evaluated in float64 end to end (yardstick only)."""
     if weight.ndim == 2:
         weight = weight[:, :, None, None]
     logits = F.conv2d(features.double(), weight.double(), bias.double())
     c2d, c3d = heads_from_logits(logits, n_points, cfg, eval_dtype=torch.float64)
-    return reconstruct_absolute(c2d, c3d, intrinsics.double(), cfg)
+    if cfg.predict_all_and_latents:
+        c2d, c3d = c2d[:, :recombination_weights.shape[0]], c3d[:, :recombination_weights.shape[0]]
+    out = reconstruct_absolute(c2d, c3d, intrinsics.double(), cfg)
+    if cfg.transform_coords or cfg.predict_all_and_latents:
+        out = linear_combine_points(out, recombination_weights.double())
+    return out
 
 
 def postprocess_from_crop_outputs(poses_flat, rot, should_flip, mirror_mapping, intrinsic_matrix,

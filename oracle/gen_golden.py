@@ -197,6 +197,41 @@ def gen_recon(ref, only=None):
              input_sha256=np.array(cases.sha256_of(c2d, rel, K)))
 
 
+def gen_latent(ref, only=None):
+    """Row a11: the REFERENCE's Metrabs (models/metrabs.py:12-64) built with affine weights, its backbone
+    an Identity over the seeded features.  The PyTorch file calls self.latent_points_to_joints (:62) but
+    never defines it; the harness supplies the TF twin's definition (metrabs_tf/models/metrabs.py:80-81 ->
+    tfu3d.linear_combine_points, tfu3d.py:48-49: einsum 'bjc,jJ->bJc') as that one method -- everything
+    else (point counts, slicing, reconstruct_absolute, the call order) is the reference's own code."""
+    import tempfile
+    from oracle import cpu_ref
+    for name in cases.LATENT_CASES:
+        if only and name != only:
+            continue
+        c = cases.latent_case(name)
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, 'affine.npz')
+            np.savez(path, w1=c['w1'].numpy(), w2=c['w2'].numpy())
+            kw = dict(cfg_kwargs(c['cfg']), affine_weights=path)
+            with rh.config(**kw), torch.inference_mode():
+                ji = rh._JointInfoStub([f'j{i}' for i in range(c['n_joints'])], [[0, 1]])
+                model = ref.metrabs_model.Metrabs(torch.nn.Identity(), ji).eval()
+                assert model.heatmap_heads.n_points == c['n_raw']
+                conv = torch.nn.Conv2d(c['weight'].shape[1], c['weight'].shape[0], 1)
+                conv.weight.copy_(c['weight'][:, :, None, None])
+                conv.bias.copy_(c['bias'])
+                model.heatmap_heads.conv_final = conv
+                if not hasattr(type(model), 'latent_points_to_joints'):
+                    model.latent_points_to_joints = lambda points, m=model: torch.einsum(
+                        'bjc,jJ->bJc', points, m.recombination_weights)
+                poses = model((c['features'], c['K']))
+                truth = cpu_ref.crop_model_from_features_fp64(
+                    c['features'], c['weight'], c['bias'], c['K'], c['n_raw'], c['cfg'], c['w2'])
+        save(f'latent_{name}', poses3d=poses, poses3d_fp64=truth,
+             reference_vs_fp64_mpjpe_mm=np.array(cpu_ref.mpjpe(poses, truth)),
+             input_sha256=np.array(cases.sha256_of(c['features'], c['weight'], c['bias'], c['K'], c['w1'], c['w2'])))
+
+
 def gen_warp(ref):
     for name in cases.WARP_CASES:
         c = cases.warp_case(name)
@@ -393,7 +428,7 @@ def main():
     torch.manual_seed(0)
     ref = rh.load()
     groups = dict(heads=gen_heads, headconv=gen_headconv, recon=gen_recon, warp=gen_warp,
-                  tta=gen_tta, e2e=gen_e2e, detpre=gen_detpre, filter=gen_filter, backbone=gen_backbone,
+                  tta=gen_tta, e2e=gen_e2e, latent=gen_latent, detpre=gen_detpre, filter=gen_filter, backbone=gen_backbone,
                   parity=gen_parity, jitter=gen_jitter)
     for name in (sys.argv[1:] or [g for g in groups if g != 'jitter']):
         if ':' in name:  # one case of a group (recon, e2e: their lstsq goldens carry run-to-run jitter)

@@ -113,20 +113,54 @@ def test_calls_under_inference_mode_and_plain_no_grad_share_the_cache(hip_lib):
         assert est.graphs.stats['replays'] >= 2, est.graphs.last_capture_error
 
 
-def test_frame_set_eviction_drops_the_graphs_that_read_it(hip_lib):
+def test_frame_set_grows_and_drops_the_graphs_that_read_the_old_one(hip_lib):
     case = cases.e2e_case('aug5')
     ref = build_estimator(case, 'auto')
     ref.graph_batches = False
     est = build_estimator(case, 'auto')
     est.graph_batches = True
     est.graphs.max_frame_sets = 1
-    for n_images in (2, 3, 2):  # the 2-frame set is evicted by the 3-frame one and rebuilt
+    for n_images in (2, 3, 2, 3):  # the 2-frame set is replaced by a 3-frame one, whose head serves 2 frames
         images, boxes, K = _inputs(case, 30 + n_images, n_images, [2] * n_images)
         a = _call(ref, images.cuda(), boxes, K, case)
         b = _call(est, images.cuda(), boxes, K, case)
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-    assert est.graphs.stats['evictions'] >= 2 and len(est.graphs.frame_sets) == 1
-    assert all(k[0] == next(iter(est.graphs.frame_sets)) for k in est.graphs.graphs)
+    fs = next(iter(est.graphs.frame_sets.values()))
+    assert est.graphs.stats['evictions'] >= 1 and len(est.graphs.frame_sets) == 1 and fs.capacity == 3
+    assert all(g.frames is fs for g in est.graphs.graphs.values())
+    assert est.graphs.stats['replays'] >= 1, est.graphs.last_capture_error
+
+
+def test_graphs_follow_the_heads_weights(hip_lib):
+    """ a graph reads the head's packed weights by address: an f32 and an f16 graph live side by
+    side (two slots, both kept alive), and an in-place edit of the head's parameters or `.half()` /
+    `.float()` on the crop model alone re-captures instead of replaying stale or freed memory."""
+    case = cases.e2e_case('aug5')
+    est = build_estimator(case, 'auto')
+    est.graph_batches = True
+    ref = build_estimator(case, 'auto')
+    ref.graph_batches = False
+    images, boxes, K = _inputs(case, 77, 2, [3, 2])
+    want32 = _call(ref, images.cuda(), boxes, K, case)
+    got = _call(est, images.cuda(), boxes, K, case)
+    assert torch.equal(got[0], want32[0])
+    heads = est.crop_model.heatmap_heads
+    assert any(slot[0] == 'packed' for slot in heads._derived)
+    # in-place edit of the head's bias: the next call must see it
+    with torch.no_grad():
+        heads.conv_final.bias.add_(0.25)
+        ref.crop_model.heatmap_heads.conv_final.bias.add_(0.25)
+    want = _call(ref, images.cuda(), boxes, K, case)
+    got = _call(est, images.cuda(), boxes, K, case)
+    assert torch.equal(got[0], want[0]) and not torch.equal(got[0], want32[0])
+    assert est.graphs.stats['stale'] >= 1
+    # moving / casting the crop model alone (not through the estimator's _apply)
+    stale0 = est.graphs.stats['stale']
+    est.crop_model.double().float()
+    got = _call(est, images.cuda(), boxes, K, case)
+    assert torch.equal(got[0], want[0]) and est.graphs.stats['stale'] > stale0
+    got = _call(est, images.cuda(), boxes, K, case)
+    assert torch.equal(got[0], want[0]) and est.graphs.stats['replays'] >= 1
 
 
 def test_loading_weights_drops_the_captured_graphs(hip_lib):

@@ -11,16 +11,22 @@ from metrabs_amd import graph_cache
 
 class FakeFrames:
     def __init__(self, n, h, w, device):
-        self.key = (n, h, w, str(device))
+        self.key = (h, w, str(device))
+        self.capacity = n
 
 
 class FakeGraph:
     fail = False
+    stale = False
 
-    def __init__(self, est, frames, batch_args, tta, aa, post):
+    def __init__(self, est, frames, batch_args, tta, aa, post, n_frames=None, pool=None):
         if FakeGraph.fail:
             raise RuntimeError('capture failed')
         self.frames = frames
+        self.n_frames = n_frames
+
+    def is_current(self, est):
+        return not FakeGraph.stale
 
 
 @pytest.fixture
@@ -29,7 +35,7 @@ def cache(monkeypatch):
     monkeypatch.setattr(graph_cache, 'BatchGraph', FakeGraph)
     monkeypatch.setattr(torch.cuda, 'is_current_stream_capturing', lambda: False)
     monkeypatch.setattr(torch.cuda, 'synchronize', lambda *a, **k: None)
-    FakeGraph.fail = False
+    FakeGraph.fail = FakeGraph.stale = False
     est = types.SimpleNamespace(graph_batches='auto', crop_dtype=torch.float32, crop_channels_last=False,
                                 crop_model=types.SimpleNamespace(input_resolution=256),
                                 _device=lambda: torch.device('cpu'))
@@ -40,9 +46,9 @@ TTA = dict(gammas=torch.ones(1))
 POST = dict(joint_transform=None, average_aug=True, skeleton=torch.arange(17))
 
 
-def call(cache, n_boxes, n_frames=2):
+def call(cache, n_boxes, n_frames=2, hw=8):
     """One call with a single internal batch of n_boxes -> 'replay' | 'capture' | 'eager'."""
-    images = torch.zeros(n_frames, 3, 8, 8, dtype=torch.uint8)
+    images = torch.zeros(n_frames, 3, hw, hw, dtype=torch.uint8)
     before = dict(cache.stats)
     plan = cache.plan_call(images, [(0, n_boxes)], TTA, 1, POST)
     if plan is None:
@@ -72,12 +78,44 @@ def test_full_cache_evicts_at_most_once_per_interval(cache):
     assert len(cache.graphs) == 2
 
 
-def test_graphs_go_with_their_frame_set(cache):
+def test_one_frame_set_per_frame_size_grows_to_the_largest_frame_count(cache):
     cache.est.graph_batches = True
-    assert call(cache, 4, n_frames=2) == 'capture'
-    assert call(cache, 4, n_frames=3) == 'capture'     # another frame shape: the 2-frame set is evicted ...
-    assert len(cache.frame_sets) == 1 and all(k[0][0] == 3 for k in cache.graphs)   # ... and its graph with it
-    assert call(cache, 4, n_frames=2) == 'capture'     # rebuilt
+    assert call(cache, 4, n_frames=3) == 'capture'
+    assert call(cache, 4, n_frames=2) == 'capture'     # fewer frames of the same size: the head of the same set
+    assert len(cache.frame_sets) == 1 and cache.stats['evictions'] == 0 and len(cache.graphs) == 2
+    assert {g.n_frames for g in cache.graphs.values()} == {2, 3}
+    assert call(cache, 4, n_frames=3) == 'replay' and call(cache, 4, n_frames=2) == 'replay'
+    assert call(cache, 4, n_frames=5) == 'capture'     # more frames than the set holds: a larger set ...
+    fs = next(iter(cache.frame_sets.values()))
+    assert fs.capacity == 5 and cache.stats['evictions'] == 2   # ... and the graphs over the old one are gone
+    assert all(g.frames is fs for g in cache.graphs.values())
+
+
+def test_cycling_over_more_frame_sizes_than_sets_does_not_recapture_every_call(cache):
+    """(ADVICE r4) max_frame_sets = 1: the second frame size may replace the first once per eviction interval;
+    in between it runs eagerly, and the size that owns the set keeps replaying."""
+    cache.est.graph_batches = True
+    assert call(cache, 4, hw=8) == 'capture'
+    assert call(cache, 4, hw=16) == 'capture'          # the first replacement is free
+    outcomes = [call(cache, 4, hw=hw) for hw in (8, 16, 8, 16)]
+    assert outcomes == ['eager', 'replay', 'eager', 'replay'], outcomes
+    assert cache.stats['captures'] == 2
+    # the pinned-frame staging of an eager call does not replace the set inside the interval either
+    assert cache.frame_set(2, 8, 8, torch.device('cpu'), optional=True) is None
+    # ... once the interval (5 batches) has passed a size that keeps coming replaces it
+    assert 'capture' in [call(cache, 4, hw=8) for _ in range(3)]
+    assert cache.stats['captures'] == 3 and len(cache.frame_sets) == 1
+
+
+def test_a_graph_whose_weights_were_replaced_is_captured_again(cache):
+    cache.est.graph_batches = True
+    assert call(cache, 4) == 'capture' and call(cache, 4) == 'replay'
+    FakeGraph.stale = True
+    try:
+        assert call(cache, 4) == 'capture' and cache.stats['stale'] == 1
+    finally:
+        FakeGraph.stale = False
+    assert call(cache, 4) == 'replay'
 
 
 def test_a_failed_capture_leaves_the_shape_eager(cache):

@@ -265,3 +265,60 @@ def test_head_plan_reads_the_batch_size_in_eights_and_the_auto_rule_not_at_all()
     assert not kernels.head_auto_choice(1280, 17, 8, 24, 24)
     assert not kernels.head_auto_choice(1280, 17, 8, 20, 20, dtype=torch.bfloat16)
     assert not kernels.head_auto_choice(1280, 17, 81, 8, 8)   # no fused kernel beyond 80 depth bins
+
+
+def test_metrabs_affine_latent_modes_follow_the_reference_constructor(tmp_path):
+    """Row a11, host side (models/metrabs.py:23-44): raw point counts per mode, the affine-weights file /
+    name / dict forms, 'affine weights not used', and which rows of conv_final a latent prefix selects."""
+    import os
+    from metrabs_amd.config import MetrabsConfig
+    from metrabs_amd.joint_info import JointInfo
+    from metrabs_amd.models.metrabs import Metrabs, MetrabsHeads, load_affine_weights
+    J, n_lat = 17, 12
+    ji = JointInfo([f'j{i}' for i in range(J)], [[0, 1]])
+    w1 = np.random.RandomState(0).rand(J, n_lat).astype(np.float32)
+    w2 = np.random.RandomState(1).rand(n_lat, J).astype(np.float32)
+    path = str(tmp_path / 'aff.npz')
+    np.savez(path, w1=w1, w2=w2)
+    os.makedirs(tmp_path / 'skeleton_conversion')
+    np.savez(str(tmp_path / 'skeleton_conversion' / 'named.npz'), w1=w1, w2=w2)
+    for mode, n_raw, out_latent, prefix in (('transform_coords', n_lat, True, None),
+                                            ('predict_all_and_latents', n_lat + J, True, n_lat),
+                                            ('regularize_to_manifold', J, False, None)):
+        m = Metrabs(torch.nn.Identity(), ji, MetrabsConfig(affine_weights=path, **{mode: True}), in_channels=8)
+        assert (m.n_raw_points, m.latent_output, m.latent_prefix, m.n_latents) == (n_raw, out_latent, prefix, n_lat)
+        assert m.heatmap_heads.conv_final.out_channels == n_raw * 9
+        assert torch.equal(m.reconstruction_weights, torch.from_numpy(w1) @ torch.from_numpy(w2))
+        assert 'recombination_weights' not in m.state_dict()   # plain attributes in the reference
+    os.environ['DATA_ROOT'], old = str(tmp_path), os.environ.get('DATA_ROOT')
+    try:
+        a, b = load_affine_weights('named')   # $DATA_ROOT/skeleton_conversion/<name>.npz (:24-25)
+    finally:
+        os.environ.pop('DATA_ROOT') if old is None else os.environ.__setitem__('DATA_ROOT', old)
+    assert a.shape == (J, n_lat) and b.shape == (n_lat, J)
+    with pytest.raises(ValueError, match='affine weights not used'):
+        Metrabs(torch.nn.Identity(), ji, MetrabsConfig(), in_channels=8, affine_weights=dict(w1=w1, w2=w2))
+    with pytest.raises(ValueError):
+        Metrabs(torch.nn.Identity(), ji, MetrabsConfig(transform_coords=True), in_channels=8)
+    with pytest.raises(ValueError):   # w2 maps to another joint count
+        Metrabs(torch.nn.Identity(), JointInfo(['a', 'b'], [[0, 1]]), MetrabsConfig(transform_coords=True),
+                in_channels=8, affine_weights=dict(w1=w1, w2=w2))
+    plain = Metrabs(torch.nn.Identity(), ji, MetrabsConfig(), in_channels=8)
+    assert plain.n_raw_points == J and not plain.latent_output and plain.n_latents is None
+    # the rows of a latent prefix: j < k of the 2D block and of every depth slice (channel J + d*J + j, :79)
+    heads = MetrabsHeads(5, MetrabsConfig(depth=2), in_channels=4)
+    assert heads._point_rows(2, 'cpu').tolist() == [0, 1, 5, 6, 10, 11]
+    wsel, bsel = heads._weights(2)
+    assert torch.equal(wsel, heads.conv_final.weight.detach()[[0, 1, 5, 6, 10, 11], :, 0, 0])
+    assert heads._weights(2)[0] is wsel                      # cached per weight version ...
+    with torch.no_grad():
+        heads.conv_final.bias.add_(1.0)
+    assert heads._weights(2)[0] is not wsel                  # ... and rebuilt after an in-place edit
+    snap = heads.packed_snapshot()
+    assert heads.snapshot_is_current(snap)
+    with torch.no_grad():
+        heads.conv_final.weight.mul_(2.0)
+    assert not heads.snapshot_is_current(snap)
+    gen0 = plain.storage_generation
+    plain.double()
+    assert plain.storage_generation > gen0

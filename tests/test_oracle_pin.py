@@ -61,6 +61,60 @@ def test_recon_vs_golden(name):
     check(out, g['poses3d'], g, atol=2e-3, exact_ok=False)
 
 
+@pytest.mark.parametrize('name', list(cases.LATENT_CASES))
+def test_latent_crop_model_vs_golden(name):
+    """Row a11: the restated Metrabs.forward with affine weights (point counts, [:n_latents] slicing,
+    latent_points_to_joints) vs the output of the reference's own Metrabs (gen_golden.gen_latent)."""
+    g = load_golden(f'latent_{name}')
+    c = cases.latent_case(name)
+    assert cases.sha256_of(c['features'], c['weight'], c['bias'], c['K'], c['w1'], c['w2']) == str(g['input_sha256'])
+    assert cpu_ref.n_raw_points(c['n_joints'], c['n_latents'], c['cfg']) == c['n_raw']
+    with torch.inference_mode():
+        out = cpu_ref.crop_model_from_features(c['features'], c['weight'], c['bias'], c['K'], c['n_raw'], c['cfg'],
+                                               c['w2'])
+    check(out, g['poses3d'], g, atol=4e-3, exact_ok=False)   # (behind the lstsq of reconstruct_absolute)
+    assert out.shape[1] == c['n_joints']
+
+
+@pytest.mark.skipif(not rh.reference_available(), reason='needs /root/reference')
+@pytest.mark.parametrize('name', list(cases.LATENT_CASES))
+def test_latent_crop_model_vs_live_reference(name, tmp_path):
+    """The reference's Metrabs built with an affine-weights FILE (models/metrabs.py:23-44); its missing
+    latent_points_to_joints supplied as the TF twin's one-liner (metrabs_tf/models/metrabs.py:80-81)."""
+    ref = rh.load()
+    c = cases.latent_case(name)
+    path = str(tmp_path / 'affine.npz')
+    np.savez(path, w1=c['w1'].numpy(), w2=c['w2'].numpy())
+    with rh.config(**dict(c['cfg'].as_dict(), affine_weights=path)), torch.inference_mode():
+        model = ref.metrabs_model.Metrabs(torch.nn.Identity(), rh._JointInfoStub(
+            [f'j{i}' for i in range(c['n_joints'])], [[0, 1]])).eval()
+        assert model.heatmap_heads.n_points == c['n_raw']
+        conv = torch.nn.Conv2d(c['weight'].shape[1], c['weight'].shape[0], 1)
+        conv.weight.copy_(c['weight'][:, :, None, None])
+        conv.bias.copy_(c['bias'])
+        model.heatmap_heads.conv_final = conv
+        model.latent_points_to_joints = lambda p: torch.einsum('bjc,jJ->bJc', p, model.recombination_weights)
+        want = model((c['features'], c['K']))
+        got = cpu_ref.crop_model_from_features(c['features'], c['weight'], c['bias'], c['K'], c['n_raw'], c['cfg'],
+                                               c['w2'])
+    # (the reference's lstsq is not run-to-run bit-stable: a whole crop moves by a few ulp of its depth)
+    assert cpu_ref.mpjpe(want, got) <= 1e-3 and float((want - got).abs().max()) <= 4e-3
+
+
+def test_kat_linear_combine_points():
+    """einsum 'bjc,jJ->bJc': identity weights reproduce the points; columns that sum to 1 commute with a
+    translation (why latent points can be reconstructed in camera space and combined afterwards)."""
+    g = cases.gen(5)
+    pts = torch.randn(3, 12, 3, generator=g) * 500
+    assert torch.equal(cpu_ref.linear_combine_points(pts, torch.eye(12)), pts)
+    _, w2 = cases.affine_weights_case(17, 12, 6)
+    assert torch.allclose(w2.sum(0), torch.ones(17), atol=1e-6)
+    shift = torch.tensor([100.0, -50.0, 3000.0])
+    a = cpu_ref.linear_combine_points(pts + shift, w2)
+    b = cpu_ref.linear_combine_points(pts, w2) + shift
+    assert float((a - b).abs().max()) < 2e-3
+
+
 @pytest.mark.parametrize('name', list(cases.WARP_CASES))
 def test_warp_vs_golden(name):
     g = load_golden(f'warp_{name}')
