@@ -16,7 +16,8 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libmetrabs_hip.so')
 BUILD_DIR = os.path.join(CSRC, 'build')
 ARCH = 'gfx950'
-FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function']
+FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function',
+         '-Wno-inline-asm']  # (the LDS-DMA asm declares its M0 clobber; clang warns that M0 is a reserved register)
 # per-source extras.  head_rt.hip: MFMA accumulators in VGPRs (gfx950's register file is unified):
 # its f32 chains are carried into f64 on the VALU every stage, and from AGPRs every element costs a
 # v_accvgpr_read first.

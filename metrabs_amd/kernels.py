@@ -275,18 +275,24 @@ def head_fused_supported(C, J, D, H, W, channels_last=False, dtype=torch.float32
 def head_auto_choice(C, J, D, H, W, channels_last=False, dtype=torch.float32):
     """MetrabsHeads(fused='auto'): True = the fused kernel, False = library 1x1 conv + mtr_softargmax_decode.
     A static table over (dtype, layout, C, H, W, J, D) read off the committed sweeps
-    (profiles/*_fused_vs_library.txt, *_head_sweep.jsonl) -- the batch size is deliberately NOT an input:
-    a slice of a sharded batch, another rank and another process all take the path of the whole batch.
+    (profiles/*_fused_vs_library.txt, *_head_sweep.jsonl, r05c_f32_depth_sweep_fused_vs_library.jsonl) -- the
+    batch size is deliberately NOT an input: a slice of a sharded batch, another rank and another process all
+    take the path of the whole batch.
     The fused kernels are ahead on every shipped configuration (8x8 / 12x12 maps, 8 depth bins, 17 - 122
     joints, f32 / f16 / bf16); the library pair is kept for
       * 16-bit features on maps of more than 256 positions (the 16-bit row-tile kernel there is behind
         rocBLAS: 20x20 bf16 65 vs 39 us, 24x24 f16 37 vs 32 us),
-      * f32 features on maps of >= 576 positions (24x24: 56 vs 50 us)."""
+      * f32 features on maps of >= 576 positions (24x24: 56 vs 50 us),
+      * f32 features with more than 16 depth bins (round 5; the sweep at 17 joints, 8x8, B = 64 / 1024: 8 bins
+        0.92 / 0.92 of the library pair's time, 16 bins 1.00 / 0.98, 24 bins 1.54 / 1.40, 32 bins 1.12 / 1.16,
+        48 bins 1.14 / 1.15, 72 bins -- the metric string's shape -- 1.17 / 1.04, 80 bins 1.31 / 1.17: a
+        joint's 1 + D rows no longer fit one 16-row tile and the multi-tile atoms quantise badly on 256 CUs).
+        16-bit features keep the fused kernel there (72 bins, f16: 45 vs 70 us at 64 crops)."""
     if not head_fused_supported(C, J, D, H, W, channels_last, dtype):
         return False
     hw = H * W
     if dtype == torch.float32:
-        return hw < 576
+        return hw < 576 and D <= 16
     return hw <= 256
 
 
@@ -420,6 +426,8 @@ def linear_combine_points(points, weights, out=None):
     j_out = weights.shape[1]
     if out is None:
         out = torch.empty(B, j_out, 3, device=points.device, dtype=torch.float32)
+    if B == 0:
+        return out
     check(_lib.load().mtr_linear_combine_points(_ptr(points), _ptr(weights), B, j_in, j_out, _ptr(out),
                                                 current_stream_ptr(points.device)),
           'mtr_linear_combine_points')

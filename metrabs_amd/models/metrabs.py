@@ -133,7 +133,8 @@ class MetrabsHeads(torch.nn.Module):
                                   self.config)
 
     def _timed_pick(self, inp, n_keep=None):
-        key = (tuple(inp.shape), inp.dtype, kernels._is_channels_last(inp), n_keep)
+        key = (tuple(inp.shape), inp.dtype, kernels._is_channels_last(inp)) + \
+            (() if n_keep in (None, self.n_points) else (n_keep,))
         if key not in self._auto_choice:
             if torch.cuda.is_current_stream_capturing():
                 return True  # nothing can be timed inside a capture; decided on an eager call

@@ -229,6 +229,7 @@ def gen_latent(ref, only=None):
                     c['features'], c['weight'], c['bias'], c['K'], c['n_raw'], c['cfg'], c['w2'])
         save(f'latent_{name}', poses3d=poses, poses3d_fp64=truth,
              reference_vs_fp64_mpjpe_mm=np.array(cpu_ref.mpjpe(poses, truth)),
+             features_checksum=np.array(float(c['features'].double().sum())),
              input_sha256=np.array(cases.sha256_of(c['features'], c['weight'], c['bias'], c['K'], c['w1'], c['w2'])))
 
 

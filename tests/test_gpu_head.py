@@ -245,6 +245,13 @@ def test_auto_head_path_is_a_static_rule(hip_lib):
         heads.fused = 'auto'
         heads(big)
         assert heads.last_path == 'library' and not kernels.head_auto_choice(256, 17, 8, 24, 24)
+        # f32 beyond 16 depth bins -- the metric string's 72 -- yields to the library pair (round 5:
+        # profiles/r05c_f32_depth_sweep_fused_vs_library.jsonl), 16-bit features keep the fused kernel
+        deep = MetrabsHeads(17, MetrabsConfig(depth=72), in_channels=64, fused='auto').cuda()
+        deep(torch.randn(2, 64, 8, 8, device='cuda'))
+        assert deep.last_path == 'library' and not kernels.head_auto_choice(64, 17, 72, 8, 8)
+        deep(torch.randn(2, 64, 8, 8, device='cuda').half())
+        assert deep.last_path == 'fused'
         heads.fused = 'time'
         t2d, t3d = heads(feat)
         assert (tuple(feat.shape), torch.float32, False) in heads._auto_choice

@@ -260,7 +260,10 @@ def test_head_plan_reads_the_batch_size_in_eights_and_the_auto_rule_not_at_all()
     # MetrabsHeads(fused='auto'): a static rule without the batch size
     import inspect
     assert 'B' not in inspect.signature(kernels.head_auto_choice).parameters
-    assert kernels.head_auto_choice(1280, 17, 8, 8, 8) and kernels.head_auto_choice(1280, 17, 72, 8, 8)
+    assert kernels.head_auto_choice(1280, 17, 8, 8, 8) and kernels.head_auto_choice(1280, 17, 16, 8, 8)
+    # f32 beyond 16 depth bins (the metric string's 72 included): the library pair is faster, 'auto' yields
+    assert not kernels.head_auto_choice(1280, 17, 72, 8, 8) and not kernels.head_auto_choice(1280, 17, 24, 8, 8)
+    assert kernels.head_auto_choice(1280, 17, 72, 8, 8, dtype=torch.float16)
     assert kernels.head_auto_choice(1280, 122, 8, 12, 12, dtype=torch.float16)
     assert not kernels.head_auto_choice(1280, 17, 8, 24, 24)
     assert not kernels.head_auto_choice(1280, 17, 8, 20, 20, dtype=torch.bfloat16)
