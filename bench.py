@@ -187,6 +187,8 @@ def build_model(args, dev):
     # (MTR_BENCH_MIOPEN_FIND=1).
     if os.environ.get('MTR_BENCH_MIOPEN_FIND', '0') == '1':
         torch.backends.cudnn.benchmark = True
+    if os.environ.get('MTR_BENCH_DETERMINISTIC') in ('0', '1'):   # (A/B of Metrabs.deterministic_backbone)
+        Metrabs.deterministic_backbone = os.environ['MTR_BENCH_DETERMINISTIC'] == '1'
     torch.manual_seed(1234)
     cfg = MetrabsConfig(proc_side=args.res, depth=args.depth)
     names = JOINT_NAMES if args.joints == 17 else [f'j{i}' for i in range(args.joints)]
@@ -805,6 +807,63 @@ def parity_probe(est, extras, cfg, args):
     return out
 
 
+def parity_from_identical_crops(est, extras, cfg, args):
+    """The north star's literal sentence: "match the reference metrabs_pytorch CPU path on identical 256x256
+    crops".  The SAME crops (the first n of the batch the bench just sampled) go through
+      ours: the GPU backbone exactly as the step runs it (PyTorch-ROCm: MIOpen / rocBLAS, batch norm folded,
+            K10 / K11 epilogues) -> mtr_head_fused -> mtr_reconstruct_absolute;
+      ref:  the network as the reference runs it on the CPU (oneDNN, batch norms as ops) -> oracle/cpu_ref.py.
+    The head is a PLAUSIBLE-POSE head for these features (cases.consistent_head_for_features: least-squares
+    weights under which the CPU backbone's features of these crops decode to a person 2.5 - 4.5 m away --
+    n <= C / (h w) crops), so the distance is read on well-conditioned poses.  Reported, not gated: it is
+    dominated by the out-of-scope backbone (MIOpen vs oneDNN arithmetic through ~40 layers, times the head's
+    gain); `head_on_reference_features` is the same comparison with the CPU features fed to our head -- the
+    in-scope part."""
+    from oracle import cases, cpu_ref
+    from metrabs_amd import kernels
+    model = est.crop_model
+    J, D, P = model.joint_info.n_joints, cfg.depth, cfg.proc_side
+    C = model.backbone.out_channels
+    side = args.res // 32
+    n = max(1, min(16, C // (side * side), len(extras['crops'])))
+    crops = extras['crops'][:n].float()
+    ocfg = cpu_ref.HeadConfig(proc_side=P, depth=D)
+    backbone_cpu = copy.deepcopy(getattr(est, 'reference_backbone', model.backbone)).to('cpu', torch.float32).eval()
+    with torch.inference_mode():
+        feats_cpu = backbone_cpu(crops.cpu())
+        w, b, K = cases.consistent_head_for_features(feats_cpu, J, D, P, amp=12.0, seed=515)
+        ref = cpu_ref.crop_model_from_features(feats_cpu, w, b, K, J, ocfg)
+        truth = cpu_ref.crop_model_from_features_fp64(feats_cpu, w, b, K, J, ocfg)
+        logits_absmax = float(torch.nn.functional.conv2d(feats_cpu, w[:, :, None, None], b).abs().max())
+        if model.autocast_dtype is not None:
+            with torch.autocast('cuda', dtype=model.autocast_dtype):
+                feats_gpu = model.backbone(extras['crops'][:n])
+        else:
+            feats_gpu = model.backbone(extras['crops'][:n])
+        packed = kernels.head_pack_weights(w.cuda(), b.cuda(), J, D, feats_gpu.dtype)
+        ours = kernels.reconstruct_absolute(*kernels.head_fused(feats_gpu, packed, C, J, model.config), K.cuda(),
+                                            model.config).cpu()
+        f_as = feats_cpu.cuda().to(feats_gpu.dtype)
+        packed_ref = kernels.head_pack_weights(w.cuda(), b.cuda(), J, D, f_as.dtype)
+        head_only = kernels.reconstruct_absolute(*kernels.head_fused(f_as, packed_ref, C, J, model.config), K.cuda(),
+                                                 model.config).cpu()
+    fd = (feats_gpu.float().cpu() - feats_cpu).abs()
+    return dict(crops=n, mpjpe_mm=cpu_ref.mpjpe(ours, ref), max_abs_mm=float((ours - ref).abs().max()),
+                head_on_reference_features=dict(mpjpe_mm=cpu_ref.mpjpe(head_only, ref),
+                                                max_abs_mm=float((head_only - ref).abs().max()),
+                                                ours_vs_fp64_mpjpe_mm=cpu_ref.mpjpe(head_only, truth),
+                                                ref_vs_fp64_mpjpe_mm=cpu_ref.mpjpe(ref, truth)),
+                backbone_features=dict(max_abs_diff=float(fd.max()), mean_abs_diff=float(fd.mean()),
+                                       reference_abs_mean=float(feats_cpu.abs().mean()),
+                                       gpu_dtype=str(feats_gpu.dtype).split('.')[-1]),
+                logits_absmax=logits_absmax, median_depth_mm=float(truth[..., 2].median()),
+                gated=False,
+                note='ours (GPU backbone as the step runs it + HIP head + reconstruction) vs the CPU path on the '
+                     'SAME crops, plausible-pose head fitted to the CPU features; the distance is the out-of-scope '
+                     'backbone\'s (MIOpen vs oneDNN) times the head\'s gain -- head_on_reference_features is the '
+                     'in-scope part on identical features')
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here --
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
@@ -1070,6 +1129,7 @@ def main():
                                     'a bare replay of the captured internal batch (metrabs_amd.pipeline.'
                                     'GraphedCropPipeline) on static inputs'),
                    'api_step_vs_captured_pipeline_max_mm': api_vs_pipeline_max_mm if step_mode == 'api' else None,
+                   'deterministic_backbone': bool(getattr(type(est.crop_model), 'deterministic_backbone', False)),
                    'backbone': 'PyTorch-ROCm (dense convolutions on rocBLAS / MIOpen' + (
                        '; depthwise layers on PyTorch\'s own kernel' if args.no_fold_bn else
                        '; inference batch norm folded into the convolutions' + (
@@ -1335,11 +1395,17 @@ def analysis(args, est, cfg, pipe, dev, step_seconds, im_h, im_w, n_box, world):
         'warp': dict(kernel='warp_rows_kernel', bound='hbm', launches=1, seconds=rot['warp'],
                      bytes=n_crops * 3 * args.res ** 2 * out_bytes + src_bytes,
                      hot_us=stages['warp'] * 1e6),
-        'head_fused': dict(kernel=head_kernel, bound='hbm' if h16 else 'mfma', launches=1,
+        'head_fused': dict(kernel=head_kernel, launches=1,
                            seconds=stages['head_fused'], flops=head_flops,
                            bytes=n_crops * (C * hw * feat_bytes + 20 * J),
                            hot_us=stages['head_fused'] * 1e6),
     }
+    # the head is matrix-bound for f32 features (76 FLOP/B against a ridge of ~20) and for
+    # J = 122 in any dtype (1098 FLOP/B of f16 features against 2.5 PF / 8 TB/s = 312); HBM-bound for 16-bit
+    # features at J = 17 (153 FLOP/B).  Decided by the shape's own intensity, not by the dtype alone.
+    hk = hw_kernels['head_fused']
+    hk['flop_per_byte'] = hk['flops'] / hk['bytes']
+    hk['bound'] = 'mfma' if hk['flop_per_byte'] > mfma_peak / HBM_PEAK else 'hbm'
     # the dominant kernel of the step AMONG THE ROWS OF SURVEY section 8 (head, sampler, pyramid), by
     # the time it takes inside the step; the backbone epilogues K10 / K11 are outside that scope and
     # stay in `hand_written_kernels`
@@ -1437,12 +1503,31 @@ def analysis(args, est, cfg, pipe, dev, step_seconds, im_h, im_w, n_box, world):
         out['decode_roofline']['traffic'] = (tjson.get('decode_nchw_kernel') or {}).get('bytes')
         out['decode_roofline']['traffic_source'] = traffic_source
     out['parity'] = parity_probe(est, extras, cfg, args)
+    if world == 1 and not args.quick:
+        try:
+            out['parity']['from_identical_crops'] = parity_from_identical_crops(est, extras, cfg, args)
+        except Exception as e:  # noqa: BLE001 -- a reported number, never a reason to lose the line
+            out['parity']['from_identical_crops'] = dict(error=repr(e)[:300])
     if world == 1 and not args.no_api_path and not args.strong:
         out['api_path'] = api_path_probe(est, args, im_h, im_w, n_box, n_box * args.num_aug / step_seconds)
     if world == 1 and args.depth != 72 and not args.no_depth72 and args.config == 1:
         out['depth72'] = depth72_variant(args, dev, im_h, im_w, n_box)
         if args.precision == 'f32':
             out['f16_autocast'] = autocast_variant(args, dev, im_h, im_w, n_box)
+        from metrabs_amd.models.metrabs import Metrabs
+        if Metrabs.deterministic_backbone:
+            # the product default pins MIOpen to its deterministic solvers (Metrabs.deterministic_backbone: replays
+            # and eager calls then agree bit for bit); the same step WITHOUT the pin, for the price of it
+            Metrabs.deterministic_backbone = False
+            try:
+                out['backbone_not_pinned_deterministic'] = backbone_variant(
+                    args, dev, im_h, im_w, n_box, not args.no_fold_bn, not args.no_fused_epilogue,
+                    'same step as `value` with torch.backends.cudnn.deterministic left at PyTorch\'s default '
+                    '(Metrabs.deterministic_backbone = False): MIOpen may pick atomically accumulating solvers -- the '
+                    'same call then differs run to run (features 7e-6 in f32, 7e-2 under f16 autocast: '
+                    'profiles/r05f_backbone_determinism.jsonl)')
+            finally:
+                Metrabs.deterministic_backbone = True
         if not args.no_fold_bn:
             out['bn_not_folded'] = backbone_variant(
                 args, dev, im_h, im_w, n_box, False, False,

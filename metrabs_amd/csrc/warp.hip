@@ -720,6 +720,12 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
     const float inv = __fdiv_rn(1.0f, oz);
 #endif
     float nx = ox * inv, ny = oy * inv;
+#if MTR_WARP_RCP == 2
+    // one residual step each: q + (ox - q oz) / oz -- the quotient the reference's IEEE division gives
+    // (project, ptu3d.py:124-126) in all but a few last-bit cases, for two FMAs per coordinate
+    nx = fmaf(fmaf(-nx, oz, ox), inv, nx);
+    ny = fmaf(fmaf(-ny, oz, oy), inv, ny);
+#endif
     if (has_dist) {
       float pa, pb, pcx, pcy;
       distortion_parts<float>(nx, ny, wp + 18, pa, pb, pcx, pcy);

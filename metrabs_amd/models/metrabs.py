@@ -268,13 +268,31 @@ class Metrabs(torch.nn.Module):
         """metrabs_tf/models/metrabs.py:86-87."""
         return kernels.linear_combine_points(points, self.reconstruction_weights)
 
+    # The backbone is PyTorch-ROCm's (MIOpen / rocBLAS): with PyTorch's default settings MIOpen may pick
+    # solvers that accumulate with atomics, and the SAME call on the SAME input then differs from run to run
+    # (measured on MI355X, EfficientNetV2-S, 64 crops: features 7e-6 apart in f32, 7e-2 under f16 autocast;
+    # poses 1e-2 mm / several mm -- tools/experiments/backbone_determinism_probe.py, profiles/
+    # r05f_backbone_determinism.jsonl).  True (default): the backbone runs under
+    # torch.backends.cudnn.flags(deterministic=True) -- eager calls, captured graphs, replays and module copies
+    # then agree bit for bit (0.0 in all five comparisons of the probe), which is what lets a replayed HIP graph
+    # be "the eager path's bits".  False leaves PyTorch's global setting alone.
+    deterministic_backbone = True
+
+    def _run_backbone(self, image):
+        if self.deterministic_backbone and image.is_cuda and not torch.backends.cudnn.deterministic:
+            cudnn = torch.backends.cudnn
+            with cudnn.flags(enabled=cudnn.enabled, benchmark=cudnn.benchmark, deterministic=True,
+                             allow_tf32=cudnn.allow_tf32):
+                return self.backbone(image)
+        return self.backbone(image)
+
     def forward(self, inp):
         image, intrinsics = inp
         if self.autocast_dtype is not None:
             with torch.autocast('cuda', dtype=self.autocast_dtype):
-                features = self.backbone(image)
+                features = self._run_backbone(image)
         else:
-            features = self.backbone(image)
+            features = self._run_backbone(image)
         # predict_all_and_latents: coords[:, :n_latents] (models/metrabs.py:52-54) -- the head computes
         # just those points
         coords2d, coords3d = self.heatmap_heads(features, first_points=self.latent_prefix)

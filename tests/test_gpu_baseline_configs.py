@@ -115,6 +115,60 @@ def test_end_to_end_every_backbone_family(backbone, res, num_aug, hip_lib):
     assert float((ours - same_feat).abs().max()) <= 0.05   # (two backbone passes: MIOpen's run-to-run noise x head gain)
 
 
+@pytest.mark.parametrize('precision', ['f32', 'f16'])
+def test_pinned_backbone_is_bit_stable_across_calls_and_captures(precision, hip_lib):
+    """Metrabs.deterministic_backbone (default True) runs the PyTorch-ROCm backbone under
+    torch.backends.cudnn.flags(deterministic=True): MIOpen then keeps to solvers without atomic accumulation
+    and the SAME crop-model call gives the SAME bits eagerly, twice, and through two separate HIP-graph
+    captures (round 4's bench reported 0.012 mm f32 / 5.4 mm f16 between two captures; round 5's probe,
+    profiles/r05f_backbone_determinism.jsonl: eager vs eager 7e-6 / 7e-2 in the features without the pin,
+    0.0 with it).  EfficientNetV2-S as the bench runs it (batch norm folded, K10 / K11 epilogues)."""
+    from metrabs_amd.backbones import build_backbone, calibrate_batchnorm, fold_batchnorm
+    from metrabs_amd.config import MetrabsConfig
+    from metrabs_amd.joint_info import JointInfo
+    from metrabs_amd.models.metrabs import Metrabs
+    torch.manual_seed(5)
+    net = calibrate_batchnorm(build_backbone('efficientnetv2-s').cuda(), 256, 'cuda', batch_size=4).eval()
+    net = fold_batchnorm(net, fused_epilogue=True)
+    dt = None if precision == 'f32' else torch.float16
+    model = Metrabs(net, JointInfo(cases.COCO17, cases.COCO17_EDGES), MetrabsConfig(), in_channels=net.out_channels,
+                    autocast_dtype=dt).cuda().eval()
+    assert model.deterministic_backbone
+    g = torch.Generator(device='cuda').manual_seed(11)
+    crops = torch.rand(32, 3, 256, 256, device='cuda', generator=g)
+    crops = crops if dt is None else crops.to(dt)
+    K = torch.tensor([[500.0, 0, 128], [0, 500.0, 128], [0, 0, 1]], device='cuda').repeat(32, 1, 1)
+
+    def capture():
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            model((crops, K))
+            st.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=st, capture_error_mode='thread_local'):
+                out = model((crops, K))
+        torch.cuda.current_stream().wait_stream(st)
+        graph.replay()
+        torch.cuda.synchronize()
+        return graph, out
+
+    with torch.inference_mode():
+        e1 = model((crops, K)).clone()
+        e2 = model((crops, K)).clone()
+        g1, o1 = capture()
+        g2, o2 = capture()
+        assert torch.isfinite(e1).all()
+        assert torch.equal(e1, e2) and torch.equal(e1, o1) and torch.equal(o1, o2)
+        g1.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(e1, o1)
+        model.deterministic_backbone = False    # (instance attribute: PyTorch's own setting decides)
+        loose = [model((crops, K)).clone() for _ in range(3)]
+    print(f'[parity] {precision}: without the pin three eager calls differ by up to '
+          f'{max(float((a - loose[0]).abs().max()) for a in loose[1:]):.2e} mm; with it: 0')
+
+
 def kernels_recon(c2d, c3d, K, cfg):
     from metrabs_amd import kernels
     return kernels.reconstruct_absolute(c2d, c3d, K, cfg)

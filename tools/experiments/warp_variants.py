@@ -1,0 +1,102 @@
+"""Compile-time variants of the crop sampler (csrc/warp.hip), built HERE (hipcc cross-compiles) and timed on
+the GPU box: only warp.hip is recompiled per variant and linked with the library's other objects.
+    python tools/experiments/warp_variants.py build          # here
+    python tools/experiments/warp_variants.py run            # on the GPU box: one JSON line per (variant, case)
+Cases: 64 crops (num_aug 1) and 320 crops (64 boxes x 5 TTA), f32 crops of 8 x 1080p uint8 frames, the frames
+rotating over 4 sets (> the Infinity Cache) -- the HBM-true number bench.py reports."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+OUT = os.path.join(ROOT, 'tools', 'experiments', '_build')
+VARIANTS = {'base': []}
+for rows in (4, 8, 16):
+    for pd in (1, 2, 3):
+        VARIANTS[f'rows{rows}_pd{pd}'] = [f'-DMTR_WARP_ROWS={rows}', f'-DMTR_WARP_PREFETCH={pd}']
+VARIANTS['rcp2'] = ['-DMTR_WARP_RCP=2']
+VARIANTS['rcp0'] = ['-DMTR_WARP_RCP=0']
+VARIANTS['rows8_pd2_rcp2'] = ['-DMTR_WARP_ROWS=8', '-DMTR_WARP_PREFETCH=2', '-DMTR_WARP_RCP=2']
+VARIANTS['lx64_rows8_pd2'] = ['-DMTR_WARP_LX=64', '-DMTR_WARP_ROWS=8', '-DMTR_WARP_PREFETCH=2']
+
+
+def build():
+    sys.path.insert(0, ROOT)
+    from metrabs_amd import build as b
+    b.build_library(verbose=False)
+    os.makedirs(OUT, exist_ok=True)
+    others = [os.path.join(b.BUILD_DIR, f + '.o') for f in b.sources() if f != 'warp.hip']
+    procs = []
+    for name, defs in VARIANTS.items():
+        obj = os.path.join(OUT, f'warp_{name}.o')
+        procs.append((name, obj, subprocess.Popen([b._hipcc(), *b.FLAGS, *defs, '-c', os.path.join(b.CSRC, 'warp.hip'),
+                                                   '-o', obj], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)))
+        if len(procs) % 6 == 0:
+            for _, _, p in procs[-6:]:
+                p.wait()
+    for name, obj, p in procs:
+        _, err = p.communicate()
+        if p.returncode:
+            sys.exit(f'{name}: {err.decode()[-2000:]}')
+        subprocess.run([b._hipcc(), '-shared', '-fPIC', f'--offload-arch={b.ARCH}', *others, obj, '-o',
+                        os.path.join(OUT, f'libmtr_warp_{name}.so')], check=True)
+    print('built', len(VARIANTS), 'variants')
+
+
+def run_one(name):
+    sys.path.insert(0, ROOT)
+    import torch
+    from metrabs_amd import _lib
+    _lib.load(os.path.join(OUT, f'libmtr_warp_{name}.so'))
+    from metrabs_amd import kernels
+    from metrabs_amd.multiperson.multiperson_model import tta_parameters
+    g = torch.Generator().manual_seed(0)
+    pyrs = [kernels.build_pyramid(torch.randint(0, 256, (8, 3, 1080, 1920), dtype=torch.uint8, generator=g).cuda())
+            for _ in range(4)]
+    for aug in (1, 5):
+        n = 64
+        tta = {k: v.cuda() for k, v in tta_parameters(aug).items()}
+        gb = torch.Generator().manual_seed(1)
+        bw = 60 + 340 * torch.rand(n, generator=gb)
+        bh = 150 + 750 * torch.rand(n, generator=gb)
+        boxes = torch.stack([torch.rand(n, generator=gb) * (1920 - bw),
+                             torch.rand(n, generator=gb) * (1080 - bh).clamp_min(1), bw, bh], 1).cuda()
+        K = torch.tensor([[1844.0, 0, 960], [0, 1844.0, 540], [0, 0, 1]]).repeat(n, 1, 1).cuda()
+        up = torch.tensor([0.0, -1, 0]).repeat(n, 1).cuda()
+        ids = (torch.arange(n) % 8).int().cuda()
+        _, _, wp = kernels.crop_geometry(boxes, K, torch.zeros(n, 12).cuda(), up, ids, tta['rotflipmat'],
+                                         tta['scales'], tta['gammas'], 256, 1)
+        o = torch.empty(n * aug, 3, 256, 256, device='cuda')
+        for _ in range(3):
+            kernels.warp_crops(pyrs[0], wp, 256, 1, out=o)
+        torch.cuda.synchronize()
+        reps = 20
+        st = torch.cuda.Stream()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(st):
+            kernels.warp_crops(pyrs[0], wp, 256, 1, out=o)
+            st.synchronize()
+            with torch.cuda.graph(graph, stream=st):
+                for i in range(reps):
+                    kernels.warp_crops(pyrs[i % len(pyrs)], wp, 256, 1, out=o)
+        graph.replay()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            graph.replay()
+        b.record()
+        torch.cuda.synchronize()
+        print(json.dumps({'variant': name, 'crops': n * aug, 'us': round(a.elapsed_time(b) / (reps * 10) * 1e3, 2),
+                          'checksum': float(o.double().sum())}), flush=True)
+
+
+if __name__ == '__main__':
+    if sys.argv[1] == 'build':
+        build()
+    elif sys.argv[1] == 'run':
+        for m in VARIANTS:
+            subprocess.run([sys.executable, __file__, 'one', m])
+    else:
+        run_one(sys.argv[2])
