@@ -610,23 +610,26 @@ def source_footprint_bytes(wp, res, im_h, im_w):
     return total
 
 
-def decode_roofline(iters=20):
+def decode_roofline(iters=20, nhwc=False, shape=(32768, 17, 8, 8)):
     """K2-K4 standalone on a batch beyond the 256 MiB Infinity Cache: J=17, 8x8, D=8, B=32768
-    (1.28 GB of fp32 logits)."""
+    (1.28 GB of fp32 logits).  nhwc: the same logits in the TF twin's layout
+    ('b h w (d j)', metrabs_tf/models/metrabs.py:100-101; torch channels_last) through decode_nhwc_kernel."""
     from metrabs_amd import kernels
     from metrabs_amd.config import MetrabsConfig
-    B, J, D = 32768, 17, 8
+    B, J, D, side = shape
     g = torch.Generator(device='cuda').manual_seed(3)
-    logits = torch.randn(B, J * (1 + D), 8, 8, device='cuda', generator=g)
-    cfg = MetrabsConfig()
+    logits = torch.randn(B, J * (1 + D), side, side, device='cuda', generator=g)
+    if nhwc:
+        logits = logits.contiguous(memory_format=torch.channels_last)
+    cfg = MetrabsConfig(depth=D, proc_side=side * 32)
     out = (torch.empty(B, J, 2, device='cuda'), torch.empty(B, J, 3, device='cuda'))
     t = time_stage(lambda: kernels.softargmax_decode(logits, J, cfg, out=out), iters)
-    bytes_per_crop = J * (1 + D) * 64 * 4 + 20 * J
+    bytes_per_crop = J * (1 + D) * side * side * 4 + 20 * J
     achieved = B * bytes_per_crop / t
     del logits
     torch.cuda.empty_cache()
-    return dict(kernel='decode_nchw_kernel<float,4,16>', bound='hbm', achieved=achieved / 1e9,
-                peak=HBM_PEAK / 1e9, unit='GB/s', frac=achieved / HBM_PEAK,
+    return dict(kernel='decode_nhwc_kernel<float>' if nhwc else 'decode_nchw_kernel<float,4,16>', bound='hbm',
+                achieved=achieved / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s', frac=achieved / HBM_PEAK,
                 frac_of_measured_copy=achieved / HBM_COPY_MEASURED, avg_launch_us=t * 1e6,
                 crops=B, bytes_per_crop=bytes_per_crop, traffic=None)
 
@@ -1502,6 +1505,11 @@ def analysis(args, est, cfg, pipe, dev, step_seconds, im_h, im_w, n_box, world):
         out['decode_roofline'] = decode_roofline()
         out['decode_roofline']['traffic'] = (tjson.get('decode_nchw_kernel') or {}).get('bytes')
         out['decode_roofline']['traffic_source'] = traffic_source
+        if not args.quick:
+            out['decode_roofline_nhwc'] = decode_roofline(nhwc=True)
+            out['decode_roofline_nhwc']['j122_12x12_b2048'] = {
+                k: v for k, v in decode_roofline(nhwc=True, shape=(2048, 122, 8, 12)).items()
+                if k in ('achieved', 'frac', 'avg_launch_us', 'crops', 'bytes_per_crop')}
     out['parity'] = parity_probe(est, extras, cfg, args)
     if world == 1 and not args.quick:
         try:

@@ -313,6 +313,53 @@ static int dispatch_decode(const void* logits, int B, int J, int D, int H, int W
 // (its 2D row and its D depth slices) stay in one workgroup, so nothing is merged across workgroups;
 // workgroup (b, k) walks the channels {j} and {J + d J + j} of its joints j0 <= j < j1 (1 + D runs of
 // j1 - j0 consecutive channels per position) with N = (j1 - j0)(1 + D) local rows.
+// The walk of ONE channel over ALL positions in map order when the whole workgroup walks together (G = 1) and
+// the map rows are whole batches of U positions (W % U == 0; U = 4, 8, or the row itself: 12, 16): a batch then lies in one map row,
+// the positions are wave-uniform (row h and first column w0 of the batch live in scalars) and the moment
+// sums factor -- per logit one f64 add (sum e) and one f64 fma with a compile-time column offset (sum u e);
+// per batch  sx += su + w0 s,  sy += h s.  Same running-maximum rule (one f64 rescale per batch that raises
+// it) and the same f64 accumulators as the generic walk: 11 VALU slots per logit instead of ~20 (the generic
+// walk recomputes row and column of every position in every lane and converts both to f64).  Round 5.
+template <typename T, int U>
+__device__ __forceinline__ void nhwc_walk_rows(const T* __restrict__ x, int ch, int NC, int HW, int W, float& m_out,
+                                               double& s_out, double& sx_out, double& sy_out) {
+  float m = -INFINITY;
+  double s = 0.0, sx = 0.0, sy = 0.0;
+  int h = 0, w0 = 0;  // (wave-uniform: functions of the loop counter alone)
+  const T* xp = x + ch;
+  for (int p0 = 0; p0 < HW; p0 += U) {
+    float v[U];
+    float mb = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      v[u] = to_f32(xp[(size_t)(p0 + u) * NC]);
+      mb = fmaxf(mb, v[u]);
+    }
+    if (mb > m) {
+      if (m != -INFINITY) {
+        const double f = exp_neg64((double)m - (double)mb);
+        s *= f; sx *= f; sy *= f;
+      }
+      m = mb;
+    }
+    const float nm = -m * kLog2e;
+    double sb = 0.0, su = 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      // (a -inf logit weighs nothing: -inf - -inf is NaN under a -inf maximum)
+      const double e = v[u] != -INFINITY ? (double)exp_shifted(v[u], nm) : 0.0;
+      sb += e;
+      su = fma(e, (double)u, su);
+    }
+    s += sb;
+    sx += fma((double)w0, sb, su);
+    sy = fma((double)h, sb, sy);
+    w0 += U;
+    if (w0 >= W) { w0 = 0; ++h; }
+  }
+  m_out = m; s_out = s; sx_out = sx; sy_out = sy;
+}
+
 template <typename T>
 __global__ __launch_bounds__(1024) void decode_nhwc_kernel(const T* __restrict__ logits, int B, int J,
                                                            int D, int H, int W, int splits, HeadScale hs,
@@ -333,6 +380,8 @@ __global__ __launch_bounds__(1024) void decode_nhwc_kernel(const T* __restrict__
   constexpr int U = 8;  // positions per batch: their loads are in flight together (a walk of one
                         // dependent load per step was the whole 12 us of a 64-crop launch)
   const float rcp_w = __frcp_rn((float)W);
+  // (workgroup-uniform) a whole map row per batch for the usual widths, else 8 or 4 positions of a row
+  const int row_batch = G != 1 ? 0 : (W == 12 || W == 16) ? W : (W % 8 == 0 ? 8 : (W % 4 == 0 ? 4 : 0));
   for (int t = threadIdx.x; t < G * N; t += blockDim.x) {
     const int n = t % N, g = t / N;
     // local row n = (slice, joint): slice 0 is the 2D row, slice 1 + d the depth slice d
@@ -340,6 +389,15 @@ __global__ __launch_bounds__(1024) void decode_nhwc_kernel(const T* __restrict__
     const int ch = slice == 0 ? j0 + jj : J + (slice - 1) * J + j0 + jj;
     float m = -INFINITY;
     double s = 0.0, sx = 0.0, sy = 0.0;
+    if (row_batch) {
+      if (row_batch == 8) nhwc_walk_rows<T, 8>(x, ch, NC, HW, W, m, s, sx, sy);
+      else if (row_batch == 12) nhwc_walk_rows<T, 12>(x, ch, NC, HW, W, m, s, sx, sy);
+      else if (row_batch == 16) nhwc_walk_rows<T, 16>(x, ch, NC, HW, W, m, s, sx, sy);
+      else nhwc_walk_rows<T, 4>(x, ch, NC, HW, W, m, s, sx, sy);
+      row_m[t] = m;
+      row_s[t * 3 + 0] = s; row_s[t * 3 + 1] = sx; row_s[t * 3 + 2] = sy;
+      continue;
+    }
     for (int p0 = g; p0 < HW; p0 += G * U) {
       float v[U];
       float mb = -INFINITY;
@@ -450,7 +508,13 @@ static int launch_decode_nhwc(const void* logits, int B, int J, int D, int H, in
     const long long resident = 2048LL * 256 / ((long long)B * splits) / rows;
     if (groups > resident) groups = resident < 1 ? 1 : resident;
     const long long want = (rows * groups + 63) / 64 * 64;
-    threads = (int)(want < 256 ? 256 : want > 1024 ? 1024 : want);
+    // (round 5: whole waves, no 256-thread floor -- N = 153 rows in one group are three waves; the fourth of
+    //  a 256-thread workgroup only held a SIMD slot)
+    threads = (int)(want < 64 ? 64 : want > 1024 ? 1024 : want);
+    if (want > 1024) {  // channels in rounds: even rounds (N = 1098: 2 x 576 lanes, not 1024 + 74)
+      const long long rounds = (want + 1023) / 1024;
+      threads = (int)(((want + rounds - 1) / rounds + 63) / 64 * 64);
+    }
   }
   // (LDS is sized for the unsplit row count: an upper bound of every part's G * N)
   const long long slots = N <= threads ? (long long)threads : N;
