@@ -46,6 +46,8 @@ class MetrabsHeads(torch.nn.Module):
 
     def _version_key(self):
         w, b = self.conv_final.weight, self.conv_final.bias
+        if w.is_inference() or b.is_inference():   # (no version counters: see _trackable)
+            return (w.data_ptr(), None, b.data_ptr(), None, w.device)
         return (w.data_ptr(), w._version, b.data_ptr(), b._version, w.device)
 
     def _trackable(self):
@@ -96,9 +98,14 @@ class MetrabsHeads(torch.nn.Module):
         """False once conv_final's parameters were edited in place, replaced or moved after `snapshot`
         was taken, or a slot of it was rebuilt (its tensor is no longer the one the graph reads)."""
         key = self._version_key()
+        trackable = self._trackable()
         for slot, (k, tensors) in snapshot.items():
+            if k != key:
+                return False
+            # (untrackable parameters: every call -- a capture included -- builds its own derived tensors, so a
+            #  graph reads the ones made inside ITS capture, whatever the slot holds now)
             cur = self._derived.get(slot)
-            if k != key or cur is None or cur[1] is not tensors:
+            if trackable and (cur is None or cur[1] is not tensors):
                 return False
         return True
 
