@@ -1482,6 +1482,9 @@ def analysis(args, est, cfg, pipe, dev, step_seconds, im_h, im_w, n_box, world):
         tr = tjson.get(a2['kernel'].split('<')[0].split(' ')[0])
         if isinstance(tr, dict) and tr.get('bytes'):
             per_kernel[k]['traffic_bytes_per_launch'] = tr['bytes']
+            # the same fraction on the bytes the counters saw (sampler: the bounding-box definition of SURVEY
+            # section 8(d) counts source texels a rotated crop's quad never touches)
+            per_kernel[k]['frac_hbm_by_counter_bytes'] = round(tr['bytes'] * a2['launches'] / t / HBM_PEAK, 4)
     for k, v in small.items():
         per_kernel[k] = dict(us_per_step=round(v * 1e6, 2), bound='latency (KB of data)')
     if not args.quick:

@@ -3,7 +3,7 @@ set -x
 #   gpurun -- 'bash tools/profile_round.sh r03h'
 # kernel trace of the bench command, the two PMC passes (one counter each, --kernel-trace only) that
 # profiles/traffic.json is reduced from, MFMA counters of the f32 head, micro-benchmarks, bench lines.
-TAG=${1:-r04t}
+TAG=${1:-r05z}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O
@@ -48,3 +48,6 @@ python bench.py --quick --force-collective --step pipeline > $O/${TAG}_bench_rcc
 python bench.py --quick --force-collective --graph-gather > $O/${TAG}_bench_rccl_one_rank_graph_gather.json 2>> $O/${TAG}_bench.err
 python bench.py --quick --force-collective > $O/${TAG}_bench_rccl_one_rank_api_step.json 2>> $O/${TAG}_bench.err
 python tools/head16_ab.py > $O/${TAG}_head16_ab.jsonl 2>/dev/null
+# round 5: the backbone's run-to-run stability with and without the deterministic pin; the f32 depth sweep
+python tools/experiments/backbone_determinism_probe.py > $O/${TAG}_backbone_determinism.jsonl 2>/dev/null
+python tools/experiments/r05_head_probe.py dsweep > $O/${TAG}_f32_depth_sweep_fused_vs_library.jsonl 2>/dev/null
