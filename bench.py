@@ -1132,7 +1132,7 @@ def main():
                                     'a bare replay of the captured internal batch (metrabs_amd.pipeline.'
                                     'GraphedCropPipeline) on static inputs'),
                    'api_step_vs_captured_pipeline_max_mm': api_vs_pipeline_max_mm if step_mode == 'api' else None,
-                   'deterministic_backbone': bool(getattr(type(est.crop_model), 'deterministic_backbone', False)),
+                   'deterministic_backbone': bool(est.crop_model.backbone_is_pinned()),
                    'backbone': 'PyTorch-ROCm (dense convolutions on rocBLAS / MIOpen' + (
                        '; depthwise layers on PyTorch\'s own kernel' if args.no_fold_bn else
                        '; inference batch norm folded into the convolutions' + (
@@ -1526,19 +1526,20 @@ def analysis(args, est, cfg, pipe, dev, step_seconds, im_h, im_w, n_box, world):
         if args.precision == 'f32':
             out['f16_autocast'] = autocast_variant(args, dev, im_h, im_w, n_box)
         from metrabs_amd.models.metrabs import Metrabs
-        if Metrabs.deterministic_backbone:
-            # the product default pins MIOpen to its deterministic solvers (Metrabs.deterministic_backbone: replays
-            # and eager calls then agree bit for bit); the same step WITHOUT the pin, for the price of it
+        if est.crop_model.backbone_is_pinned():
+            # the product default pins MIOpen to its deterministic solvers for f32 arithmetic (Metrabs.
+            # deterministic_backbone: replays and eager calls then agree bit for bit); the same step WITHOUT the pin
+            before = Metrabs.deterministic_backbone
             Metrabs.deterministic_backbone = False
             try:
                 out['backbone_not_pinned_deterministic'] = backbone_variant(
                     args, dev, im_h, im_w, n_box, not args.no_fold_bn, not args.no_fused_epilogue,
                     'same step as `value` with torch.backends.cudnn.deterministic left at PyTorch\'s default '
                     '(Metrabs.deterministic_backbone = False): MIOpen may pick atomically accumulating solvers -- the '
-                    'same call then differs run to run (features 7e-6 in f32, 7e-2 under f16 autocast: '
-                    'profiles/r05f_backbone_determinism.jsonl)')
+                    'same call can then differ run to run (features 7e-6 in f32, 7e-2 under f16 autocast on one box, '
+                    '0.0 on another: profiles/r05f_ / r05z_backbone_determinism.jsonl)')
             finally:
-                Metrabs.deterministic_backbone = True
+                Metrabs.deterministic_backbone = before
         if not args.no_fold_bn:
             out['bn_not_folded'] = backbone_variant(
                 args, dev, im_h, im_w, n_box, False, False,

@@ -277,16 +277,23 @@ class Metrabs(torch.nn.Module):
 
     # The backbone is PyTorch-ROCm's (MIOpen / rocBLAS): with PyTorch's default settings MIOpen may pick
     # solvers that accumulate with atomics, and the SAME call on the SAME input then differs from run to run
-    # (measured on MI355X, EfficientNetV2-S, 64 crops: features 7e-6 apart in f32, 7e-2 under f16 autocast;
-    # poses 1e-2 mm / several mm -- tools/experiments/backbone_determinism_probe.py, profiles/
-    # r05f_backbone_determinism.jsonl).  True (default): the backbone runs under
-    # torch.backends.cudnn.flags(deterministic=True) -- eager calls, captured graphs, replays and module copies
-    # then agree bit for bit (0.0 in all five comparisons of the probe), which is what lets a replayed HIP graph
-    # be "the eager path's bits".  False leaves PyTorch's global setting alone.
-    deterministic_backbone = True
+    # (measured on one MI355X box, EfficientNetV2-S, 64 crops: features 7e-6 apart in f32, 7e-2 under f16
+    # autocast; poses 1e-2 mm / several mm; on another box 0.0 -- it depends on the box's MIOpen state:
+    # tools/experiments/backbone_determinism_probe.py, profiles/r05f_ / r05z_backbone_determinism.jsonl).
+    # True: the backbone runs under torch.backends.cudnn.flags(deterministic=True) -- eager calls, captured
+    # graphs, replays and module copies then agree bit for bit, which is what lets a replayed HIP graph be "the
+    # eager path's bits".  False: PyTorch's global setting decides.  None (default): pinned for f32 arithmetic --
+    # the parity target, where the pin costs 0.6 - 2.2 % of the step -- and not under 16-bit autocast, whose own
+    # rounding (1.8 mm mean from the f32 model) is the size of the run-to-run noise and where the pin costs up
+    # to 13 % (EfficientNetV2-L 384 f16: 1.86 k -> 1.62 k crops/s, profiles/r05z_bench_config4.json).
+    deterministic_backbone = None
+
+    def backbone_is_pinned(self):
+        d = self.deterministic_backbone
+        return bool(self.autocast_dtype is None if d is None else d)
 
     def _run_backbone(self, image):
-        if self.deterministic_backbone and image.is_cuda and not torch.backends.cudnn.deterministic:
+        if self.backbone_is_pinned() and image.is_cuda and not torch.backends.cudnn.deterministic:
             cudnn = torch.backends.cudnn
             with cudnn.flags(enabled=cudnn.enabled, benchmark=cudnn.benchmark, deterministic=True,
                              allow_tf32=cudnn.allow_tf32):
