@@ -136,13 +136,18 @@ int mtr_softargmax_decode(const void* logits, int dtype, int layout, int B, int 
 typedef struct mtr_head_options {
   uint32_t struct_size;            /* sizeof(mtr_head_options) as the CALLER knows it (see above)            */
   int32_t rt_tiles_per_workgroup;  /* f32: row tiles per workgroup for one-tile atoms, 1..5; 0 = by launch size */
-  int32_t groups_per_workgroup;    /* 16-bit: joint groups per workgroup, 1..3; 0 = by launch size        */
+  int32_t groups_per_workgroup;    /* 16-bit: joint groups per workgroup, 1..3 (dma_staging 4: 2..4 = waves
+                                      per workgroup); 0 = by launch size                                    */
   int32_t dma_staging;             /* 16-bit: 1 = global_load_lds where possible, 0 = through registers,
                                       2 = global_load_lds issued by a fifth, LOADER wave (320 threads; same
                                       bits; measured 10 - 25 % SLOWER than 1 on every shape of
                                       profiles/r04c_head16_ab.jsonl -- kept for A/B runs, never the library's
                                       choice), 3 = global_load_lds with the copies of stage s + 1 issued first in
                                       stage s and the fragments read per 16-channel step (round 4; same bits),
+                                      4 = weights in registers (round 5, head_areg.hip: a wave per joint group
+                                      against all column tiles, weights loaded per lane from the fragment-major
+                                      section of the blob, only the features through LDS; 3 - 5 column tiles,
+                                      C % 64 == 0; same bits; elsewhere: as -1),
                                       -1 = library's choice (NB: a zeroed struct selects registers) */
   int32_t rt_column_blocks;        /* f32, maps of > 64 positions: 64-position column blocks per workgroup
                                       tile, 2..4 (one K loop for all of them); 1 = one K loop per column
@@ -190,6 +195,8 @@ enum {
   MTR_HEAD_KERNEL_16_DMA = 11,   /* head_fused16dma_kernel: 16-bit features staged by global_load_lds      */
   MTR_HEAD_KERNEL_16_DMA_EARLY = 14,  /* head_fused16dma_kernel<..., EARLY>: copies of stage s + 1 issued first in stage s */
   MTR_HEAD_KERNEL_16_DMA_LOADER = 13, /* head_fused16dma_kernel<..., LD>: the same with a loader wave (dma_staging 2) */
+  MTR_HEAD_KERNEL_16_AREG = 15,  /* head_fused16areg_kernel: weights in registers, a wave per joint group (dma_staging 4;
+                                    the library's choice for >= 512 crops of >= 8 joint groups on 5 column tiles)  */
   MTR_HEAD_KERNEL_16_RT = 12     /* head_rt16_kernel: 16-bit features on the row-tile core (1 + D > 64 rows per
                                     joint, or maps of more than 256 positions); NCHW features: needs the
                                     workspace (one transposing pass in front)                              */

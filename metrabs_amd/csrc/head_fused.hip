@@ -37,24 +37,10 @@
 
 #include "common.h"
 #include "head_rt.h"
+#include "head16.h"
 
 namespace mtr {
 
-constexpr int kRows = 64;       // rows (output channels) per joint group = 4 waves x 16
-
-struct HeadGeom {
-  int n_groups;      // joint groups
-  int jg;            // joints per group (last group may hold fewer)
-};
-
-__host__ __device__ inline HeadGeom head_geom(int J, int D) {
-  HeadGeom g;
-  const int per = 1 + D;
-  const int jg_max = kRows / per;  // >= 1 is checked by the caller
-  g.n_groups = (J + jg_max - 1) / jg_max;
-  g.jg = (J + g.n_groups - 1) / g.n_groups;  // balanced groups
-  return g;
-}
 
 // packed (16-bit feature dtypes) = [n_groups][64] bias (f32), then the 16-bit weights (below)
 __global__ void head_pack_bias_kernel(const float* __restrict__ bias, int J, int D, HeadGeom g,
@@ -72,136 +58,6 @@ __global__ void head_pack_bias_kernel(const float* __restrict__ bias, int J, int
   }
 }
 
-using v4f = __attribute__((ext_vector_type(4))) float;
-using v2u = __attribute__((ext_vector_type(2))) unsigned;
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-
-// 16-byte slot swizzle of the K-contiguous LDS tiles: slot ^= swz(row) (found by exhaustive search:
-// conflict-free for the ds_read_b128 lane groups of the 32x32 MFMA operands)
-__device__ __forceinline__ int swz(int row) { return ((row >> 1) & 7) ^ ((row >> 4) & 1); }
-
-template <int CT>
-__host__ __device__ constexpr int hw_pad32() { return CT * 32 + 4; }
-
-// ---- decode epilogue shared by the 16-bit kernels: logits of one joint group in LDS [64][HWP]
-
-// (row = jl*(1+D) + {0: 2D map, 1+d: depth slice d}); a half-wave (32 lanes) per joint (<= 8 joints
-// in flight).  The logits are on chip and the epilogue is a few % of the GEMM, so the f64-accumulate
-// mode also takes exp in f64: the decode error then is the f32 rounding of the outputs only, which
-// matters because reconstruct_absolute amplifies coords3d_rel errors ~7x.
-// PV = positions per lane and step: 4 for maps of more than 64 positions, 2 below (an 8x8 map
-// then keeps all 32 lanes of the half-wave busy instead of 16).
-template <bool ACC64, int PV>
-__device__ __forceinline__ void decode_group_from_lds_pv(const float* Ls, int HWP, int grp,
-                                                         const HeadGeom& g, int crop, int J, int D,
-                                                         int H, int W, const HeadScale& hs,
-                                                         float* __restrict__ coords2d,
-                                                         float* __restrict__ coords3d_rel, int wid,
-                                                         int lane) {
-  using vecf = __attribute__((ext_vector_type(PV))) float;
-  const int HW = H * W;
-  const int per = 1 + D;
-  const int li = lane & 31;
-  const float rcp_w = __frcp_rn((float)W);
-  for (int jl = wid * 2 + (lane >> 5); jl < g.jg; jl += 8) {
-    const int j = grp * g.jg + jl;
-    if (j >= J) continue;
-    const float* row2d = Ls + (size_t)(jl * per) * HWP;
-    const float* row3d = row2d + HWP;
-    float m2 = -INFINITY, m3 = -INFINITY;
-    for (int p = li * PV; p < HW; p += 32 * PV) {
-      const vecf v = *reinterpret_cast<const vecf*>(row2d + p);
-#pragma unroll
-      for (int q = 0; q < PV; ++q) m2 = fmaxf(m2, v[q]);
-      for (int d = 0; d < D; ++d) {
-        const vecf u = *reinterpret_cast<const vecf*>(row3d + (size_t)d * HWP + p);
-#pragma unroll
-        for (int q = 0; q < PV; ++q) m3 = fmaxf(m3, u[q]);
-      }
-    }
-    m2 = group_max<32>(m2);
-    m3 = group_max<32>(m3);
-    // exp(x - m) as ONE v_exp_f32 of fma(x, log2 e, -m log2 e) (round 4; was libm's expf: ~12 instructions
-    // per logit of a VALU-bound epilogue) -- what the f32 row-tile kernel and the stand-alone decode do
-    // (common.h: exp_shifted; the sums stay f64)
-    const float nm2 = -m2 * kLog2e, nm3 = -m3 * kLog2e;
-    double s2 = 0, sx2 = 0, sy2 = 0, s3 = 0, sx3 = 0, sy3 = 0, sz3 = 0, sz3b = 0;
-    for (int p = li * PV; p < HW; p += 32 * PV) {
-      const vecf v2 = *reinterpret_cast<const vecf*>(row2d + p);
-      // two depth slices per pass, each with its own f64 chains (even / odd slices): the epilogue runs at
-      // two waves per SIMD, where one dependent chain of f64 adds per lane is latency, not throughput
-      double col[PV], colb[PV];
-#pragma unroll
-      for (int q = 0; q < PV; ++q) col[q] = colb[q] = 0;
-      int d = 0;
-      for (; d + 1 < D; d += 2) {
-        const vecf ua = *reinterpret_cast<const vecf*>(row3d + (size_t)d * HWP + p);
-        const vecf ub = *reinterpret_cast<const vecf*>(row3d + (size_t)(d + 1) * HWP + p);
-#pragma unroll
-        for (int q = 0; q < PV; ++q) {
-          const double ea = ACC64 ? exp_neg64((double)ua[q] - (double)m3) : (double)exp_shifted(ua[q], nm3);
-          const double eb = ACC64 ? exp_neg64((double)ub[q] - (double)m3) : (double)exp_shifted(ub[q], nm3);
-          col[q] += ea;
-          colb[q] += eb;
-          sz3 += ea * (double)d;
-          sz3b += eb * (double)(d + 1);
-        }
-      }
-      if (d < D) {
-        const vecf ua = *reinterpret_cast<const vecf*>(row3d + (size_t)d * HWP + p);
-#pragma unroll
-        for (int q = 0; q < PV; ++q) {
-          const double ea = ACC64 ? exp_neg64((double)ua[q] - (double)m3) : (double)exp_shifted(ua[q], nm3);
-          col[q] += ea;
-          sz3 += ea * (double)d;
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < PV; ++q) {
-        // (narrow maps wrap more than once; no integer division: exact for positions < 2^16, head_rt.hip)
-        const int h = HW <= 65536 ? (int)(((float)(p + q) + 0.5f) * rcp_w) : (p + q) / W, w = (p + q) - h * W;
-        const double e2 = ACC64 ? exp_neg64((double)v2[q] - (double)m2) : (double)exp_shifted(v2[q], nm2);
-        const double c = col[q] + colb[q];
-        s2 += e2; sx2 += e2 * w; sy2 += e2 * h;
-        s3 += c; sx3 += c * w; sy3 += c * h;
-      }
-    }
-    sz3 += sz3b;
-    s2 = group_sum<32>(s2); sx2 = group_sum<32>(sx2); sy2 = group_sum<32>(sy2);
-    s3 = group_sum<32>(s3); sx3 = group_sum<32>(sx3); sy3 = group_sum<32>(sy3);
-    sz3 = group_sum<32>(sz3);
-    if (li == 0) {
-      const size_t o = (size_t)crop * J + j;
-      coords2d[o * 2 + 0] = heatmap_to_px(axis_coord(sx2, s2, W), hs);
-      coords2d[o * 2 + 1] = heatmap_to_px(axis_coord(sy2, s2, H), hs);
-      coords3d_rel[o * 3 + 0] = heatmap_to_mm_xy(axis_coord(sx3, s3, W), hs);
-      coords3d_rel[o * 3 + 1] = heatmap_to_mm_xy(axis_coord(sy3, s3, H), hs);
-      coords3d_rel[o * 3 + 2] = heatmap_to_mm_z(axis_coord(sz3, s3, D), hs);
-    }
-  }
-}
-
-// Positions per lane and step of the half-wave that decodes a joint: the choice that leaves the fewest idle
-// lane-slots, ceil(HW / (32 PV)) * PV minimal (ties: the wider read).  Round 4: a 12x12 map (144 positions)
-// ran PV = 4, i.e. two steps of 128 positions with 112 of the second step's 128 slots idle -- 44 % of the
-// epilogue's lane-slots; at PV = 1 it is five steps of 32 with 16 idle.  The epilogue was 44 - 52 % of
-// the 16-bit kernels' time (tools/experiments/head_fixed_vs_stage.py: the same launch at C = 64 ... 1280).
-template <bool ACC64, int PVMAX>
-__device__ __forceinline__ void decode_group_from_lds(const float* Ls, int HWP, int grp,
-                                                      const HeadGeom& g, int crop, int J, int D,
-                                                      int H, int W, const HeadScale& hs,
-                                                      float* __restrict__ coords2d,
-                                                      float* __restrict__ coords3d_rel, int wid,
-                                                      int lane) {
-  const int HW = H * W;
-  const int c1 = (HW + 31) / 32, c2 = (HW + 63) / 64 * 2, c4 = (HW + 127) / 128 * 4;  // lane-slots per row
-  if (PVMAX >= 4 && c4 <= c2 && c4 <= c1)
-    decode_group_from_lds_pv<ACC64, 4>(Ls, HWP, grp, g, crop, J, D, H, W, hs, coords2d, coords3d_rel, wid, lane);
-  else if (c2 <= c1)
-    decode_group_from_lds_pv<ACC64, 2>(Ls, HWP, grp, g, crop, J, D, H, W, hs, coords2d, coords3d_rel, wid, lane);
-  else
-    decode_group_from_lds_pv<ACC64, 1>(Ls, HWP, grp, g, crop, J, D, H, W, hs, coords2d, coords3d_rel, wid, lane);
-}
 
 // LDS (40-90 KiB per workgroup) already caps residency at <= 4 waves per SIMD; asking for 2 lets the
 
@@ -219,25 +75,6 @@ __device__ __forceinline__ void decode_group_from_lds(const float* Ls, int HWP, 
 //   loads one dword (positions 2p, 2p + 1) from each of 8 consecutive channels -- a wave reads
 //   whole 128-byte rows -- and v_perm_b32 packs the low / high halves into the two positions'
 //   8-channel slots: two ds_write_b128 instead of sixteen ds_write_b16.
-using v4u = __attribute__((ext_vector_type(4))) unsigned;
-using h16x8 = __attribute__((ext_vector_type(8))) _Float16;
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-
-template <typename T> struct Mfma16;
-template <> struct Mfma16<__half> {
-  static __device__ __forceinline__ f32x16 run(v4u a, v4u b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a),
-                                                  __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
-  }
-};
-template <> struct Mfma16<__hip_bfloat16> {
-  static __device__ __forceinline__ f32x16 run(v4u a, v4u b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
-                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-  }
-};
-
-constexpr int kKH = 64;  // channels per stage of the 16-bit core
 
 // packed (16-bit feature dtypes) = [n_groups][64] bias (f32), then
 //   [n_groups][ceil(C / 64)][64 rows][64 ch] weights rounded to the feature dtype
@@ -256,6 +93,31 @@ __global__ void head_pack16_kernel(const float* __restrict__ w, int C, int J, in
     float v = 0.0f;
     if (jl < g.jg && j < J && c < C) v = w[(size_t)((k == 0) ? j : J + (k - 1) * J + j) * C + c];
     w16[t] = T(v);
+  }
+}
+
+// The same weights FRAGMENT-MAJOR (round 5, head_areg.hip): per (group, stage) an 8 KiB block
+// [row block 0..1][16-channel step 0..3][lane 0..63][8 channels] -- lane (fi = row & 31, fg) of step u holds channels
+// 16 u + 8 fg .. + 7 of row 32 rb + fi: exactly one lane's operand of v_mfma_f32_32x32x16, so that a wave-wide
+// 16-byte-per-lane load is 1 KiB contiguous.
+template <typename T>
+__global__ void head_pack16_frag_kernel(const float* __restrict__ w, int C, int J, int D, HeadGeom g,
+                                        int n_st, T* __restrict__ wfrag) {
+  const int per = 1 + D;
+  const size_t total = (size_t)g.n_groups * n_st * kRows * kKH;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (size_t)gridDim.x * blockDim.x) {
+    const int idx = (int)(t % ((size_t)kKH * kRows));
+    const size_t blk = t / ((size_t)kKH * kRows);
+    const int st = (int)(blk % n_st), grp = (int)(blk / n_st);
+    const int e = idx & 7, ln = (idx >> 3) & 63, ru = idx >> 9;
+    const int rb = ru >> 2, u = ru & 3, fi = ln & 31, fg = ln >> 5;
+    const int row = rb * 32 + fi, c = st * kKH + 16 * u + 8 * fg + e;
+    const int jl = row / per, k = row % per;
+    const int j = grp * g.jg + jl;
+    float v = 0.0f;
+    if (jl < g.jg && j < J && c < C) v = w[(size_t)((k == 0) ? j : J + (k - 1) * J + j) * C + c];
+    wfrag[t] = T(v);
   }
 }
 
@@ -529,32 +391,6 @@ __global__ __launch_bounds__(256, MTR_H16_MINWAVES) void head_fused16_kernel(
 // The builtin has to sit in a __device__ function: used directly in the kernel template (or in a
 // lambda there) it compiles for the device but the host pass drops the kernel's handle, and the
 // library then fails to load with an undefined symbol.
-__device__ __forceinline__ void dma16_to_lds(const void* src, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds(src, lds_wave_base, 16, 0, 0);  // lane L -> base + 16 L
-}
-
-// The same copy issued from inline asm: the compiler does not know that LDS is written, so it neither
-// waits for vmcnt(0) in front of every later ds_read (what it does behind the builtin: prefetch distance
-// zero for anything issued before the reads) nor orders anything for us -- the kernel waits for its own
-// copies (s_waitcnt vmcnt) in front of the stage barrier.  LDS address = M0 + 16 * lane.
-__device__ __forceinline__ void dma16_to_lds_asm(const void* src, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
-               :
-               : "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(src)
-               : "memory", "m0");  // (M0 is overwritten: the register allocator must know)
-}
-__device__ __forceinline__ unsigned lds_byte_addr(const void* p) {
-  return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
-}
-
-// two transposing 8-byte LDS reads = one 8-channel MFMA operand (semantics: see the kernel)
-__device__ __forceinline__ v4u lds_read_tr16_pair(const char* p0, const char* p1) {
-  using trv = __attribute__((ext_vector_type(4))) short;
-  using lds_trv = __attribute__((address_space(3))) trv;
-  struct Two { trv a, b; };
-  return __builtin_bit_cast(v4u, Two{__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_trv*)p0),
-                                     __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_trv*)p1)});
-}
 
 #ifndef MTR_H16_EARLY_DEFAULT
 #define MTR_H16_EARLY_DEFAULT -1  // -1: the library's rule (head16_early_copies); 0 / 1: force (ablation builds)
@@ -981,11 +817,29 @@ static int head16_groups_per_wg(int B, int ct, const HeadGeom& g, const HeadOpts
   return gpw;
 }
 
+static size_t h16_frag_offset(int C, int J, int D);  // (defined with the blob's other sizes below)
+
+// The weights-in-registers kernel (head_areg.hip): joint groups (= waves) per workgroup, 0 = not taken.
+// dma_staging 4 forces it (groups_per_workgroup 2 ... 4, default 3).  The library's own choice (-1), from
+// profiles/r05m_areg_frag.jsonl (MI355X, J = 122 on 12x12, f16, NCHW / NHWC; all variants bit-identical): four
+// groups per workgroup on launches of >= 512 crops with >= 8 joint groups per crop -- 1024 crops 639 / 623 us
+// against the early-copies kernel's 687 / 673; it is behind at 256 crops (194 vs 177 - 187) and below.
+static int head16_areg_groups(const HeadOpts& opt, int B, int C, int H, int W, int layout, const HeadGeom& g) {
+  if (!head16_areg_supported(C, H, W, layout)) return 0;
+  if (opt.dma == 4) return opt.groups_per_wg >= 2 ? opt.groups_per_wg : 3;
+  if (opt.dma != -1 || opt.groups_per_wg != 0) return 0;
+  return (B >= 512 && g.n_groups >= 8 && (H * W + 31) / 32 == 5) ? 4 : 0;
+}
+
 template <typename FeatT, int CT, bool NHWC>
 static int dispatch_head16(const void* feat, const float* packed, int B, int C, int H, int W, int J,
                            int D, const HeadGeom& g, const HeadScale& hs, float* c2d, float* c3d,
                            const HeadOpts& opt, hipStream_t stream) {
   constexpr int kMaxGpw = CT <= 2 ? 3 : (CT <= 6 ? 2 : 1);
+  if (const int ag = head16_areg_groups(opt, B, C, H, W, NHWC ? MTR_NHWC : MTR_NCHW, g))  // weights in registers
+    return head16_areg_launch(std::is_same<FeatT, __half>::value ? MTR_F16 : MTR_BF16, NHWC ? MTR_NHWC : MTR_NCHW, ag,
+                              feat, packed, (const char*)packed + h16_frag_offset(C, J, D), B, C, H, W, J, D, g, hs,
+                              c2d, c3d, stream);
   const int gpw = head16_groups_per_wg(B, CT, g, opt);
   if constexpr (kMaxGpw >= 3)
     if (gpw == 3) return launch_head16<FeatT, CT, 3, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, opt, stream);
@@ -1033,6 +887,14 @@ static size_t h16_blob_bytes(int C, int J, int D) {
 
 static size_t h16_blob_padded(int C, int J, int D) { return (h16_blob_bytes(C, J, D) + 15) & ~(size_t)15; }
 
+// the fragment-major copy of the joint-group weights (head_areg.hip): whole 64-channel stages only
+static size_t h16_frag_bytes(int C, int J, int D) {
+  if (!h16_shape_ok(C, J, D) || C % kKH != 0) return 0;
+  return (size_t)head_geom(J, D).n_groups * (C / kKH) * kRows * kKH * 2;
+}
+static size_t rt16_section_padded(int C, int J, int D) { return (rt16_section_bytes(C, J, D) + 15) & ~(size_t)15; }
+static size_t h16_frag_offset(int C, int J, int D) { return h16_blob_padded(C, J, D) + rt16_section_padded(C, J, D); }
+
 }  // namespace mtr
 
 // host-only: the row plan of the row-tile core (which conv_final channel each packed row holds)
@@ -1059,8 +921,11 @@ extern "C" size_t mtr_head_packed_bytes(int C, int J, int D, int feat_dtype) {
   if (C <= 0 || J <= 0 || D <= 0) return 0;
   if (feat_dtype == MTR_F32) return mtr::rt_section_bytes(C, J, D);
   // 16-bit: [joint-group blob (1 + D <= 64, C % 8 == 0), padded to 16 bytes][row-tile section (C % 64 == 0)]
-  if (feat_dtype == MTR_F16 || feat_dtype == MTR_BF16)
-    return mtr::h16_blob_padded(C, J, D) + mtr::rt16_section_bytes(C, J, D);
+  // [the joint-group weights fragment-major (1 + D <= 64, C % 64 == 0; round 5)]
+  if (feat_dtype == MTR_F16 || feat_dtype == MTR_BF16) {
+    const size_t frag = mtr::h16_frag_bytes(C, J, D);
+    return frag ? mtr::h16_frag_offset(C, J, D) + frag : mtr::h16_blob_padded(C, J, D) + mtr::rt16_section_bytes(C, J, D);
+  }
   return 0;
 }
 
@@ -1095,6 +960,16 @@ extern "C" int mtr_head_pack_weights(const float* weight, const float* bias, int
     hipLaunchKernelGGL(mtr::head_pack16_kernel<__hip_bfloat16>, dim3((unsigned)blocks16), dim3(256),
                        0, (hipStream_t)stream, weight, C, J, D, g, n_st, (__hip_bfloat16*)w16);
   MTR_CHECK_LAUNCH();
+  if (mtr::h16_frag_bytes(C, J, D)) {
+    void* wfrag = (char*)packed + mtr::h16_frag_offset(C, J, D);
+    if (feat_dtype == MTR_F16)
+      hipLaunchKernelGGL(mtr::head_pack16_frag_kernel<__half>, dim3((unsigned)blocks16), dim3(256), 0,
+                         (hipStream_t)stream, weight, C, J, D, g, n_st, (__half*)wfrag);
+    else
+      hipLaunchKernelGGL(mtr::head_pack16_frag_kernel<__hip_bfloat16>, dim3((unsigned)blocks16), dim3(256), 0,
+                         (hipStream_t)stream, weight, C, J, D, g, n_st, (__hip_bfloat16*)wfrag);
+    MTR_CHECK_LAUNCH();
+  }
   return MTR_OK;
 }
 
@@ -1115,8 +990,8 @@ static int parse_head_options(const mtr_head_options* caller, mtr::HeadOpts& opt
   memcpy(&mine, caller, size < sizeof mine ? size : sizeof mine);
   const mtr_head_options* options = &mine;
   if (options->rt_tiles_per_workgroup < 0 || options->rt_tiles_per_workgroup > 5 ||
-      options->groups_per_workgroup < 0 || options->groups_per_workgroup > 3 ||
-      options->dma_staging < -1 || options->dma_staging > 3 ||
+      options->groups_per_workgroup < 0 || options->groups_per_workgroup > 4 ||
+      options->dma_staging < -1 || options->dma_staging > 4 ||
       options->rt_column_blocks < 0 || options->rt_column_blocks > 4 ||
       options->rt_k_groups < 0 || options->rt_k_groups > 2 ||
       options->rt_loader < 0 || options->rt_loader > 2 ||
@@ -1160,6 +1035,12 @@ extern "C" int mtr_head_plan(int feat_dtype, int layout, int B, int C, int H, in
   const mtr::HeadGeom g = mtr::head_geom(J, D);
   int ct = (H * W + 31) / 32;
   if (ct == 7) ct = 8;
+  if (const int ag = mtr::head16_areg_groups(opt, B, C, H, W, layout, g)) {
+    plan->kernel = MTR_HEAD_KERNEL_16_AREG;
+    plan->tiles_per_workgroup = ag;
+    plan->workgroups = (long long)((B + 7) / 8) * 8 * ((g.n_groups + ag - 1) / ag);
+    return MTR_OK;
+  }
   const int gpw = mtr::head16_groups_per_wg(B, ct, g, opt);
   const bool dma_ok = C % mtr::kKH == 0 && (layout == MTR_NHWC || ((H * W) % 8 == 0 && H * W >= 64));
   plan->kernel = !(opt.dma != 0 && dma_ok) ? MTR_HEAD_KERNEL_16

@@ -63,7 +63,8 @@ def test_version_strerror_and_host_side_argument_checks(lib):
     # f16 features: 3 joint groups x 64 rows of bias (f32) + 3 x 20 stages x 64 rows x 64 channels x 2 B
     # + the 16-bit row-tile section (C % 64 == 0): 20 stages x 10 tiles x 2 KiB + 160 rows x 8 B
     joint_groups = 3 * 64 * 4 + 3 * 20 * 64 * 64 * 2
-    assert lib.mtr_head_packed_bytes(1280, 17, 8, 1) == joint_groups + 20 * 10 * 2048 + 160 * 8
+    # + (round 5) the joint-group weights once more, fragment-major (whole 64-channel stages): 3 x 20 x 8 KiB
+    assert lib.mtr_head_packed_bytes(1280, 17, 8, 1) == joint_groups + 20 * 10 * 2048 + 160 * 8 + 3 * 20 * 8192
     assert lib.mtr_head_packed_bytes(1283, 17, 8, 1) == 0   # C % 8 != 0: no 16-byte operands
     assert lib.mtr_head_packed_bytes(1288, 17, 8, 1) == 3 * 64 * 4 + 3 * 21 * 64 * 64 * 2  # C % 64 != 0: joint groups only
     # a joint's 73 rows exceed the 64-row group: the row-tile section alone (17 atoms of 5 tiles)

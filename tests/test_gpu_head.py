@@ -165,7 +165,10 @@ def test_fused_head_16bit_odd_shapes(shape, dtype, hip_lib):
                     dict(dma_staging=1), dict(dma_staging=2), dict(dma_staging=2, groups_per_workgroup=1),
                     dict(dma_staging=2, groups_per_workgroup=2), dict(dma_staging=2, groups_per_workgroup=3),
                     dict(dma_staging=3), dict(dma_staging=3, groups_per_workgroup=1),
-                    dict(dma_staging=3, groups_per_workgroup=2), dict(dma_staging=3, groups_per_workgroup=3)):
+                    dict(dma_staging=3, groups_per_workgroup=2), dict(dma_staging=3, groups_per_workgroup=3),
+                    # round 5: weights in registers (3 - 5 column tiles with whole stages; elsewhere = the default)
+                    dict(dma_staging=4), dict(dma_staging=4, groups_per_workgroup=2),
+                    dict(dma_staging=4, groups_per_workgroup=4)):
         # (dma_staging 1 = four waves that copy and multiply, 2 = four MFMA waves + a loader wave)
         v2d, v3d = run_fused(feat, w, b, J, cfg, **options)
         assert torch.equal(v3d, c3d) and torch.equal(v2d, c2d), options
@@ -613,7 +616,7 @@ def test_head_options_are_validated(hip_lib):
     w, b = cases.default_conv_init(153, 64, cases.gen(1))
     packed = kernels.head_pack_weights(w.cuda(), b.cuda(), 17, 8)
     feat = torch.randn(2, 64, 8, 8, device='cuda')
-    for bad in (dict(rt_tiles=6), dict(groups_per_workgroup=4), dict(dma_staging=4), dict(rt_column_blocks=5),
+    for bad in (dict(rt_tiles=6), dict(groups_per_workgroup=5), dict(dma_staging=5), dict(rt_column_blocks=5),
                 dict(rt_k_groups=3), dict(rt_loader=3), dict(rt_split=3)):
         with pytest.raises(RuntimeError):
             kernels.head_fused(feat, packed, 64, 17, MetrabsConfig(), **bad)

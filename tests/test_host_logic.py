@@ -325,3 +325,23 @@ def test_metrabs_affine_latent_modes_follow_the_reference_constructor(tmp_path):
     gen0 = plain.storage_generation
     plain.double()
     assert plain.storage_generation > gen0
+
+
+def test_head_plan_takes_the_weights_in_registers_kernel_on_large_wide_launches():
+    """Round 5 (csrc/head_areg.hip): the library's own choice for >= 512 crops of >= 8 joint groups on 5 column
+    tiles (J = 122 on 12x12, 16-bit) -- 7 % ahead of the early-copies kernel at 1024 crops, behind it at 256
+    (profiles/r05m_areg_frag.jsonl); dma_staging 4 forces it wherever it exists, with 2 - 4 waves per workgroup."""
+    from metrabs_amd import kernels
+    name = 'head_fused16areg_kernel (weights in registers)'
+    big = kernels.head_plan(1024, 1280, 12, 12, 122, 8, torch.float16)
+    assert big['kernel'] == name and big['tiles_per_workgroup'] == 4 and big['workgroups'] == 1024 * 5
+    assert kernels.head_plan(256, 1280, 12, 12, 122, 8, torch.float16)['kernel'] != name     # configs[4]'s sizes:
+    assert kernels.head_plan(32, 1280, 12, 12, 122, 8, torch.float16)['kernel'] != name      # the early-copies kernel
+    assert kernels.head_plan(1024, 1280, 12, 12, 17, 8, torch.float16)['kernel'] != name     # 3 joint groups
+    assert kernels.head_plan(1024, 1280, 8, 8, 122, 8, torch.float16)['kernel'] != name      # 2 column tiles
+    forced = kernels.head_plan(32, 1280, 12, 12, 122, 8, torch.bfloat16, dma_staging=4, groups_per_workgroup=2)
+    assert forced['kernel'] == name and forced['tiles_per_workgroup'] == 2 and forced['workgroups'] == 32 * 9
+    assert kernels.head_plan(32, 1280, 8, 8, 17, 8, torch.float16, dma_staging=4)['kernel'] != name   # no such tile: as -1
+    # the blob carries the fragment-major copy of the joint-group weights wherever that kernel exists
+    lib = kernels._lib.load()
+    assert lib.mtr_head_packed_bytes(1280, 122, 8, 1) - lib.mtr_head_packed_bytes(1288, 122, 8, 1) > 18 * 20 * 8192
