@@ -174,8 +174,10 @@ class _CallPlan:
 
 
 class GraphCache:
-    def __init__(self, estimator, max_graphs=32, max_frame_sets=4, min_batches_between_evictions=128):
+    def __init__(self, estimator, max_graphs=64, max_frame_sets=4, min_batches_between_evictions=128):
         self.est = estimator
+        # (64 since round 5: every box count of an internal batch of up to 64 crops fits; the captured batches share
+        #  one allocator pool, so a graph costs its own static parameters and output, not a set of activations)
         self.max_graphs = max_graphs
         self.max_frame_sets = max_frame_sets
         # A capture costs a few eager batches (warm-up + the capture itself).  While the cache has room a
