@@ -283,7 +283,7 @@ class Metrabs(torch.nn.Module):
     # True: the backbone runs under torch.backends.cudnn.flags(deterministic=True) -- eager calls, captured
     # graphs, replays and module copies then agree bit for bit, which is what lets a replayed HIP graph be "the
     # eager path's bits".  False: PyTorch's global setting decides.  None (default): pinned for f32 arithmetic --
-    # the parity target, where the pin costs 0.6 - 2.2 % of the step -- and not under 16-bit autocast, whose own
+    # the parity target, where the pin costs 0.6 - 2.2 % of the step (EfficientNetV2-S; 5 % at EfficientNetV2-L) -- and not under 16-bit autocast, whose own
     # rounding (1.8 mm mean from the f32 model) is the size of the run-to-run noise and where the pin costs up
     # to 13 % (EfficientNetV2-L 384 f16: 1.86 k -> 1.62 k crops/s, profiles/r05z_bench_config4.json).
     deterministic_backbone = None
