@@ -62,6 +62,13 @@ def load_crop_model(model_dir, map_location='cpu', fold_batchnorm=False, fused_e
     folded convolutions as one in-place HIP pass, K10); the default keeps the checkpoint's own
     arithmetic."""
     cfg, raw = load_config(model_dir)
+    # config.affine_weights (models/metrabs.py:23-32) is a path or a name under $DATA_ROOT/skeleton_conversion;
+    # a file of that name shipped INSIDE the model directory is found too
+    if isinstance(cfg.affine_weights, str) and cfg.affine_weights and not os.path.exists(cfg.affine_weights):
+        for cand in (cfg.affine_weights, cfg.affine_weights + '.npz', 'affine_weights.npz'):
+            if os.path.exists(os.path.join(model_dir, cand)):
+                cfg.affine_weights = os.path.join(model_dir, cand)
+                break
     backbone = backbone_from_config(raw)
     # (the reference materialises its LazyConv2d head with a dummy forward, demo_image.py:69-72;
     #  the channel count is known here)

@@ -104,6 +104,34 @@ def test_model_directory_round_trip(tmp_path):
         loading.load_crop_model(d)
 
 
+def test_model_directory_with_affine_weights(tmp_path):
+    """Row a11 through the loader: config.yaml names the affine-weights file (models/metrabs.py:23-32); a file of
+    that name inside the model directory is found, the head gets the mode's raw point count and the checkpoint
+    loads strictly."""
+    from metrabs_amd import backbones, loading
+    from metrabs_amd.config import MetrabsConfig
+    from metrabs_amd.joint_info import JointInfo
+    from metrabs_amd.models.metrabs import Metrabs
+    w1, w2 = cases.affine_weights_case(17, 12, 77)
+    raw = dict(proc_side=256, depth=8, backbone='resnet18', affine_weights='latents12', predict_all_and_latents=True)
+    bb = backbones.build_backbone('resnet18')
+    model = Metrabs(bb, JointInfo(cases.COCO17, cases.COCO17_EDGES), MetrabsConfig.from_any(raw),
+                    in_channels=bb.out_channels, affine_weights=dict(w1=w1, w2=w2))
+    assert model.heatmap_heads.conv_final.out_channels == (12 + 17) * 9
+    d = str(tmp_path / 'model')
+    loading.save_model_dir(d, model, raw, {'': dict(indices=list(range(17)), names=cases.COCO17,
+                                                    edges=cases.COCO17_EDGES)}, np.eye(17, dtype=np.float32))
+    with pytest.raises(FileNotFoundError):      # the named file is nowhere: the reference fails the same way
+        loading.load_crop_model(d)
+    np.savez(os.path.join(d, 'latents12.npz'), w1=w1.numpy(), w2=w2.numpy())
+    loaded = loading.load_crop_model(d)
+    assert loaded.n_latents == 12 and loaded.latent_prefix == 12 and loaded.latent_output
+    assert torch.equal(loaded.recombination_weights, w2)
+    assert loaded.heatmap_heads.conv_final.weight.shape[0] == 29 * 9
+    for (k1, v1), (k2, v2) in zip(model.state_dict().items(), loaded.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+
+
 def test_tf_to_pt_layouts():
     from metrabs_amd import loading
     g = np.random.default_rng(0)
