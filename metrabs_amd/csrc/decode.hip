@@ -192,6 +192,28 @@ __global__ __launch_bounds__(256) void decode_nchw_kernel(
         float col[VEC], colz[VEC];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) col[v] = colz[v] = 0.0f;
+        if constexpr (VEC % 2 == 0) {
+          // (round 5) the two accumulations of a column PAIR are one v_pk_add_f32 and one v_pk_fma_f32 (full rate
+          // on gfx950: two f32 lanes per instruction; the same IEEE operations, so the same bits) -- the 16-bit
+          // instantiation is VALU-bound and a quarter of its slots were these adds
+          using v2f = __attribute__((ext_vector_type(2))) float;
+          v2f c2[VEC / 2], z2[VEC / 2];
+#pragma unroll
+          for (int v = 0; v < VEC / 2; ++v) c2[v] = z2[v] = v2f{0.0f, 0.0f};
+#pragma unroll
+          for (int k = 0; k < CH; ++k) {
+            const float fz = (float)(d0 + k);
+            const float nmk = (d0 + k < D) ? nm : -INFINITY;  // wave-uniform select
+#pragma unroll
+            for (int v = 0; v < VEC / 2; ++v) {
+              const v2f e = v2f{exp_shifted(x3(k, 2 * v), nmk), exp_shifted(x3(k, 2 * v + 1), nmk)};
+              c2[v] += e;
+              z2[v] = __builtin_elementwise_fma(e, v2f{fz, fz}, z2[v]);
+            }
+          }
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) { col[v] = c2[v >> 1][v & 1]; colz[v] = z2[v >> 1][v & 1]; }
+        } else {
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
           const float fz = (float)(d0 + k);
@@ -202,6 +224,7 @@ __global__ __launch_bounds__(256) void decode_nchw_kernel(
             col[v] += e;
             colz[v] = fmaf(e, fz, colz[v]);
           }
+        }
         }
         if constexpr (VEC > 1) {
           double S = 0.0, Sv = 0.0;
