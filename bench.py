@@ -463,9 +463,19 @@ def rotating_sampler_times(pipe, est, args, wp, iters):
         t_warp = time_rotating(lambda i: kernels.warp_crops(
             pyrs[i], wp, args.res, 1, out_dtype=est.crop_dtype, channels_last=est.crop_channels_last),
             n_sets, iters)
+        # the same frames with interleaved channels ([N,H,W,3] memory, channels_last): what a decoder hands over;
+        # sampled in place by mtr_build_pyramid_u8_hwc / mtr_warp_crops_u8_hwc (two gathers per sample, not six)
+        del pyrs
+        frames = [f.contiguous(memory_format=torch.channels_last) for f in frames]
+        t_pyr_il = time_rotating(lambda i: kernels.build_pyramid(frames[i]), n_sets, iters)
+        pyrs = [kernels.build_pyramid(f) for f in frames]
+        assert all(p.hwc for p in pyrs)
+        t_warp_il = time_rotating(lambda i: kernels.warp_crops(
+            pyrs[i], wp, args.res, 1, out_dtype=est.crop_dtype, channels_last=est.crop_channels_last),
+            n_sets, iters)
     del frames, pyrs
     torch.cuda.empty_cache()
-    return dict(pyramid=t_pyr, warp=t_warp, n_sets=n_sets)
+    return dict(pyramid=t_pyr, warp=t_warp, n_sets=n_sets, pyramid_interleaved=t_pyr_il, warp_interleaved=t_warp_il)
 
 
 def detector_pre_probe(pipe, iters):
@@ -1488,6 +1498,12 @@ def analysis(args, est, cfg, pipe, dev, step_seconds, im_h, im_w, n_box, world):
             per_kernel[k]['TFLOPs'] = round(a2['flops'] / t / 1e12, 2)
             per_kernel[k]['frac_mfma'] = round(a2['flops'] / t / mfma_peak, 4)
         if k in ('pyramid', 'warp'):
+            t_il = rot[k + '_interleaved']
+            per_kernel[k]['interleaved_frames'] = dict(
+                us_per_step=round(t_il * 1e6, 2), frac_hbm=round(a2['bytes'] / t_il / HBM_PEAK, 4),
+                note='the same launch on [N,H,W,3] frames (channels_last: what a decoder hands over), sampled in '
+                     'place with the planar path\'s bits; `value` and the roofline object use the reference\'s '
+                     'planar [N,3,H,W] frames')
             per_kernel[k]['us_on_the_steps_own_cache_resident_frames'] = round(a2['hot_us'], 2)
             per_kernel[k]['frac_hbm_cache_assisted'] = round(a2['bytes'] / (a2['hot_us'] * 1e-6) / HBM_PEAK, 4)
         if k.startswith('K1'):

@@ -297,6 +297,18 @@ int mtr_warp_crops_u8(const uint8_t* level0_u8, const float* lut, const float* l
                       const float* level2, int N, int Hi, int Wi, const float* warp_params,
                       int n_crops, int res, int antialias, int out_dtype, int out_layout, void* out,
                       mtr_stream_t stream);
+/* The same two calls for frames with interleaved channels, images_u8 [N,Hi,Wi,3] (the memory of a
+ * torch channels_last [N,3,Hi,Wi] tensor; what image decoders and numpy hand over; the reference
+ * accepts such a tensor through its strides, `images.float()` at multiperson_model.py:196).  Levels 1
+ * and 2 are the same f32 planes; the crops are bit-identical to mtr_warp_crops_u8 on the planar copy
+ * of the frames.  The two x-taps of a row are then 6 consecutive bytes for all three channels: one
+ * 12-byte gather per row instead of three 8-byte ones. */
+int mtr_build_pyramid_u8_hwc(const uint8_t* images_u8, int N, int Hi, int Wi, float* lut /*[256]*/,
+                             float* level1, float* level2, mtr_stream_t stream);
+int mtr_warp_crops_u8_hwc(const uint8_t* level0_u8, const float* lut, const float* level1,
+                          const float* level2, int N, int Hi, int Wi, const float* warp_params,
+                          int n_crops, int res, int antialias, int out_dtype, int out_layout, void* out,
+                          mtr_stream_t stream);
 int mtr_crop_geometry(const float* boxes, int box_stride, const float* intrinsics,
                       const float* distortion, const float* camspace_up, const int32_t* image_ids,
                       const float* aug_rotflipmat, const float* aug_scales, const float* aug_gammas,

@@ -109,6 +109,10 @@ SIGNATURES = {
                                      c_void_p]),
     'mtr_warp_crops_u8': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                   c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'mtr_build_pyramid_u8_hwc': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                         c_void_p]),
+    'mtr_warp_crops_u8_hwc': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                      c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'mtr_pyramid_from_level0': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'mtr_crop_geometry': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,

@@ -14,6 +14,8 @@
 // The reference spends ~10 launches per crop in a Python loop (~100 crops/s on 8 CPU cores); here
 // the whole internal batch is ONE launch.  Bound: HBM for the streaming output (3*res^2*sizeof(out)
 // per crop) plus the clipped source footprint, which normally stays in L2 / Infinity Cache.
+#include <type_traits>
+
 #include "common.h"
 #include "resize_aa.h"
 
@@ -43,7 +45,7 @@
 #endif
 #ifndef MTR_WARP_ABLATE
 #define MTR_WARP_ABLATE 0   // developer-only timing ablations (tools/experiments/ablate_warp.py); in warp_rows_kernel:
-                            // 1 = no tap loads, 2 = no LUT reads, 4 = no gamma pow, 8 = no stores.  Round 3, 64 crops,
+                            // 1 = no tap loads, 2 = no LUT reads, 4 = no gamma pow, 8 = no stores, 16 = one gather pair for all channels.  Round 3, 64 crops,
                             // cache-resident / rotating frames: full 24.5 / 30.3 us, no taps 18.7 / 18.8, no stores
                             // 17.6 / 20.1, none of the four 11.1 / 11.0 -- arithmetic, taps and stores are nearly
                             // additive; neither fewer VALU instructions (this macro's LEAN) nor a quarter of the store
@@ -57,7 +59,9 @@ namespace mtr {
 // avg_pool2d accumulates row-major ((a+b)+c)+d and divides by 4 (exact in fp32).
 // WRITE_L0 = false: the f32 level 0 (64 % of the pyramid's bytes) is NOT materialised; the sampler
 // reads level 0 straight from the uint8 frame through the 256-entry LUT exported to `lut_out`.
-template <bool FROM_U8, bool WRITE_L0>
+// HWC (uint8 only, level 0 not written): the frames are interleaved [N,H,W,3]; plane pl = image pl / 3,
+// channel pl % 3, its pixels 3 bytes apart (the path of odd frame sizes: one byte per load).
+template <bool FROM_U8, bool WRITE_L0, bool HWC = false>
 __global__ __launch_bounds__(256) void build_pyramid_kernel(
     const void* __restrict__ src_any, int planes, int Hi, int Wi, float* __restrict__ l0,
     float* __restrict__ l1, float* __restrict__ l2, float* __restrict__ lut_out, GammaLut lut_in,
@@ -88,11 +92,12 @@ __global__ __launch_bounds__(256) void build_pyramid_kernel(
       pl = (int)(t / ((long long)bw * bh));
     }
     const int x0 = bx * 4, y0 = by * 4;
-    const uint8_t* sp = src + (size_t)pl * Hi * Wi;
+    const uint8_t* sp = HWC ? src + (size_t)(pl / 3) * 3 * Hi * Wi + (pl % 3) : src + (size_t)pl * Hi * Wi;
+    constexpr int PS = HWC ? 3 : 1;
     const float* spf = srcf + (size_t)pl * Hi * Wi;
     float* d0 = l0 + (size_t)pl * Hi * Wi;
     float v[4][4];
-    const bool fast = (Wi % 4 == 0) && (x0 + 4 <= Wi) && (y0 + 4 <= Hi);
+    const bool fast = !HWC && (Wi % 4 == 0) && (x0 + 4 <= Wi) && (y0 + 4 <= Hi);
     if (!FROM_U8) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(256) void build_pyramid_kernel(
           const int y = y0 + r, x = x0 + c;
           float val = 0.0f;
           if (y < Hi && x < Wi) {
-            val = lut[sp[(size_t)y * Wi + x]];
+            val = lut[sp[((size_t)y * Wi + x) * PS]];
             if (WRITE_L0) d0[(size_t)y * Wi + x] = val;
           }
           v[r][c] = val;
@@ -154,6 +159,10 @@ __global__ __launch_bounds__(256) void build_pyramid_kernel(
 // The gamma LUT is replicated once per LDS bank ([value][32]): lanes l and l+32 of a ds_read_b32
 // are serviced separately and lane l always reads bank l & 31, so the lookups are conflict-free
 // whatever the pixel values (random pixels averaged ~3.5 ways on the shared 256-entry table).
+// HWC: interleaved frames [N,H,W,3]; `planes` is then the number of IMAGES and a thread owns the 8x8
+// tile of all three channels: 24 contiguous bytes per row (three 8-byte loads, lane-contiguous across
+// the wave as 1,536 B per row), the same level-1 / level-2 stores into each channel's plane.
+template <bool HWC>
 __global__ __launch_bounds__(256) void build_pyramid_u8_wide_kernel(
     const uint8_t* __restrict__ src, int planes, int Hi, int Wi, float* __restrict__ l1,
     float* __restrict__ l2, float* __restrict__ lut_out, GammaLut lut_in, FastDiv by_tw, FastDiv by_th) {
@@ -184,31 +193,36 @@ __global__ __launch_bounds__(256) void build_pyramid_u8_wide_kernel(
       ty = (int)((t / tw) % th);
       pl = (int)(t / ((long long)tw * th));
     }
-    const uint8_t* sp = src + ((size_t)pl * Hi + (size_t)ty * 8) * Wi + (size_t)tx * 8;
-    uint2 raw[8];
+    constexpr int NC = HWC ? 3 : 1, RD = HWC ? 6 : 2;  // channels per thread, dwords per tile row
+    const uint8_t* sp = src + (((size_t)pl * Hi + (size_t)ty * 8) * Wi + (size_t)tx * 8) * NC;
+    uint32_t raw[8][RD];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) raw[r] = *reinterpret_cast<const uint2*>(sp + (size_t)r * Wi);
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int k = 0; k < RD / 2; ++k) {
+        const uint2 w = *reinterpret_cast<const uint2*>(sp + (size_t)r * Wi * NC + 8 * k);
+        raw[r][2 * k] = w.x;
+        raw[r][2 * k + 1] = w.y;
+      }
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch) {
+    const int opl = HWC ? pl * 3 + ch : pl;  // the plane of levels 1 / 2 this channel goes to
     float q[4][4];  // level 1: 4 rows x 4 px
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float v[2][8];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const uint32_t w0 = raw[2 * r + i].x, w1 = raw[2 * r + i].y;
-        v[i][0] = mylut[(w0 & 0xff) << 5];
-        v[i][1] = mylut[((w0 >> 8) & 0xff) << 5];
-        v[i][2] = mylut[((w0 >> 16) & 0xff) << 5];
-        v[i][3] = mylut[(w0 >> 24) << 5];
-        v[i][4] = mylut[(w1 & 0xff) << 5];
-        v[i][5] = mylut[((w1 >> 8) & 0xff) << 5];
-        v[i][6] = mylut[((w1 >> 16) & 0xff) << 5];
-        v[i][7] = mylut[(w1 >> 24) << 5];
-      }
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int px = 0; px < 8; ++px) {
+          const int k = px * NC + ch;  // byte of the row segment (compile-time after unrolling)
+          v[i][px] = mylut[((raw[2 * r + i][k >> 2] >> ((k & 3) * 8)) & 0xff) << 5];
+        }
 #pragma unroll
       for (int c = 0; c < 4; ++c)
         q[r][c] = __fadd_rn(__fadd_rn(__fadd_rn(v[0][2 * c], v[0][2 * c + 1]), v[1][2 * c]),
                             v[1][2 * c + 1]) * 0.25f;
-      *reinterpret_cast<float4*>(l1 + ((size_t)pl * H1 + (size_t)ty * 4 + r) * W1 + (size_t)tx * 4) =
+      *reinterpret_cast<float4*>(l1 + ((size_t)opl * H1 + (size_t)ty * 4 + r) * W1 + (size_t)tx * 4) =
           make_float4(q[r][0], q[r][1], q[r][2], q[r][3]);
     }
 #pragma unroll
@@ -218,9 +232,10 @@ __global__ __launch_bounds__(256) void build_pyramid_u8_wide_kernel(
       for (int c = 0; c < 2; ++c)
         o[c] = __fadd_rn(__fadd_rn(__fadd_rn(q[2 * r][2 * c], q[2 * r][2 * c + 1]), q[2 * r + 1][2 * c]),
                          q[2 * r + 1][2 * c + 1]) * 0.25f;
-      *reinterpret_cast<float2*>(l2 + ((size_t)pl * H2 + (size_t)ty * 2 + r) * W2 + (size_t)tx * 2) =
+      *reinterpret_cast<float2*>(l2 + ((size_t)opl * H2 + (size_t)ty * 2 + r) * W2 + (size_t)tx * 2) =
           make_float2(o[0], o[1]);
     }
+    }  // ch
   }
 }
 
@@ -417,19 +432,23 @@ __device__ __forceinline__ void pair_weights(int i, int s, int n, float t0, floa
   else if (i == n - 1) { w_second = t0; }            // only tap i = n-1 is inside (s = n-2)
 }
 
+// (px_stride 1: a plane of [N,3,H,W]; 3: one channel of an interleaved [N,H,W,3] frame)
 __device__ __forceinline__ float tap_u8(const uint8_t* __restrict__ plane, const float* lut, int x,
-                                        int y, int W, int H) {
-  return (x >= 0 && x < W && y >= 0 && y < H) ? lut[plane[(size_t)y * W + x]] : 0.0f;
+                                        int y, int W, int H, int px_stride = 1) {
+  return (x >= 0 && x < W && y >= 0 && y < H) ? lut[plane[((size_t)y * W + x) * px_stride]] : 0.0f;
 }
 
 // L0U8: level 0 is the uint8 frame itself (l0 is then a uint8 pointer) decoded through a copy of
 // the gamma LUT in LDS.  One 8-byte load from the 4-byte-aligned address below the tap still
 // yields both x-taps of a row: bytes (off&3) and (off&3)+1 of the 64-bit word.
-template <typename OutT, int AA, int PX, bool L0U8>
+// L0 = 2: the uint8 frame is interleaved [N,H,W,3]; the two x-taps of a channel are then bytes
+// (off & 3) and (off & 3) + 3 of the same 8-byte window.
+template <typename OutT, int AA, int PX, int L0>
 __global__ __launch_bounds__(256) void warp_crops_kernel(
     const void* __restrict__ l0_any, const float* __restrict__ l1, const float* __restrict__ l2,
     const float* __restrict__ lut_g, LevelDims dims, unsigned u8_bytes,
     const float* __restrict__ wp_all, int n_crops, int res, int nhwc, OutT* __restrict__ out) {
+  constexpr bool L0U8 = L0 != 0, HWC = L0 == 2;
   __shared__ float lut[L0U8 ? 256 : 1];
   if (L0U8) {
     lut[threadIdx.x] = lut_g[threadIdx.x];
@@ -533,7 +552,10 @@ __global__ __launch_bounds__(256) void warp_crops_kernel(
             unsigned long long tw_keep = 0, bw_keep = 0;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-              const int ot = img_off + c * plane_elems + ys * W + xs, ob = ot + W;  // byte offsets
+              // byte offsets of the top-left tap and of the one below it
+              const int ot = HWC ? img_off + (ys * W + xs) * 3 + c : img_off + c * plane_elems + ys * W + xs;
+              const int ob = ot + (HWC ? 3 * W : W);
+              constexpr int RS = HWC ? 24 : 8;  // bit position of the right-hand tap in the window
               unsigned long long tw, bw;
               if ((MTR_WARP_ABLATE & 16) && c > 0) {  // timing probe: one gather pair serves all channels
                 tw = tw_keep; bw = bw_keep;
@@ -549,11 +571,11 @@ __global__ __launch_bounds__(256) void warp_crops_kernel(
               if (MTR_WARP_ABLATE & 16) { tw_keep = tw; bw_keep = bw; }
               float ta, tb, ba, bb;
               if (MTR_WARP_ABLATE & 2) {
-                ta = (float)(tw & 0xff); tb = (float)((tw >> 8) & 0xff);
-                ba = (float)(bw & 0xff); bb = (float)((bw >> 8) & 0xff);
+                ta = (float)(tw & 0xff); tb = (float)((tw >> RS) & 0xff);
+                ba = (float)(bw & 0xff); bb = (float)((bw >> RS) & 0xff);
               } else {
-                ta = lut[tw & 0xff]; tb = lut[(tw >> 8) & 0xff];
-                ba = lut[bw & 0xff]; bb = lut[(bw >> 8) & 0xff];
+                ta = lut[tw & 0xff]; tb = lut[(tw >> RS) & 0xff];
+                ba = lut[bw & 0xff]; bb = lut[(bw >> RS) & 0xff];
               }
               acc[p][c] += fmaf(bb, w11, fmaf(ba, w10, fmaf(tb, w01, ta * w00)));
             }
@@ -562,9 +584,10 @@ __global__ __launch_bounds__(256) void warp_crops_kernel(
           const float wnw = tx0 * ty0, wne = tx1 * ty0, wsw = tx0 * ty1, wse = tx1 * ty1;
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            const uint8_t* __restrict__ pl = planes_u8 + (size_t)c * plane_elems;
-            const float nw = tap_u8(pl, lut, x0, y0, W, H), ne = tap_u8(pl, lut, x0 + 1, y0, W, H);
-            const float sw = tap_u8(pl, lut, x0, y0 + 1, W, H), se = tap_u8(pl, lut, x0 + 1, y0 + 1, W, H);
+            const uint8_t* __restrict__ pl = planes_u8 + (HWC ? (size_t)c : (size_t)c * plane_elems);
+            constexpr int PS = HWC ? 3 : 1;
+            const float nw = tap_u8(pl, lut, x0, y0, W, H, PS), ne = tap_u8(pl, lut, x0 + 1, y0, W, H, PS);
+            const float sw = tap_u8(pl, lut, x0, y0 + 1, W, H, PS), se = tap_u8(pl, lut, x0 + 1, y0 + 1, W, H, PS);
             acc[p][c] += fmaf(se, wse, fmaf(sw, wsw, fmaf(ne, wne, nw * wnw)));
           }
         } else {
@@ -644,11 +667,16 @@ struct TapSet {
   int off;                    // element (f32 levels) or byte (uint8 level 0) offset of the top-left tap
 };
 
-template <typename OutT, int AA, int ROWS, bool L0U8>
+// L0: representation of level 0 -- 0 = f32 planes, 1 = the uint8 frame [N,3,H,W], 2 = the uint8 frame
+// with interleaved channels [N,H,W,3] (what decoders and numpy hand over): there the two x-taps of a
+// row for ALL three channels are six consecutive bytes, so one 12-byte load from the aligned address
+// below them replaces three 8-byte ones -- two gathers per sample instead of six.
+template <typename OutT, int AA, int ROWS, int L0>
 __global__ __launch_bounds__(256) void warp_rows_kernel(
     const void* __restrict__ l0_any, const float* __restrict__ l1, const float* __restrict__ l2,
     const float* __restrict__ lut_g, LevelDims dims, unsigned u8_bytes,
     const float* __restrict__ wp_all, int n_crops, int res, int nhwc, OutT* __restrict__ out) {
+  constexpr bool L0U8 = L0 != 0, HWC = L0 == 2;
   __shared__ float lut[L0U8 ? 256 : 1];
   if (L0U8) {
     lut[threadIdx.x] = lut_g[threadIdx.x];
@@ -689,7 +717,7 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
   // tensor, see warp_crops_kernel; f32 levels: the image's three planes)
   const int sh = bytes0 ? 0 : 2;
   const int plane_bytes = __builtin_amdgcn_readfirstlane(plane_elems << sh);
-  const int row_bytes = __builtin_amdgcn_readfirstlane(W << sh);
+  const int row_bytes = __builtin_amdgcn_readfirstlane(HWC && bytes0 ? 3 * W : W << sh);
   const buffer_rsrc_t rsrc =
       bytes0 ? make_rsrc(uniform_ptr((const uint8_t*)l0_any), (unsigned)u8_bytes)
              : make_rsrc(uniform_ptr(planes), (unsigned)(3 * plane_elems) * 4u);
@@ -706,6 +734,11 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
                                         (unsigned)(3 * res * res) * (unsigned)sizeof(OutT));
   const int chan_bytes = __builtin_amdgcn_readfirstlane(res * res * (int)sizeof(OutT));
 
+  // The sample pipeline, instantiated per kind of source: IL = interleaved uint8 level 0 (only in the
+  // L0 == 2 kernel, whose levels 1 and 2 are f32 planes like everyone's: the split is made ONCE per
+  // wave, below, so that each instance stays straight-line code).
+  auto run = [&](auto il_tag) {
+  constexpr bool IL = decltype(il_tag)::value;
   // sample s of this lane: row s / (AA*AA), sub-sample (sj, si) in the reference's loop order
   auto request = [&](int s) -> TapSet {
     const int r = s / (AA * AA), sj = (s / AA) % AA, si = s % AA;
@@ -762,6 +795,18 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
     if (!sane) wl = wr = 0.0f;  // (also non-finite coordinates) the sample contributes nothing
 #endif
     t.w00 = wl * wt; t.w01 = wr * wt; t.w10 = wl * wb; t.w11 = wr * wb;
+    if constexpr (IL) {
+      // bytes off .. off + 5 = (R, G, B) of texel xs and of texel xs + 1; the 12 bytes from (off & ~3) hold them
+      t.off = (__mul24(ys, W) + xs) * 3 + img_off;
+      const int ob = t.off + row_bytes;
+      const auto top = __builtin_amdgcn_raw_buffer_load_b96(rsrc, t.off & ~3, 0, 0);
+      const auto bot = __builtin_amdgcn_raw_buffer_load_b96(rsrc, ob & ~3, 0, 0);
+      t.raw[0] = (unsigned long long)top[0] | ((unsigned long long)top[1] << 32);
+      t.raw[1] = top[2];
+      t.raw[2] = (unsigned long long)bot[0] | ((unsigned long long)bot[1] << 32);
+      t.raw[3] = bot[2];
+      return t;
+    }
     t.off = ((__mul24(ys, W) + xs) << sh) + img_off;  // (full-rate 24-bit multiply: ys, W < 2^24)
     if (MTR_WARP_LEAN && same_shift) {
       // pitches that are multiples of 4: (off + c * plane + r * row) & ~3 = (off & ~3) + c * plane + r * row,
@@ -771,6 +816,11 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
       for (int c = 0; c < 3; ++c) {
         if (MTR_WARP_ABLATE & 1) {  // (timing ablation: no tap loads)
           t.raw[2 * c] = t.raw[2 * c + 1] = (unsigned long long)(unsigned)base * 0x0101010101ull + c;
+          continue;
+        }
+        if ((MTR_WARP_ABLATE & 16) && c > 0) {  // (timing ablation: ONE gather pair serves the three channels)
+          t.raw[2 * c] = t.raw[0] + c;
+          t.raw[2 * c + 1] = t.raw[1] + c;
           continue;
         }
         t.raw[2 * c] = __builtin_bit_cast(unsigned long long,
@@ -793,7 +843,21 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
 
   auto finish = [&](const TapSet& t, float* acc) {
     struct F2 { float a, b; };
-    if (!bytes0) {
+    if constexpr (IL) {
+      const unsigned at = (unsigned)t.off & 3u, ab = (unsigned)(t.off + row_bytes) & 3u;
+      // bytes 0..3 / 4..7 of the window that starts at the top-left tap: R0 G0 B0 R1 / G1 B1 . .
+      const unsigned t_lo = __builtin_amdgcn_alignbyte((unsigned)(t.raw[0] >> 32), (unsigned)t.raw[0], at);
+      const unsigned t_hi = __builtin_amdgcn_alignbyte((unsigned)t.raw[1], (unsigned)(t.raw[0] >> 32), at);
+      const unsigned b_lo = __builtin_amdgcn_alignbyte((unsigned)(t.raw[2] >> 32), (unsigned)t.raw[2], ab);
+      const unsigned b_hi = __builtin_amdgcn_alignbyte((unsigned)t.raw[3], (unsigned)(t.raw[2] >> 32), ab);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float ta = lut[(t_lo >> (8 * c)) & 0xff], ba = lut[(b_lo >> (8 * c)) & 0xff];
+        const float tb = lut[c == 0 ? t_lo >> 24 : (t_hi >> (8 * (c - 1))) & 0xff];
+        const float bb = lut[c == 0 ? b_lo >> 24 : (b_hi >> (8 * (c - 1))) & 0xff];
+        acc[c] += fmaf(bb, t.w11, fmaf(ba, t.w10, fmaf(tb, t.w01, ta * t.w00)));
+      }
+    } else if (!bytes0) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const F2 tp = __builtin_bit_cast(F2, t.raw[2 * c]), bt = __builtin_bit_cast(F2, t.raw[2 * c + 1]);
@@ -870,13 +934,20 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
       }
     }
   }
+  };  // run
+  if constexpr (HWC) {
+    if (bytes0) run(std::true_type{});
+    else run(std::false_type{});
+  } else {
+    run(std::false_type{});
+  }
 }
 
 #ifndef MTR_WARP_ROWS
 #define MTR_WARP_ROWS 4  // rows per wave of warp_rows_kernel; 0 = warp_crops_kernel everywhere
 #endif
 
-template <typename OutT, int AA, bool L0U8>
+template <typename OutT, int AA, int L0>
 static int launch_warp(const void* l0, const float* l1, const float* l2, const float* lut,
                        const LevelDims& dims, unsigned u8_bytes, const float* wp, int n_crops,
                        int res, int nhwc, void* out, hipStream_t stream) {
@@ -891,7 +962,7 @@ static int launch_warp(const void* l0, const float* l1, const float* l2, const f
     const long long nblocks = (long long)((n_crops + 7) / 8) * 8 * tiles;
     if (nblocks > 0x7fffffffLL) return MTR_E_SHAPE;
     MTR_CLEAR_STALE();
-    hipLaunchKernelGGL((warp_rows_kernel<OutT, AA, ROWS ? ROWS : 1, L0U8>), dim3((unsigned)nblocks),
+    hipLaunchKernelGGL((warp_rows_kernel<OutT, AA, ROWS ? ROWS : 1, L0>), dim3((unsigned)nblocks),
                        dim3(256), 0, stream, l0, l1, l2, lut, dims, u8_bytes, wp, n_crops, res, nhwc,
                        (OutT*)out);
     MTR_CHECK_LAUNCH();
@@ -902,28 +973,29 @@ static int launch_warp(const void* l0, const float* l1, const float* l2, const f
   const long long blocks = (long long)((n_crops + 7) / 8) * 8 * per_crop;
   if (blocks > 0x7fffffffLL) return MTR_E_SHAPE;
   MTR_CLEAR_STALE();
-  hipLaunchKernelGGL((warp_crops_kernel<OutT, AA, PX, L0U8>), dim3((unsigned)blocks), dim3(256), 0,
+  hipLaunchKernelGGL((warp_crops_kernel<OutT, AA, PX, L0>), dim3((unsigned)blocks), dim3(256), 0,
                      stream, l0, l1, l2, lut, dims, u8_bytes, wp, n_crops, res, nhwc, (OutT*)out);
   MTR_CHECK_LAUNCH();
   return MTR_OK;
 }
 
-template <typename OutT, bool L0U8>
+template <typename OutT, int L0>
 static int dispatch_warp_aa(const void* l0, const float* l1, const float* l2, const float* lut,
                             const LevelDims& dims, unsigned u8_bytes, const float* wp, int n_crops,
                             int res, int aa, int nhwc, void* out, hipStream_t stream) {
   switch (aa) {
-    case 1: return launch_warp<OutT, 1, L0U8>(l0, l1, l2, lut, dims, u8_bytes, wp, n_crops, res, nhwc, out, stream);
-    case 2: return launch_warp<OutT, 2, L0U8>(l0, l1, l2, lut, dims, u8_bytes, wp, n_crops, res, nhwc, out, stream);
-    case 4: return launch_warp<OutT, 4, L0U8>(l0, l1, l2, lut, dims, u8_bytes, wp, n_crops, res, nhwc, out, stream);
+    case 1: return launch_warp<OutT, 1, L0>(l0, l1, l2, lut, dims, u8_bytes, wp, n_crops, res, nhwc, out, stream);
+    case 2: return launch_warp<OutT, 2, L0>(l0, l1, l2, lut, dims, u8_bytes, wp, n_crops, res, nhwc, out, stream);
+    case 4: return launch_warp<OutT, 4, L0>(l0, l1, l2, lut, dims, u8_bytes, wp, n_crops, res, nhwc, out, stream);
     default: return MTR_E_SHAPE;  // the reference needs torchvision for aa > 4 (:312-315)
   }
 }
 
-template <bool L0U8>
+template <int L0>
 static int warp_entry(const void* level0, const float* lut, const float* level1, const float* level2,
                       int N, int Hi, int Wi, const float* warp_params, int n_crops, int res,
                       int antialias, int out_dtype, int out_layout, void* out, hipStream_t s) {
+  constexpr bool L0U8 = L0 != 0;
   if (N <= 0 || Hi <= 0 || Wi <= 0 || n_crops < 0 || res <= 0) return MTR_E_SHAPE;
   // a pyramid level of a tiny image may be empty: its pointer may then be NULL
   const bool l1_empty = (Hi / 2) * (Wi / 2) == 0, l2_empty = (Hi / 4) * (Wi / 4) == 0;
@@ -956,13 +1028,13 @@ static int warp_entry(const void* level0, const float* lut, const float* level1,
   const int nhwc = out_layout == MTR_NHWC;
   switch (out_dtype) {
     case MTR_F32:
-      return dispatch_warp_aa<float, L0U8>(level0, level1, level2, lut, dims, u8_bytes, warp_params,
+      return dispatch_warp_aa<float, L0>(level0, level1, level2, lut, dims, u8_bytes, warp_params,
                                            n_crops, res, antialias, nhwc, out, s);
     case MTR_F16:
-      return dispatch_warp_aa<__half, L0U8>(level0, level1, level2, lut, dims, u8_bytes, warp_params,
+      return dispatch_warp_aa<__half, L0>(level0, level1, level2, lut, dims, u8_bytes, warp_params,
                                             n_crops, res, antialias, nhwc, out, s);
     case MTR_BF16:
-      return dispatch_warp_aa<__hip_bfloat16, L0U8>(level0, level1, level2, lut, dims, u8_bytes,
+      return dispatch_warp_aa<__hip_bfloat16, L0>(level0, level1, level2, lut, dims, u8_bytes,
                                                     warp_params, n_crops, res, antialias, nhwc, out, s);
     default: return MTR_E_DTYPE;
   }
@@ -1029,8 +1101,8 @@ static bool pyramid_wide_ok(const void* src, const void* l1, const void* l2, int
   return Wi % 8 == 0 && Hi % 8 == 0 && ((uintptr_t)src % 8) == 0 && ((uintptr_t)l1 % 16) == 0 &&
          ((uintptr_t)l2 % 8) == 0;
 }
-static int pyramid_wide_grid(int N, int Hi, int Wi) {
-  const long long tiles = (long long)N * 3 * (Hi / 8) * (Wi / 8);
+static int pyramid_wide_grid(long long planes, int Hi, int Wi) {
+  const long long tiles = planes * (Hi / 8) * (Wi / 8);
   long long grid = (tiles + 255) / 256;
   if (grid > 256 * 5) grid = 256 * 5;  // persistent: 5 workgroups per CU (32 KiB LUT each)
   return (int)grid;
@@ -1059,8 +1131,9 @@ extern "C" int mtr_build_pyramid(const uint8_t* images_u8, int N, int Hi, int Wi
   return MTR_OK;
 }
 
-extern "C" int mtr_build_pyramid_u8(const uint8_t* images_u8, int N, int Hi, int Wi, float* lut,
-                                    float* level1, float* level2, mtr_stream_t stream) {
+template <bool HWC>
+static int build_pyramid_u8_entry(const uint8_t* images_u8, int N, int Hi, int Wi, float* lut, float* level1,
+                                  float* level2, hipStream_t stream) {
   if (N < 0 || Hi <= 0 || Wi <= 0) return MTR_E_SHAPE;
   if (!images_u8 || !lut || (!level1 && (Hi / 2) * (Wi / 2) > 0) || (!level2 && (Hi / 4) * (Wi / 4) > 0))
     return MTR_E_NULL;
@@ -1068,18 +1141,30 @@ extern "C" int mtr_build_pyramid_u8(const uint8_t* images_u8, int N, int Hi, int
   if ((uintptr_t)images_u8 % 4) return MTR_E_ALIGN;
   MTR_CLEAR_STALE();
   if (pyramid_wide_ok(images_u8, level1, level2, Hi, Wi)) {
-    hipLaunchKernelGGL(mtr::build_pyramid_u8_wide_kernel, dim3(pyramid_wide_grid(N, Hi, Wi)), dim3(256),
-                       0, (hipStream_t)stream, images_u8, N * 3, Hi, Wi, level1, level2, lut, mtr::gamma_lut_host(),
-                       mtr::make_fastdiv((unsigned)(Wi / 8)), mtr::make_fastdiv((unsigned)(Hi / 8)));
+    // (interleaved frames: a third of the threads, three channels each)
+    hipLaunchKernelGGL(mtr::build_pyramid_u8_wide_kernel<HWC>, dim3(pyramid_wide_grid(HWC ? N : 3LL * N, Hi, Wi)),
+                       dim3(256), 0, stream, images_u8, HWC ? N : N * 3, Hi, Wi, level1, level2, lut,
+                       mtr::gamma_lut_host(), mtr::make_fastdiv((unsigned)(Wi / 8)),
+                       mtr::make_fastdiv((unsigned)(Hi / 8)));
     MTR_CHECK_LAUNCH();
     return MTR_OK;
   }
-  hipLaunchKernelGGL((mtr::build_pyramid_kernel<true, false>), dim3(pyramid_grid(N, Hi, Wi)),
-                     dim3(256), 0, (hipStream_t)stream, (const void*)images_u8, N * 3, Hi, Wi,
+  hipLaunchKernelGGL((mtr::build_pyramid_kernel<true, false, HWC>), dim3(pyramid_grid(N, Hi, Wi)),
+                     dim3(256), 0, stream, (const void*)images_u8, N * 3, Hi, Wi,
                      (float*)nullptr, level1, level2, lut, mtr::gamma_lut_host(), mtr::make_fastdiv((unsigned)((Wi + 3) / 4)),
                      mtr::make_fastdiv((unsigned)((Hi + 3) / 4)));
   MTR_CHECK_LAUNCH();
   return MTR_OK;
+}
+
+extern "C" int mtr_build_pyramid_u8(const uint8_t* images_u8, int N, int Hi, int Wi, float* lut,
+                                    float* level1, float* level2, mtr_stream_t stream) {
+  return build_pyramid_u8_entry<false>(images_u8, N, Hi, Wi, lut, level1, level2, (hipStream_t)stream);
+}
+
+extern "C" int mtr_build_pyramid_u8_hwc(const uint8_t* images_u8, int N, int Hi, int Wi, float* lut,
+                                        float* level1, float* level2, mtr_stream_t stream) {
+  return build_pyramid_u8_entry<true>(images_u8, N, Hi, Wi, lut, level1, level2, (hipStream_t)stream);
 }
 
 extern "C" int mtr_pyramid_from_level0(const float* level0, int N, int Hi, int Wi, float* level1,
@@ -1122,7 +1207,7 @@ extern "C" int mtr_warp_crops(const float* level0, const float* level1, const fl
                               int Hi, int Wi, const float* warp_params, int n_crops, int res,
                               int antialias, int out_dtype, int out_layout, void* out,
                               mtr_stream_t stream) {
-  return mtr::warp_entry<false>(level0, nullptr, level1, level2, N, Hi, Wi, warp_params, n_crops, res,
+  return mtr::warp_entry<0>(level0, nullptr, level1, level2, N, Hi, Wi, warp_params, n_crops, res,
                                 antialias, out_dtype, out_layout, out, (hipStream_t)stream);
 }
 
@@ -1130,8 +1215,16 @@ extern "C" int mtr_warp_crops_u8(const uint8_t* level0_u8, const float* lut, con
                                  const float* level2, int N, int Hi, int Wi, const float* warp_params,
                                  int n_crops, int res, int antialias, int out_dtype, int out_layout,
                                  void* out, mtr_stream_t stream) {
-  return mtr::warp_entry<true>(level0_u8, lut, level1, level2, N, Hi, Wi, warp_params, n_crops, res,
-                               antialias, out_dtype, out_layout, out, (hipStream_t)stream);
+  return mtr::warp_entry<1>(level0_u8, lut, level1, level2, N, Hi, Wi, warp_params, n_crops, res,
+                            antialias, out_dtype, out_layout, out, (hipStream_t)stream);
+}
+
+extern "C" int mtr_warp_crops_u8_hwc(const uint8_t* level0_u8, const float* lut, const float* level1,
+                                     const float* level2, int N, int Hi, int Wi, const float* warp_params,
+                                     int n_crops, int res, int antialias, int out_dtype, int out_layout,
+                                     void* out, mtr_stream_t stream) {
+  return mtr::warp_entry<2>(level0_u8, lut, level1, level2, N, Hi, Wi, warp_params, n_crops, res,
+                            antialias, out_dtype, out_layout, out, (hipStream_t)stream);
 }
 
 extern "C" size_t mtr_crops_shrink_workspace_bytes(int n_crops, int res, int antialias) {

@@ -10,7 +10,8 @@ on exactly the same shapes, so a replay returns the eager path's bits.
 
 * ``FrameSet`` -- static uint8 frames + their pyramid for one frame size (H, W), with room for the
   largest number of frames seen: the fixed addresses a graph's sampler reads (a call with fewer frames
-  uses the head of the buffers).  A call copies its frames in (host frames: the H2D copy lands there
+  uses the head of the buffers); frames with interleaved channels (channels_last) get a set of their own
+  and stay interleaved.  A call copies its frames in (host frames: the H2D copy lands there
   directly) and rebuilds the pyramid with one eager launch.
 * ``BatchGraph`` -- one internal batch of n boxes captured against a FrameSet; static copies of the six
   per-box parameter arrays, one ``hipGraphLaunch`` per replay, the result cloned out.
@@ -33,14 +34,16 @@ from metrabs_amd.pipeline import CAPTURE_ERROR_MODE
 
 
 class FrameSet:
-    def __init__(self, n, h, w, device):
-        self.key = (h, w, str(device))
+    def __init__(self, n, h, w, device, hwc=False):
+        self.key = (h, w, str(device), bool(hwc))
         self.capacity = n
+        self.hwc = bool(hwc)   # frames kept (and sampled) with interleaved channels, as the caller's are
         # (buffers that outlive the call and are written in place by later ones: made OUTSIDE inference mode,
         #  or a first call under torch.inference_mode() would leave inference tensors that a later call under
         #  plain no_grad may not update)
         with torch.inference_mode(False):
-            self.images = torch.empty(n, 3, h, w, dtype=torch.uint8, device=device)
+            self.images = (torch.empty(n, h, w, 3, dtype=torch.uint8, device=device).permute(0, 3, 1, 2) if hwc
+                           else torch.empty(n, 3, h, w, dtype=torch.uint8, device=device))
             _, self._l1, self._l2 = kernels._alloc_levels(n, h, w, device, with_level0=False)
             self._lut = torch.empty(256, device=device, dtype=torch.float32)
         self._views = {}
@@ -53,7 +56,7 @@ class FrameSet:
         are frame-major)."""
         if n not in self._views:
             self._views[n] = kernels.Pyramid([None, self._l1[:n], self._l2[:n]], images_u8=self.images[:n],
-                                             lut=self._lut)
+                                             lut=self._lut, hwc=self.hwc)
         return self._views[n]
 
     def load(self, images):
@@ -227,7 +230,8 @@ class GraphCache:
         est = self.est
         dev = est._device()
         n, _, h, w = images.shape
-        skey = (h, w, str(dev))
+        hwc = kernels.frames_are_interleaved(images)
+        skey = (h, w, str(dev), hwc)
         fkey = (n,) + skey
         jt = post['joint_transform']
         base = (fkey, len(tta['gammas']), int(antialias_factor), est.crop_dtype, bool(est.crop_channels_last),
@@ -264,15 +268,15 @@ class GraphCache:
         if not any(use):
             self.stats['eager_batches'] += len(use)
             return None
-        frames = self.frame_set(n, h, w, dev)
+        frames = self.frame_set(n, h, w, dev, hwc=hwc)
         return _CallPlan(self, frames, keys, use, tta, antialias_factor, post)
 
-    def frame_set(self, n, h, w, dev, optional=False):
+    def frame_set(self, n, h, w, dev, optional=False, hwc=False):
         """The static frame + pyramid buffers for n frames of this size (one set per frame size, grown to the
         largest n seen; LRU over max_frame_sets; the graphs captured against a replaced set go with it).
         optional=True (the pinned-frame staging of an eager call): None instead of a replacement the
-        eviction interval does not allow yet."""
-        skey = (h, w, str(dev))
+        eviction interval does not allow yet.  hwc: frames with interleaved channels (a set of its own)."""
+        skey = (h, w, str(dev), bool(hwc))
         frames = self.frame_sets.get(skey)
         if frames is not None and frames.capacity >= n:
             self.frame_sets.move_to_end(skey)
@@ -283,7 +287,7 @@ class GraphCache:
             self._last_eviction_at = self._batches
         if frames is not None:       # more frames than the set has room for: a larger one takes its place
             self._drop_frame_set(skey)
-        frames = FrameSet(n, h, w, dev)
+        frames = FrameSet(n, h, w, dev, hwc=hwc)
         self.frame_sets[skey] = frames
         while len(self.frame_sets) > self.max_frame_sets:
             self._drop_frame_set(next(iter(self.frame_sets)))

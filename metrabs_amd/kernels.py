@@ -105,15 +105,26 @@ class Pyramid:
       * ``levels[0]`` f32 [N,3,H,W] (materialised -- what warping.warp_images_with_pyramid builds);
       * ``images_u8`` + ``lut``: level 0 stays the uint8 frame, decoded through the 256-entry gamma
         LUT inside the sampler (``levels[0]`` is None).  Same numbers, 64 % fewer pyramid bytes.
-    ``levels[1]``, ``levels[2]`` are always f32."""
+    ``levels[1]``, ``levels[2]`` are always f32 planes.  ``hwc``: ``images_u8`` is [N,3,H,W] over
+    interleaved memory ([N,H,W,3]: torch channels_last, what decoders / numpy frames are) and is sampled
+    as it lies -- the sampler then needs two gathers per sample instead of six."""
 
-    def __init__(self, levels, images_u8=None, lut=None):
+    def __init__(self, levels, images_u8=None, lut=None, hwc=False):
         self.levels = levels
         self.images_u8 = images_u8
         self.lut = lut
+        self.hwc = bool(hwc)
         ref = images_u8 if levels[0] is None else levels[0]
         self.n, _, self.h, self.w = ref.shape
         self.device = ref.device
+
+
+def frames_are_interleaved(images):
+    """[N,3,H,W] frames whose memory is [N,H,W,3] (``x.permute(0, 3, 1, 2)`` of an HWC batch,
+    ``memory_format=torch.channels_last``)?  Plain contiguous frames -- also the shapes where the two
+    orders coincide -- are not."""
+    return (images.ndim == 4 and images.shape[1] == 3 and not images.is_contiguous()
+            and images.permute(0, 2, 3, 1).is_contiguous())
 
 
 def _alloc_levels(n, h, w, device, with_level0=True):
@@ -131,15 +142,19 @@ MAX_U8_FRAME_BYTES = (1 << 31) - 8
 def build_pyramid(images_u8, materialize_level0=False, out=None):
     """uint8 [N,3,H,W] -> Pyramid: fused gamma decode (u8/255)**2.2 + two 2x2 box levels.  By
     default level 0 is NOT written as f32 (the sampler reads the uint8 frame through the LUT).
+    Frames over interleaved memory (frames_are_interleaved) are used as they lie.
     out: a Pyramid made by this function over the SAME frame tensor: its levels and LUT are rewritten
     in place (fixed addresses for captured HIP graphs)."""
     require_cuda(images_u8)
     if images_u8.dtype != torch.uint8 or images_u8.ndim != 4 or images_u8.shape[1] != 3:
         raise ValueError('images must be uint8 [N,3,H,W]')
-    images_u8 = images_u8.contiguous()
+    hwc = frames_are_interleaved(images_u8) and not materialize_level0
+    if not hwc:
+        images_u8 = images_u8.contiguous()
     n, _, h, w = images_u8.shape
     lib = _lib.load()
     stream = current_stream_ptr(images_u8.device)
+    build_u8 = lib.mtr_build_pyramid_u8_hwc if hwc else lib.mtr_build_pyramid_u8
     if materialize_level0:
         l0, l1, l2 = _alloc_levels(n, h, w, images_u8.device)
         check(lib.mtr_build_pyramid(_ptr(images_u8), n, h, w, _ptr(l0), _ptr(l1), _ptr(l2), stream),
@@ -147,16 +162,15 @@ def build_pyramid(images_u8, materialize_level0=False, out=None):
         return Pyramid([l0, l1, l2])
     if out is not None:
         if out.images_u8 is None or out.images_u8.data_ptr() != images_u8.data_ptr() or \
-                (out.n, out.h, out.w) != (n, h, w):
+                (out.n, out.h, out.w) != (n, h, w) or out.hwc != hwc:
             raise ValueError('build_pyramid(out=): the pyramid was not built over this frame tensor')
-        check(lib.mtr_build_pyramid_u8(_ptr(images_u8), n, h, w, _ptr(out.lut), _ptr(out.levels[1]),
-                                       _ptr(out.levels[2]), stream), 'mtr_build_pyramid_u8')
+        check(build_u8(_ptr(images_u8), n, h, w, _ptr(out.lut), _ptr(out.levels[1]),
+                       _ptr(out.levels[2]), stream), 'mtr_build_pyramid_u8')
         return out
     _, l1, l2 = _alloc_levels(n, h, w, images_u8.device, with_level0=False)
     lut = torch.empty(256, device=images_u8.device, dtype=torch.float32)
-    check(lib.mtr_build_pyramid_u8(_ptr(images_u8), n, h, w, _ptr(lut), _ptr(l1), _ptr(l2), stream),
-          'mtr_build_pyramid_u8')
-    return Pyramid([None, l1, l2], images_u8=images_u8, lut=lut)
+    check(build_u8(_ptr(images_u8), n, h, w, _ptr(lut), _ptr(l1), _ptr(l2), stream), 'mtr_build_pyramid_u8')
+    return Pyramid([None, l1, l2], images_u8=images_u8, lut=lut, hwc=hwc)
 
 
 def pyramid_from_level0(images_linear):
@@ -218,8 +232,10 @@ def warp_crops(pyramid, warp_params, res, antialias=1, out_dtype=torch.float32,
             dtype_code(out.dtype), _lib.MTR_NHWC if channels_last else _lib.MTR_NCHW, _ptr(out),
             current_stream_ptr(dev))
     if l0 is None:
-        check(_lib.load().mtr_warp_crops_u8(_ptr(pyramid.images_u8), _ptr(pyramid.lut), _ptr(l1),
-                                            _ptr(l2), *tail), 'mtr_warp_crops_u8')
+        lib = _lib.load()
+        warp_u8 = lib.mtr_warp_crops_u8_hwc if pyramid.hwc else lib.mtr_warp_crops_u8
+        check(warp_u8(_ptr(pyramid.images_u8), _ptr(pyramid.lut), _ptr(l1), _ptr(l2), *tail),
+              'mtr_warp_crops_u8')
     else:
         check(_lib.load().mtr_warp_crops(_ptr(l0), _ptr(l1), _ptr(l2), *tail), 'mtr_warp_crops')
     return out

@@ -468,7 +468,8 @@ class Pose3dEstimator(torch.nn.Module):
                 and not per_batch_pyramids):
             # pinned host frames: the PCIe copy runs on a copy stream under the previous call's compute
             # (None: no frame set free for this frame size right now -- the plain blocking upload below)
-            staging = self.graphs.frame_set(len(images), images.shape[2], images.shape[3], dev, optional=True)
+            staging = self.graphs.frame_set(len(images), images.shape[2], images.shape[3], dev, optional=True,
+                                            hwc=kernels.frames_are_interleaved(images))
         if plan is not None:
             pyramid = plan.frames.load(images)   # static frame + pyramid buffers the graphs read
         elif staging is not None:

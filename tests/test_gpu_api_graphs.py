@@ -73,6 +73,34 @@ def test_graphed_api_equals_eager_bit_for_bit(name, hip_lib):
     assert torch.equal(a3, b3) and torch.equal(a2, b2)
 
 
+def test_interleaved_frames_through_the_api(hip_lib):
+    """Frames handed over as [N,3,H,W] views of HWC memory (``torch.from_numpy(frames_hwc).permute(0, 3, 1, 2)``,
+    channels_last) are sampled in place -- eager, captured, from the device, from pageable and from pinned host
+    memory -- with the planar frames' bits, and keep a frame set and graphs of their own."""
+    case = cases.e2e_case('aug5')
+    eager, graphed = build_estimator(case, 'auto'), build_estimator(case, 'auto')
+    eager.graph_batches, graphed.graph_batches = False, True
+    per_image = [3, 0, 4, 2]
+    for seed in (31, 32, 33):
+        images, boxes, K = _inputs(case, seed, 4, per_image)
+        hwc = images.permute(0, 2, 3, 1).contiguous()          # what a decoder hands over
+        inter = hwc.permute(0, 3, 1, 2)                        # the [N,3,H,W] view of it
+        want3, want2 = _call(eager, images.cuda(), boxes, K, case)
+        for est in (eager, graphed):
+            for frames in (inter.cuda(), inter, torch.from_numpy(hwc.numpy()).permute(0, 3, 1, 2),
+                           inter.pin_memory() if seed == 33 else inter):
+                got3, got2 = _call(est, frames, boxes, K, case)
+                assert torch.equal(want3, got3) and torch.equal(want2, got2), (seed, float((want3 - got3).abs().max()))
+    assert all(fs.hwc and not fs.images.is_contiguous() for fs in graphed.graphs.frame_sets.values())
+    st = graphed.graphs.stats
+    assert st['captures'] >= 1 and st['replays'] >= 4 * st['captures'], st
+    # the planar layout of the same frame size: another frame set, other graphs, the same bits
+    images, boxes, K = _inputs(case, 34, 4, per_image)
+    a3, _ = _call(graphed, images.cuda(), boxes, K, case)
+    b3, _ = _call(graphed, images.cuda().contiguous(memory_format=torch.channels_last), boxes, K, case)
+    assert torch.equal(a3, b3) and len(graphed.graphs.frame_sets) == 2
+
+
 def test_auto_mode_captures_on_the_second_occurrence_and_results_do_not_alias(hip_lib):
     case = cases.e2e_case('aug5')
     est = build_estimator(case, 'auto')

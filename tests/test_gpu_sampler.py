@@ -280,6 +280,65 @@ def test_u8_level0_path_is_bit_identical(aa, dtype, hip_lib):
         assert torch.equal(slow, fast), (h, w, float((slow.float() - fast.float()).abs().max()))
 
 
+@pytest.mark.parametrize('aa,dtype', [(1, torch.float32), (2, torch.float32), (1, torch.float16), (4, torch.float32),
+                                      (1, torch.bfloat16)])
+def test_interleaved_frames_are_sampled_in_place_with_the_planar_bits(aa, dtype, hip_lib):
+    """Frames over [N,H,W,3] memory (torch channels_last; what decoders and numpy hand over -- the reference
+    takes them through their strides, multiperson_model.py:196) are NOT copied to planes: the pyramid kernel
+    and the sampler read them as they lie (mtr_build_pyramid_u8_hwc / mtr_warp_crops_u8_hwc).  Same levels 1 / 2
+    and the same crop bits as the planar path -- all three levels, distortion, borders, the corner texels of
+    the last frame, W % 4 != 0 (top and bottom windows differently aligned), the wide pyramid kernel
+    (sizes % 8 == 0) and the byte-wise one, degenerate levels (the per-tap path), both crop layouts."""
+    from metrabs_amd import kernels
+    for (h, w, seed) in [(120, 160, 1), (97, 131, 2), (3, 5, 3), (64, 66, 4), (1, 7, 5)]:
+        planar = cases.synth_images(2, h, w, 60 + seed).cuda()
+        inter = planar.contiguous(memory_format=torch.channels_last)
+        assert kernels.frames_are_interleaved(inter) and not kernels.frames_are_interleaved(planar)
+        n, res = 12, 32
+        g = cases.gen(70 + seed)
+        boxes = torch.stack([torch.rand(n, generator=g) * w * 0.7 - 5, torch.rand(n, generator=g) * h * 0.6 - 5,
+                             (0.1 + torch.rand(n, generator=g)) * w, (0.2 + torch.rand(n, generator=g)) * h], 1)
+        boxes[-1] = torch.tensor([w * 0.5, h * 0.5, w * 0.6, h * 0.6])   # over the bottom-right corner
+        K = cases.intrinsics_for(h, w, 55.0, seed)[None].repeat(n, 1, 1)
+        d12 = torch.zeros(n, 12)
+        d12[::2, :5] = torch.tensor(cases.DISTORTION_5)
+        tta = cpu_ref.tta_params(3)
+        up = torch.tensor([[0.0, -1.0, 0.0]]).repeat(n, 1)
+        ids = torch.arange(n) % 2   # (the last box reads the LAST frame: the end of the buffer descriptor)
+        _, _, wp = kernels.crop_geometry(boxes.cuda(), K.cuda(), d12.cuda(), up.cuda(), ids.cuda(),
+                                         tta['rotflipmat'].cuda(), tta['scales'].cuda(),
+                                         tta['gammas'].cuda(), res, aa)
+        p_planar, p_inter = kernels.build_pyramid(planar), kernels.build_pyramid(inter)
+        assert p_inter.hwc and not p_planar.hwc and p_inter.images_u8.data_ptr() == inter.data_ptr()
+        for a, b in zip(p_planar.levels[1:], p_inter.levels[1:]):
+            assert torch.equal(a, b), (h, w)
+        assert torch.equal(p_planar.lut, p_inter.lut)
+        for cl in (False, True):
+            want = kernels.warp_crops(p_planar, wp, res, aa, out_dtype=dtype, channels_last=cl)
+            got = kernels.warp_crops(p_inter, wp, res, aa, out_dtype=dtype, channels_last=cl)
+            assert torch.equal(want, got), (h, w, cl, float((want.float() - got.float()).abs().max()))
+        if min(h, w) >= 8:
+            assert (wp[:, 31] == 0).any(), 'fixture must contain level-0 crops'
+
+
+def test_interleaved_full_size_frames(hip_lib):
+    """configs[1]'s frames (8 x 1080p), 64 crops of 256 px: the interleaved path gives the planar path's bits."""
+    from metrabs_amd import kernels
+    n_img, h, w, res = 8, 1080, 1920, 256
+    planar = cases.synth_images(n_img, h, w, 21).cuda()
+    inter = planar.contiguous(memory_format=torch.channels_last)
+    boxes = torch.cat(cases.synth_boxes(n_img, h, w, 8, 22, min_boxes=8))
+    K = cases.intrinsics_for(h, w)[None].repeat(64, 1, 1)
+    ids = torch.repeat_interleave(torch.arange(n_img), 8)
+    tta = cpu_ref.tta_params(1)
+    up = torch.tensor([[0.0, -1.0, 0.0]]).repeat(64, 1)
+    _, _, wp = kernels.crop_geometry(boxes.cuda(), K.cuda(), torch.zeros(64, 12).cuda(), up.cuda(), ids.cuda(),
+                                     tta['rotflipmat'].cuda(), tta['scales'].cuda(), tta['gammas'].cuda(), res, 1)
+    p_planar, p_inter = kernels.build_pyramid(planar), kernels.build_pyramid(inter)
+    assert torch.equal(p_planar.levels[1], p_inter.levels[1]) and torch.equal(p_planar.levels[2], p_inter.levels[2])
+    assert torch.equal(kernels.warp_crops(p_planar, wp, res), kernels.warp_crops(p_inter, wp, res))
+
+
 def test_sampling_arithmetic_is_no_noisier_than_the_references(hip_lib):
     """"the sampler is the HIP side that is worse than the reference" came from a yardstick
     that evaluates the REFERENCE's matrices in double (cpu_ref.get_crops(eval_dtype=float64): its f32

@@ -10,9 +10,10 @@ from metrabs_amd import graph_cache
 
 
 class FakeFrames:
-    def __init__(self, n, h, w, device):
-        self.key = (h, w, str(device))
+    def __init__(self, n, h, w, device, hwc=False):
+        self.key = (h, w, str(device), hwc)
         self.capacity = n
+        self.hwc = hwc
 
 
 class FakeGraph:
@@ -46,9 +47,11 @@ TTA = dict(gammas=torch.ones(1))
 POST = dict(joint_transform=None, average_aug=True, skeleton=torch.arange(17))
 
 
-def call(cache, n_boxes, n_frames=2, hw=8):
+def call(cache, n_boxes, n_frames=2, hw=8, interleaved=False):
     """One call with a single internal batch of n_boxes -> 'replay' | 'capture' | 'eager'."""
     images = torch.zeros(n_frames, 3, hw, hw, dtype=torch.uint8)
+    if interleaved:
+        images = images.contiguous(memory_format=torch.channels_last)
     before = dict(cache.stats)
     plan = cache.plan_call(images, [(0, n_boxes)], TTA, 1, POST)
     if plan is None:
@@ -89,6 +92,17 @@ def test_one_frame_set_per_frame_size_grows_to_the_largest_frame_count(cache):
     fs = next(iter(cache.frame_sets.values()))
     assert fs.capacity == 5 and cache.stats['evictions'] == 2   # ... and the graphs over the old one are gone
     assert all(g.frames is fs for g in cache.graphs.values())
+
+
+def test_interleaved_frames_get_a_frame_set_and_graphs_of_their_own(cache):
+    """Frames over [N,H,W,3] memory stay interleaved in their frame set (the sampler reads them as they
+    lie): the layout is part of the frame-set key and of every graph key."""
+    cache.est.graph_batches = True
+    cache.max_frame_sets = 2
+    assert call(cache, 4) == 'capture' and call(cache, 4, interleaved=True) == 'capture'
+    assert len(cache.frame_sets) == 2 and sorted(fs.hwc for fs in cache.frame_sets.values()) == [False, True]
+    assert call(cache, 4) == 'replay' and call(cache, 4, interleaved=True) == 'replay'
+    assert cache.stats['evictions'] == 0
 
 
 def test_cycling_over_more_frame_sizes_than_sets_does_not_recapture_every_call(cache):

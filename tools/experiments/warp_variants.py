@@ -11,14 +11,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, 'tools', 'experiments', '_build')
-VARIANTS = {'base': []}
-for rows in (4, 8, 16):
-    for pd in (1, 2, 3):
-        VARIANTS[f'rows{rows}_pd{pd}'] = [f'-DMTR_WARP_ROWS={rows}', f'-DMTR_WARP_PREFETCH={pd}']
-VARIANTS['rcp2'] = ['-DMTR_WARP_RCP=2']
-VARIANTS['rcp0'] = ['-DMTR_WARP_RCP=0']
-VARIANTS['rows8_pd2_rcp2'] = ['-DMTR_WARP_ROWS=8', '-DMTR_WARP_PREFETCH=2', '-DMTR_WARP_RCP=2']
-VARIANTS['lx64_rows8_pd2'] = ['-DMTR_WARP_LX=64', '-DMTR_WARP_ROWS=8', '-DMTR_WARP_PREFETCH=2']
+VARIANTS = {'base': [], 'late_lut': ['-DMTR_WARP_LATE_LUT=1'], 'late_lut_nothing': ['-DMTR_WARP_LATE_LUT=1', '-DMTR_WARP_ABLATE=15'],
+            'nothing': ['-DMTR_WARP_ABLATE=15']}
 
 
 def build():
@@ -44,7 +38,7 @@ def build():
     print('built', len(VARIANTS), 'variants')
 
 
-def run_one(name):
+def run_one(name, interleaved=False):
     sys.path.insert(0, ROOT)
     import torch
     from metrabs_amd import _lib
@@ -52,8 +46,10 @@ def run_one(name):
     from metrabs_amd import kernels
     from metrabs_amd.multiperson.multiperson_model import tta_parameters
     g = torch.Generator().manual_seed(0)
-    pyrs = [kernels.build_pyramid(torch.randint(0, 256, (8, 3, 1080, 1920), dtype=torch.uint8, generator=g).cuda())
-            for _ in range(4)]
+    fmt = torch.channels_last if interleaved else torch.contiguous_format
+    pyrs = [kernels.build_pyramid(torch.randint(0, 256, (8, 3, 1080, 1920), dtype=torch.uint8, generator=g).cuda()
+                                  .contiguous(memory_format=fmt)) for _ in range(4)]
+    assert all(p.hwc == interleaved for p in pyrs)
     for aug in (1, 5):
         n = 64
         tta = {k: v.cuda() for k, v in tta_parameters(aug).items()}
@@ -88,7 +84,7 @@ def run_one(name):
             graph.replay()
         b.record()
         torch.cuda.synchronize()
-        print(json.dumps({'variant': name, 'crops': n * aug, 'us': round(a.elapsed_time(b) / (reps * 10) * 1e3, 2),
+        print(json.dumps({'variant': name, 'frames': 'interleaved' if interleaved else 'planar', 'crops': n * aug, 'us': round(a.elapsed_time(b) / (reps * 10) * 1e3, 2),
                           'checksum': float(o.double().sum())}), flush=True)
 
 
@@ -97,6 +93,7 @@ if __name__ == '__main__':
         build()
     elif sys.argv[1] == 'run':
         for m in VARIANTS:
-            subprocess.run([sys.executable, __file__, 'one', m])
+            for layout in ('planar', 'interleaved'):
+                subprocess.run([sys.executable, __file__, 'one', m, layout])
     else:
-        run_one(sys.argv[2])
+        run_one(sys.argv[2], len(sys.argv) > 3 and sys.argv[3] == 'interleaved')
