@@ -11,8 +11,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, 'tools', 'experiments', '_build')
-VARIANTS = {'base': [], 'late_lut': ['-DMTR_WARP_LATE_LUT=1'], 'late_lut_nothing': ['-DMTR_WARP_LATE_LUT=1', '-DMTR_WARP_ABLATE=15'],
-            'nothing': ['-DMTR_WARP_ABLATE=15']}
+# (round 5, profiles/r05v_*: ablations of the shipped kernel; the unaligned-load and late-LUT variants measured there
+#  were source edits that were not kept)
+VARIANTS = {'base': [], 'one_gather_pair': ['-DMTR_WARP_ABLATE=16'], 'no_taps': ['-DMTR_WARP_ABLATE=1'],
+            'no_stores': ['-DMTR_WARP_ABLATE=8'], 'arithmetic_only': ['-DMTR_WARP_ABLATE=15']}
 
 
 def build():
