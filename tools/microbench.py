@@ -121,7 +121,13 @@ def bench_warp_pyramid():
         nbytes = 8 * 3 * (1080 * 1920 * (1 + l0b) + 540 * 960 * 4 + 270 * 480 * 4)
         out.append(dict(kernel='pyramid', case=name, us=round(t * 1e6, 1),
                         GBps=round(nbytes / t / 1e9, 1), frac_hbm=round(nbytes / t / HBM, 3)))
+    frames_il = frames.contiguous(memory_format=torch.channels_last)   # [N,H,W,3] memory, sampled in place
+    t = timeit(lambda: kernels.build_pyramid(frames_il))
+    nbytes = 8 * 3 * (1080 * 1920 + 540 * 960 * 4 + 270 * 480 * 4)
+    out.append(dict(kernel='pyramid', case='8 x 1080p, uint8 level 0, interleaved frames', us=round(t * 1e6, 1),
+                    GBps=round(nbytes / t / 1e9, 1), frac_hbm=round(nbytes / t / HBM, 3)))
     pyr = kernels.build_pyramid(frames)
+    pyr_il = kernels.build_pyramid(frames_il)
     for name, n, num_aug, aa, dt in [('64 crops 256px f32', 64, 1, 1, torch.float32),
                                      ('64 crops 256px f16', 64, 1, 1, torch.float16),
                                      ('320 crops (64x5 aug) f16', 64, 5, 1, torch.float16),
@@ -151,6 +157,8 @@ def bench_warp_pyramid():
                         out_GBps=round(nbytes / t / 1e9, 1), crops_per_s=round(n * num_aug / t),
                         algorithmic_MB=round((nbytes + src) / 1e6, 1),
                         frac_hbm_cache_assisted=round((nbytes + src) / t / HBM, 3)))
+        t_il = timeit(lambda: kernels.warp_crops(pyr_il, wp, 256, aa, out=o))
+        out[-1]['interleaved_frames_us'] = round(t_il * 1e6, 1)
     return out
 
 
