@@ -185,6 +185,16 @@ def pyramid_from_level0(images_linear):
     return Pyramid([l0, l1, l2])
 
 
+def pyramid_of_frames(images):
+    """The pyramid of a call's frames [N,3,H,W] on the device.  uint8 frames: the fused LUT path (level 0 stays
+    the frame).  Any other dtype -- the reference only ever says ``(images.float() / 255) ** 2.2``
+    (multiperson_model.py:196), so float frames, also with non-integer values, are legal input -- by that very
+    expression on the device and a materialised f32 level 0."""
+    if images.dtype == torch.uint8:
+        return build_pyramid(images)
+    return pyramid_from_level0((images.float() / 255) ** 2.2)
+
+
 def crop_geometry(boxes, intrinsics, distortion12, camspace_up, image_ids, aug_rotflipmat,
                   aug_scales, aug_gammas, res, antialias):
     """Per (aug, box): new intrinsics [A,n,3,3], R [A,n,3,3] and the warp parameter rows

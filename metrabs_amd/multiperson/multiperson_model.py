@@ -428,7 +428,7 @@ class Pose3dEstimator(torch.nn.Module):
         else:
             ranges_by_rank = [distributed.shard_internal_batches(n_total, boxes_per_batch, r, world)
                               for r in range(world)]
-        if image_id_host is not None and images.numel() >= kernels.MAX_U8_FRAME_BYTES:
+        if image_id_host is not None and images.dtype == torch.uint8 and images.numel() >= kernels.MAX_U8_FRAME_BYTES:
             # the sampler's limit, checked for EVERY rank's ranges before any kernel or collective runs
             # (and before the frames are cut down to this rank's), so that all ranks
             # raise the same error together (one rank raising inside the loop would leave the others
@@ -456,16 +456,19 @@ class Pose3dEstimator(torch.nn.Module):
         # the frames ITS boxes reference (at most boxes_per_batch of them).
         per_batch_pyramids = images.numel() >= kernels.MAX_U8_FRAME_BYTES
         dev = boxes_flat.device
+        # frames of another dtype than uint8 (legal for the reference: `images.float() / 255`, :196) take the
+        # materialised f32 level 0 and stay outside the static uint8 frame sets / graphs
+        u8_frames = images.dtype == torch.uint8
         # HIP graphs (graph_cache.py): the internal batches of this call whose shape has a captured
         # graph, or is due for one, replay it; the others run the same launches eagerly
         plan = None
         if (post is not None and not exact and not per_batch_pyramids and len(images) and dev.type == 'cuda'
-                and self.graph_batches and type(self)._predict_single_batch is Pose3dEstimator._predict_single_batch
+                and u8_frames and self.graph_batches and type(self)._predict_single_batch is Pose3dEstimator._predict_single_batch
                 and '_predict_single_batch' not in self.__dict__):
             plan = self.graphs.plan_call(images, ranges, tta, antialias_factor, post)
         staging = None
         if (plan is None and dev.type == 'cuda' and not images.is_cuda and images.is_pinned() and len(images)
-                and not per_batch_pyramids):
+                and not per_batch_pyramids and u8_frames):
             # pinned host frames: the PCIe copy runs on a copy stream under the previous call's compute
             # (None: no frame set free for this frame size right now -- the plain blocking upload below)
             staging = self.graphs.frame_set(len(images), images.shape[2], images.shape[3], dev, optional=True,
@@ -476,7 +479,7 @@ class Pose3dEstimator(torch.nn.Module):
             pyramid = staging.load(images)
         else:
             images = images.to(dev)
-            pyramid = kernels.build_pyramid(images) if len(images) and not per_batch_pyramids else None
+            pyramid = kernels.pyramid_of_frames(images) if len(images) and not per_batch_pyramids else None
         if exact:
             if not hasattr(self.crop_model, 'exact_monolithic'):
                 raise RuntimeError("shard_across_ranks='exact_monolithic' needs metrabs_amd's Metrabs "
@@ -537,12 +540,12 @@ class Pose3dEstimator(torch.nn.Module):
         """-> (pyramid of the frames `image_ids` reference, the ids renumbered into it)."""
         needed, local_ids = torch.unique(image_ids.long(), sorted=True, return_inverse=True)
         frames = images[needed.to(images.device)].to(image_ids.device)
-        if frames.numel() >= kernels.MAX_U8_FRAME_BYTES:
+        if frames.dtype == torch.uint8 and frames.numel() >= kernels.MAX_U8_FRAME_BYTES:
             raise ValueError(
                 f'one internal batch references {len(needed)} frames = {frames.numel()} bytes; the '
                 f'sampler takes < {kernels.MAX_U8_FRAME_BYTES} bytes of uint8 frames per call: lower '
                 f'internal_batch_size')
-        return kernels.build_pyramid(frames), local_ids.to(image_ids.dtype)
+        return kernels.pyramid_of_frames(frames), local_ids.to(image_ids.dtype)
 
     def _get_crops(self, pyramid, intrinsic_matrix, distortion12, camspace_up, boxes, image_ids, tta,
                    antialias_factor):

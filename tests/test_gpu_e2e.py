@@ -67,6 +67,30 @@ def test_estimate_poses_vs_golden(name, fused_head, hip_lib):
     assert float(d2.median()) <= 2e-3 and float(torch.quantile(d2, 0.95)) <= 0.05
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.int16, torch.float16])
+def test_frames_of_other_dtypes_are_taken_as_the_reference_takes_them(dtype, hip_lib):
+    """The reference never asks for uint8: `(images.float() / 255) ** 2.2` (multiperson_model.py:196).  Frames of
+    another dtype holding the same values must give the golden output of the uint8 frames (same bound), through
+    the materialised f32 level 0, from the host or the device, with graphs requested or not (such frames stay
+    eager)."""
+    name = 'aug5'
+    g = load_golden(f'e2e_{name}')
+    case = cases.e2e_case(name)
+    est = build_estimator(case, True)
+    est.graph_batches = True
+    g3 = torch.from_numpy(g['poses3d'])
+    b_mpjpe, b_max = E2E_BOUND[name]
+    for frames in (case['images'].to(dtype), case['images'].to(dtype).cuda()):
+        for _ in range(2):
+            res = est.estimate_poses_batched(
+                frames, case['boxes'], intrinsic_matrix=case['K'], distortion_coeffs=case['dist'],
+                extrinsic_matrix=case['extr'], world_up_vector=case['world_up'], internal_batch_size=case['ibs'],
+                antialias_factor=case['aa'], num_aug=case['num_aug'], average_aug=case['average_aug'])
+            p3 = torch.cat(res['poses3d']).cpu()
+            assert cpu_ref.mpjpe(p3, g3) <= b_mpjpe and float((p3 - g3).abs().max()) <= b_max
+    assert est.graphs.stats['captures'] == 0 and not est.graphs.frame_sets
+
+
 def test_public_api_shapes_and_detector(hip_lib):
     """detect_poses / estimate_poses (single image) and the batched variants, pluggable detector,
     an image with zero boxes, skeleton selection, average_aug=False."""

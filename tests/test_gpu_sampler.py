@@ -339,6 +339,31 @@ def test_interleaved_full_size_frames(hip_lib):
     assert torch.equal(kernels.warp_crops(p_planar, wp, res), kernels.warp_crops(p_inter, wp, res))
 
 
+def test_float_frames_with_fractional_values_follow_the_reference_expression(hip_lib):
+    """kernels.pyramid_of_frames on non-uint8 frames = the reference's `(images.float() / 255) ** 2.2` + box pyramid:
+    crops of float frames with NON-integer values against the oracle's sampler on the same linear-light frames."""
+    from metrabs_amd import kernels
+    n_img, h, w, res, n = 2, 240, 320, 64, 8
+    g = cases.gen(91)
+    frames = torch.rand(n_img, 3, h, w, generator=g) * 255.0
+    boxes = torch.cat(cases.synth_boxes(n_img, h, w, 4, 92, min_boxes=4))[:, :4]
+    K = cases.intrinsics_for(h, w)[None].repeat(n, 1, 1)
+    ids = torch.repeat_interleave(torch.arange(n_img), 4)
+    tta = cpu_ref.tta_params(1)
+    up = torch.tensor([[0.0, -1.0, 0.0]]).repeat(n, 1)
+    pyr = kernels.pyramid_of_frames(frames.cuda())
+    assert pyr.levels[0] is not None and pyr.levels[0].dtype == torch.float32
+    _, _, wp = kernels.crop_geometry(boxes.cuda(), K.cuda(), torch.zeros(n, 12).cuda(), up.cuda(), ids.cuda(),
+                                     tta['rotflipmat'].cuda(), tta['scales'].cuda(), tta['gammas'].cuda(), res, 1)
+    ours = kernels.warp_crops(pyr, wp, res).cpu()
+    with torch.inference_mode():
+        ref, _, _ = cpu_ref.get_crops((frames / 255) ** 2.2, K, torch.zeros(n, 5), up, boxes, ids, tta['rotflipmat'],
+                                      tta['scales'], tta['gammas'], 1, res)
+    d = (ours - ref[0]).abs()
+    print(f'[parity] float frames, crops vs oracle: max {float(d.max()):.2e} mean {float(d.mean()):.2e}')
+    assert float(d.max()) <= 2e-3 and float(d.mean()) <= 2e-5   # (noise frames: neighbouring texels differ by up to 1)
+
+
 def test_sampling_arithmetic_is_no_noisier_than_the_references(hip_lib):
     """"the sampler is the HIP side that is worse than the reference" came from a yardstick
     that evaluates the REFERENCE's matrices in double (cpu_ref.get_crops(eval_dtype=float64): its f32
