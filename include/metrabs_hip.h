@@ -148,6 +148,13 @@ typedef struct mtr_head_options {
                                       against all column tiles, weights loaded per lane from the fragment-major
                                       section of the blob, only the features through LDS; 3 - 5 column tiles,
                                       C % 64 == 0; same bits; elsewhere: as -1),
+                                      5 = weights RESIDENT in registers, persistent workgroups (round 5,
+                                      head_res.hip: a workgroup keeps a pair of joint groups' weights for the
+                                      whole launch and streams its share of the crops through a ring of feature
+                                      stages; C = 1280, 3 - 5 column tiles; same bits; 20 - 40 % SLOWER than the
+                                      library's choice on every shape of profiles/r05y_* -- its decode epilogue
+                                      has no second workgroup's K loop to hide behind; kept for A/B runs;
+                                      elsewhere: as -1),
                                       -1 = library's choice (NB: a zeroed struct selects registers) */
   int32_t rt_column_blocks;        /* f32, maps of > 64 positions: 64-position column blocks per workgroup
                                       tile, 2..4 (one K loop for all of them); 1 = one K loop per column
@@ -197,6 +204,7 @@ enum {
   MTR_HEAD_KERNEL_16_DMA_LOADER = 13, /* head_fused16dma_kernel<..., LD>: the same with a loader wave (dma_staging 2) */
   MTR_HEAD_KERNEL_16_AREG = 15,  /* head_fused16areg_kernel: weights in registers, a wave per joint group (dma_staging 4;
                                     the library's choice for >= 512 crops of >= 8 joint groups on 5 column tiles)  */
+  MTR_HEAD_KERNEL_16_RES = 16,   /* head_fused16res_kernel: weights RESIDENT in registers, persistent workgroups (dma_staging 5) */
   MTR_HEAD_KERNEL_16_RT = 12     /* head_rt16_kernel: 16-bit features on the row-tile core (1 + D > 64 rows per
                                     joint, or maps of more than 256 positions); NCHW features: needs the
                                     workspace (one transposing pass in front)                              */

@@ -206,4 +206,11 @@ int head16_areg_launch(int feat_dtype, int layout, int gpw, const void* feat, co
                        int B, int C, int H, int W, int J, int D, const HeadGeom& g, const HeadScale& hs, float* c2d,
                        float* c3d, hipStream_t stream);
 
+// head_res.hip: weights RESIDENT in registers, persistent workgroups (a pair of joint groups per workgroup for
+// the whole launch, crops streamed through a ring of feature stages); C = 1280, 3 - 5 column tiles.
+bool head16_res_supported(int C, int H, int W, int layout);
+int head16_res_launch(int feat_dtype, int layout, const void* feat, const float* bias, const void* wfrag, int B, int C,
+                      int H, int W, int J, int D, const HeadGeom& g, const HeadScale& hs, float* c2d, float* c3d,
+                      hipStream_t stream);
+
 }  // namespace mtr

@@ -831,11 +831,22 @@ static int head16_areg_groups(const HeadOpts& opt, int B, int C, int H, int W, i
   return (B >= 512 && g.n_groups >= 8 && (H * W + 31) / 32 == 5) ? 4 : 0;
 }
 
+// The resident-weights kernel (head_res.hip).  dma_staging 5 forces it.
+static bool head16_res_taken(const HeadOpts& opt, int B, int C, int H, int W, int layout, const HeadGeom& g) {
+  (void)B; (void)g;
+  if (!head16_res_supported(C, H, W, layout)) return false;
+  return opt.dma == 5;
+}
+
 template <typename FeatT, int CT, bool NHWC>
 static int dispatch_head16(const void* feat, const float* packed, int B, int C, int H, int W, int J,
                            int D, const HeadGeom& g, const HeadScale& hs, float* c2d, float* c3d,
                            const HeadOpts& opt, hipStream_t stream) {
   constexpr int kMaxGpw = CT <= 2 ? 3 : (CT <= 6 ? 2 : 1);
+  if (head16_res_taken(opt, B, C, H, W, NHWC ? MTR_NHWC : MTR_NCHW, g))  // weights resident, persistent workgroups
+    return head16_res_launch(std::is_same<FeatT, __half>::value ? MTR_F16 : MTR_BF16, NHWC ? MTR_NHWC : MTR_NCHW,
+                             feat, packed, (const char*)packed + h16_frag_offset(C, J, D), B, C, H, W, J, D, g, hs,
+                             c2d, c3d, stream);
   if (const int ag = head16_areg_groups(opt, B, C, H, W, NHWC ? MTR_NHWC : MTR_NCHW, g))  // weights in registers
     return head16_areg_launch(std::is_same<FeatT, __half>::value ? MTR_F16 : MTR_BF16, NHWC ? MTR_NHWC : MTR_NCHW, ag,
                               feat, packed, (const char*)packed + h16_frag_offset(C, J, D), B, C, H, W, J, D, g, hs,
@@ -991,7 +1002,7 @@ static int parse_head_options(const mtr_head_options* caller, mtr::HeadOpts& opt
   const mtr_head_options* options = &mine;
   if (options->rt_tiles_per_workgroup < 0 || options->rt_tiles_per_workgroup > 5 ||
       options->groups_per_workgroup < 0 || options->groups_per_workgroup > 4 ||
-      options->dma_staging < -1 || options->dma_staging > 4 ||
+      options->dma_staging < -1 || options->dma_staging > 5 ||
       options->rt_column_blocks < 0 || options->rt_column_blocks > 4 ||
       options->rt_k_groups < 0 || options->rt_k_groups > 2 ||
       options->rt_loader < 0 || options->rt_loader > 2 ||
@@ -1035,6 +1046,12 @@ extern "C" int mtr_head_plan(int feat_dtype, int layout, int B, int C, int H, in
   const mtr::HeadGeom g = mtr::head_geom(J, D);
   int ct = (H * W + 31) / 32;
   if (ct == 7) ct = 8;
+  if (mtr::head16_res_taken(opt, B, C, H, W, layout, g)) {
+    plan->kernel = MTR_HEAD_KERNEL_16_RES;
+    plan->tiles_per_workgroup = 2;
+    plan->workgroups = (long long)((g.n_groups + 1) / 2) * (B < 256 / ((g.n_groups + 1) / 2) ? B : 256 / ((g.n_groups + 1) / 2));
+    return MTR_OK;
+  }
   if (const int ag = mtr::head16_areg_groups(opt, B, C, H, W, layout, g)) {
     plan->kernel = MTR_HEAD_KERNEL_16_AREG;
     plan->tiles_per_workgroup = ag;

@@ -1,0 +1,295 @@
+// K1 + K2-K4 fused, 16-bit features, WEIGHTS RESIDENT IN REGISTERS, persistent workgroups (round 5): the
+// joint-group head kernel for many-joint models (configs[4]: J = 122 on 12x12 maps, C = 1280).
+//
+// Replaces MetrabsHeads.forward (metrabs_pytorch/models/metrabs.py:75-85) like the kernels of head_fused.hip
+// and head_areg.hip, whose stages, MFMA order per accumulator and decode epilogue it shares -- the results are
+// bit-identical (tests/test_gpu_head.py compares every dispatch choice with torch.equal).
+//
+// Why.  Every other 16-bit kernel re-fetches a joint group's weights for every crop: 160 KB per (crop, group)
+// through the CU's vector-memory path, next to 20 KB of features per stage -- at J = 122 a launch of 256 crops
+// pulls 1.7 GB into the CUs for 104 GFLOP and the matrix pipe is a third busy.  Here
+//   * a workgroup is PERSISTENT: it owns two joint groups (one 32-row MFMA block per wave: 4 waves) for the whole
+//     launch and walks the crops of its share; its weights -- 32 rows x C channels per wave = 320 registers per
+//     lane at C = 1280 -- are loaded ONCE from the fragment-major section of the packed blob and stay in
+//     registers (one wave per SIMD, the 512-register budget);
+//   * per crop only the features move: 20 KiB per 64-channel stage by global_load_lds into a ring of three
+//     stage buffers that runs on ACROSS crops (the copies of the next crop's first stages are in flight during
+//     the last stages and the decode epilogue of this one);
+//   * every feature fragment read from LDS feeds this wave's row block against all column tiles; no MFMA
+//     multiplies a padding tile.
+#include "common.h"
+#include "head16.h"
+
+namespace mtr {
+
+// one wave-wide 1 KiB copy global -> LDS: lane L reads 16 bytes at sbase + voff, they land at lds_addr + 16 L
+__device__ __forceinline__ void res_dma16(const void* sbase_uniform, unsigned voff, unsigned lds_addr) {
+  const unsigned long long p = (unsigned long long)sbase_uniform;
+  const unsigned long long su = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(p >> 32)) << 32) |
+                                (unsigned)__builtin_amdgcn_readfirstlane((int)p);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+               :
+               : "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(su)
+               : "memory", "m0");
+}
+
+constexpr int kResBuf = 3;  // stage buffers of the feature ring
+#ifndef MTR_RES_DEBUG
+#define MTR_RES_DEBUG 0   // developer bisecting: 1 = no feature copies, 2 = no weight loads, 4 = no epilogue
+#endif
+
+template <typename FeatT, int CT, bool NHWC, int NST>
+__global__ __launch_bounds__(256, 1) void head_fused16res_kernel(
+    const FeatT* __restrict__ feat, const float* __restrict__ bias, const FeatT* __restrict__ wfrag, int B, int H,
+    int W, int J, int D, HeadGeom g, HeadScale hs, int n_pairs, int n_sub, float* __restrict__ coords2d,
+    float* __restrict__ coords3d_rel) {
+  constexpr int C = NST * kKH;
+  constexpr int NW = 4;
+  constexpr int HWP = hw_pad32<CT>();
+  constexpr int B_STAGE = CT * 32 * 128;          // bytes of one stage buffer
+  constexpr int NPIECE = 4 * CT;                  // 1 KiB copy pieces per stage
+  constexpr int PPW = (NPIECE + NW - 1) / NW;     // ... per wave
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* Bs = reinterpret_cast<char*>(smem);                                   // [kResBuf][CT*32][128 B]
+  float* Ls = reinterpret_cast<float*>(Bs + kResBuf * B_STAGE);               // [2][64][HWP]: the pair's logits
+
+  // workgroup -> (pair of joint groups, share of the crops): consecutive indices WITHIN an XCD (block b runs on
+  // XCD b % 8) walk the pairs of one share, so the workgroups that read a crop's features mostly share an L2
+  const int per_xcd = gridDim.x / 8;
+  const int L = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if (L >= n_pairs * n_sub) return;
+  const int pair = L % n_pairs, sub = L / n_pairs;
+  if (sub >= B) return;
+
+  const int HW = H * W;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q_grp = wid >> 1, rb = wid & 1;       // this wave: group q_grp of the pair, row block rb
+  const int fi = lane & 31, fg = lane >> 5;
+
+  for (int v = tid; v < kResBuf * B_STAGE / 16; v += 64 * NW)
+    reinterpret_cast<v4u*>(Bs)[v] = v4u{0u, 0u, 0u, 0u};
+
+  // ---- the resident weights: lane L of (stage st, step u) holds the 16 bytes at [rb][u][L] of the stage's 8 KiB
+  // fragment-major block of this wave's group
+  const int my_grp = min(pair * 2 + q_grp, g.n_groups - 1);
+  const bool grp_real = pair * 2 + q_grp < g.n_groups;
+  v4u a[NST * 4];
+  {
+    const char* ap = reinterpret_cast<const char*>(wfrag + (size_t)my_grp * NST * (kRows * kKH)) + rb * 4096 + lane * 16;
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      if (MTR_RES_DEBUG & 2) { a[st * 4 + 0] = a[st * 4 + 1] = a[st * 4 + 2] = a[st * 4 + 3] = v4u{1u, 2u, 3u, (unsigned)st}; continue; }
+      // (plain loads: the compiler parks most of these in AGPRs right away and must know when they have landed)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[st * 4 + u] = *reinterpret_cast<const v4u*>(ap + st * (kRows * kKH * 2) + u * 1024);
+    }
+  }
+
+  // ---- feature copies: piece p = i * NW + wave of a stage; per-lane byte offset inside the crop's stage 0
+  const int lr = lane >> 3, ls = lane & 7;
+  unsigned b_voff[PPW];   // (EVERY lane of EVERY piece copies: lanes past the stage's data re-read its first bytes
+                          //  into padding rows / the buffer's unused tail -- a wave's copies per stage are then
+                          //  exactly PPW, what the counted waits below rely on)
+  static_assert(NPIECE % NW == 0, "whole pieces per wave");
+  const int n_chunks = HW >> 3;
+  const unsigned b_stage_bytes = (unsigned)((NHWC ? (size_t)kKH : (size_t)kKH * HW) * sizeof(FeatT));
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int piece = i * NW + wid;
+    if constexpr (NHWC) {
+      const int pos = piece * 8 + lr;
+      b_voff[i] = (unsigned)(((size_t)(pos < HW ? pos : 0) * C + ((ls ^ swz(pos)) << 3)) * sizeof(FeatT));
+    } else {
+      const int cid = piece * 64 + lane;  // linear 16-byte chunk of the stage in LDS
+      const bool on = cid < kKH * n_chunks;
+      const int k = on ? cid / n_chunks : 0, jl = on ? cid - k * n_chunks : 0;
+      const int rot = ((k >> 1) & 1) << 2;
+      const int j = jl >= rot ? jl - rot : jl - rot + n_chunks;  // source chunk of LDS chunk jl
+      b_voff[i] = (unsigned)(((size_t)k * HW + j * 8) * sizeof(FeatT));
+    }
+  }
+  int b_off[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) {
+    if constexpr (NHWC) {
+      const int pos = t * 32 + fi;
+      b_off[t] = pos * 128 + ((fg ^ swz(pos)) << 4);
+    } else {  // ds_read_b64_tr_b16 addressing: see head_fused16dma_kernel
+      const int G = lane >> 4, r = lane & 15, qq = r & 3, ci = r >> 2;
+      const int P = t * 32 + 16 * (G & 1) + 4 * qq;
+      const int Pc = P < HW ? P : 0;
+      int jl = (Pc >> 3) + (((ci >> 1) & 1) << 2);
+      jl = jl >= n_chunks ? jl - n_chunks : jl;
+      b_off[t] = (8 * fg + ci) * (HW * 2) + jl * 16 + (Pc & 7) * 2;
+    }
+  }
+  const int tr_pitch4 = 4 * HW * 2;
+
+  // the crops of this share: sub, sub + n_sub, ...; global stage counter gs = crop index * NST + stage
+  const int n_my = (B - sub + n_sub - 1) / n_sub;
+  const int total_stages = n_my * NST;
+  const unsigned Bs_a = lds_byte_addr(Bs);
+  const size_t crop_bytes = (size_t)C * HW * sizeof(FeatT);
+  auto issue = [&](int gs) {   // (wave-uniform) the copies of global stage gs into buffer gs % kResBuf
+    const int ci = gs / NST, st = gs - ci * NST;
+    const char* base = reinterpret_cast<const char*>(feat) + (size_t)(sub + ci * n_sub) * crop_bytes +
+                       (size_t)st * b_stage_bytes;
+    const unsigned buf = Bs_a + (unsigned)(gs % kResBuf) * B_STAGE;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i)
+      if (!(MTR_RES_DEBUG & 1)) res_dma16(base, b_voff[i], buf + (i * NW + wid) * 1024);
+  };
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the weights have landed: from here on the vector-memory queue
+                                                     // holds this wave's feature copies (and the odd epilogue access)
+  __syncthreads();  // zero fill done
+  issue(0);
+  if (total_stages > 1) issue(1);
+
+  f32x16 acc[CT];
+  int gs = 0;
+  for (int ci = 0; ci < n_my; ++ci) {
+    const int crop = sub + ci * n_sub;
+#pragma unroll
+    for (int t = 0; t < CT; ++t) acc[t] = f32x16{0};
+#pragma unroll
+    for (int st = 0; st < NST; ++st, ++gs) {
+      // this wave's copies of stage gs have landed (those of gs + 1 may be in flight) ...
+      if (gs + 1 < total_stages) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // ... everyone's; and every wave is done with the buffer of stage gs - 1
+      const char* Bb = Bs + (gs % kResBuf) * B_STAGE;
+      // fragment reads of step u + 1 are issued in front of the MFMAs of step u (two fragment sets); behind the
+      // stage barrier the reads of step 0 go out FIRST and the copies of stage gs + 2 are issued while they fly
+      // (sched_barrier: the compiler otherwise keeps ONE fragment set and waits for every read in front of its
+      // MFMA -- seen in the ISA)
+      v4u bf[2][CT];
+      auto read_step = [&](int u, v4u* dst) {
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+          if constexpr (NHWC) {
+            dst[t] = *reinterpret_cast<const v4u*>(Bb + (b_off[t] ^ (u << 5)));
+          } else {
+            const char* p = Bb + b_off[t] + u * (4 * tr_pitch4);
+            dst[t] = lds_read_tr16_pair(p, p + tr_pitch4);
+          }
+        }
+      };
+      read_step(0, bf[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (gs + 2 < total_stages) issue(gs + 2);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (u < 3) read_step(u + 1, bf[(u + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[t] = Mfma16<FeatT>::run(a[st * 4 + u], bf[u & 1][t], acc[t]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (MTR_RES_DEBUG & 4) {  // (every accumulator stays live)
+      float sum = 0.0f;
+#pragma unroll
+      for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += acc[t][r];
+      if (sum == 12345.0f) coords2d[0] = 1.0f;
+      continue;
+    }
+    // ---- epilogue of the crop: both groups' logits into LDS (each wave its 32 rows), decoded by all waves.
+    // (Ls is outside the ring: the next crop's first stages are landing meanwhile.)
+    {
+      const float* bgrp = bias + (size_t)my_grp * kRows;
+      float* Lq = Ls + q_grp * (kRows * HWP);
+#pragma unroll
+      for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rb * 32 + 8 * (r >> 2) + 4 * fg + (r & 3);
+          Lq[row * HWP + t * 32 + fi] = acc[t][r] + bgrp[row];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (pair * 2 + q < g.n_groups)
+        decode_group_from_lds<false, (CT > 2 ? 4 : 2), NW>(Ls + q * (kRows * HWP), HWP, pair * 2 + q, g, crop, J, D, H,
+                                                            W, hs, coords2d, coords3d_rel, wid, lane);
+    // (the next write of Ls is a crop's worth of stage barriers away)
+  }
+  (void)grp_real;
+}
+
+template <int CT>
+constexpr size_t head16_res_lds_bytes() {
+  return (size_t)kResBuf * CT * 32 * 128 + 2 * (size_t)kRows * hw_pad32<CT>() * sizeof(float);
+}
+
+static int res_cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+template <typename FeatT, int CT, bool NHWC, int NST>
+static int launch_res(const void* feat, const float* bias, const void* wfrag, int B, int H, int W, int J, int D,
+                      const HeadGeom& g, const HeadScale& hs, float* c2d, float* c3d, hipStream_t stream) {
+  constexpr size_t lds = head16_res_lds_bytes<CT>();
+  const int n_pairs = (g.n_groups + 1) / 2;
+  int cus = res_cu_count() / 8 * 8;
+  if (cus < 8) cus = 8;
+  int n_sub = cus / n_pairs;
+  if (n_sub < 1) n_sub = 1;
+  if (n_sub > B) n_sub = B;
+  const int need = n_pairs * n_sub;
+  const int grid = (need + 7) / 8 * 8;   // (a multiple of 8: the index map above walks XCD by XCD)
+  auto kern = head_fused16res_kernel<FeatT, CT, NHWC, NST>;
+  const int rc = allow_dynamic_lds((const void*)kern, lds);
+  if (rc != MTR_OK) return rc;
+  MTR_CLEAR_STALE();
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, (const FeatT*)feat, bias, (const FeatT*)wfrag,
+                     B, H, W, J, D, g, hs, n_pairs, n_sub, c2d, c3d);
+  MTR_CHECK_LAUNCH();
+  return MTR_OK;
+}
+
+template <typename FeatT, bool NHWC>
+static int res_by_tiles(int ct, const void* feat, const float* bias, const void* wfrag, int B, int H, int W, int J,
+                        int D, const HeadGeom& g, const HeadScale& hs, float* c2d, float* c3d, hipStream_t stream) {
+  switch (ct) {
+    case 3: return launch_res<FeatT, 3, NHWC, 20>(feat, bias, wfrag, B, H, W, J, D, g, hs, c2d, c3d, stream);
+    case 4: return launch_res<FeatT, 4, NHWC, 20>(feat, bias, wfrag, B, H, W, J, D, g, hs, c2d, c3d, stream);
+    case 5: return launch_res<FeatT, 5, NHWC, 20>(feat, bias, wfrag, B, H, W, J, D, g, hs, c2d, c3d, stream);
+    default: return MTR_E_SHAPE;
+  }
+}
+
+bool head16_res_supported(int C, int H, int W, int layout) {
+  const int hw = H * W, ct = (hw + 31) / 32;
+  return C == 20 * kKH && ct >= 3 && ct <= 5 && (layout == MTR_NHWC || (hw % 8 == 0 && hw >= 64)) &&
+         (size_t)C * hw * 2 < (1u << 31);
+}
+
+int head16_res_launch(int feat_dtype, int layout, const void* feat, const float* bias, const void* wfrag, int B, int C,
+                      int H, int W, int J, int D, const HeadGeom& g, const HeadScale& hs, float* c2d, float* c3d,
+                      hipStream_t stream) {
+  if (!head16_res_supported(C, H, W, layout)) return MTR_E_SHAPE;
+  if (B <= 0) return MTR_OK;
+  const int ct = (H * W + 31) / 32;
+  if (feat_dtype == MTR_F16) {
+    if (layout == MTR_NHWC) return res_by_tiles<__half, true>(ct, feat, bias, wfrag, B, H, W, J, D, g, hs, c2d, c3d, stream);
+    return res_by_tiles<__half, false>(ct, feat, bias, wfrag, B, H, W, J, D, g, hs, c2d, c3d, stream);
+  }
+  if (layout == MTR_NHWC)
+    return res_by_tiles<__hip_bfloat16, true>(ct, feat, bias, wfrag, B, H, W, J, D, g, hs, c2d, c3d, stream);
+  return res_by_tiles<__hip_bfloat16, false>(ct, feat, bias, wfrag, B, H, W, J, D, g, hs, c2d, c3d, stream);
+}
+
+}  // namespace mtr

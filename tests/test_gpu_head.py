@@ -129,6 +129,32 @@ def test_fused_head_16bit_features(dtype, hip_lib):
 
 
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(9, 1280, 17, 8, 12, 12), (30, 1280, 122, 8, 8, 12), (61, 1280, 24, 8, 10, 10),
+                                   (300, 1280, 40, 8, 12, 12)])
+def test_resident_weights_kernel_gives_the_same_bits(shape, dtype, hip_lib):
+    """head_fused16res_kernel (dma_staging 5, csrc/head_res.hip): persistent workgroups that keep a pair of joint
+    groups' weights in registers and stream the crops of their share through a ring of feature stages.  An odd
+    number of joint groups (17 joints: 3), 3 / 4 / 5 column tiles, fewer crops than shares and several crops per
+    workgroup (the ring runs on across crops), both layouts: the default kernel's bits."""
+    from metrabs_amd import _lib, kernels
+    B, C, J, D, H, W = shape
+    cfg = cpu_ref.HeadConfig(depth=D, proc_side=max(H, W) * 8, stride_test=8, stride_train=8)
+    g = cases.gen(8700 + sum(shape))
+    feat = torch.randn(B, C, H, W, generator=g).to(dtype).cuda()
+    w, b = cases.default_conv_init(J * (1 + D), C, g)
+    packed = kernels.head_pack_weights((w * 3).cuda(), (b * 3).cuda(), J, D, dtype)
+    for f in (feat, feat.contiguous(memory_format=torch.channels_last)):
+        nhwc = f is not feat
+        plan = kernels.head_plan(B, C, H, W, J, D, dtype, nhwc, dma_staging=5)
+        # (NCHW rows are copied in whole 16-byte chunks: H*W % 8 == 0; elsewhere the option is the default kernel)
+        assert (plan['kernel'] == _lib.HEAD_KERNEL_NAMES[16]) == (nhwc or (H * W) % 8 == 0), plan
+        base = kernels.head_fused(f, packed, C, J, mcfg(cfg))
+        res = kernels.head_fused(f, packed, C, J, mcfg(cfg), dma_staging=5)
+        assert torch.isfinite(base[1]).all()
+        assert torch.equal(res[0], base[0]) and torch.equal(res[1], base[1]), (shape, nhwc)
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('shape', [(3, 40, 17, 8, 8, 8), (2, 24, 5, 8, 4, 4), (2, 136, 17, 8, 12, 12),
                                    (1, 64, 3, 8, 16, 16), (2, 96, 30, 4, 10, 10), (9, 32, 1, 8, 8, 8),
                                    (2, 100, 7, 8, 2, 8), (3, 72, 17, 8, 6, 6), (2, 33, 9, 8, 8, 12),
@@ -168,7 +194,9 @@ def test_fused_head_16bit_odd_shapes(shape, dtype, hip_lib):
                     dict(dma_staging=3, groups_per_workgroup=2), dict(dma_staging=3, groups_per_workgroup=3),
                     # round 5: weights in registers (3 - 5 column tiles with whole stages; elsewhere = the default)
                     dict(dma_staging=4), dict(dma_staging=4, groups_per_workgroup=2),
-                    dict(dma_staging=4, groups_per_workgroup=4)):
+                    dict(dma_staging=4, groups_per_workgroup=4),
+                    # ... and weights RESIDENT in registers, persistent workgroups (C = 1280, 3 - 5 column tiles)
+                    dict(dma_staging=5)):
         # (dma_staging 1 = four waves that copy and multiply, 2 = four MFMA waves + a loader wave)
         v2d, v3d = run_fused(feat, w, b, J, cfg, **options)
         assert torch.equal(v3d, c3d) and torch.equal(v2d, c2d), options
@@ -616,7 +644,7 @@ def test_head_options_are_validated(hip_lib):
     w, b = cases.default_conv_init(153, 64, cases.gen(1))
     packed = kernels.head_pack_weights(w.cuda(), b.cuda(), 17, 8)
     feat = torch.randn(2, 64, 8, 8, device='cuda')
-    for bad in (dict(rt_tiles=6), dict(groups_per_workgroup=5), dict(dma_staging=5), dict(rt_column_blocks=5),
+    for bad in (dict(rt_tiles=6), dict(groups_per_workgroup=5), dict(dma_staging=6), dict(rt_column_blocks=5),
                 dict(rt_k_groups=3), dict(rt_loader=3), dict(rt_split=3)):
         with pytest.raises(RuntimeError):
             kernels.head_fused(feat, packed, 64, 17, MetrabsConfig(), **bad)
