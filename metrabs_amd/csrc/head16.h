@@ -40,7 +40,14 @@ __host__ __device__ constexpr int hw_pad32() { return CT * 32 + 4; }
 // matters because reconstruct_absolute amplifies coords3d_rel errors ~7x.
 // PV = positions per lane and step: 4 for maps of more than 64 positions, 2 below (an 8x8 map
 // then keeps all 32 lanes of the half-wave busy instead of 16).
-template <bool ACC64, int PV, int NW = 4>
+// DC: the number of depth slices when known at compile time (8: every shipped model), 0 = read from D.  Same
+// operations in the same order per accumulator -- the same bits; with DC the slice loops are straight-line code:
+// no loop counters, no int -> double conversions of the slice index, the eight reads and exponentials of a
+// position in flight together.
+#ifndef MTR_DECODE_DC8
+#define MTR_DECODE_DC8 1
+#endif
+template <bool ACC64, int PV, int NW = 4, int DC = 0>
 __device__ __forceinline__ void decode_group_from_lds_pv(const float* Ls, int HWP, int grp,
                                                          const HeadGeom& g, int crop, int J, int D,
                                                          int H, int W, const HeadScale& hs,
@@ -49,6 +56,7 @@ __device__ __forceinline__ void decode_group_from_lds_pv(const float* Ls, int HW
                                                          int lane) {
   using vecf = __attribute__((ext_vector_type(PV))) float;
   const int HW = H * W;
+  if (DC > 0) D = DC;
   const int per = 1 + D;
   const int li = lane & 31;
   const float rcp_w = __frcp_rn((float)W);
@@ -62,7 +70,8 @@ __device__ __forceinline__ void decode_group_from_lds_pv(const float* Ls, int HW
       const vecf v = *reinterpret_cast<const vecf*>(row2d + p);
 #pragma unroll
       for (int q = 0; q < PV; ++q) m2 = fmaxf(m2, v[q]);
-      for (int d = 0; d < D; ++d) {
+#pragma unroll
+      for (int d = 0; d < (DC > 0 ? DC : D); ++d) {
         const vecf u = *reinterpret_cast<const vecf*>(row3d + (size_t)d * HWP + p);
 #pragma unroll
         for (int q = 0; q < PV; ++q) m3 = fmaxf(m3, u[q]);
@@ -83,7 +92,8 @@ __device__ __forceinline__ void decode_group_from_lds_pv(const float* Ls, int HW
 #pragma unroll
       for (int q = 0; q < PV; ++q) col[q] = colb[q] = 0;
       int d = 0;
-      for (; d + 1 < D; d += 2) {
+#pragma unroll
+      for (; d + 1 < (DC > 0 ? DC : D); d += 2) {
         const vecf ua = *reinterpret_cast<const vecf*>(row3d + (size_t)d * HWP + p);
         const vecf ub = *reinterpret_cast<const vecf*>(row3d + (size_t)(d + 1) * HWP + p);
 #pragma unroll
@@ -96,7 +106,7 @@ __device__ __forceinline__ void decode_group_from_lds_pv(const float* Ls, int HW
           sz3b += eb * (double)(d + 1);
         }
       }
-      if (d < D) {
+      if (d < (DC > 0 ? DC : D)) {
         const vecf ua = *reinterpret_cast<const vecf*>(row3d + (size_t)d * HWP + p);
 #pragma unroll
         for (int q = 0; q < PV; ++q) {
@@ -144,12 +154,18 @@ __device__ __forceinline__ void decode_group_from_lds(const float* Ls, int HWP, 
                                                       int lane) {
   const int HW = H * W;
   const int c1 = (HW + 31) / 32, c2 = (HW + 63) / 64 * 2, c4 = (HW + 127) / 128 * 4;  // lane-slots per row
-  if (PVMAX >= 4 && c4 <= c2 && c4 <= c1)
-    decode_group_from_lds_pv<ACC64, 4, NW>(Ls, HWP, grp, g, crop, J, D, H, W, hs, coords2d, coords3d_rel, wid, lane);
-  else if (c2 <= c1)
-    decode_group_from_lds_pv<ACC64, 2, NW>(Ls, HWP, grp, g, crop, J, D, H, W, hs, coords2d, coords3d_rel, wid, lane);
-  else
-    decode_group_from_lds_pv<ACC64, 1, NW>(Ls, HWP, grp, g, crop, J, D, H, W, hs, coords2d, coords3d_rel, wid, lane);
+  const bool d8 = MTR_DECODE_DC8 && D == 8;   // (uniform)
+#define MTR_DECODE_CALL(PV_)                                                                                        \
+  do {                                                                                                              \
+    if (d8) decode_group_from_lds_pv<ACC64, PV_, NW, 8>(Ls, HWP, grp, g, crop, J, D, H, W, hs, coords2d,            \
+                                                        coords3d_rel, wid, lane);                                   \
+    else decode_group_from_lds_pv<ACC64, PV_, NW, 0>(Ls, HWP, grp, g, crop, J, D, H, W, hs, coords2d, coords3d_rel, \
+                                                     wid, lane);                                                    \
+  } while (0)
+  if (PVMAX >= 4 && c4 <= c2 && c4 <= c1) MTR_DECODE_CALL(4);
+  else if (c2 <= c1) MTR_DECODE_CALL(2);
+  else MTR_DECODE_CALL(1);
+#undef MTR_DECODE_CALL
 }
 
 using v4u = __attribute__((ext_vector_type(4))) unsigned;
