@@ -145,7 +145,9 @@ __device__ __forceinline__ void decode_group_from_lds_pv(const float* Ls, int HW
 // ran PV = 4, i.e. two steps of 128 positions with 112 of the second step's 128 slots idle -- 44 % of the
 // epilogue's lane-slots; at PV = 1 it is five steps of 32 with 16 idle.  The epilogue was 44 - 52 % of
 // the 16-bit kernels' time (tools/experiments/head_fixed_vs_stage.py: the same launch at C = 64 ... 1280).
-template <bool ACC64, int PVMAX, int NW = 4>
+// UNROLL8: take the straight-line form when D == 8 (head_areg.hip, 244 registers at five column tiles, keeps the
+// loops: the unrolled epilogue spilled there)
+template <bool ACC64, int PVMAX, int NW = 4, bool UNROLL8 = true>
 __device__ __forceinline__ void decode_group_from_lds(const float* Ls, int HWP, int grp,
                                                       const HeadGeom& g, int crop, int J, int D,
                                                       int H, int W, const HeadScale& hs,
@@ -154,7 +156,7 @@ __device__ __forceinline__ void decode_group_from_lds(const float* Ls, int HWP, 
                                                       int lane) {
   const int HW = H * W;
   const int c1 = (HW + 31) / 32, c2 = (HW + 63) / 64 * 2, c4 = (HW + 127) / 128 * 4;  // lane-slots per row
-  const bool d8 = MTR_DECODE_DC8 && D == 8;   // (uniform)
+  const bool d8 = MTR_DECODE_DC8 && UNROLL8 && D == 8;   // (uniform)
 #define MTR_DECODE_CALL(PV_)                                                                                        \
   do {                                                                                                              \
     if (d8) decode_group_from_lds_pv<ACC64, PV_, NW, 8>(Ls, HWP, grp, g, crop, J, D, H, W, hs, coords2d,            \

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64 * GPW, 2) void head_fused16areg_kernel(
           }
     }
     __syncthreads();
-    decode_group_from_lds<false, (CT > 2 ? 4 : 2), NW>(Ls, HWP, grp0 + q, g, crop, J, D, H, W, hs, coords2d,
+    decode_group_from_lds<false, (CT > 2 ? 4 : 2), NW, false>(Ls, HWP, grp0 + q, g, crop, J, D, H, W, hs, coords2d,
                                                         coords3d_rel, wid, lane);
   }
 }

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256, 1) void head_fused16res_kernel(
 #pragma unroll
     for (int q = 0; q < 2; ++q)
       if (pair * 2 + q < g.n_groups)
-        decode_group_from_lds<false, (CT > 2 ? 4 : 2), NW>(Ls + q * (kRows * HWP), HWP, pair * 2 + q, g, crop, J, D, H,
+        decode_group_from_lds<false, (CT > 2 ? 4 : 2), NW, false>(Ls + q * (kRows * HWP), HWP, pair * 2 + q, g, crop, J, D, H,
                                                             W, hs, coords2d, coords3d_rel, wid, lane);
     // (the next write of Ls is a crop's worth of stage barriers away)
   }
