@@ -18,10 +18,11 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None, force_group=False):
+def init_from_env(backend=None, force_group=False, timeout_s=None):
     """Initialises torch.distributed from RANK / WORLD_SIZE / MASTER_* (as torchrun sets them).
     Returns (rank, world_size, local_rank).  World size 1 needs no process group (force_group: make
-    one anyway -- a one-rank RCCL communicator on a 1-GPU box)."""
+    one anyway -- a one-rank RCCL communicator on a 1-GPU box).  timeout_s: the collectives' watchdog
+    timeout (default: torch's, 10 minutes on RCCL)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', str(rank)))
@@ -33,7 +34,11 @@ def init_from_env(backend=None, force_group=False):
         # dmabuf IPC: what RCCL's intra-node transport needs on this driver stack (the legacy IPC
         # path fails with hipIpcGetMemHandle: invalid argument)
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if timeout_s is not None:
+            import datetime
+            kw['timeout'] = datetime.timedelta(seconds=timeout_s)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local_rank
 
 

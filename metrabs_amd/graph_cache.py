@@ -102,6 +102,31 @@ class FrameSet:
         return kernels.build_pyramid(dst, out=pyramid)
 
 
+def _last_parameter(module):
+    """The parameter `list(module.parameters())[-1]` would give, found along the tail of the module tree
+    only (a module's own parameters precede its children's)."""
+    for child in reversed(list(module._modules.values())):
+        if child is not None:
+            p = _last_parameter(child)
+            if p is not None:
+                return p
+    own = [p for p in module._parameters.values() if p is not None]
+    return own[-1] if own else None
+
+
+def backbone_fingerprint(crop_model):
+    """Cheap identity of the storage a captured graph reads the BACKBONE's weights from: the module object and
+    the address / dtype / device of its first and last parameter.  `.half()`, `.to()`, `.cuda()` on the backbone
+    alone, or a replaced backbone, change it (Metrabs._apply only sees calls on the whole crop model; ADVICE r5:
+    a replay would otherwise read freed storage).  In-place edits of backbone parameters keep the addresses and
+    are, as documented, the caller's to announce (`estimator.graphs.clear()`)."""
+    bb = getattr(crop_model, 'backbone', None)
+    if not isinstance(bb, torch.nn.Module):
+        return (id(bb),)
+    edge = (next(bb.parameters(), None), _last_parameter(bb))
+    return (id(bb),) + tuple(None if p is None else (p.data_ptr(), p.dtype, str(p.device)) for p in edge)
+
+
 class BatchGraph:
     """One internal batch captured in a HIP graph.  ``replay(batch_args)`` -> [n, (A,) S, 5]."""
 
@@ -111,6 +136,7 @@ class BatchGraph:
         pyramid = frames.pyramid if n_frames is None else frames.pyramid_of(n_frames)
         self.heads = getattr(est.crop_model, 'heatmap_heads', None)
         self.storage_generation = getattr(est.crop_model, 'storage_generation', None)
+        self.backbone = backbone_fingerprint(est.crop_model)
         with torch.inference_mode(False):  # (written in place by every later replay, whatever mode it runs under)
             self.static = [torch.empty(a.shape, dtype=a.dtype, device=a.device) for a in batch_args]
         self._load(batch_args)
@@ -141,8 +167,10 @@ class BatchGraph:
 
     def is_current(self, est):
         """False when the weights this graph read were replaced or edited since its capture (the head's
-        parameters / derived tensors; the crop model moved or cast as a module)."""
+        parameters / derived tensors; the crop model, or its backbone alone, moved, cast or replaced)."""
         if getattr(est.crop_model, 'storage_generation', None) != self.storage_generation:
+            return False
+        if backbone_fingerprint(est.crop_model) != self.backbone:   # the backbone alone was cast / moved / replaced
             return False
         heads = getattr(est.crop_model, 'heatmap_heads', None)
         if heads is not self.heads:
@@ -277,6 +305,10 @@ class GraphCache:
         optional=True (the pinned-frame staging of an eager call): None instead of a replacement the
         eviction interval does not allow yet.  hwc: frames with interleaved channels (a set of its own)."""
         skey = (h, w, str(dev), bool(hwc))
+        if optional:
+            # an eager call's staging counts towards the eviction interval too: with graph_batches off nothing
+            # else advances the counter and the first replacement would otherwise block every later one (ADVICE r5)
+            self._batches += 1
         frames = self.frame_sets.get(skey)
         if frames is not None and frames.capacity >= n:
             self.frame_sets.move_to_end(skey)
@@ -284,6 +316,12 @@ class GraphCache:
         if self._set_needs_eviction(n, skey):
             if optional and not self._eviction_allowed():
                 return None
+            if optional:
+                # the set that would go: this size's own (too small) or the least recently used one.  Graphs that
+                # read it would go with it -- for a call that replays none of them: take the plain upload instead
+                victim = frames if frames is not None else self.frame_sets[next(iter(self.frame_sets))]
+                if any(g.frames is victim for g in self.graphs.values()):
+                    return None
             self._last_eviction_at = self._batches
         if frames is not None:       # more frames than the set has room for: a larger one takes its place
             self._drop_frame_set(skey)

@@ -303,7 +303,10 @@ def head_auto_choice(C, J, D, H, W, channels_last=False, dtype=torch.float32):
     A static table over (dtype, layout, C, H, W, J, D) read off the committed sweeps
     (profiles/*_fused_vs_library.txt, *_head_sweep.jsonl, r05c_f32_depth_sweep_fused_vs_library.jsonl) -- the
     batch size is deliberately NOT an input: a slice of a sharded batch, another rank and another process all
-    take the path of the whole batch.
+    take the path of the whole batch.  (INSIDE the fused path the library's launch plan may pick another kernel
+    VARIANT by launch size -- f32 tile blocks, the 16-bit weights-in-registers kernel at >= 512 crops -- every one
+    of which is bit-identical to the others on the same crop: tests/test_gpu_head.py asserts `torch.equal`
+    across every dispatch choice, the default one at B = 512 against launches of 64 included.)
     The fused kernels are ahead on every shipped configuration (8x8 / 12x12 maps, 8 depth bins, 17 - 122
     joints, f32 / f16 / bf16); the library pair is kept for
       * 16-bit features on maps of more than 256 positions (the 16-bit row-tile kernel there is behind

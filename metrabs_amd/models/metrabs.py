@@ -5,6 +5,7 @@ the fused 1x1-projection GEMM + soft-argmax decode (csrc/head_fused.hip) or, wit
 ``fused=False``, a library GEMM for the 1x1 conv followed by the HIP decode kernel
 (csrc/decode.hip).  There is no CPU path."""
 import os
+import threading
 
 import numpy as np
 import torch
@@ -197,6 +198,33 @@ def load_affine_weights(spec):
     return w1, w2
 
 
+class _deterministic_convolutions:
+    """torch.backends.cudnn.deterministic = True for as long as ANY thread of the process is inside a pinned
+    backbone call.  The flag is process-global: a plain `cudnn.flags(...)` per forward lets thread A's exit
+    switch it off under thread B's running backbone.  A lock-protected depth counter: the first
+    pinned call to enter saves the caller's setting and sets the flag, the last one to leave restores it; a
+    user who set the flag themselves keeps it (restore puts back what was found)."""
+    _lock = threading.Lock()
+    _depth = 0
+    _found = False
+
+    def __enter__(self):
+        cls = _deterministic_convolutions
+        with cls._lock:
+            if cls._depth == 0:
+                cls._found = torch.backends.cudnn.deterministic
+                torch.backends.cudnn.deterministic = True
+            cls._depth += 1
+
+    def __exit__(self, *exc):
+        cls = _deterministic_convolutions
+        with cls._lock:
+            cls._depth -= 1
+            if cls._depth == 0:
+                torch.backends.cudnn.deterministic = cls._found
+        return False
+
+
 class Metrabs(torch.nn.Module):
     """models/metrabs.py:15-64 (TF twin metrabs_tf/models/metrabs.py:16-87), the affine-latent options
     included: with ``affine_weights`` the head predicts ``n_latents`` latent points
@@ -293,17 +321,35 @@ class Metrabs(torch.nn.Module):
         return bool(self.autocast_dtype is None if d is None else d)
 
     def _run_backbone(self, image):
-        if self.backbone_is_pinned() and image.is_cuda and not torch.backends.cudnn.deterministic:
-            cudnn = torch.backends.cudnn
-            with cudnn.flags(enabled=cudnn.enabled, benchmark=cudnn.benchmark, deterministic=True,
-                             allow_tf32=cudnn.allow_tf32):
+        if self.backbone_is_pinned() and image.is_cuda:
+            with _deterministic_convolutions():
                 return self.backbone(image)
         return self.backbone(image)
 
-    def forward(self, inp):
+    def predict_multi(self, image, intrinsic_matrix):
+        """The bare-bones crop-model entry of the TF twin (metrabs_tf/models/metrabs.py:71-78,
+        docs/INFERENCE.md:112-132): ``image`` float16 [N, res, res, 3] -- crops the caller made itself,
+        principal point at the crop centre --, ``intrinsic_matrix`` float32 [N, 3, 3] -> poses3d float32
+        [N, J, 3] in the crop camera's frame (mm).  The TF signature is strict about both dtypes and so is
+        this one.  The interleaved crops are handed to the backbone as the NCHW VIEW of the same memory
+        (torch channels_last: no layout copy), the crop model runs under 16-bit autocast (the exported TF
+        model's mixed_float16 policy; `autocast_dtype` if the model names one) and the head consumes the
+        NHWC 16-bit features in place."""
+        if image.dtype != torch.float16 or image.dim() != 4 or image.shape[-1] != 3:
+            raise TypeError(f'predict_multi: image must be float16 [N, H, W, 3], got {image.dtype} '
+                            f'{tuple(image.shape)}')
+        if intrinsic_matrix.dtype != torch.float32 or tuple(intrinsic_matrix.shape) != (image.shape[0], 3, 3):
+            raise TypeError(f'predict_multi: intrinsic_matrix must be float32 [{image.shape[0]}, 3, 3], got '
+                            f'{intrinsic_matrix.dtype} {tuple(intrinsic_matrix.shape)}')
+        kernels.require_cuda(image, intrinsic_matrix)
+        crops = image.contiguous().permute(0, 3, 1, 2)   # [N, 3, H, W] over NHWC memory
+        return self.forward((crops, intrinsic_matrix), autocast_dtype=self.autocast_dtype or torch.float16)
+
+    def forward(self, inp, autocast_dtype=None):
         image, intrinsics = inp
-        if self.autocast_dtype is not None:
-            with torch.autocast('cuda', dtype=self.autocast_dtype):
+        autocast_dtype = self.autocast_dtype if autocast_dtype is None else autocast_dtype
+        if autocast_dtype is not None:
+            with torch.autocast('cuda', dtype=autocast_dtype):
                 features = self._run_backbone(image)
         else:
             features = self._run_backbone(image)

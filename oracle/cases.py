@@ -442,6 +442,71 @@ def tiny_head_weights(c_in, n_points, depth, seed, gain=6.0):
     return w * gain, b * gain
 
 
+class PlausiblePoseBackbone(torch.nn.Module):
+    """Stand-in backbone whose features, under the head of `plausible_pose_model`, describe a person
+    filling most of the crop 1.5 - 4 m away -- for estimator tests that compare two EXECUTION ORDERS
+    of the same crops (ranks, slices, graphs) and must not sit on the x / z singularity a random head
+    produces (tests/test_gpu_sharded_estimator.py).
+
+    The pose is a function of the CROP alone: twelve colour statistics of the crop (quadrant means per
+    channel, float64, quantised to 2^-12 so that a reduction-order difference cannot move them) perturb
+    a fixed base pose; the target logits are consistent_head_case's Gaussian bumps; the head is an
+    matrix Q [N, C] of orthonormal rows (C = 160 >= N channels), so features = Q^T (target - bias),
+    evaluated in float64 and rounded to float32 once: a crop's features do not depend on the batch it
+    travels in."""
+
+    def __init__(self, n_joints, depth, hw, seed, channels=160, amp=6.0, spread=0.18, zoom=1.5):
+        super().__init__()
+        g = gen(seed)
+        n = n_joints * (1 + depth)
+        assert channels >= n
+        q, _ = torch.linalg.qr(torch.randn(channels, n, generator=g, dtype=torch.float64))
+        self.n_joints, self.depth, self.hw, self.amp, self.spread, self.zoom = n_joints, depth, hw, amp, spread, zoom
+        self.out_channels = channels
+        self.register_buffer('q', q.T.contiguous())                                       # head weight [N, C]
+        self.register_buffer('bias', (torch.rand(n, generator=g, dtype=torch.float64) * 2 - 1) * 0.05)
+        base = (torch.randn(n_joints, 3, generator=g, dtype=torch.float64) *
+                torch.tensor([0.13, 0.17, 0.12], dtype=torch.float64)).clamp(-0.25, 0.25)
+        self.register_buffer('base', base)
+        self.register_buffer('mix', torch.randn(12, n_joints * 3, generator=g, dtype=torch.float64))
+
+    def head_parameters(self):
+        return self.q.float(), self.bias.float()
+
+    def forward(self, image):
+        B, J, D, hw = image.shape[0], self.n_joints, self.depth, self.hw
+        x = image.double()
+        h2, w2 = x.shape[2] // 2, x.shape[3] // 2
+        stats = torch.stack([x[:, :, :h2, :w2].mean((2, 3)), x[:, :, :h2, w2:].mean((2, 3)),
+                             x[:, :, h2:, :w2].mean((2, 3)), x[:, :, h2:, w2:].mean((2, 3))], dim=2).reshape(B, 12)
+        stats = torch.round(stats * 4096) / 4096
+        rel = (self.base[None] + 0.06 * torch.tanh(3 * (stats - 0.3) @ self.mix).reshape(B, J, 3)).clamp(-0.3, 0.3)
+        u3 = 0.5 + rel
+        u2 = 0.5 + self.zoom * rel[..., :2] / (1.0 + 0.5 * rel[..., 2:])
+        gx = torch.linspace(0, 1, hw, dtype=torch.float64, device=x.device)
+        gz = torch.linspace(0, 1, D, dtype=torch.float64, device=x.device)
+        s2 = 2 * self.spread * self.spread
+        d2 = ((gx[None, None, None, :] - u2[..., 0, None, None]) ** 2 +
+              (gx[None, None, :, None] - u2[..., 1, None, None]) ** 2)
+        l2 = self.amp * torch.exp(-d2 / s2)
+        d3 = ((gx[None, None, None, None, :] - u3[..., 0, None, None, None]) ** 2 +
+              (gx[None, None, None, :, None] - u3[..., 1, None, None, None]) ** 2 +
+              (gz[None, None, :, None, None] - u3[..., 2, None, None, None]) ** 2)
+        l3 = self.amp * torch.exp(-d3 / s2)
+        target = torch.cat([l2, l3.permute(0, 2, 1, 3, 4).reshape(B, D * J, hw, hw)], dim=1)
+        target = target - self.bias[None, :, None, None]
+        feat = torch.einsum('nc,bnp->bcp', self.q, target.reshape(B, -1, hw * hw))
+        return feat.reshape(B, -1, hw, hw).float()
+
+
+def with_plausible_pose_model(case, seed=977):
+    """An e2e_case whose crop model is PlausiblePoseBackbone + its orthonormal-row head (C = 160 channels)."""
+    cfg = case['cfg']
+    bb = PlausiblePoseBackbone(17, cfg.depth, cfg.proc_side // cfg.stride_test, seed)
+    w, b = bb.head_parameters()
+    return dict(case, backbone=bb, head_w=w, head_b=b, C=bb.out_channels)
+
+
 E2E_CASES = {
     # res 64 keeps the golden crops small; geometry/TTA/post-processing code paths are identical.
     'aug1': dict(seed=401, n_images=2, imh=120, imw=160, res=64, num_aug=1, aa=1, dist=None,

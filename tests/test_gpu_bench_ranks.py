@@ -86,3 +86,50 @@ def test_gpus_2_strong_scaling_line(hip_lib):
     assert len(two['multi_gpu']['per_rank_ms_per_step']) == 2
     assert two['value'] > 0
     keep('bench_gpus2_shared_device_config2.json', two)
+
+
+@pytest.mark.parametrize('config, global_batch, scaling', [(1, 8 * 64, 'weak'), (2, 256, 'strong')])
+def test_gpus_8_line_with_the_full_analysis(hip_lib, config, global_batch, scaling):
+    """The command the driver's 8-GPU run issues (VERDICT r5 next #4a), all eight ranks on cuda:0 over gloo:
+    self-spawn of 8 ranks, rank binding, sharding, barrier + max-over-ranks timing, the gather, and -- NOT
+    --quick -- rank 0's whole post-timing analysis while seven ranks wait at the final barrier.  The line must
+    carry a roofline object and no `<probe>_error` key."""
+    flags = ['--gpus', '8', '--steps', '3', '--warmup', '1']
+    if config != 1:
+        flags += ['--config', str(config)]
+    r, line, lines = run_bench(*flags, timeout=1500)
+    assert r.returncode == 0 and line is not None, r.stderr[-3000:]
+    assert len(lines) == 1, 'only rank 0 prints the line'
+    assert CONTRACT_KEYS <= set(line)
+    assert line['n_gpus'] == 8 and line['scaling'] == scaling
+    assert line['config']['global_batch'] == global_batch
+    m = line['multi_gpu']
+    assert len(m['per_rank_ms_per_step']) == 8 and m['world_size'] == 8
+    assert abs(max(m['per_rank_ms_per_step']) - line['ms_per_step']) < 1e-2
+    assert line['value'] > 0 and abs(line['value'] - global_batch / line['ms_per_step'] * 1e3) < 1e-6 * line['value'] + 1e-3
+    assert line['roofline'] is not None and 0 < line['roofline']['frac'] < 1
+    assert line['cpu_baseline'] is None   # (rank 0 at N = 1 only)
+    errors = {k: v for k, v in line.items() if k.endswith('_error')}
+    assert not errors, errors
+    keep(f'bench_gpus8_shared_device_config{config}.json', line)
+
+
+def test_a_failing_probe_does_not_lose_the_line(hip_lib):
+    """every probe of the post-timing analysis is guarded.  MTR_BENCH_FAIL_PROBE makes the named
+    probes raise; the contract line still comes out, with roofline / cpu_baseline computed (they run first) and the
+    failures named."""
+    env_before = os.environ.get('MTR_BENCH_FAIL_PROBE')
+    os.environ['MTR_BENCH_FAIL_PROBE'] = 'parity,pcie_inclusive,detector_pre'
+    try:
+        r, line, _ = run_bench('--steps', '3', '--warmup', '1', '--no-pmc', '--no-depth72', '--no-api-path',
+                               '--no-decode-roofline', '--cpu-seconds', '2', shared=False, timeout=900)
+    finally:
+        if env_before is None:
+            os.environ.pop('MTR_BENCH_FAIL_PROBE')
+        else:
+            os.environ['MTR_BENCH_FAIL_PROBE'] = env_before
+    assert r.returncode == 0 and line is not None, r.stderr[-3000:]
+    assert CONTRACT_KEYS <= set(line)
+    assert line['roofline'] is not None and line['cpu_baseline'] is not None
+    assert {'parity_error', 'pcie_inclusive_error', 'detector_pre_error'} <= set(line)
+    assert line['parity'] is None

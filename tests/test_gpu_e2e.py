@@ -32,7 +32,7 @@ def build_estimator(case, fused_head):
     from metrabs_amd.multiperson.multiperson_model import Pose3dEstimator
     cfg = MetrabsConfig.from_any(case['cfg'].as_dict())
     ji = JointInfo(cases.COCO17, cases.COCO17_EDGES)
-    model = Metrabs(case['backbone'], ji, cfg, in_channels=cases.E2E_C, fused_head=fused_head)
+    model = Metrabs(case['backbone'], ji, cfg, in_channels=case.get('C', cases.E2E_C), fused_head=fused_head)
     with torch.no_grad():
         model.heatmap_heads.conv_final.weight.copy_(case['head_w'][:, :, None, None])
         model.heatmap_heads.conv_final.bias.copy_(case['head_b'])

@@ -155,6 +155,32 @@ def test_resident_weights_kernel_gives_the_same_bits(shape, dtype, hip_lib):
 
 
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_default_dispatch_of_large_16bit_launches_gives_the_small_launch_bits(dtype, hip_lib):
+    """ The library's DEFAULT 16-bit kernel depends on the launch size: >= 512 crops of >= 8 joint groups
+    on five column tiles take head_fused16areg_kernel (weights in registers), fewer crops the early-copies LDS
+    kernel.  `head_auto_choice` promises that a slice, a rank and the whole batch give the same bits, which here
+    rests on the two kernels being bit-identical: B = 512, J = 122, 12x12, default options, both layouts -- the
+    plan names kernel 15 and every crop equals the same crop computed in launches of 64 (kernel 14)."""
+    from metrabs_amd import _lib, kernels
+    B, C, J, D, H, W = 512, 1280, 122, 8, 12, 12
+    cfg = cpu_ref.HeadConfig(depth=D, proc_side=384)
+    g = cases.gen(8642)
+    feat = torch.randn(B, C, H, W, generator=g).to(dtype).cuda()
+    w, b = cases.default_conv_init(J * (1 + D), C, g)
+    packed = kernels.head_pack_weights((w * 3).cuda(), (b * 3).cuda(), J, D, dtype)
+    for f in (feat, feat.contiguous(memory_format=torch.channels_last)):
+        nhwc = f is not feat
+        assert kernels.head_plan(B, C, H, W, J, D, dtype, nhwc)['kernel'] == _lib.HEAD_KERNEL_NAMES[15]
+        assert kernels.head_plan(64, C, H, W, J, D, dtype, nhwc)['kernel'] == _lib.HEAD_KERNEL_NAMES[14]
+        big = kernels.head_fused(f, packed, C, J, mcfg(cfg))
+        assert torch.isfinite(big[1]).all()
+        for start in range(0, B, 64):
+            small = kernels.head_fused(f[start:start + 64], packed, C, J, mcfg(cfg))
+            assert torch.equal(small[0], big[0][start:start + 64]) and torch.equal(small[1], big[1][start:start + 64]), \
+                (dtype, nhwc, start)
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('shape', [(3, 40, 17, 8, 8, 8), (2, 24, 5, 8, 4, 4), (2, 136, 17, 8, 12, 12),
                                    (1, 64, 3, 8, 16, 16), (2, 96, 30, 4, 10, 10), (9, 32, 1, 8, 8, 8),
                                    (2, 100, 7, 8, 2, 8), (3, 72, 17, 8, 6, 6), (2, 33, 9, 8, 8, 12),

@@ -146,3 +146,48 @@ def test_empty_ranges_and_disabled_cache(cache):
     images = torch.zeros(2, 3, 8, 8, dtype=torch.uint8)
     assert cache.plan_call(images, [(3, 3)], TTA, 1, POST) is None    # an empty slice is never a graph
     assert cache.stats['captures'] == 0
+
+
+def test_eager_staging_advances_the_eviction_interval_on_its_own(cache):
+    """ graph_batches off + pinned host frames: only frame_set(optional=True) runs.  The first
+    replacement must not block every later one: each staging call counts as a batch of the interval."""
+    dev = torch.device('cpu')
+    a = cache.frame_set(2, 8, 8, dev, optional=True)
+    assert a is not None
+    b = cache.frame_set(2, 16, 16, dev, optional=True)      # the first replacement is free
+    assert b is not None and len(cache.frame_sets) == 1
+    got = [cache.frame_set(2, 8, 8, dev, optional=True) for _ in range(6)]
+    assert got[0] is None                                    # inside the interval: plain upload
+    assert any(g is not None for g in got)                   # ... and allowed again once 5 staging calls went by
+
+
+def test_eager_staging_never_drops_a_frame_set_that_live_graphs_read(cache):
+    """ an eager call replays no graph: its staging takes the plain upload rather than replacing (or
+    growing) a frame set captured graphs read."""
+    cache.est.graph_batches = True
+    assert call(cache, 4, hw=8) == 'capture'
+    dev = torch.device('cpu')
+    for _ in range(8):                                       # (well past the eviction interval)
+        assert cache.frame_set(2, 16, 16, dev, optional=True) is None     # would push out the 8x8 set (LRU)
+        assert cache.frame_set(5, 8, 8, dev, optional=True) is None       # would grow, i.e. replace, the 8x8 set
+    assert len(cache.graphs) == 1 and cache.stats['evictions'] == 0
+    assert cache.frame_set(2, 8, 8, dev, optional=True) is next(iter(cache.frame_sets.values()))
+    assert call(cache, 4, hw=8) == 'replay'
+
+
+def test_backbone_fingerprint_sees_the_backbone_alone_being_cast_moved_or_replaced():
+    """ Metrabs._apply only sees .half() / .to() on the WHOLE crop model; a graph must also go stale when
+    the backbone alone changes storage."""
+    bb = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 1), torch.nn.ReLU(), torch.nn.Sequential(torch.nn.Conv2d(4, 4, 1), torch.nn.ReLU()))
+    model = types.SimpleNamespace(backbone=bb)
+    fp = graph_cache.backbone_fingerprint(model)
+    assert fp == graph_cache.backbone_fingerprint(model)
+    assert graph_cache._last_parameter(bb) is list(bb.parameters())[-1]
+    bb.half()
+    fp16 = graph_cache.backbone_fingerprint(model)
+    assert fp16 != fp
+    bb[2][0] = torch.nn.Conv2d(4, 4, 1).half()              # the last layer replaced
+    assert graph_cache.backbone_fingerprint(model) != fp16
+    model.backbone = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 1))
+    assert graph_cache.backbone_fingerprint(model)[0] != fp[0]
+    assert graph_cache.backbone_fingerprint(types.SimpleNamespace(backbone=lambda x: x))   # (a callable stub: its identity)

@@ -345,3 +345,54 @@ def test_head_plan_takes_the_weights_in_registers_kernel_on_large_wide_launches(
     # the blob carries the fragment-major copy of the joint-group weights wherever that kernel exists
     lib = kernels._lib.load()
     assert lib.mtr_head_packed_bytes(1280, 122, 8, 1) - lib.mtr_head_packed_bytes(1288, 122, 8, 1) > 18 * 20 * 8192
+
+
+def test_the_determinism_pin_is_held_while_any_thread_is_inside_a_backbone_call():
+    """ torch.backends.cudnn.deterministic is process-global: the pin is a lock-protected depth counter,
+    so one thread leaving its backbone call cannot switch the flag off under another thread's running call, and
+    the caller's own setting is what comes back at the end."""
+    import threading
+    from metrabs_amd.models.metrabs import _deterministic_convolutions as pin
+    before = torch.backends.cudnn.deterministic
+    try:
+        for found in (False, True):
+            torch.backends.cudnn.deterministic = found
+            inside_a, release_a, seen = threading.Event(), threading.Event(), {}
+
+            def thread_a():
+                with pin():
+                    inside_a.set()
+                    release_a.wait(10)
+                    seen['a_at_exit'] = torch.backends.cudnn.deterministic
+
+            t = threading.Thread(target=thread_a)
+            t.start()
+            assert inside_a.wait(10)
+            with pin():   # thread B enters and leaves while A is still inside
+                assert torch.backends.cudnn.deterministic
+            assert torch.backends.cudnn.deterministic, 'B leaving must not unpin A'
+            release_a.set()
+            t.join(10)
+            assert seen['a_at_exit'] is True
+            assert torch.backends.cudnn.deterministic is found   # the caller's own setting is back
+    finally:
+        torch.backends.cudnn.deterministic = before
+
+
+def test_predict_multi_is_strict_about_the_tf_signature():
+    """metrabs_tf/models/metrabs.py:71-73: float16 [N, H, W, 3] crops and float32 [N, 3, 3] intrinsics; anything
+    else is a TypeError (tf.function's input_signature), CPU tensors are rejected like everywhere (no fallback)."""
+    from metrabs_amd.joint_info import JointInfo
+    from metrabs_amd.models.metrabs import Metrabs
+    m = Metrabs(torch.nn.Identity(), JointInfo(cases.COCO17, cases.COCO17_EDGES), in_channels=8)
+    K = torch.eye(3)[None].repeat(2, 1, 1)
+    with pytest.raises(TypeError):
+        m.predict_multi(torch.zeros(2, 64, 64, 3), K)                       # f32 crops
+    with pytest.raises(TypeError):
+        m.predict_multi(torch.zeros(2, 3, 64, 64, dtype=torch.float16), K)  # NCHW crops
+    with pytest.raises(TypeError):
+        m.predict_multi(torch.zeros(2, 64, 64, 3, dtype=torch.float16), K.double())
+    with pytest.raises(TypeError):
+        m.predict_multi(torch.zeros(2, 64, 64, 3, dtype=torch.float16), K[:1])
+    with pytest.raises((RuntimeError, ValueError, TypeError)):              # CPU tensors: no CPU path
+        m.predict_multi(torch.zeros(2, 64, 64, 3, dtype=torch.float16), K)
