@@ -155,6 +155,10 @@ typedef struct mtr_head_options {
                                       library's choice on every shape of profiles/r05y_* -- its decode epilogue
                                       has no second workgroup's K loop to hide behind; kept for A/B runs;
                                       elsewhere: as -1),
+                                      6 = eight waves in two alternating halves (round 6, head_pp.hip: four joint
+                                      groups per workgroup; one half multiplies a 64-channel stage while the other
+                                      issues the next stage's copies; C % 64 == 0, 3 - 5 column tiles; same bits;
+                                      elsewhere: as -1),
                                       -1 = library's choice (NB: a zeroed struct selects registers) */
   int32_t rt_column_blocks;        /* f32, maps of > 64 positions: 64-position column blocks per workgroup
                                       tile, 2..4 (one K loop for all of them); 1 = one K loop per column
@@ -205,6 +209,8 @@ enum {
   MTR_HEAD_KERNEL_16_AREG = 15,  /* head_fused16areg_kernel: weights in registers, a wave per joint group (dma_staging 4;
                                     the library's choice for >= 512 crops of >= 8 joint groups on 5 column tiles)  */
   MTR_HEAD_KERNEL_16_RES = 16,   /* head_fused16res_kernel: weights RESIDENT in registers, persistent workgroups (dma_staging 5) */
+  MTR_HEAD_KERNEL_16_PP = 17,    /* head_fused16pp_kernel: eight waves in two alternating halves, four joint groups per
+                                    workgroup (dma_staging 6; round 6)                                        */
   MTR_HEAD_KERNEL_16_RT = 12     /* head_rt16_kernel: 16-bit features on the row-tile core (1 + D > 64 rows per
                                     joint, or maps of more than 256 positions); NCHW features: needs the
                                     workspace (one transposing pass in front)                              */

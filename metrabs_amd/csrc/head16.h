@@ -231,4 +231,11 @@ int head16_res_launch(int feat_dtype, int layout, const void* feat, const float*
                       int H, int W, int J, int D, const HeadGeom& g, const HeadScale& hs, float* c2d, float* c3d,
                       hipStream_t stream);
 
+// head_pp.hip (round 6): eight waves in two alternating halves -- one half multiplies a stage while the other issues
+// the next stage's copies; four joint groups per workgroup; C % 64 == 0, 3 - 5 column tiles.  Reads the row-major blob.
+constexpr int kPpGroupsPerWorkgroup = 4;
+bool head16_pp_supported(int C, int H, int W, int layout);
+int head16_pp_launch(int feat_dtype, int layout, const void* feat, const float* packed, int B, int C, int H, int W,
+                     int J, int D, const HeadGeom& g, const HeadScale& hs, float* c2d, float* c3d, hipStream_t stream);
+
 }  // namespace mtr

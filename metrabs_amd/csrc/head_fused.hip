@@ -838,11 +838,21 @@ static bool head16_res_taken(const HeadOpts& opt, int B, int C, int H, int W, in
   return opt.dma == 5;
 }
 
+// The two-halves kernel (head_pp.hip).  dma_staging 6 forces it.
+static bool head16_pp_taken(const HeadOpts& opt, int B, int C, int H, int W, int layout, const HeadGeom& g) {
+  (void)B; (void)g;
+  if (!head16_pp_supported(C, H, W, layout)) return false;
+  return opt.dma == 6;
+}
+
 template <typename FeatT, int CT, bool NHWC>
 static int dispatch_head16(const void* feat, const float* packed, int B, int C, int H, int W, int J,
                            int D, const HeadGeom& g, const HeadScale& hs, float* c2d, float* c3d,
                            const HeadOpts& opt, hipStream_t stream) {
   constexpr int kMaxGpw = CT <= 2 ? 3 : (CT <= 6 ? 2 : 1);
+  if (head16_pp_taken(opt, B, C, H, W, NHWC ? MTR_NHWC : MTR_NCHW, g))   // eight waves, two alternating halves
+    return head16_pp_launch(std::is_same<FeatT, __half>::value ? MTR_F16 : MTR_BF16, NHWC ? MTR_NHWC : MTR_NCHW, feat,
+                            packed, B, C, H, W, J, D, g, hs, c2d, c3d, stream);
   if (head16_res_taken(opt, B, C, H, W, NHWC ? MTR_NHWC : MTR_NCHW, g))  // weights resident, persistent workgroups
     return head16_res_launch(std::is_same<FeatT, __half>::value ? MTR_F16 : MTR_BF16, NHWC ? MTR_NHWC : MTR_NCHW,
                              feat, packed, (const char*)packed + h16_frag_offset(C, J, D), B, C, H, W, J, D, g, hs,
@@ -1002,7 +1012,7 @@ static int parse_head_options(const mtr_head_options* caller, mtr::HeadOpts& opt
   const mtr_head_options* options = &mine;
   if (options->rt_tiles_per_workgroup < 0 || options->rt_tiles_per_workgroup > 5 ||
       options->groups_per_workgroup < 0 || options->groups_per_workgroup > 4 ||
-      options->dma_staging < -1 || options->dma_staging > 5 ||
+      options->dma_staging < -1 || options->dma_staging > 6 ||
       options->rt_column_blocks < 0 || options->rt_column_blocks > 4 ||
       options->rt_k_groups < 0 || options->rt_k_groups > 2 ||
       options->rt_loader < 0 || options->rt_loader > 2 ||
@@ -1046,6 +1056,12 @@ extern "C" int mtr_head_plan(int feat_dtype, int layout, int B, int C, int H, in
   const mtr::HeadGeom g = mtr::head_geom(J, D);
   int ct = (H * W + 31) / 32;
   if (ct == 7) ct = 8;
+  if (mtr::head16_pp_taken(opt, B, C, H, W, layout, g)) {
+    plan->kernel = MTR_HEAD_KERNEL_16_PP;
+    plan->tiles_per_workgroup = mtr::kPpGroupsPerWorkgroup;
+    plan->workgroups = (long long)((B + 7) / 8) * 8 * ((g.n_groups + mtr::kPpGroupsPerWorkgroup - 1) / mtr::kPpGroupsPerWorkgroup);
+    return MTR_OK;
+  }
   if (mtr::head16_res_taken(opt, B, C, H, W, layout, g)) {
     plan->kernel = MTR_HEAD_KERNEL_16_RES;
     plan->tiles_per_workgroup = 2;

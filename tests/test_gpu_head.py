@@ -155,6 +155,36 @@ def test_resident_weights_kernel_gives_the_same_bits(shape, dtype, hip_lib):
 
 
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(9, 1280, 17, 8, 12, 12), (30, 1280, 122, 8, 8, 12), (61, 1280, 24, 8, 10, 10),
+                                   (300, 1280, 40, 8, 12, 12), (5, 128, 122, 8, 12, 12), (3, 64, 30, 8, 12, 12),
+                                   (2, 192, 7, 8, 12, 12), (11, 320, 60, 8, 16, 8), (1, 1280, 122, 8, 12, 12)])
+def test_two_halves_kernel_gives_the_same_bits(shape, dtype, hip_lib):
+    """head_fused16pp_kernel (dma_staging 6, csrc/head_pp.hip; round 6): eight waves, one half multiplies a stage while
+    the other issues the next stage's copies, four joint groups per workgroup.  Workgroups whose second pair of
+    groups is missing or half there (3 groups: one; 18 = 4 x 4 + 2), a single group, one / two / twenty stages,
+    3 / 4 / 5 column tiles, both layouts: the default kernel's bits (the same stages, MFMA order per accumulator and
+    decode)."""
+    from metrabs_amd import _lib, kernels
+    B, C, J, D, H, W = shape
+    cfg = cpu_ref.HeadConfig(depth=D, proc_side=max(H, W) * 8, stride_test=8, stride_train=8)
+    g = cases.gen(8900 + sum(shape))
+    feat = torch.randn(B, C, H, W, generator=g).to(dtype).cuda()
+    w, b = cases.default_conv_init(J * (1 + D), C, g)
+    packed = kernels.head_pack_weights((w * 3).cuda(), (b * 3).cuda(), J, D, dtype)
+    for f in (feat, feat.contiguous(memory_format=torch.channels_last)):
+        nhwc = f is not feat
+        plan = kernels.head_plan(B, C, H, W, J, D, dtype, nhwc, dma_staging=6)
+        # (NCHW rows are copied in whole 16-byte chunks: H*W % 8 == 0; elsewhere the option is the default kernel)
+        assert (plan['kernel'] == _lib.HEAD_KERNEL_NAMES[17]) == (nhwc or (H * W) % 8 == 0), plan
+        base = kernels.head_fused(f, packed, C, J, mcfg(cfg), dma_staging=3)
+        res = kernels.head_fused(f, packed, C, J, mcfg(cfg), dma_staging=6)
+        assert torch.isfinite(base[1]).all()
+        assert torch.equal(res[0], base[0]) and torch.equal(res[1], base[1]), (shape, nhwc, float((res[1] - base[1]).abs().max()))
+        default = kernels.head_fused(f, packed, C, J, mcfg(cfg))
+        assert torch.equal(res[0], default[0]) and torch.equal(res[1], default[1]), (shape, nhwc, 'default')
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 def test_default_dispatch_of_large_16bit_launches_gives_the_small_launch_bits(dtype, hip_lib):
     """ The library's DEFAULT 16-bit kernel depends on the launch size: >= 512 crops of >= 8 joint groups
     on five column tiles take head_fused16areg_kernel (weights in registers), fewer crops the early-copies LDS
@@ -222,7 +252,7 @@ def test_fused_head_16bit_odd_shapes(shape, dtype, hip_lib):
                     dict(dma_staging=4), dict(dma_staging=4, groups_per_workgroup=2),
                     dict(dma_staging=4, groups_per_workgroup=4),
                     # ... and weights RESIDENT in registers, persistent workgroups (C = 1280, 3 - 5 column tiles)
-                    dict(dma_staging=5)):
+                    dict(dma_staging=5), dict(dma_staging=6)):
         # (dma_staging 1 = four waves that copy and multiply, 2 = four MFMA waves + a loader wave)
         v2d, v3d = run_fused(feat, w, b, J, cfg, **options)
         assert torch.equal(v3d, c3d) and torch.equal(v2d, c2d), options
@@ -670,7 +700,7 @@ def test_head_options_are_validated(hip_lib):
     w, b = cases.default_conv_init(153, 64, cases.gen(1))
     packed = kernels.head_pack_weights(w.cuda(), b.cuda(), 17, 8)
     feat = torch.randn(2, 64, 8, 8, device='cuda')
-    for bad in (dict(rt_tiles=6), dict(groups_per_workgroup=5), dict(dma_staging=6), dict(rt_column_blocks=5),
+    for bad in (dict(rt_tiles=6), dict(groups_per_workgroup=5), dict(dma_staging=7), dict(rt_column_blocks=5),
                 dict(rt_k_groups=3), dict(rt_loader=3), dict(rt_split=3)):
         with pytest.raises(RuntimeError):
             kernels.head_fused(feat, packed, 64, 17, MetrabsConfig(), **bad)

@@ -13,10 +13,10 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 
 // every wave copies JPW KiB per stage; DEPTH stages in flight; stage = waves * JPW KiB
 template <int MODE, int JPW, int DEPTH>
-__global__ void ingest(const char* __restrict__ src, size_t per_wg, int stages, float* sink) {
+__global__ void ingest(const char* __restrict__ src, size_t per_wg, size_t stride, int stages, float* sink) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), waves = blockDim.x >> 6;
-  const char* base = src + (size_t)blockIdx.x * per_wg;
+  const char* base = src + (size_t)blockIdx.x * stride;
   {
     const unsigned long long u = (unsigned long long)base;
     base = (const char*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
@@ -61,19 +61,21 @@ __global__ void ingest(const char* __restrict__ src, size_t per_wg, int stages, 
 }
 
 template <int MODE, int JPW, int DEPTH>
-static void run(const char* name, const char* src, size_t per_wg, int threads, int wgs, float* sink) {
+static void run(const char* name, const char* src, size_t per_wg, int threads, int wgs, float* sink, bool shared = false) {
   const int waves = threads / 64, stages = 400;
   const size_t lds = (size_t)DEPTH * waves * JPW * 1024;
   hipFuncSetAttribute((const void*)ingest<MODE, JPW, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   for (int rep = 0; rep < 2; ++rep) {
     hipEventRecord(a);
-    hipLaunchKernelGGL((ingest<MODE, JPW, DEPTH>), dim3(wgs), dim3(threads), lds, 0, src, per_wg, stages, sink);
+    // shared (round 6): every workgroup streams the SAME 640 KB (stride 0) -- all L2 hits after the first touch per XCD:
+    // the L2 -> CU ceiling with every CU pulling, which the private-region runs (Infinity Cache bound) cannot show
+    hipLaunchKernelGGL((ingest<MODE, JPW, DEPTH>), dim3(wgs), dim3(threads), lds, 0, src, per_wg, shared ? (size_t)0 : per_wg, stages, sink);
     hipEventRecord(b); hipEventSynchronize(b);
   }
   float ms; hipEventElapsedTime(&ms, a, b);
   const double bytes = (double)wgs * stages * waves * JPW * 1024;
-  printf("%-34s threads %4d wgs %4d  %7.1f us  %7.1f GB/s per WG  %6.2f TB/s chip\n", name, threads, wgs, ms * 1e3,
+  printf("%-34s %s threads %4d wgs %4d  %7.1f us  %7.1f GB/s per WG  %6.2f TB/s chip\n", name, shared ? "SHARED " : "private", threads, wgs, ms * 1e3,
          bytes / wgs / (ms * 1e-3) / 1e9, bytes / (ms * 1e-3) / 1e12);
 }
 
@@ -89,6 +91,14 @@ int main() {
     run<1, 4, 2>("registers 4 KiB/wave", src, per_wg, 256, wgs, sink);
     run<1, 8, 2>("registers 8 KiB/wave", src, per_wg, 256, wgs, sink);
     run<1, 4, 2>("registers 4 KiB/wave", src, per_wg, 512, wgs, sink);
+  }
+  for (int wgs : {256, 512}) {
+    run<0, 4, 4>("lds-dma  4 KiB/wave depth 4", src, per_wg, 256, wgs, sink, true);
+    run<0, 8, 4>("lds-dma  8 KiB/wave depth 4", src, per_wg, 256, wgs, sink, true);
+    run<0, 4, 4>("lds-dma  4 KiB/wave depth 4", src, per_wg, 512, wgs, sink, true);
+    run<0, 2, 4>("lds-dma  2 KiB/wave depth 4", src, per_wg, 512, wgs, sink, true);
+    run<1, 4, 2>("registers 4 KiB/wave", src, per_wg, 256, wgs, sink, true);
+    run<1, 4, 2>("registers 4 KiB/wave", src, per_wg, 512, wgs, sink, true);
   }
   return 0;
 }
