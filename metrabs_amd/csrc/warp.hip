@@ -671,7 +671,11 @@ struct TapSet {
 // with interleaved channels [N,H,W,3] (what decoders and numpy hand over): there the two x-taps of a
 // row for ALL three channels are six consecutive bytes, so one 12-byte load from the aligned address
 // below them replaces three 8-byte ones -- two gathers per sample instead of six.
-template <typename OutT, int AA, int ROWS, int L0>
+// PERSIST (round 6, developer builds: -DMTR_WARP_PERSIST=<workgroups per CU>): a FIXED grid of workgroups, each
+// walking a contiguous run of (crop, tile) items of its XCD crop-major -- the LUT is filled once per workgroup and
+// a crop's 36 warp-row scalars, descriptors and level choice are set up once per run of its tiles instead of once
+// per 32 x 32 tile.  Same per-sample arithmetic, same bits.
+template <typename OutT, int AA, int ROWS, int L0, bool PERSIST = false>
 __global__ __launch_bounds__(256) void warp_rows_kernel(
     const void* __restrict__ l0_any, const float* __restrict__ l1, const float* __restrict__ l2,
     const float* __restrict__ lut_g, LevelDims dims, unsigned u8_bytes,
@@ -690,9 +694,20 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
   const int x_tiles = (res + LX - 1) / LX;
   const int per_crop = row_tiles * x_tiles;
   const int id = blockIdx.x;
-  const int crop = (id / (8 * per_crop)) * 8 + (id % 8);
-  if (crop >= n_crops) return;
-  const int tile = (id / 8) % per_crop;
+  // items of this workgroup: one (its own tile), or -- PERSIST -- the slot-th run of the items of XCD id % 8, whose
+  // crops are 8 k + id % 8 and whose items are (k, tile) in crop-major order
+  int item = 0, item_end = 1;
+  if constexpr (PERSIST) {
+    const int slots = gridDim.x >> 3, slot = id >> 3;
+    const int total = ((n_crops + 7) >> 3) * per_crop;
+    const int run = (total + slots - 1) / slots;
+    item = slot * run;
+    item_end = min(total, item + run);
+  }
+  for (; item < item_end; ++item) {
+  const int crop = PERSIST ? (item / per_crop) * 8 + (id & 7) : (id / (8 * per_crop)) * 8 + (id % 8);
+  if (crop >= n_crops) continue;
+  const int tile = PERSIST ? item % per_crop : (id / 8) % per_crop;
   const int ty = tile / x_tiles, tx = tile - ty * x_tiles;
 
   const float* __restrict__ wp = wp_all + (size_t)crop * MTR_WARP_PARAM_FLOATS;
@@ -724,7 +739,7 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
 
   const int x = tx * LX + (threadIdx.x & (LX - 1));
   const int v_first = (ty * 4 + (threadIdx.x >> 6)) * ROWS * RI + ((threadIdx.x & 63) / LX);
-  if (x >= res || v_first >= res) return;
+  if (x >= res || v_first >= res) continue;
 #if !MTR_WARP_LEAN
   const float fW = (float)W, fH = (float)H;
 #endif
@@ -941,8 +956,12 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
   } else {
     run(std::false_type{});
   }
+  }  // items
 }
 
+#ifndef MTR_WARP_PERSIST
+#define MTR_WARP_PERSIST 0  // developer builds: workgroups per CU of the persistent launch of warp_rows_kernel (0 = one workgroup per tile)
+#endif
 #ifndef MTR_WARP_ROWS
 #define MTR_WARP_ROWS 4  // rows per wave of warp_rows_kernel; 0 = warp_crops_kernel everywhere
 #endif
@@ -962,9 +981,15 @@ static int launch_warp(const void* l0, const float* l1, const float* l2, const f
     const long long nblocks = (long long)((n_crops + 7) / 8) * 8 * tiles;
     if (nblocks > 0x7fffffffLL) return MTR_E_SHAPE;
     MTR_CLEAR_STALE();
-    hipLaunchKernelGGL((warp_rows_kernel<OutT, AA, ROWS ? ROWS : 1, L0>), dim3((unsigned)nblocks),
-                       dim3(256), 0, stream, l0, l1, l2, lut, dims, u8_bytes, wp, n_crops, res, nhwc,
-                       (OutT*)out);
+    if constexpr (MTR_WARP_PERSIST > 0) {
+      const long long want = 256LL * MTR_WARP_PERSIST;   // (a multiple of 8: whole slots per XCD)
+      hipLaunchKernelGGL((warp_rows_kernel<OutT, AA, ROWS ? ROWS : 1, L0, true>), dim3((unsigned)(nblocks < want ? nblocks : want)),
+                         dim3(256), 0, stream, l0, l1, l2, lut, dims, u8_bytes, wp, n_crops, res, nhwc, (OutT*)out);
+    } else {
+      hipLaunchKernelGGL((warp_rows_kernel<OutT, AA, ROWS ? ROWS : 1, L0>), dim3((unsigned)nblocks),
+                         dim3(256), 0, stream, l0, l1, l2, lut, dims, u8_bytes, wp, n_crops, res, nhwc,
+                         (OutT*)out);
+    }
     MTR_CHECK_LAUNCH();
     return MTR_OK;
   }

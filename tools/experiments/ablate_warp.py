@@ -24,6 +24,10 @@ VARIANTS.update({'px8': ['-DMTR_WARP_PX=8'], 'px8_nostore': ['-DMTR_WARP_PX=8', 
                  'px2_nomem': ['-DMTR_WARP_PX=2', '-DMTR_WARP_ABLATE=15'], 'px8_nomem': ['-DMTR_WARP_PX=8', '-DMTR_WARP_ABLATE=15']})
 VARIANTS.update({f'r{m}': [f'-DMTR_WARP_ABLATE={m}'] for m in (0, 1, 2, 4, 8, 3, 15)})  # the same bits in warp_rows_kernel
 VARIANTS.update({'r0_fat': ['-DMTR_WARP_LEAN=0']})
+# round 6: the persistent launch (workgroups per CU), alone and with longer bands / deeper prefetch per wave
+VARIANTS.update({f'persist{n}': [f'-DMTR_WARP_PERSIST={n}'] for n in (1, 2, 4, 8)})
+VARIANTS.update({'persist4r8': ['-DMTR_WARP_PERSIST=4', '-DMTR_WARP_ROWS=8'], 'persist8pd2': ['-DMTR_WARP_PERSIST=8', '-DMTR_WARP_PREFETCH=2'],
+                 'persist4pd3': ['-DMTR_WARP_PERSIST=4', '-DMTR_WARP_PREFETCH=3']})
 if os.environ.get('ABLATE_ONLY'):
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ['ABLATE_ONLY'].split(',')}
 
@@ -91,8 +95,10 @@ def run_one(mask):
         graph.replay()
     b.record()
     torch.cuda.synchronize()
+    import hashlib
     print(json.dumps({'variant': mask, 'us': round(a.elapsed_time(b) / (n * 10) * 1e3, 1),
-                      'checksum': float(o.double().sum())}), flush=True)
+                      'checksum': float(o.double().sum()),
+                      'sha256_16': hashlib.sha256(o.cpu().numpy().tobytes()).hexdigest()[:16]}), flush=True)
 
 
 if __name__ == '__main__':
