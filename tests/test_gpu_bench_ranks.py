@@ -89,14 +89,14 @@ def test_gpus_2_strong_scaling_line(hip_lib):
 
 
 @pytest.mark.parametrize('config, global_batch, scaling', [(1, 8 * 64, 'weak'), (2, 256, 'strong')])
-def test_gpus_8_line_with_the_full_analysis(hip_lib, config, global_batch, scaling):
+def test_gpus_8_line(hip_lib, config, global_batch, scaling):
     """The command the driver's 8-GPU run issues (VERDICT r5 next #4a), all eight ranks on cuda:0 over gloo:
     self-spawn of 8 ranks, rank binding, sharding, barrier + max-over-ranks timing, the gather, and -- NOT
     --quick -- rank 0's whole post-timing analysis while seven ranks wait at the final barrier.  The line must
     carry a roofline object and no `<probe>_error` key."""
     flags = ['--gpus', '8', '--steps', '3', '--warmup', '1']
     if config != 1:
-        flags += ['--config', str(config)]
+        flags += ['--config', str(config), '--quick']   # (the post-timing analysis at N = 8 is exercised by configs[1])
     r, line, lines = run_bench(*flags, timeout=1500)
     assert r.returncode == 0 and line is not None, r.stderr[-3000:]
     assert len(lines) == 1, 'only rank 0 prints the line'
@@ -107,7 +107,8 @@ def test_gpus_8_line_with_the_full_analysis(hip_lib, config, global_batch, scali
     assert len(m['per_rank_ms_per_step']) == 8 and m['world_size'] == 8
     assert abs(max(m['per_rank_ms_per_step']) - line['ms_per_step']) < 1e-2
     assert line['value'] > 0 and abs(line['value'] - global_batch / line['ms_per_step'] * 1e3) < 1e-6 * line['value'] + 1e-3
-    assert line['roofline'] is not None and 0 < line['roofline']['frac'] < 1
+    if config == 1:
+        assert line['roofline'] is not None and 0 < line['roofline']['frac'] < 1
     assert line['cpu_baseline'] is None   # (rank 0 at N = 1 only)
     errors = {k: v for k, v in line.items() if k.endswith('_error')}
     assert not errors, errors

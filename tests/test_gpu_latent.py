@@ -51,8 +51,14 @@ def test_latent_model_vs_reference_golden_and_oracle(name, fused_head, hip_lib):
     # the north-star bound on the reference's own output and on the oracle; the stored reference is itself
     # up to 8.8e-4 mm MPJPE (2.5e-3 max) from an fp64 evaluation, so ours-vs-fp64 is gated tighter beside it
     floor = float(g['reference_vs_fp64_mpjpe_mm'])
-    assert cpu_ref.mpjpe(ours, ref) <= max(1e-3, 1.5 * floor) and cpu_ref.mpjpe(ours, port) <= max(1e-3, 1.5 * floor)
+    assert cpu_ref.mpjpe(ours, ref) <= max(1e-3, 1.5 * floor)
     assert cpu_ref.mpjpe(ours, truth) <= 5e-4 and e_truth <= 2e-3 and e_ref <= 5e-3
+    # the oracle evaluated HERE, on the GPU box's host: its lstsq / oneDNN path moves with the host and the thread
+    # count (round 6: 1.13e-3 mm from ours in one of three runs of the same commit, the stored reference 3.96e-4 in all
+    # three) -- gated by what it can soundly be: its own distance to the fp64 evaluation plus ours
+    port_floor = cpu_ref.mpjpe(port, truth)
+    print(f'[parity] latent {name}: oracle on this host vs fp64 {port_floor:.2e} mm MPJPE')
+    assert cpu_ref.mpjpe(ours, port) <= port_floor + 5e-4 and port_floor <= 3e-3
 
 
 def test_latent_prefix_of_the_head_is_the_full_heads_slice(hip_lib):
