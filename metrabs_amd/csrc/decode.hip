@@ -343,6 +343,9 @@ static int dispatch_decode(const void* logits, int B, int J, int D, int H, int W
 // per batch  sx += su + w0 s,  sy += h s.  Same running-maximum rule (one f64 rescale per batch that raises
 // it) and the same f64 accumulators as the generic walk: 11 VALU slots per logit instead of ~20 (the generic
 // walk recomputes row and column of every position in every lane and converts both to f64).  Round 5.
+#ifndef MTR_NHWC_PREFETCH
+#define MTR_NHWC_PREFETCH 1   // 0: one batch of loads in flight (the round-5 walk; developer A/B builds)
+#endif
 template <typename T, int U>
 __device__ __forceinline__ void nhwc_walk_rows(const T* __restrict__ x, int ch, int NC, int HW, int W, float& m_out,
                                                double& s_out, double& sx_out, double& sy_out) {
@@ -350,12 +353,23 @@ __device__ __forceinline__ void nhwc_walk_rows(const T* __restrict__ x, int ch, 
   double s = 0.0, sx = 0.0, sy = 0.0;
   int h = 0, w0 = 0;  // (wave-uniform: functions of the loop counter alone)
   const T* xp = x + ch;
+  // Round 6: the NEXT batch's U loads are issued before this batch is summed (two batches = 2 U loads per lane in
+  // flight).  A workgroup walks its crop in HW / U dependent round trips of memory latency; with one batch in flight
+  // the 1.28 GB shape ran at 4.8 TB/s on a full chip of resident workgroups -- Little's law, not arithmetic.
+  // Same values, same order of every sum: the same bits.
+  T raw[U], nxt[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) raw[u] = xp[(size_t)u * NC];
   for (int p0 = 0; p0 < HW; p0 += U) {
+    if (MTR_NHWC_PREFETCH && p0 + U < HW) {  // (uniform)
+#pragma unroll
+      for (int u = 0; u < U; ++u) nxt[u] = xp[(size_t)(p0 + U + u) * NC];
+    }
     float v[U];
     float mb = -INFINITY;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      v[u] = to_f32(xp[(size_t)(p0 + u) * NC]);
+      v[u] = to_f32(raw[u]);
       mb = fmaxf(mb, v[u]);
     }
     if (mb > m) {
@@ -379,6 +393,13 @@ __device__ __forceinline__ void nhwc_walk_rows(const T* __restrict__ x, int ch, 
     sy = fma((double)h, sb, sy);
     w0 += U;
     if (w0 >= W) { w0 = 0; ++h; }
+    if (MTR_NHWC_PREFETCH) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) raw[u] = nxt[u];
+    } else if (p0 + U < HW) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) raw[u] = xp[(size_t)(p0 + U + u) * NC];
+    }
   }
   m_out = m; s_out = s; sx_out = sx; sy_out = sy;
 }

@@ -395,6 +395,9 @@ __global__ __launch_bounds__(256, MTR_H16_MINWAVES) void head_fused16_kernel(
 #ifndef MTR_H16_EARLY_DEFAULT
 #define MTR_H16_EARLY_DEFAULT -1  // -1: the library's rule (head16_early_copies); 0 / 1: force (ablation builds)
 #endif
+#ifndef MTR_H16_FRAG_PIPE
+#define MTR_H16_FRAG_PIPE 0   // 1: explicit fragment double-buffering in the early-copies K loop (see there)
+#endif
 #ifndef MTR_H16_DMA_ABLATE
 #define MTR_H16_DMA_ABLATE 0   // developer-only timing ablations of head_fused16dma_kernel (tools/experiments/
                                // ablate_head16dma.py): 1 = no decode, 2 = no logits store + no decode, 4 = no MFMA,
@@ -602,9 +605,7 @@ __global__ __launch_bounds__(LD ? 320 : 256, EARLY ? 2 : 1) void head_fused16dma
       if (st + 1 < n_st && !(MTR_H16_DMA_ABLATE & 8)) issue_early(st + 1, cur ^ 1);
       const char* Ab = As + cur * A_STAGE;
       const char* Bb = Bs + cur * B_STAGE;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        v4u af[GPW], bf[TPW];
+      auto read_frags = [&](int u, v4u (&af)[GPW], v4u (&bf)[TPW]) {
 #pragma unroll
         for (int q = 0; q < GPW; ++q)
           af[q] = (MTR_H16_DMA_ABLATE & 16) ? v4u{(unsigned)a_off[q], 1u, 2u, (unsigned)st}
@@ -620,13 +621,27 @@ __global__ __launch_bounds__(LD ? 320 : 256, EARLY ? 2 : 1) void head_fused16dma
             bf[t] = lds_read_tr16_pair(p, p + tr_pitch4);
           }
         }
+      };
+      // MTR_H16_FRAG_PIPE (round 6): the fragments of step u + 1 are requested before the MFMAs of step u are issued
+      // (two register sets, scheduling barriers around the MFMA block) instead of leaving the order to the compiler,
+      // which issues each ds_read one or two MFMAs ahead of its use and drains lgkmcnt at every step.  Same MFMAs in
+      // the same order per accumulator.
+      v4u af[MTR_H16_FRAG_PIPE ? 2 : 1][GPW], bf[MTR_H16_FRAG_PIPE ? 2 : 1][TPW];
+      if (MTR_H16_FRAG_PIPE) read_frags(0, af[0], bf[0]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        constexpr int kSets = MTR_H16_FRAG_PIPE ? 2 : 1;
+        if (!MTR_H16_FRAG_PIPE) read_frags(u, af[0], bf[0]);
+        else if (u + 1 < 4) read_frags(u + 1, af[(u + 1) % kSets], bf[(u + 1) % kSets]);
+        if (MTR_H16_FRAG_PIPE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < TPW; ++t)
 #pragma unroll
           for (int q = 0; q < GPW; ++q) {
-            if (MTR_H16_DMA_ABLATE & 4) acc[q][t][0] += __builtin_bit_cast(float, af[q][0] ^ bf[t][0]);
-            else acc[q][t] = Mfma16<FeatT>::run(af[q], bf[t], acc[q][t]);
+            if (MTR_H16_DMA_ABLATE & 4) acc[q][t][0] += __builtin_bit_cast(float, af[u % kSets][q][0] ^ bf[u % kSets][t][0]);
+            else acc[q][t] = Mfma16<FeatT>::run(af[u % kSets][q], bf[u % kSets][t], acc[q][t]);
           }
+        if (MTR_H16_FRAG_PIPE) __builtin_amdgcn_sched_barrier(0);
       }
     }
   } else {

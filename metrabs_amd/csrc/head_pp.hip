@@ -150,30 +150,41 @@ __global__ __launch_bounds__(512, 2) void head_fused16pp_kernel(
 #pragma unroll
   for (int t = 0; t < CT; ++t) acc[t] = f32x16{0};
 
-  auto compute = [&](int st) {   // this wave's 4 CT MFMAs of a stage
+  // this wave's 4 CT MFMAs of a stage.  The fragments of step u + 1 are REQUESTED before the MFMAs of step u are
+  // issued (two register sets; __builtin_amdgcn_sched_barrier keeps the compiler from sinking the reads back down):
+  // left to itself the compiler issued every ds_read one or two MFMAs ahead of its use and drained lgkmcnt at every
+  // step -- 20 MFMAs took ~1,650 cycles of a phase instead of 640 (the first build of this kernel, 200 vs 168 us at
+  // 256 crops; profiles/r06b_head16_pp.jsonl).  Same MFMAs in the same order per accumulator.
+  auto read_frags = [&](const char* Ab, const char* Bb, int u, v4u& af, v4u (&bf)[CT]) {
+    af = (MTR_PP_ABLATE & 16) ? v4u{(unsigned)a_off, 1u, 2u, (unsigned)u}
+                              : *reinterpret_cast<const v4u*>(Ab + (a_off ^ (u << 5)));
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+      if (MTR_PP_ABLATE & 16) {
+        bf[t] = v4u{(unsigned)b_off[t], 1u, 2u, (unsigned)u};
+      } else if constexpr (NHWC) {
+        bf[t] = *reinterpret_cast<const v4u*>(Bb + (b_off[t] ^ (u << 5)));
+      } else {
+        const char* p = Bb + b_off[t] + u * (4 * tr_pitch4);
+        bf[t] = lds_read_tr16_pair(p, p + tr_pitch4);
+      }
+    }
+  };
+  auto compute = [&](int st) {
     const char* Ab = As + (st & 1) * kPpAStage;
     const char* Bb = Bs + (st & 1) * B_STAGE;
+    v4u af[2], bf[2][CT];
+    read_frags(Ab, Bb, 0, af[0], bf[0]);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      v4u af, bf[CT];
-      af = (MTR_PP_ABLATE & 16) ? v4u{(unsigned)a_off, 1u, 2u, (unsigned)st}
-                                : *reinterpret_cast<const v4u*>(Ab + (a_off ^ (u << 5)));
+      if (u + 1 < 4) read_frags(Ab, Bb, u + 1, af[(u + 1) & 1], bf[(u + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < CT; ++t) {
-        if (MTR_PP_ABLATE & 16) {
-          bf[t] = v4u{(unsigned)b_off[t], 1u, 2u, (unsigned)st};
-        } else if constexpr (NHWC) {
-          bf[t] = *reinterpret_cast<const v4u*>(Bb + (b_off[t] ^ (u << 5)));
-        } else {
-          const char* p = Bb + b_off[t] + u * (4 * tr_pitch4);
-          bf[t] = lds_read_tr16_pair(p, p + tr_pitch4);
-        }
+        if (MTR_PP_ABLATE & 4) acc[t][0] += __builtin_bit_cast(float, af[u & 1][0] ^ bf[u & 1][t][0]);
+        else acc[t] = Mfma16<FeatT>::run(af[u & 1], bf[u & 1][t], acc[t]);
       }
-#pragma unroll
-      for (int t = 0; t < CT; ++t) {
-        if (MTR_PP_ABLATE & 4) acc[t][0] += __builtin_bit_cast(float, af[0] ^ bf[t][0]);
-        else acc[t] = Mfma16<FeatT>::run(af, bf[t], acc[t]);
-      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 

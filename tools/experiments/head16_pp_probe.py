@@ -11,6 +11,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from bench import graph_time  # noqa: E402
+if os.environ.get('MTR_PROBE_LIB'):   # a developer build of the library (tools/experiments/variant_lib.py) instead of the product's
+    from metrabs_amd import _lib  # noqa: E402
+    _lib.load(os.environ['MTR_PROBE_LIB'])
 from metrabs_amd import kernels  # noqa: E402
 from metrabs_amd.config import MetrabsConfig  # noqa: E402
 
