@@ -344,7 +344,9 @@ static int dispatch_decode(const void* logits, int B, int J, int D, int H, int W
 // it) and the same f64 accumulators as the generic walk: 11 VALU slots per logit instead of ~20 (the generic
 // walk recomputes row and column of every position in every lane and converts both to f64).  Round 5.
 #ifndef MTR_NHWC_PREFETCH
-#define MTR_NHWC_PREFETCH 1   // 0: one batch of loads in flight (the round-5 walk; developer A/B builds)
+#define MTR_NHWC_PREFETCH 0   // 1: the next batch of loads requested before the current one is summed (round 6: measured SLOWER,
+                              // 288 vs 272 us on the 1.28 GB shape, 308 vs 255 us with 16-bit logits -- profiles/r06c_nhwc_decode_ab.jsonl;
+                              // the walk is not bound by its dependent round trips)
 #endif
 template <typename T, int U>
 __device__ __forceinline__ void nhwc_walk_rows(const T* __restrict__ x, int ch, int NC, int HW, int W, float& m_out,
@@ -353,10 +355,9 @@ __device__ __forceinline__ void nhwc_walk_rows(const T* __restrict__ x, int ch, 
   double s = 0.0, sx = 0.0, sy = 0.0;
   int h = 0, w0 = 0;  // (wave-uniform: functions of the loop counter alone)
   const T* xp = x + ch;
-  // Round 6: the NEXT batch's U loads are issued before this batch is summed (two batches = 2 U loads per lane in
-  // flight).  A workgroup walks its crop in HW / U dependent round trips of memory latency; with one batch in flight
-  // the 1.28 GB shape ran at 4.8 TB/s on a full chip of resident workgroups -- Little's law, not arithmetic.
-  // Same values, same order of every sum: the same bits.
+  // MTR_NHWC_PREFETCH (round 6, a developer option): the NEXT batch's U loads are issued before this batch is summed
+  // (two batches = 2 U loads per lane in flight).  Same values, same order of every sum: the same bits -- and slower
+  // (see the macro): the extra registers cost more resident workgroups than the deeper queue buys.
   T raw[U], nxt[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) raw[u] = xp[(size_t)u * NC];

@@ -33,6 +33,11 @@ constexpr int kPpGroups = kPpGroupsPerWorkgroup;   // joint groups per workgroup
 constexpr int kPpRows = kPpGroups * kRows;         // 256 tile rows
 constexpr int kPpAStage = kPpRows * 128;           // bytes of a weight stage in LDS
 
+#ifndef MTR_PP_TRACE
+#define MTR_PP_TRACE 0    // developer builds (tools/experiments/head16_pp_trace.py): cycle stamps (s_memtime) of the phases of
+                          // every stage, summed per wave; the workgroups whose blockIdx % 293 == 0 write theirs BEHIND the
+                          // launch's coords2d (the probe passes a longer buffer): 128 floats per workgroup, 16 per wave
+#endif
 #ifndef MTR_PP_ABLATE
 #define MTR_PP_ABLATE 0   // developer-only timing ablations (tools/experiments/head16_pp_probe.py): 1 = no decode,
                           // 2 = no logits store + no decode, 4 = no MFMA, 8 = no copies in the K loop, 16 = no fragment reads
@@ -188,29 +193,50 @@ __global__ __launch_bounds__(512, 2) void head_fused16pp_kernel(
     }
   };
 
+#if MTR_PP_TRACE
+  unsigned long long tr_t = __builtin_amdgcn_s_memtime(), tr_start = tr_t;
+  unsigned tr_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define MTR_PP_STAMP(K)                                        \
+  {                                                            \
+    const unsigned long long now = __builtin_amdgcn_s_memtime(); \
+    tr_sum[K] += (unsigned)(now - tr_t);                       \
+    tr_t = now;                                                \
+  }
+#else
+#define MTR_PP_STAMP(K)
+#endif
   __syncthreads();  // zero fill done
   issue(0, 0);      // (X's rows and the features by the Y waves, Y's rows by the X waves: the steady-state shares)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  MTR_PP_STAMP(6)   // prologue: zero fill, addresses, stage 0
   for (int st = 0; st < n_st; ++st) {
     const bool more = st + 1 < n_st && !(MTR_PP_ABLATE & 8);
     // ---- phase 0: X multiplies stage st; Y issues the features and X's rows of stage st + 1 into the other
     // buffer (last read in phase 1 of stage st - 1 by Y, phase 0 by X)
     if (!is_y) {
       compute(st);
+      MTR_PP_STAMP(0)   // X: reads + MFMAs issued;  Y: copies issued
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // Y's rows of stage st (issued in phase 1 of st - 1)
     } else if (more) {
       issue(st + 1, (st + 1) & 1);
+      MTR_PP_STAMP(0)
     }
+    MTR_PP_STAMP(1)     // X: its wait for copies
     __syncthreads();
+    MTR_PP_STAMP(2)     // barrier
     // ---- phase 1: Y multiplies stage st; X issues Y's rows of stage st + 1
     if (is_y) {
       if (y_active) compute(st);
+      MTR_PP_STAMP(3)   // Y: reads + MFMAs issued;  X: copies issued
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // features + X's rows of stage st + 1
     } else if (more) {
       issue(st + 1, (st + 1) & 1);
+      MTR_PP_STAMP(3)
     }
+    MTR_PP_STAMP(4)     // Y: its wait for copies
     __syncthreads();
+    MTR_PP_STAMP(5)     // barrier
   }
 
   // ---- epilogue: two joint groups at a time through LDS [128][HWP] (written by the half that owns them), decoded by
@@ -240,6 +266,17 @@ __global__ __launch_bounds__(512, 2) void head_fused16pp_kernel(
       decode_group_from_lds<false, (CT > 2 ? 4 : 2)>(Ls + (size_t)(wid >> 2) * kRows * HWP, HWP, grp, g, crop, J, D, H, W,
                                                      hs, coords2d, coords3d_rel, wi, lane);
   }
+#if MTR_PP_TRACE
+  MTR_PP_STAMP(7)   // epilogue
+  if (id % 293 == 0 && lane == 0) {
+    float* o = coords2d + (size_t)B * J * 2 + (size_t)(id / 293) * 128 + wid * 16;   // (BEHIND the launch's own outputs)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (float)tr_sum[k];
+    o[8] = (float)(unsigned)(tr_t - tr_start);
+    o[9] = (float)id;
+    o[10] = (float)n_st;
+  }
+#endif
 }
 
 template <int CT>
