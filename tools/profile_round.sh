@@ -3,7 +3,7 @@ set -x
 #   gpurun -- 'bash tools/profile_round.sh r03h'
 # kernel trace of the bench command, the two PMC passes (one counter each, --kernel-trace only) that
 # profiles/traffic.json is reduced from, MFMA counters of the f32 head, micro-benchmarks, bench lines.
-TAG=${1:-r05z}
+TAG=${1:-r06z}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O
