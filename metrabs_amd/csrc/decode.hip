@@ -343,6 +343,9 @@ static int dispatch_decode(const void* logits, int B, int J, int D, int H, int W
 // per batch  sx += su + w0 s,  sy += h s.  Same running-maximum rule (one f64 rescale per batch that raises
 // it) and the same f64 accumulators as the generic walk: 11 VALU slots per logit instead of ~20 (the generic
 // walk recomputes row and column of every position in every lane and converts both to f64).  Round 5.
+#ifndef MTR_NHWC_ONE_KERNEL
+#define MTR_NHWC_ONE_KERNEL 0   // 1 (developer A/B builds): one kernel holding all four row walks, as in round 5
+#endif
 #ifndef MTR_NHWC_PREFETCH
 #define MTR_NHWC_PREFETCH 0   // 1: the next batch of loads requested before the current one is summed (round 6: measured SLOWER,
                               // 288 vs 272 us on the 1.28 GB shape, 308 vs 255 us with 16-bit logits -- profiles/r06c_nhwc_decode_ab.jsonl;
@@ -405,7 +408,10 @@ __device__ __forceinline__ void nhwc_walk_rows(const T* __restrict__ x, int ch, 
   m_out = m; s_out = s; sx_out = sx; sy_out = sy;
 }
 
-template <typename T>
+// RB: the map-row batch this instantiation's factored walk is compiled for (4, 8, 12, 16; 0 = none): one walk per
+// instantiation instead of all four in one kernel (round 6) -- the register allocation of a launch is its own
+// walk's, not the 16-position one's.
+template <typename T, int RB>
 __global__ __launch_bounds__(1024) void decode_nhwc_kernel(const T* __restrict__ logits, int B, int J,
                                                            int D, int H, int W, int splits, HeadScale hs,
                                                            AxisInv ai, float* __restrict__ coords2d,
@@ -426,7 +432,8 @@ __global__ __launch_bounds__(1024) void decode_nhwc_kernel(const T* __restrict__
                         // dependent load per step was the whole 12 us of a 64-crop launch)
   const float rcp_w = __frcp_rn((float)W);
   // (workgroup-uniform) a whole map row per batch for the usual widths, else 8 or 4 positions of a row
-  const int row_batch = G != 1 ? 0 : (W == 12 || W == 16) ? W : (W % 8 == 0 ? 8 : (W % 4 == 0 ? 4 : 0));
+  // (the host instantiates RB by the same rule; RB = -1, developer A/B builds: round 5's one kernel with all four walks)
+  const int row_batch = G != 1 ? 0 : RB >= 0 ? RB : (W == 12 || W == 16) ? W : (W % 8 == 0 ? 8 : (W % 4 == 0 ? 4 : 0));
   for (int t = threadIdx.x; t < G * N; t += blockDim.x) {
     const int n = t % N, g = t / N;
     // local row n = (slice, joint): slice 0 is the 2D row, slice 1 + d the depth slice d
@@ -434,14 +441,20 @@ __global__ __launch_bounds__(1024) void decode_nhwc_kernel(const T* __restrict__
     const int ch = slice == 0 ? j0 + jj : J + (slice - 1) * J + j0 + jj;
     float m = -INFINITY;
     double s = 0.0, sx = 0.0, sy = 0.0;
-    if (row_batch) {
-      if (row_batch == 8) nhwc_walk_rows<T, 8>(x, ch, NC, HW, W, m, s, sx, sy);
-      else if (row_batch == 12) nhwc_walk_rows<T, 12>(x, ch, NC, HW, W, m, s, sx, sy);
-      else if (row_batch == 16) nhwc_walk_rows<T, 16>(x, ch, NC, HW, W, m, s, sx, sy);
-      else nhwc_walk_rows<T, 4>(x, ch, NC, HW, W, m, s, sx, sy);
-      row_m[t] = m;
-      row_s[t * 3 + 0] = s; row_s[t * 3 + 1] = sx; row_s[t * 3 + 2] = sy;
-      continue;
+    if constexpr (RB != 0) {
+      if (row_batch) {
+        if constexpr (RB > 0) {
+          nhwc_walk_rows<T, RB>(x, ch, NC, HW, W, m, s, sx, sy);
+        } else {
+          if (row_batch == 8) nhwc_walk_rows<T, 8>(x, ch, NC, HW, W, m, s, sx, sy);
+          else if (row_batch == 12) nhwc_walk_rows<T, 12>(x, ch, NC, HW, W, m, s, sx, sy);
+          else if (row_batch == 16) nhwc_walk_rows<T, 16>(x, ch, NC, HW, W, m, s, sx, sy);
+          else nhwc_walk_rows<T, 4>(x, ch, NC, HW, W, m, s, sx, sy);
+        }
+        row_m[t] = m;
+        row_s[t * 3 + 0] = s; row_s[t * 3 + 1] = sx; row_s[t * 3 + 2] = sy;
+        continue;
+      }
     }
     for (int p0 = g; p0 < HW; p0 += G * U) {
       float v[U];
@@ -565,7 +578,15 @@ static int launch_decode_nhwc(const void* logits, int B, int J, int D, int H, in
   const long long slots = N <= threads ? (long long)threads : N;
   const size_t lds = (size_t)((slots * 4 + 15) & ~15LL) + (size_t)slots * 24 + (size_t)N * 4;
   if (lds > 160 * 1024 - 256) return MTR_E_SHAPE;  // > 5,800 channels per position
-  auto kern = decode_nhwc_kernel<T>;
+  // a whole map row per batch for the usual widths, else 8 or 4 positions of a row (the kernel's rule)
+  const int rb = (W == 12 || W == 16) ? W : (W % 8 == 0 ? 8 : (W % 4 == 0 ? 4 : 0));
+#if MTR_NHWC_ONE_KERNEL
+  auto kern = decode_nhwc_kernel<T, -1>;
+  (void)rb;
+#else
+  auto kern = rb == 16 ? decode_nhwc_kernel<T, 16> : rb == 12 ? decode_nhwc_kernel<T, 12>
+              : rb == 8 ? decode_nhwc_kernel<T, 8> : rb == 4 ? decode_nhwc_kernel<T, 4> : decode_nhwc_kernel<T, 0>;
+#endif
   if (lds > 64 * 1024) {
     const int rc = allow_dynamic_lds((const void*)kern, lds);
     if (rc != MTR_OK) return rc;

@@ -38,6 +38,9 @@ constexpr int kPpAStage = kPpRows * 128;           // bytes of a weight stage in
                           // every stage, summed per wave; the workgroups whose blockIdx % 293 == 0 write theirs BEHIND the
                           // launch's coords2d (the probe passes a longer buffer): 128 floats per workgroup, 16 per wave
 #endif
+#ifndef MTR_PP_SAMECROP
+#define MTR_PP_SAMECROP 0
+#endif
 #ifndef MTR_PP_ABLATE
 #define MTR_PP_ABLATE 0   // developer-only timing ablations (tools/experiments/head16_pp_probe.py): 1 = no decode,
                           // 2 = no logits store + no decode, 4 = no MFMA, 8 = no copies in the K loop, 16 = no fragment reads
@@ -70,7 +73,11 @@ __global__ __launch_bounds__(512, 2) void head_fused16pp_kernel(
   const int n_st = C / kKH;
   const float* bias = packed;
   const FeatT* w16 = reinterpret_cast<const FeatT*>(packed + (size_t)g.n_groups * kRows);
+#if MTR_PP_SAMECROP   // (developer timing probe: every workgroup reads crop 0's features -- all L2 hits; the poses are garbage)
+  const FeatT* fcrop = feat;
+#else
   const FeatT* fcrop = feat + (size_t)crop * C * HW;
+#endif
   const int fi = lane & 31, fg = lane >> 5;
 
   // NHWC rows of positions >= HW stay zero (masked copy lanes)

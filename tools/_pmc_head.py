@@ -14,6 +14,7 @@ if nhwc:
 w = torch.randn(J * 9, 1280, device='cuda', generator=g) * 0.03
 packed = kernels.head_pack_weights(w, torch.zeros(J * 9, device='cuda'), J, 8, dt)
 cfg = MetrabsConfig(proc_side=side * 32)
+opts = dict(dma_staging=int(os.environ['PMC_DMA'])) if os.environ.get('PMC_DMA') else {}   # (a forced 16-bit kernel variant)
 for _ in range(5):
-    kernels.head_fused(feat, packed, 1280, J, cfg)
+    kernels.head_fused(feat, packed, 1280, J, cfg, **opts)
 torch.cuda.synchronize()

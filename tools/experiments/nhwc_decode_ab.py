@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, 'tools', 'experiments', '_build')
-VARIANTS = {'pf1': [], 'pf0': ['-DMTR_NHWC_PREFETCH=0']}
+VARIANTS = {'per_walk_kernels': [], 'one_kernel_r05': ['-DMTR_NHWC_ONE_KERNEL=1'], 'prefetch': ['-DMTR_NHWC_PREFETCH=1']}
 SHAPES = [(32768, 17, 8, 8), (4096, 17, 8, 8), (256, 17, 8, 8), (2048, 122, 8, 12), (8192, 17, 8, 12), (4096, 17, 8, 16)]
 
 
