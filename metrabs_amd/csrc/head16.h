@@ -208,6 +208,18 @@ __device__ __forceinline__ unsigned lds_byte_addr(const void* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
 
+// NCHW feature tiles keep the memory layout [channel k][HW positions] (rows of n_chunks = HW / 8 sixteen-byte chunks)
+// and are transposed by ds_read_b64_tr_b16.  Chunk j of channel row k sits at chunk (j + nchw_chunk_rot(k)) % n_chunks
+// of the row, so that the FOUR channel rows a 32-lane group of the transposing read touches (k & 3 = 0 .. 3, sixteen
+// dwords each) fall on four different quarters of the 64 banks.  Rows of 18 chunks (12x12 maps; round 6) start 8 banks
+// apart by themselves: a rotation of 2 (k & 3) chunks spreads them 16 apart -- 0, 16, 32, 48.  The first rule,
+// 4 ((k >> 1) & 1), was laid out for 8x8 maps (rows 32 banks apart: 0, 32, 16, 48) and left rows 0 / 1 and 2 / 3 of a
+// 12x12 tile overlapping in 8 banks each: SQ_LDS_BANK_CONFLICT 8.85 M cycles of the kernel's 30.2 M LDS cycles at
+// 256 crops of configs[4] (profiles/r06g_lds_dma3_nchw.md; NHWC tiles: 0).  Only k & 3 matters to a reader lane.
+__device__ __forceinline__ int nchw_chunk_rot(int k, int n_chunks) {
+  return n_chunks == 18 ? (k & 3) << 1 : ((k >> 1) & 1) << 2;
+}
+
 // two transposing 8-byte LDS reads = one 8-channel MFMA operand (semantics: see the kernel)
 __device__ __forceinline__ v4u lds_read_tr16_pair(const char* p0, const char* p1) {
   using trv = __attribute__((ext_vector_type(4))) short;

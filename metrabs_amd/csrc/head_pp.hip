@@ -112,7 +112,7 @@ __global__ __launch_bounds__(512, 2) void head_fused16pp_kernel(
       const int cid = piece * 64 + lane;
       b_on[i] = cid < kKH * n_chunks;
       const int k = b_on[i] ? cid / n_chunks : 0, jl = b_on[i] ? cid - k * n_chunks : 0;
-      const int rot = ((k >> 1) & 1) << 2;
+      const int rot = nchw_chunk_rot(k, n_chunks);
       const int j = jl >= rot ? jl - rot : jl - rot + n_chunks;
       b_src[i] = fcrop + (size_t)k * HW + j * 8;
     }
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(512, 2) void head_fused16pp_kernel(
       const int G = lane >> 4, r = lane & 15, q = r & 3, ci = r >> 2;
       const int P = t * 32 + 16 * (G & 1) + 4 * q;
       const int Pc = P < HW ? P : 0;
-      int jl = (Pc >> 3) + (((ci >> 1) & 1) << 2);
+      int jl = (Pc >> 3) + nchw_chunk_rot(ci, n_chunks);
       jl = jl >= n_chunks ? jl - n_chunks : jl;
       b_off[t] = (8 * fg + ci) * (HW * 2) + jl * 16 + (Pc & 7) * 2;
     }
