@@ -159,6 +159,9 @@ typedef struct mtr_head_options {
                                       groups per workgroup; one half multiplies a 64-channel stage while the other
                                       issues the next stage's copies; C % 64 == 0, 3 - 5 column tiles; same bits;
                                       elsewhere: as -1),
+                                      7 = early copies on a tight feature stage (round 6: H*W positions instead of
+                                      whole 32-position tiles, exactly two stages of LDS; groups_per_workgroup 1
+                                      (default) or 2; H*W % 8 == 0; same bits; elsewhere: as -1),
                                       -1 = library's choice (NB: a zeroed struct selects registers) */
   int32_t rt_column_blocks;        /* f32, maps of > 64 positions: 64-position column blocks per workgroup
                                       tile, 2..4 (one K loop for all of them); 1 = one K loop per column
@@ -211,6 +214,9 @@ enum {
   MTR_HEAD_KERNEL_16_RES = 16,   /* head_fused16res_kernel: weights RESIDENT in registers, persistent workgroups (dma_staging 5) */
   MTR_HEAD_KERNEL_16_PP = 17,    /* head_fused16pp_kernel: eight waves in two alternating halves, four joint groups per
                                     workgroup (dma_staging 6; round 6)                                        */
+  MTR_HEAD_KERNEL_16_DMA_EARLY_TIGHT = 18, /* the early-copies kernel on a feature stage of exactly H*W positions and two stages
+                                    of LDS: one joint group per workgroup = 52 KiB at 12x12, three workgroups per CU (round 6;
+                                    dma_staging 7; the library's choice where its round model says so)          */
   MTR_HEAD_KERNEL_16_RT = 12     /* head_rt16_kernel: 16-bit features on the row-tile core (1 + D > 64 rows per
                                     joint, or maps of more than 256 positions); NCHW features: needs the
                                     workspace (one transposing pass in front)                              */

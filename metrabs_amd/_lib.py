@@ -46,7 +46,8 @@ HEAD_KERNEL_NAMES = {1: 'head_rt_kernel', 2: 'head_rt_ld_kernel', 3: 'head_rt_ks
                      13: 'head_fused16dma_kernel (loader wave)', 14: 'head_fused16dma_kernel (early copies)',
                      15: 'head_fused16areg_kernel (weights in registers)',
                      16: 'head_fused16res_kernel (weights resident, persistent workgroups)',
-                     17: 'head_fused16pp_kernel (two alternating halves)'}
+                     17: 'head_fused16pp_kernel (two alternating halves)',
+                     18: 'head_fused16dma_kernel (early copies, tight stage)'}
 
 
 class ReconParams(ctypes.Structure):

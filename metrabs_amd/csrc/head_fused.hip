@@ -424,7 +424,10 @@ __global__ __launch_bounds__(256, MTR_H16_MINWAVES) void head_fused16_kernel(
 // kernel drops from 228 + 96 registers (one workgroup per CU at 12x12, GPW 2: every phase of the workgroup
 // serialised, the ablations' parts added up to the whole) to two workgroups per CU.  Same stages, same MFMA
 // order per accumulator, same sums: the bits of the other variants.
-template <typename FeatT, int CT, int GPW, bool NHWC, bool LD = false, bool EARLY = false>
+// TIGHT (round 6, EARLY only; dma_staging 7): the feature stage holds the map's H*W positions instead of CT * 32 (12x12:
+// 18 instead of 20 KiB; the reader lanes of the padding columns address a valid row) and the launch asks for exactly two
+// stages -- one joint group per workgroup then needs 52 KiB and THREE workgroups share a CU.
+template <typename FeatT, int CT, int GPW, bool NHWC, bool LD = false, bool EARLY = false, bool TIGHT = false>
 __global__ __launch_bounds__(LD ? 320 : 256, EARLY ? 2 : 1) void head_fused16dma_kernel(
     const FeatT* __restrict__ feat, const float* __restrict__ packed, int B, int C, int H, int W,
     int J, int D, HeadGeom g, HeadScale hs, float* __restrict__ coords2d,
@@ -440,6 +443,7 @@ __global__ __launch_bounds__(LD ? 320 : 256, EARLY ? 2 : 1) void head_fused16dma
   float* Ls = smem;                           // epilogue alias: [64][HWP], one group at a time
 
   const int HW = H * W;
+  const int b_stage = TIGHT ? HW * 128 : B_STAGE;   // bytes of a feature stage in LDS (NHWC: [HW][128 B]; NCHW: [64 ch][HW * 2 B])
   const int wg_per_crop = (g.n_groups + GPW - 1) / GPW;
   const int chunk = 8 * wg_per_crop;
   const int id = blockIdx.x;
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(LD ? 320 : 256, EARLY ? 2 : 1) void head_fused16dma
   const FeatT* w16 = reinterpret_cast<const FeatT*>(packed + (size_t)g.n_groups * kRows);
   const FeatT* fcrop = feat + (size_t)crop * C * HW;
 
-  for (int v = tid; v < 2 * B_STAGE / 16; v += NT)
+  for (int v = tid; v < 2 * b_stage / 16; v += NT)
     reinterpret_cast<v4u*>(Bs)[v] = v4u{0u, 0u, 0u, 0u};
 
   if constexpr (LD) {
@@ -560,7 +564,8 @@ __global__ __launch_bounds__(LD ? 320 : 256, EARLY ? 2 : 1) void head_fused16dma
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
     on[t] = cp + 2 * t < CT;
-    const int pos = (on[t] ? cp + 2 * t : 0) * 32 + fi;
+    const int pos_full = (on[t] ? cp + 2 * t : 0) * 32 + fi;
+    const int pos = TIGHT && pos_full >= HW ? fi : pos_full;   // (TIGHT: the rows behind the map do not exist; any valid row)
     if constexpr (NHWC) {
       b_off[t] = pos * 128 + ((fg ^ swz(pos)) << 4);
     } else {
@@ -594,7 +599,7 @@ __global__ __launch_bounds__(LD ? 320 : 256, EARLY ? 2 : 1) void head_fused16dma
 #pragma unroll
       for (int i = 0; i < CT; ++i)
         if (b_on[i])
-          dma16_to_lds_asm(b_src[i] + (size_t)stage * b_stage_elems, Bs_a + buf * B_STAGE + (i * 4 + wid) * 1024);
+          dma16_to_lds_asm(b_src[i] + (size_t)stage * b_stage_elems, Bs_a + buf * b_stage + (i * 4 + wid) * 1024);
     };
     __syncthreads();  // zero fill done
     issue_early(0, 0);
@@ -604,7 +609,7 @@ __global__ __launch_bounds__(LD ? 320 : 256, EARLY ? 2 : 1) void head_fused16dma
       const int cur = st & 1;
       if (st + 1 < n_st && !(MTR_H16_DMA_ABLATE & 8)) issue_early(st + 1, cur ^ 1);
       const char* Ab = As + cur * A_STAGE;
-      const char* Bb = Bs + cur * B_STAGE;
+      const char* Bb = Bs + cur * b_stage;
       auto read_frags = [&](int u, v4u (&af)[GPW], v4u (&bf)[TPW]) {
 #pragma unroll
         for (int q = 0; q < GPW; ++q)
@@ -756,7 +761,7 @@ static bool head16_early_copies(const HeadOpts& opt, bool nhwc, int ct, int n_gr
 template <typename FeatT, int CT, int GPW, bool NHWC>
 static int launch_head16(const void* feat, const float* packed, int B, int C, int H, int W, int J,
                          int D, const HeadGeom& g, const HeadScale& hs, float* c2d, float* c3d,
-                         const HeadOpts& opt, hipStream_t stream) {
+                         const HeadOpts& opt, hipStream_t stream, bool tight = false) {
   constexpr size_t lds = head16_lds_bytes<CT, GPW>();
   const int chunk = 8 * ((g.n_groups + GPW - 1) / GPW);
   const long long blocks = (long long)((B + 7) / 8) * chunk;
@@ -765,6 +770,19 @@ static int launch_head16(const void* feat, const float* packed, int B, int C, in
   // stages exist; NHWC: any map; NCHW: whole 16-byte chunks per channel row (H*W % 8 == 0, at
   // least the 8 chunks the bank rotation assumes)
   const bool dma_ok = C % kKH == 0 && (NHWC || ((H * W) % 8 == 0 && H * W >= 64));
+  if (tight && dma_ok && (H * W) % 8 == 0) {   // early copies, tight feature stage, exactly two stages of LDS
+    auto dma = head_fused16dma_kernel<FeatT, CT, GPW, NHWC, false, true, true>;
+    const size_t stage2 = 2 * ((size_t)GPW * kRows * 128 + (size_t)H * W * 128);
+    const size_t logits = (size_t)kRows * hw_pad32<CT>() * sizeof(float);
+    const size_t tight = stage2 > logits ? stage2 : logits;
+    const int rc = allow_dynamic_lds((const void*)dma, tight);
+    if (rc != MTR_OK) return rc;
+    MTR_CLEAR_STALE();
+    hipLaunchKernelGGL(dma, dim3((unsigned)blocks), dim3(256), tight, stream, (const FeatT*)feat, packed, B, C, H, W, J,
+                       D, g, hs, c2d, c3d);
+    MTR_CHECK_LAUNCH();
+    return MTR_OK;
+  }
   if (opt.dma != 0 && dma_ok && head16_early_copies(opt, NHWC, CT, g.n_groups)) {
     auto dma = head_fused16dma_kernel<FeatT, CT, GPW, NHWC, false, true>;
     if (lds > 64 * 1024) {
@@ -832,6 +850,34 @@ static int head16_groups_per_wg(int B, int ct, const HeadGeom& g, const HeadOpts
   return gpw;
 }
 
+// Round 6: ONE joint group per workgroup on a tight feature stage (52 KiB of LDS at 12x12: THREE workgroups per CU)
+// against the rule above (two groups, two workgroups per CU).  In steady state two groups per workgroup are the more
+// efficient (36.7 us per CU-round of 2 x 2 groups against 30.5 us per round of 3 x 1 at C = 1280; per workgroup alone
+// on its CU: 30 / 17 us), but a launch is a whole number of resident rounds and the finer grain wastes less of the
+// last one: configs[4]'s 32 crops 35.7 -> 32.1 us (NCHW; NHWC 33.4 -> 30.7), 64 crops 58.5 -> 52.6, J = 60 at 128
+// crops 58.5 -> 52.4 -- and 48 crops 39.0 -> 43.7 the other way (profiles/r06l_head16_tight_crossover.jsonl).  The
+// choice is a host-side model of the launch's rounds (whole rounds at the full-CU time + the trailing partial round,
+// which overlaps its predecessor, at 0.85 of its own), taken only when it promises 7 % or more; same bits either way.
+static double h16_round_model(long long n_wg, int slots, const double* t_by_residency) {
+  const long long per_round = 256LL * slots, full = n_wg / per_round, rem = n_wg % per_round;
+  double t = (double)full * t_by_residency[slots - 1];
+  if (rem) t += t_by_residency[(rem + 255) / 256 - 1] * (full ? 0.85 : 1.0);
+  return t;
+}
+static bool head16_tight_taken(const HeadOpts& opt, int B, int C, int H, int W, int layout, const HeadGeom& g, int ct,
+                               int gpw_rule) {
+  const bool ok = C % kKH == 0 && (H * W) % 8 == 0 && (layout == MTR_NHWC || H * W >= 64);
+  if (!ok) return false;
+  if (opt.dma == 7) return true;
+  if (opt.dma != -1 || opt.groups_per_wg != 0) return false;
+  if (ct != 5 || g.n_groups < 6) return false;   // (measured on 12x12 maps with 6 ... 18 joint groups)
+  static const double t_gpw1[3] = {17.0, 22.2, 30.5}, t_gpw2[2] = {30.0, 36.7};
+  const double tight = h16_round_model((long long)B * g.n_groups, 3, t_gpw1);
+  const double rule = gpw_rule == 1 ? h16_round_model((long long)B * g.n_groups, 2, t_gpw1)
+                                    : h16_round_model((long long)B * ((g.n_groups + 1) / 2), 2, t_gpw2);
+  return tight < 0.93 * rule || (gpw_rule == 1 && tight <= rule);   // (one group either way: the same kernel, one more slot)
+}
+
 static size_t h16_frag_offset(int C, int J, int D);  // (defined with the blob's other sizes below)
 
 // The weights-in-registers kernel (head_areg.hip): joint groups (= waves) per workgroup, 0 = not taken.
@@ -877,6 +923,13 @@ static int dispatch_head16(const void* feat, const float* packed, int B, int C, 
                               feat, packed, (const char*)packed + h16_frag_offset(C, J, D), B, C, H, W, J, D, g, hs,
                               c2d, c3d, stream);
   const int gpw = head16_groups_per_wg(B, CT, g, opt);
+  const bool tight = head16_tight_taken(opt, B, C, H, W, NHWC ? MTR_NHWC : MTR_NCHW, g, CT, gpw);
+  if (tight) {   // one group per workgroup (the library's own choice), or two on request (dma_staging 7)
+    if constexpr (kMaxGpw >= 2)
+      if (opt.dma == 7 && opt.groups_per_wg == 2)
+        return launch_head16<FeatT, CT, 2, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, opt, stream, true);
+    return launch_head16<FeatT, CT, 1, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, opt, stream, true);
+  }
   if constexpr (kMaxGpw >= 3)
     if (gpw == 3) return launch_head16<FeatT, CT, 3, NHWC>(feat, packed, B, C, H, W, J, D, g, hs, c2d, c3d, opt, stream);
   if constexpr (kMaxGpw >= 2)
@@ -1027,7 +1080,7 @@ static int parse_head_options(const mtr_head_options* caller, mtr::HeadOpts& opt
   const mtr_head_options* options = &mine;
   if (options->rt_tiles_per_workgroup < 0 || options->rt_tiles_per_workgroup > 5 ||
       options->groups_per_workgroup < 0 || options->groups_per_workgroup > 4 ||
-      options->dma_staging < -1 || options->dma_staging > 6 ||
+      options->dma_staging < -1 || options->dma_staging > 7 ||
       options->rt_column_blocks < 0 || options->rt_column_blocks > 4 ||
       options->rt_k_groups < 0 || options->rt_k_groups > 2 ||
       options->rt_loader < 0 || options->rt_loader > 2 ||
@@ -1090,6 +1143,13 @@ extern "C" int mtr_head_plan(int feat_dtype, int layout, int B, int C, int H, in
     return MTR_OK;
   }
   const int gpw = mtr::head16_groups_per_wg(B, ct, g, opt);
+  if (mtr::head16_tight_taken(opt, B, C, H, W, layout, g, ct, gpw)) {
+    const int tg = (opt.dma == 7 && opt.groups_per_wg == 2 && ct <= 6) ? 2 : 1;
+    plan->kernel = MTR_HEAD_KERNEL_16_DMA_EARLY_TIGHT;
+    plan->tiles_per_workgroup = tg;
+    plan->workgroups = (long long)((B + 7) / 8) * 8 * ((g.n_groups + tg - 1) / tg);
+    return MTR_OK;
+  }
   const bool dma_ok = C % mtr::kKH == 0 && (layout == MTR_NHWC || ((H * W) % 8 == 0 && H * W >= 64));
   plan->kernel = !(opt.dma != 0 && dma_ok) ? MTR_HEAD_KERNEL_16
                  : mtr::head16_early_copies(opt, layout == MTR_NHWC, ct, g.n_groups) ? MTR_HEAD_KERNEL_16_DMA_EARLY

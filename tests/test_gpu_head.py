@@ -185,12 +185,48 @@ def test_two_halves_kernel_gives_the_same_bits(shape, dtype, hip_lib):
 
 
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_tight_stage_kernel_is_the_default_at_configs4_and_gives_the_same_bits(dtype, hip_lib):
+    """Round 6: at configs[4]'s own launch (32 crops, J = 122, 12x12) the library takes the early-copies kernel with ONE
+    joint group per workgroup on a tight feature stage (kernel 18: three workgroups per CU); 48 crops keep two groups per
+    workgroup (kernel 14).  Both, the forced two-group tight variant and odd batch sizes: the same bits, both layouts."""
+    from metrabs_amd import _lib, kernels
+    C, J, D, H, W = 1280, 122, 8, 12, 12
+    cfg = cpu_ref.HeadConfig(depth=D, proc_side=384)
+    g = cases.gen(8643)
+    w, b = cases.default_conv_init(J * (1 + D), C, g)
+    packed = kernels.head_pack_weights((w * 3).cuda(), (b * 3).cuda(), J, D, dtype)
+    for B in (32, 5, 48, 67):
+        feat = torch.randn(B, C, H, W, generator=g).to(dtype).cuda()
+        for f in (feat, feat.contiguous(memory_format=torch.channels_last)):
+            nhwc = f is not feat
+            plan = kernels.head_plan(B, C, H, W, J, D, dtype, nhwc)['kernel']
+            assert plan == _lib.HEAD_KERNEL_NAMES[14 if B == 48 else 18], (B, plan)
+            base = kernels.head_fused(f, packed, C, J, mcfg(cfg), dma_staging=3, groups_per_workgroup=2)
+            assert torch.isfinite(base[1]).all()
+            for opts in (dict(), dict(dma_staging=7), dict(dma_staging=7, groups_per_workgroup=2), dict(dma_staging=3)):
+                out = kernels.head_fused(f, packed, C, J, mcfg(cfg), **opts)
+                assert torch.equal(out[0], base[0]) and torch.equal(out[1], base[1]), (B, nhwc, opts)
+    # other tight shapes: 8x8 (two column tiles), 16x8, C = 128 (two stages)
+    for (B, C2, J2, H2, W2) in ((9, 128, 17, 8, 8), (4, 1280, 40, 16, 8), (3, 64, 122, 12, 12)):
+        cfg2 = cpu_ref.HeadConfig(depth=D, proc_side=max(H2, W2) * 32)
+        w2, b2 = cases.default_conv_init(J2 * (1 + D), C2, g)
+        packed2 = kernels.head_pack_weights(w2.cuda(), b2.cuda(), J2, D, dtype)
+        feat = torch.randn(B, C2, H2, W2, generator=g).to(dtype).cuda()
+        for f in (feat, feat.contiguous(memory_format=torch.channels_last)):
+            base = kernels.head_fused(f, packed2, C2, J2, mcfg(cfg2), dma_staging=3)
+            for gp in (1, 2):
+                out = kernels.head_fused(f, packed2, C2, J2, mcfg(cfg2), dma_staging=7, groups_per_workgroup=gp)
+                assert torch.equal(out[0], base[0]) and torch.equal(out[1], base[1]), (B, C2, J2, H2, W2, gp)
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 def test_default_dispatch_of_large_16bit_launches_gives_the_small_launch_bits(dtype, hip_lib):
     """ The library's DEFAULT 16-bit kernel depends on the launch size: >= 512 crops of >= 8 joint groups
     on five column tiles take head_fused16areg_kernel (weights in registers), fewer crops the early-copies LDS
     kernel.  `head_auto_choice` promises that a slice, a rank and the whole batch give the same bits, which here
     rests on the two kernels being bit-identical: B = 512, J = 122, 12x12, default options, both layouts -- the
-    plan names kernel 15 and every crop equals the same crop computed in launches of 64 (kernel 14)."""
+    plan names kernel 15 and every crop equals the same crop computed in launches of 64 (kernel 18 since round 6: the
+    early-copies kernel with one joint group per workgroup on a tight stage)."""
     from metrabs_amd import _lib, kernels
     B, C, J, D, H, W = 512, 1280, 122, 8, 12, 12
     cfg = cpu_ref.HeadConfig(depth=D, proc_side=384)
@@ -201,7 +237,7 @@ def test_default_dispatch_of_large_16bit_launches_gives_the_small_launch_bits(dt
     for f in (feat, feat.contiguous(memory_format=torch.channels_last)):
         nhwc = f is not feat
         assert kernels.head_plan(B, C, H, W, J, D, dtype, nhwc)['kernel'] == _lib.HEAD_KERNEL_NAMES[15]
-        assert kernels.head_plan(64, C, H, W, J, D, dtype, nhwc)['kernel'] == _lib.HEAD_KERNEL_NAMES[14]
+        assert kernels.head_plan(64, C, H, W, J, D, dtype, nhwc)['kernel'] == _lib.HEAD_KERNEL_NAMES[18]   # (round 6: the tight stage)
         big = kernels.head_fused(f, packed, C, J, mcfg(cfg))
         assert torch.isfinite(big[1]).all()
         for start in range(0, B, 64):
@@ -252,7 +288,9 @@ def test_fused_head_16bit_odd_shapes(shape, dtype, hip_lib):
                     dict(dma_staging=4), dict(dma_staging=4, groups_per_workgroup=2),
                     dict(dma_staging=4, groups_per_workgroup=4),
                     # ... and weights RESIDENT in registers, persistent workgroups (C = 1280, 3 - 5 column tiles)
-                    dict(dma_staging=5), dict(dma_staging=6)):
+                    dict(dma_staging=5), dict(dma_staging=6),
+                    # ... early copies with a tight feature stage (three workgroups per CU at one group each)
+                    dict(dma_staging=7, groups_per_workgroup=1), dict(dma_staging=7, groups_per_workgroup=2)):
         # (dma_staging 1 = four waves that copy and multiply, 2 = four MFMA waves + a loader wave)
         v2d, v3d = run_fused(feat, w, b, J, cfg, **options)
         assert torch.equal(v3d, c3d) and torch.equal(v2d, c2d), options
@@ -700,7 +738,7 @@ def test_head_options_are_validated(hip_lib):
     w, b = cases.default_conv_init(153, 64, cases.gen(1))
     packed = kernels.head_pack_weights(w.cuda(), b.cuda(), 17, 8)
     feat = torch.randn(2, 64, 8, 8, device='cuda')
-    for bad in (dict(rt_tiles=6), dict(groups_per_workgroup=5), dict(dma_staging=7), dict(rt_column_blocks=5),
+    for bad in (dict(rt_tiles=6), dict(groups_per_workgroup=5), dict(dma_staging=8), dict(rt_column_blocks=5),
                 dict(rt_k_groups=3), dict(rt_loader=3), dict(rt_split=3)):
         with pytest.raises(RuntimeError):
             kernels.head_fused(feat, packed, 64, 17, MetrabsConfig(), **bad)

@@ -396,3 +396,27 @@ def test_predict_multi_is_strict_about_the_tf_signature():
         m.predict_multi(torch.zeros(2, 64, 64, 3, dtype=torch.float16), K[:1])
     with pytest.raises((RuntimeError, ValueError, TypeError)):              # CPU tensors: no CPU path
         m.predict_multi(torch.zeros(2, 64, 64, 3, dtype=torch.float16), K)
+
+
+def test_head_plan_takes_one_group_per_workgroup_on_a_tight_stage_where_the_round_model_says_so():
+    """Round 6: the 16-bit early-copies kernel with one joint group per workgroup on a feature stage of exactly H*W
+    positions (52 KiB of LDS at 12x12: three workgroups per CU) -- the library's choice where its model of the launch's
+    resident rounds promises >= 7 % over two groups per workgroup (profiles/r06l_head16_tight_crossover.jsonl: 32 and 64
+    crops of J = 122 yes, 48 / 96 / 160 / 256 no), never for other map sizes, few joint groups or forced options."""
+    from metrabs_amd import _lib, kernels
+    tight, early = _lib.HEAD_KERNEL_NAMES[18], _lib.HEAD_KERNEL_NAMES[14]
+    plan = lambda B, J=122, side=12, **kw: kernels.head_plan(B, 1280, side, side, J, 8, torch.float16, **kw)
+    for layout in (False, True):
+        assert plan(32, channels_last=layout)['kernel'] == tight
+        assert plan(32, channels_last=layout)['tiles_per_workgroup'] == 1 and plan(32, channels_last=layout)['workgroups'] == 32 * 18
+        assert plan(64, channels_last=layout)['kernel'] == tight
+        for B in (48, 96, 160, 256):
+            assert plan(B, channels_last=layout)['kernel'] == early, B
+        assert plan(8, channels_last=layout)['kernel'] == tight            # (one group either way: one more slot per CU)
+    assert plan(128, J=60)['kernel'] == tight and plan(256, J=60)['kernel'] == tight    # 9 joint groups
+    assert plan(32, J=17)['kernel'] != tight                                              # 3 joint groups: the old rule
+    assert plan(32, side=8)['kernel'] != tight and plan(32, side=16)['kernel'] != tight   # other map sizes
+    assert plan(32, dma_staging=3)['kernel'] == early and plan(32, groups_per_workgroup=2)['kernel'] == early
+    forced = plan(256, dma_staging=7, groups_per_workgroup=2)
+    assert forced['kernel'] == tight and forced['tiles_per_workgroup'] == 2
+    assert plan(512)['kernel'] == _lib.HEAD_KERNEL_NAMES[15]                              # large launches: weights in registers

@@ -37,7 +37,8 @@ def main():
             packed = kernels.head_pack_weights(w, b, J, D, dt)
             base = kernels.head_fused(feat, packed, C, J, cfg, dma_staging=3)
             flops = 2.0 * C * J * (1 + D) * H * W * B
-            variants = [dict(), dict(dma_staging=3), dict(dma_staging=6), dict(dma_staging=4, groups_per_workgroup=4)]
+            variants = [dict(), dict(dma_staging=3), dict(dma_staging=6), dict(dma_staging=4, groups_per_workgroup=4),
+                        dict(dma_staging=7, groups_per_workgroup=1), dict(dma_staging=7, groups_per_workgroup=2)]
             times = {i: [] for i in range(len(variants))}
             eq = {}
             for i, opts in enumerate(variants):
