@@ -16,8 +16,6 @@
 //     fma + one v_exp_f32; the depth sums of a column run in fp32 (<= 8 terms) and are promoted to
 //     fp64 once per column; the four moment sums (total, x, y, z) are fp64 and are merged across
 //     the group with DPP butterflies.
-#include <type_traits>
-
 #include "common.h"
 
 namespace mtr {
@@ -408,6 +406,72 @@ __device__ __forceinline__ void nhwc_walk_rows(const T* __restrict__ x, int ch, 
   m_out = m; s_out = s; sx_out = sx; sy_out = sy;
 }
 
+// (Round 6, measured and removed: FOUR CHANNELS PER LANE -- thread (g, q) loads the 16 bytes of channels 4 q .. 4 q + 3 at
+// the eight positions g, g + G, ... in one burst (a wave-wide load ~1 KiB of consecutive memory, as in the NCHW kernel),
+// maxima in registers, the G = H*W / 8 partial states of a channel merged in LDS: 495 vs 270 us on the 1.28 GB shape,
+// 409 vs 138 us on 12x12 maps (profiles/r06n_nhwc_quad_ab.jsonl) -- 34 - 77 KB of partial states per workgroup leave four
+// workgroups per CU, each of which loads for a third of its life and merges 8 - 18 x the states.)
+// The tail of the NHWC kernel: [G][N] partial online-softmax states in LDS (row_m: running maxima, row_s: (s, sx, sy)
+// in f64) -> merged per channel in group order, scaled per joint over its slices, summed in slice order, stored.
+__device__ __forceinline__ void nhwc_merge_and_store(float* row_m, double* row_s, int G, int N, int nj, int j0, int J,
+                                                     int D, int b, const HeadScale& hs, const AxisInv& ai,
+                                                     float* __restrict__ coords2d, float* __restrict__ coords3d_rel) {
+  __syncthreads();
+  // The merges -- the groups of a channel, then the slices of a joint -- are online-softmax merges:
+  // every partial sum is scaled by exp(its max - the common max) in f64 and added in order.  The
+  // factors are evaluated by one thread per PARTIAL (all G N of them side by side, then all N), the
+  // ordered additions by one thread per channel / per joint: the first version looped the f64 exps
+  // inside those (G per channel, D per joint, one after the other: 72 of them for 72 depth slices).
+  const float* chan_m = row_m;  // running maximum of channel n over all its positions
+  if (G > 1) {
+    float* cm = reinterpret_cast<float*>(row_s + (size_t)G * N * 3);  // [N]
+    for (int t = threadIdx.x; t < G * N; t += blockDim.x) {
+      const int n = t % N;
+      float M = row_m[n];
+      for (int g = 1; g < G; ++g) M = fmaxf(M, row_m[g * N + n]);
+      const double f = row_m[t] == -INFINITY ? 0.0 : exp_neg64((double)row_m[t] - (double)M);
+      row_s[t * 3 + 0] *= f; row_s[t * 3 + 1] *= f; row_s[t * 3 + 2] *= f;
+      if (t < N) cm[n] = M;
+    }
+    chan_m = cm;
+    __syncthreads();
+  }
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    double S = row_s[n * 3], SX = row_s[n * 3 + 1], SY = row_s[n * 3 + 2];
+    for (int g = 1; g < G; ++g) {  // group order
+      const int t = g * N + n;
+      S += row_s[t * 3]; SX += row_s[t * 3 + 1]; SY += row_s[t * 3 + 2];
+    }
+    const int slice = n / nj, jj = n - slice * nj;
+    if (slice > 0) {  // a depth slice: scaled to the maximum over its joint's slices
+      float M = -INFINITY;
+      for (int d = 0; d < D; ++d) M = fmaxf(M, chan_m[nj + d * nj + jj]);
+      const double f = chan_m[n] == -INFINITY ? 0.0 : exp_neg64((double)chan_m[n] - (double)M);
+      S *= f; SX *= f; SY *= f;
+    }
+    row_s[n * 3 + 0] = S; row_s[n * 3 + 1] = SX; row_s[n * 3 + 2] = SY;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < nj; j += blockDim.x) {
+    const size_t o = (size_t)b * J + j0 + j;
+    {
+      const double i2 = fast_rcp64(row_s[j * 3]);
+      coords2d[o * 2 + 0] = heatmap_to_px(axis_coord_rcp(row_s[j * 3 + 1], i2, ai.w), hs);
+      coords2d[o * 2 + 1] = heatmap_to_px(axis_coord_rcp(row_s[j * 3 + 2], i2, ai.h), hs);
+    }
+    double S = 0.0, SX = 0.0, SY = 0.0, SZ = 0.0;
+    for (int d = 0; d < D; ++d) {  // slice order
+      const int n = nj + d * nj + j;
+      const double sd = row_s[n * 3];
+      S += sd; SX += row_s[n * 3 + 1]; SY += row_s[n * 3 + 2]; SZ += sd * (double)d;
+    }
+    const double i3 = fast_rcp64(S);
+    coords3d_rel[o * 3 + 0] = heatmap_to_mm_xy(axis_coord_rcp(SX, i3, ai.w), hs);
+    coords3d_rel[o * 3 + 1] = heatmap_to_mm_xy(axis_coord_rcp(SY, i3, ai.h), hs);
+    coords3d_rel[o * 3 + 2] = heatmap_to_mm_z(axis_coord_rcp(SZ, i3, ai.d), hs);
+  }
+}
+
 // RB: the map-row batch this instantiation's factored walk is compiled for (4, 8, 12, 16; 0 = none): one walk per
 // instantiation instead of all four in one kernel (round 6) -- the register allocation of a launch is its own
 // walk's, not the 16-position one's.
@@ -491,60 +555,7 @@ __global__ __launch_bounds__(1024) void decode_nhwc_kernel(const T* __restrict__
     row_m[t] = m;
     row_s[t * 3 + 0] = s; row_s[t * 3 + 1] = sx; row_s[t * 3 + 2] = sy;
   }
-  __syncthreads();
-  // The merges -- the groups of a channel, then the slices of a joint -- are online-softmax merges:
-  // every partial sum is scaled by exp(its max - the common max) in f64 and added in order.  The
-  // factors are evaluated by one thread per PARTIAL (all G N of them side by side, then all N), the
-  // ordered additions by one thread per channel / per joint: the first version looped the f64 exps
-  // inside those (G per channel, D per joint, one after the other: 72 of them for 72 depth slices).
-  const float* chan_m = row_m;  // running maximum of channel n over all its positions
-  if (G > 1) {
-    float* cm = reinterpret_cast<float*>(row_s + (size_t)G * N * 3);  // [N]
-    for (int t = threadIdx.x; t < G * N; t += blockDim.x) {
-      const int n = t % N;
-      float M = row_m[n];
-      for (int g = 1; g < G; ++g) M = fmaxf(M, row_m[g * N + n]);
-      const double f = row_m[t] == -INFINITY ? 0.0 : exp_neg64((double)row_m[t] - (double)M);
-      row_s[t * 3 + 0] *= f; row_s[t * 3 + 1] *= f; row_s[t * 3 + 2] *= f;
-      if (t < N) cm[n] = M;
-    }
-    chan_m = cm;
-    __syncthreads();
-  }
-  for (int n = threadIdx.x; n < N; n += blockDim.x) {
-    double S = row_s[n * 3], SX = row_s[n * 3 + 1], SY = row_s[n * 3 + 2];
-    for (int g = 1; g < G; ++g) {  // group order
-      const int t = g * N + n;
-      S += row_s[t * 3]; SX += row_s[t * 3 + 1]; SY += row_s[t * 3 + 2];
-    }
-    const int slice = n / nj, jj = n - slice * nj;
-    if (slice > 0) {  // a depth slice: scaled to the maximum over its joint's slices
-      float M = -INFINITY;
-      for (int d = 0; d < D; ++d) M = fmaxf(M, chan_m[nj + d * nj + jj]);
-      const double f = chan_m[n] == -INFINITY ? 0.0 : exp_neg64((double)chan_m[n] - (double)M);
-      S *= f; SX *= f; SY *= f;
-    }
-    row_s[n * 3 + 0] = S; row_s[n * 3 + 1] = SX; row_s[n * 3 + 2] = SY;
-  }
-  __syncthreads();
-  for (int j = threadIdx.x; j < nj; j += blockDim.x) {
-    const size_t o = (size_t)b * J + j0 + j;
-    {
-      const double i2 = fast_rcp64(row_s[j * 3]);
-      coords2d[o * 2 + 0] = heatmap_to_px(axis_coord_rcp(row_s[j * 3 + 1], i2, ai.w), hs);
-      coords2d[o * 2 + 1] = heatmap_to_px(axis_coord_rcp(row_s[j * 3 + 2], i2, ai.h), hs);
-    }
-    double S = 0.0, SX = 0.0, SY = 0.0, SZ = 0.0;
-    for (int d = 0; d < D; ++d) {  // slice order
-      const int n = nj + d * nj + j;
-      const double sd = row_s[n * 3];
-      S += sd; SX += row_s[n * 3 + 1]; SY += row_s[n * 3 + 2]; SZ += sd * (double)d;
-    }
-    const double i3 = fast_rcp64(S);
-    coords3d_rel[o * 3 + 0] = heatmap_to_mm_xy(axis_coord_rcp(SX, i3, ai.w), hs);
-    coords3d_rel[o * 3 + 1] = heatmap_to_mm_xy(axis_coord_rcp(SY, i3, ai.h), hs);
-    coords3d_rel[o * 3 + 2] = heatmap_to_mm_z(axis_coord_rcp(SZ, i3, ai.d), hs);
-  }
+  nhwc_merge_and_store(row_m, row_s, G, N, nj, j0, J, D, b, hs, ai, coords2d, coords3d_rel);
 }
 
 template <typename T>

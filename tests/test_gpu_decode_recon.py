@@ -141,7 +141,9 @@ def test_decode_channels_last_logits_vs_golden(name, hip_lib):
 
 
 @pytest.mark.parametrize('B,J,D,H', [(1, 17, 8, 8), (3, 17, 8, 8), (64, 17, 8, 8), (100, 24, 8, 8), (255, 17, 8, 8),
-                                     (256, 17, 8, 8), (300, 17, 8, 8), (64, 122, 8, 12), (2, 3, 72, 8), (40, 1, 8, 8)])
+                                     (256, 17, 8, 8), (300, 17, 8, 8), (64, 122, 8, 12), (2, 3, 72, 8), (40, 1, 8, 8),
+                                     # (round 6) more unsplit launches: N % 4 == 0, 12x12, 16x16, a large one
+                                     (257, 16, 8, 8), (260, 17, 8, 12), (300, 5, 8, 16), (256, 17, 8, 16), (1024, 17, 8, 8)])
 def test_decode_channels_last_joint_splits(B, J, D, H, hip_lib):
     """Batches under 256 crops deal a crop's joints to 256 // B workgroups (at most J): every split
     count, joint counts that do not divide, one joint, 72 depth slices and the unsplit launch, against
@@ -160,6 +162,29 @@ def test_decode_channels_last_joint_splits(B, J, D, H, hip_lib):
         o2d, o3d = cpu_ref.heads_from_logits(logits[:k].cpu(), J, cpu_ref.HeadConfig(depth=D, proc_side=H * 32))
     assert float((c3d[:k].cpu() - o3d).abs().max()) <= 1e-3
     assert float((c2d[:k].cpu() - o2d).abs().max()) <= 2e-4
+
+
+def test_decode_channels_last_large_batches_equal_the_small_batch_kernel(hip_lib):
+    """Launches of >= 256 crops (one workgroup per crop, the factored row walk) against launches of < 256 on the same
+    crops (which deal a crop's joints to several workgroups with position groups merged in LDS): two orders of the same
+    f64 sums -- a last bit of the f32 outputs here and there (coordinates up to 1,500 mm: 1.2e-4 per ulp): <= 5e-4 mm /
+    1e-4 px; -inf logits (a masked channel, a masked position, single entries) weigh nothing in either."""
+    from metrabs_amd import kernels
+    from metrabs_amd.config import MetrabsConfig
+    for (B, J, D, H) in ((300, 17, 8, 8), (270, 17, 8, 12)):
+        cfg = MetrabsConfig(depth=D, proc_side=H * 32)
+        g = torch.Generator(device='cuda').manual_seed(77 + H)
+        logits = torch.randn(B, J * (1 + D), H, H, generator=g, device='cuda') * 4.0
+        logits[3, 5] = -float('inf')                 # a whole channel (a depth slice of a joint)
+        logits[4, :, 2, 3] = -float('inf')           # a position of every channel
+        logits[5, 40:60, 1, 1] = -float('inf')
+        logits[3, 5, 0, 0] = 1.0                     # ... one finite entry left in the masked channel
+        x = logits.contiguous(memory_format=torch.channels_last)
+        big2, big3 = kernels.softargmax_decode(x, J, cfg)
+        parts = [kernels.softargmax_decode(x[i:i + 100], J, cfg) for i in range(0, B, 100)]
+        small2, small3 = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+        assert torch.isfinite(big3).all() and torch.isfinite(big2).all()
+        assert float((big3 - small3).abs().max()) <= 5e-4 and float((big2 - small2).abs().max()) <= 1e-4, (B, J, D, H)
 
 
 @pytest.mark.parametrize('name', list(cases.RECON_CASES))
