@@ -774,11 +774,13 @@ static int launch_head16(const void* feat, const float* packed, int B, int C, in
     auto dma = head_fused16dma_kernel<FeatT, CT, GPW, NHWC, false, true, true>;
     const size_t stage2 = 2 * ((size_t)GPW * kRows * 128 + (size_t)H * W * 128);
     const size_t logits = (size_t)kRows * hw_pad32<CT>() * sizeof(float);
-    const size_t tight = stage2 > logits ? stage2 : logits;
-    const int rc = allow_dynamic_lds((const void*)dma, tight);
-    if (rc != MTR_OK) return rc;
+    const size_t lds_tight = stage2 > logits ? stage2 : logits;
+    if (lds_tight > 64 * 1024) {
+      const int rc = allow_dynamic_lds((const void*)dma, lds_tight);
+      if (rc != MTR_OK) return rc;
+    }
     MTR_CLEAR_STALE();
-    hipLaunchKernelGGL(dma, dim3((unsigned)blocks), dim3(256), tight, stream, (const FeatT*)feat, packed, B, C, H, W, J,
+    hipLaunchKernelGGL(dma, dim3((unsigned)blocks), dim3(256), lds_tight, stream, (const FeatT*)feat, packed, B, C, H, W, J,
                        D, g, hs, c2d, c3d);
     MTR_CHECK_LAUNCH();
     return MTR_OK;

@@ -1786,8 +1786,13 @@ static double rt_launch_us(int mode, int r, long long crops, int n_tiles, int k_
   const int slots = mode == 1 ? 1 : 2;
   // (solo time, paired slowdown) of the two block sizes
   const double t_full = w_full.fixed + w_full.loop, t_last = w_last.fixed + w_last.loop;
-  const double f_full = (w_full.fixed + kRtPairedKLoop[r] * w_full.loop) / t_full;
-  const double f_last = (w_last.fixed + kRtPairedKLoop[r] * w_last.loop) / t_last;
+  // (round 6) blocks of 2 tiles that pair up in a launch of at most ONE round of pairs are slower together than the
+  // steady-state figure: configs[2]'s own launch (32 crops of 12x12, column blocks split: 360 workgroups, 104 CUs
+  // paired) measured 32.8 us for a predicted 28.2 -- 2.2 x -- and the plan took it over the loader-wave kernel's
+  // 216 solo workgroups of 4, 4, 2 tiles (predicted 29.1, measured 29.9; profiles/r06z_head_sweep.jsonl)
+  const double paired = (r == 2 && n_wg <= 2LL * kRtModelCus) ? 2.2 : kRtPairedKLoop[r];
+  const double f_full = (w_full.fixed + paired * w_full.loop) / t_full;
+  const double f_last = (w_last.fixed + paired * w_last.loop) / t_last;
   if (n_wg > 32768) {  // far into the steady state: work over throughput
     const double work = (double)crops * ((per_crop - 1) * t_full * (slots == 2 ? f_full / 2 : 1.0) +
                                          t_last * (slots == 2 ? f_last / 2 : 1.0));

@@ -175,7 +175,7 @@ def test_bench_cli_contract_and_kernel_naming(monkeypatch):
     assert bench.head_kernel_name(64, 1024, 17, 8) == 'head_rt_kernel'               # large launch: 5-tile blocks
     assert bench.head_kernel_name(64, 64, 17, 8, 'f32', 1283) == 'head_rt_kernel'    # C % 32 != 0: no loader kernel
     assert bench.head_kernel_name(64, 1024, 17, 72) == 'head_rt_kernel'              # D <= 80: 5-tile atoms
-    assert bench.head_kernel_name(144, 32, 17, 8).startswith('head_rt_kernel (+ head_rt_merge_kernel: 3 ')
+    assert bench.head_kernel_name(144, 32, 17, 8).startswith('head_rt_ld_kernel (+ head_rt_merge_kernel: 3 ')   # (round 6: 216 solo blocks of 4, 4, 2 tiles)
     assert bench.head_kernel_name(64, 64, 17, 8, 'f16', 1280) == 'head_fused16dma_kernel (early copies)'
     assert bench.head_kernel_name(36, 64, 17, 8, 'f16', 1280) == 'head_fused16_kernel'   # 6x6: registers
     assert bench.head_kernel_name(64, 64, 17, 8, 'f16', 1283).startswith('library')      # C % 8 != 0
@@ -193,7 +193,7 @@ def test_head_plan_follows_the_measured_model():
     # (32 crops x 5 blocks of 2 tiles x 2.25 column blocks = 360 workgroups instead of 480)
     p = kernels.head_plan(32, 1280, 12, 12, 17, 8)
     assert (p['kernel'], p['tiles_per_workgroup'], p['split_column_blocks'], p['workgroups']) == \
-        ('head_rt_kernel', 2, 3, 360)
+        ('head_rt_ld_kernel', 4, 3, 216)   # (round 6: 2-tile blocks paired in a single round are 2.2 x, not 1.8 x: measured)
     p = kernels.head_plan(32, 1280, 12, 12, 122, 8)   # configs[4]'s head in f32: 69 row tiles
     assert (p['kernel'], p['tiles_per_workgroup'], p['split_column_blocks'], p['workgroups']) == \
         ('head_rt_kernel', 5, 3, 32 * 14 * 2 + 8 * 14)
@@ -256,7 +256,7 @@ def test_head_plan_reads_the_batch_size_in_eights_and_the_auto_rule_not_at_all()
     from metrabs_amd import kernels
     plans = [kernels.head_plan(B, 1280, 8, 8, 17, 8) for B in range(57, 65)]
     assert all(p == plans[0] for p in plans)
-    assert kernels.head_plan(65, 1280, 8, 8, 17, 8)['workgroups'] > plans[0]['workgroups']
+    assert kernels.head_plan(65, 1280, 8, 8, 17, 8)['workgroups'] != plans[0]['workgroups']   # (72 crops: another plan)
     # MetrabsHeads(fused='auto'): a static rule without the batch size
     import inspect
     assert 'B' not in inspect.signature(kernels.head_auto_choice).parameters
