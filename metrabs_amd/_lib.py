@@ -80,6 +80,8 @@ SIGNATURES = {
     'mtr_strerror': (c_char_p, [c_int]),
     'mtr_softargmax_decode': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                       POINTER(HeadParams), c_void_p, c_void_p, c_void_p]),
+    'mtr_softargmax_decode_opts': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                           POINTER(HeadParams), c_int, c_void_p, c_void_p, c_void_p]),
     'mtr_head_row_plan': (c_int, [c_int, c_int, POINTER(c_int32), POINTER(c_int32), c_void_p, c_int]),
     'mtr_head_packed_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'mtr_head_pack_weights': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,

@@ -349,12 +349,60 @@ static int dispatch_decode(const void* logits, int B, int J, int D, int H, int W
                               // 288 vs 272 us on the 1.28 GB shape, 308 vs 255 us with 16-bit logits -- profiles/r06c_nhwc_decode_ab.jsonl;
                               // the walk is not bound by its dependent round trips)
 #endif
+// One lane's online-softmax state of its channel over the map, advanced a batch of U positions of ONE map row at a time
+// (the factored walk described above).  Both NHWC kernels -- the one that loads its logits from global memory and the
+// one that reads them out of a staged copy in LDS -- advance this state with the same calls in the same order: the
+// same bits.
+template <typename T, int U>
+struct NhwcRowWalk {
+  float m = -INFINITY;                 // the level q of the sums below (an integer, or -inf: nothing finite yet)
+  double s = 0.0, sx = 0.0, sy = 0.0;  // sum of 2^(x log2 e - q), ... times column, ... times row
+  int h = 0, w0 = 0;  // (wave-uniform: functions of the batch counter alone)
+  __device__ __forceinline__ void batch(const T (&raw)[U], int W) {
+    float v[U];
+    float mb = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      v[u] = to_f32(raw[u]);
+      mb = fmaxf(mb, v[u]);
+    }
+    // The reference level of the weights is a POWER OF TWO: m = q = ceil(max * log2 e), an integer, and a logit weighs
+    // exp2(x log2 e - q) (the product exact inside the fma, one rounding; the largest weights lie in (1/2, 1]).  Raising q
+    // rescales what has been summed by 2^(q_old - q_new) -- an exponent shift (v_ldexp_f64), EXACT, a handful of
+    // instructions -- where the walk used to evaluate exp(m_old - m_new) in f64 (a degree-11 polynomial: ~45 VALU
+    // instructions that a wave paid in nearly every batch, since one lane out of 64 raising its maximum is enough).
+    const float t = mb * kLog2e;
+    if (t > m) {
+      const float qn = ceilf(t);
+      if (m != -INFINITY) {
+        const int d = (int)(m - qn);  // (integers: exact; saturates far below the underflow of the sums)
+        s = ldexp(s, d); sx = ldexp(sx, d); sy = ldexp(sy, d);
+      }
+      m = qn;
+    }
+    // A -inf logit weighs nothing: under a finite level fma(-inf, log2e, -q) = -inf and exp2(-inf) = +0 by itself; -inf
+    // - -inf would be NaN under a -inf level (nothing finite yet, this batch included): the shift is 0 there and every
+    // weight of the batch +0 again.  (One select per batch; it was a compare and two selects per logit.)
+    const float nm = m == -INFINITY ? 0.0f : -m;
+    double sb = 0.0, su = 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const double e = (double)exp_shifted(v[u], nm);
+      sb += e;
+      su = fma(e, (double)u, su);
+    }
+    s += sb;
+    sx += fma((double)w0, sb, su);
+    sy = fma((double)h, sb, sy);
+    w0 += U;
+    if (w0 >= W) { w0 = 0; ++h; }
+  }
+};
+
 template <typename T, int U>
 __device__ __forceinline__ void nhwc_walk_rows(const T* __restrict__ x, int ch, int NC, int HW, int W, float& m_out,
                                                double& s_out, double& sx_out, double& sy_out) {
-  float m = -INFINITY;
-  double s = 0.0, sx = 0.0, sy = 0.0;
-  int h = 0, w0 = 0;  // (wave-uniform: functions of the loop counter alone)
+  NhwcRowWalk<T, U> st;
   const T* xp = x + ch;
   // MTR_NHWC_PREFETCH (round 6, a developer option): the NEXT batch's U loads are issued before this batch is summed
   // (two batches = 2 U loads per lane in flight).  Same values, same order of every sum: the same bits -- and slower
@@ -367,34 +415,7 @@ __device__ __forceinline__ void nhwc_walk_rows(const T* __restrict__ x, int ch, 
 #pragma unroll
       for (int u = 0; u < U; ++u) nxt[u] = xp[(size_t)(p0 + U + u) * NC];
     }
-    float v[U];
-    float mb = -INFINITY;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      v[u] = to_f32(raw[u]);
-      mb = fmaxf(mb, v[u]);
-    }
-    if (mb > m) {
-      if (m != -INFINITY) {
-        const double f = exp_neg64((double)m - (double)mb);
-        s *= f; sx *= f; sy *= f;
-      }
-      m = mb;
-    }
-    const float nm = -m * kLog2e;
-    double sb = 0.0, su = 0.0;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      // (a -inf logit weighs nothing: -inf - -inf is NaN under a -inf maximum)
-      const double e = v[u] != -INFINITY ? (double)exp_shifted(v[u], nm) : 0.0;
-      sb += e;
-      su = fma(e, (double)u, su);
-    }
-    s += sb;
-    sx += fma((double)w0, sb, su);
-    sy = fma((double)h, sb, sy);
-    w0 += U;
-    if (w0 >= W) { w0 = 0; ++h; }
+    st.batch(raw, W);
     if (MTR_NHWC_PREFETCH) {
 #pragma unroll
       for (int u = 0; u < U; ++u) raw[u] = nxt[u];
@@ -403,7 +424,7 @@ __device__ __forceinline__ void nhwc_walk_rows(const T* __restrict__ x, int ch, 
       for (int u = 0; u < U; ++u) raw[u] = xp[(size_t)(p0 + U + u) * NC];
     }
   }
-  m_out = m; s_out = s; sx_out = sx; sy_out = sy;
+  m_out = st.m; s_out = st.s; sx_out = st.sx; sy_out = st.sy;
 }
 
 // (Round 6, measured and removed: FOUR CHANNELS PER LANE -- thread (g, q) loads the 16 bytes of channels 4 q .. 4 q + 3 at
@@ -417,20 +438,21 @@ __device__ __forceinline__ void nhwc_merge_and_store(float* row_m, double* row_s
                                                      int D, int b, const HeadScale& hs, const AxisInv& ai,
                                                      float* __restrict__ coords2d, float* __restrict__ coords3d_rel) {
   __syncthreads();
-  // The merges -- the groups of a channel, then the slices of a joint -- are online-softmax merges:
-  // every partial sum is scaled by exp(its max - the common max) in f64 and added in order.  The
-  // factors are evaluated by one thread per PARTIAL (all G N of them side by side, then all N), the
-  // ordered additions by one thread per channel / per joint: the first version looped the f64 exps
-  // inside those (G per channel, D per joint, one after the other: 72 of them for 72 depth slices).
-  const float* chan_m = row_m;  // running maximum of channel n over all its positions
+  // The merges -- the groups of a channel, then the slices of a joint -- are online-softmax merges: every partial
+  // sum is brought to the common level and added in order.  Levels are integers (powers of two, NhwcRowWalk::batch):
+  // the factor 2^(its level - the common level) is an exponent shift, exact (round 6; it was exp(difference of
+  // maxima) evaluated in f64, a degree-11 polynomial per partial).  One thread per PARTIAL shifts (all G N of
+  // them side by side, then all N), one thread per channel / per joint adds in order.
+  const float* chan_m = row_m;  // level of channel n over all its positions
   if (G > 1) {
     float* cm = reinterpret_cast<float*>(row_s + (size_t)G * N * 3);  // [N]
     for (int t = threadIdx.x; t < G * N; t += blockDim.x) {
       const int n = t % N;
       float M = row_m[n];
       for (int g = 1; g < G; ++g) M = fmaxf(M, row_m[g * N + n]);
-      const double f = row_m[t] == -INFINITY ? 0.0 : exp_neg64((double)row_m[t] - (double)M);
-      row_s[t * 3 + 0] *= f; row_s[t * 3 + 1] *= f; row_s[t * 3 + 2] *= f;
+      const int d = row_m[t] == -INFINITY ? 0 : (int)(row_m[t] - M);  // (a -inf level: sums of 0)
+      row_s[t * 3 + 0] = ldexp(row_s[t * 3 + 0], d); row_s[t * 3 + 1] = ldexp(row_s[t * 3 + 1], d);
+      row_s[t * 3 + 2] = ldexp(row_s[t * 3 + 2], d);
       if (t < N) cm[n] = M;
     }
     chan_m = cm;
@@ -446,8 +468,8 @@ __device__ __forceinline__ void nhwc_merge_and_store(float* row_m, double* row_s
     if (slice > 0) {  // a depth slice: scaled to the maximum over its joint's slices
       float M = -INFINITY;
       for (int d = 0; d < D; ++d) M = fmaxf(M, chan_m[nj + d * nj + jj]);
-      const double f = chan_m[n] == -INFINITY ? 0.0 : exp_neg64((double)chan_m[n] - (double)M);
-      S *= f; SX *= f; SY *= f;
+      const int d = chan_m[n] == -INFINITY ? 0 : (int)(chan_m[n] - M);
+      S = ldexp(S, d); SX = ldexp(SX, d); SY = ldexp(SY, d);
     }
     row_s[n * 3 + 0] = S; row_s[n * 3 + 1] = SX; row_s[n * 3 + 2] = SY;
   }
@@ -529,16 +551,16 @@ __global__ __launch_bounds__(1024) void decode_nhwc_kernel(const T* __restrict__
         v[u] = p < HW ? to_f32(x[(size_t)p * NC + ch]) : -INFINITY;
         mb = fmaxf(mb, v[u]);
       }
-      if (mb > m) {  // rescale what has been summed under the old maximum, once per batch and in f64
-        // (a 2-ulp f32 factor at every update of the running maximum would add ~1e-7 relative per
-        // update to the expectation: a few 1e-4 mm of the 1e-3 mm budget)
+      const float tq = mb * kLog2e;
+      if (tq > m) {  // raise the power-of-two level of the sums (NhwcRowWalk::batch): an exact exponent shift
+        const float qn = ceilf(tq);
         if (m != -INFINITY) {  // (nothing summed yet otherwise)
-          const double f = exp_neg64((double)m - (double)mb);
-          s *= f; sx *= f; sy *= f;
+          const int d = (int)(m - qn);
+          s = ldexp(s, d); sx = ldexp(sx, d); sy = ldexp(sy, d);
         }
-        m = mb;
+        m = qn;
       }
-      const float nm = -m * kLog2e;
+      const float nm = -m;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int p = p0 + u * G;
@@ -558,10 +580,155 @@ __global__ __launch_bounds__(1024) void decode_nhwc_kernel(const T* __restrict__
   nhwc_merge_and_store(row_m, row_s, G, N, nj, j0, J, D, b, hs, ai, coords2d, coords3d_rel);
 }
 
+// ---- NHWC, staged (round 6).  The walk above keeps U dword loads per lane in flight (a wave: U x 256 bytes that
+// straddle 128-byte lines -- a position's 153 channels are 612 bytes) and nothing while it sums: a CU's ~30 waves hold
+// ~30 KB in flight on average, about half of what the HBM latency asks for.  Here the logits of a crop reach LDS
+// through a RING of batch slots filled by global_load_lds_dwordx4 -- 16 bytes per lane, consecutive lanes consecutive
+// addresses (a crop is one contiguous run), no registers, R - 1 batches in flight per workgroup WHILE it sums -- and
+// the same walk (NhwcRowWalk: the same calls in the same order, the same bits) reads its channel out of LDS: lane n
+// reads dword p*N + n of a slot, consecutive lanes consecutive banks.  One workgroup per crop, one lane per channel,
+// one barrier per batch: [own copies of batch k landed] barrier [copies of batch k + R - 1 issued into the slot batch
+// k - 1 left] [batch k summed].  A batch's copy starts at the 16-byte granule that holds its first byte.
+// Slots R of the ring, measured on one MI355X (profiles/r06r_nhwc_staged_ab*.jsonl, R = 2 / 3 / 4; 6 is slower
+// everywhere): f32 logits in launches that run for many rounds (32,768 crops of 8x8x153: 230 / 222 / 219 us) want
+// three batches in flight, everything else (16-bit logits: the walk is VALU-bound; launches of one or two rounds:
+// 1,024 crops 9.4 / 10.3 / 10.4 us) the shortest prologue and the most workgroups per CU.  The bits do not depend on R.
+__device__ __forceinline__ void nhwc_dma16(const void* sbase, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+               :
+               : "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(sbase)
+               : "memory", "m0");  // (M0 is overwritten: the register allocator must know)
+}
+template <typename T>
+__device__ __forceinline__ T nhwc_lds_at(const __attribute__((address_space(3))) char* p) {
+  if constexpr (sizeof(T) == 4) {
+    return __builtin_bit_cast(T, *reinterpret_cast<const __attribute__((address_space(3))) unsigned*>(p));
+  } else {
+    return __builtin_bit_cast(T, *reinterpret_cast<const __attribute__((address_space(3))) unsigned short*>(p));
+  }
+}
+// at most n of this wave's vector-memory operations still outstanding (n wave-uniform; the instruction takes an immediate)
+__device__ __forceinline__ void nhwc_wait_vmcnt_le(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: case 10: case 11: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;  // (stricter than asked: safe)
+  }
+}
+
+template <typename T, int U, int R>
+__global__ __launch_bounds__(1024) void decode_nhwc_staged_kernel(const T* __restrict__ logits, int B, int J, int D,
+                                                                  int H, int W, unsigned slot_bytes, HeadScale hs,
+                                                                  AxisInv ai, float* __restrict__ coords2d,
+                                                                  float* __restrict__ coords3d_rel) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int N = J * (1 + D), HW = H * W;
+  const int b = blockIdx.x;
+  const int n_batches = HW / U;
+  const unsigned pitch = (unsigned)N * (unsigned)sizeof(T);  // bytes between positions
+  const unsigned batch_bytes = (unsigned)U * pitch;
+  const char* crop = uniform_ptr(reinterpret_cast<const char*>(logits) + (size_t)b * HW * pitch);
+  const unsigned crop_lo = (unsigned)(reinterpret_cast<uintptr_t>(crop) & 15u);  // (wave-uniform)
+  const auto lds = (const __attribute__((address_space(3))) char*)smem_raw;
+  const unsigned lds0 = (unsigned)(size_t)lds;
+  const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63,
+                 nw = blockDim.x >> 6;
+  // the copies of batch k: granules [start - shift, start + batch_bytes) -> slot k % R; returns this wave's count
+  auto issue = [&](int k) -> int {
+    const unsigned shift = (crop_lo + (unsigned)k * batch_bytes) & 15u;
+    const char* src = crop + (size_t)k * batch_bytes - shift;
+    const unsigned total = shift + batch_bytes;
+    const unsigned slot = lds0 + (unsigned)(k % R) * slot_bytes;
+    int count = 0;
+    for (unsigned q = wave * 1024u; q < total; q += nw * 1024u) {  // (wave-uniform trip count)
+      const unsigned off = q + lane * 16u;
+      // (the last granule may reach <= 15 bytes past the batch: the same 16-byte granule, the same page)
+      if (off < total) nhwc_dma16(src, off, slot + q);
+      ++count;
+    }
+    return count;
+  };
+  int ahead[R - 1];  // this wave's copy counts of the batches in flight, oldest first
+#pragma unroll
+  for (int r = 0; r < R - 1; ++r) ahead[r] = r < n_batches ? issue(r) : 0;
+
+  const int t = threadIdx.x;
+  const unsigned mine = (unsigned)t * (unsigned)sizeof(T);
+  NhwcRowWalk<T, U> st;
+  for (int k = 0; k < n_batches; ++k) {
+    int later = 0;
+#pragma unroll
+    for (int r = 1; r < R - 1; ++r) later += ahead[r];
+    nhwc_wait_vmcnt_le(__builtin_amdgcn_readfirstlane(later));  // this wave's copies of batch k have landed ...
+    __syncthreads();            // ... everyone's have, and everyone has left batch k - 1
+#pragma unroll
+    for (int r = 0; r + 1 < R - 1; ++r) ahead[r] = ahead[r + 1];
+    ahead[R - 2] = k + R - 1 < n_batches ? issue(k + R - 1) : 0;
+    if (t < N) {
+      const unsigned shift = (crop_lo + (unsigned)k * batch_bytes) & 15u;
+      const auto from = lds + (unsigned)(k % R) * slot_bytes + shift + mine;
+      T raw[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) raw[u] = nhwc_lds_at<T>(from + (unsigned)u * pitch);
+      st.batch(raw, W);
+    }
+  }
+  __syncthreads();  // every walk has left the ring: the states below overlay it
+  float* row_m = reinterpret_cast<float*>(smem_raw);                           // [N]
+  double* row_s = reinterpret_cast<double*>(smem_raw + ((N * 4 + 15) & ~15));  // [N][3]
+  if (t < N) {
+    row_m[t] = st.m;
+    row_s[t * 3 + 0] = st.s; row_s[t * 3 + 1] = st.sx; row_s[t * 3 + 2] = st.sy;
+  }
+  nhwc_merge_and_store(row_m, row_s, 1, N, J, 0, J, D, b, hs, ai, coords2d, coords3d_rel);
+}
+
+// The staged kernel's shapes: one lane per channel, the factored walk (W a multiple of 4), a ring of at most 48 KiB.
+inline size_t nhwc_slot_bytes(long long N, int U, size_t elem) { return ((size_t)U * N * elem + 30 + 15) & ~(size_t)15; }
+inline int nhwc_ring_slots(long long B, long long N, size_t elem) { return elem == 4 && B >= 8192 && N >= 128 ? 4 : 2; }
+inline bool nhwc_staged_fits(long long N, int W, int U, int R, size_t elem) {
+  return N <= 1024 && W % 4 == 0 && nhwc_slot_bytes(N, U, elem) * R <= 48 * 1024;
+}
+
+template <typename T, int R>
+static void launch_decode_nhwc_staged(const void* logits, int B, int J, int D, int H, int W, int rb, const HeadScale& hs,
+                                      float* c2d, float* c3d, hipStream_t stream) {
+  const long long N = (long long)J * (1 + D);
+  auto kern = rb == 16 ? decode_nhwc_staged_kernel<T, 16, R> : rb == 12 ? decode_nhwc_staged_kernel<T, 12, R>
+              : rb == 8 ? decode_nhwc_staged_kernel<T, 8, R> : decode_nhwc_staged_kernel<T, 4, R>;
+  const size_t slot = nhwc_slot_bytes(N, rb, sizeof(T));
+  const size_t ring = slot * R;
+  const size_t tail = (size_t)((N * 4 + 15) & ~15LL) + (size_t)N * 24;
+  const size_t lds = ring > tail ? ring : tail;
+  const int threads = (int)((N + 63) / 64 * 64);
+  hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(threads), lds, stream, (const T*)logits, B, J, D, H, W,
+                     (unsigned)slot, hs, make_axis_inv(W, H, D), c2d, c3d);
+}
+
 template <typename T>
 static int launch_decode_nhwc(const void* logits, int B, int J, int D, int H, int W, const HeadScale& hs,
-                              float* c2d, float* c3d, hipStream_t stream) {
+                              float* c2d, float* c3d, hipStream_t stream, int staging = 0) {
   const long long N = (long long)J * (1 + D);
+  // staging: 0 = the library's rule (launches of >= 256 crops), 1 = never, 2 = whenever the shape allows
+  {
+    const int rb = (W == 12 || W == 16) ? W : (W % 8 == 0 ? 8 : 4);
+    const int R = nhwc_ring_slots(B, N, sizeof(T));
+    if (staging != 1 && nhwc_staged_fits(N, W, rb, R, sizeof(T)) && (staging == 2 || B >= 256)) {
+      MTR_CLEAR_STALE();
+      if (R == 4) launch_decode_nhwc_staged<T, 4>(logits, B, J, D, H, W, rb, hs, c2d, c3d, stream);
+      else launch_decode_nhwc_staged<T, 2>(logits, B, J, D, H, W, rb, hs, c2d, c3d, stream);
+      MTR_CHECK_LAUNCH();
+      return MTR_OK;
+    }
+  }
   // 1024 threads (up to 6 position groups per channel at N = 153) while a crop is ONE workgroup and the
   // batch does not fill the chip; large batches keep 256 threads (4+ workgroups per CU hide the walk)
   // joints of a crop over `splits` workgroups while the batch leaves CUs idle (B = 64: 4 x 64 workgroups)
@@ -614,6 +781,13 @@ static int launch_decode_nhwc(const void* logits, int B, int J, int D, int H, in
 extern "C" int mtr_softargmax_decode(const void* logits, int dtype, int layout, int B, int J, int D,
                                      int H, int W, const mtr_head_params* p, float* coords2d,
                                      float* coords3d_rel, mtr_stream_t stream) {
+  return mtr_softargmax_decode_opts(logits, dtype, layout, B, J, D, H, W, p, 0, coords2d, coords3d_rel, stream);
+}
+
+extern "C" int mtr_softargmax_decode_opts(const void* logits, int dtype, int layout, int B, int J, int D,
+                                          int H, int W, const mtr_head_params* p, int nhwc_staging, float* coords2d,
+                                          float* coords3d_rel, mtr_stream_t stream) {
+  if (nhwc_staging < 0 || nhwc_staging > 2) return MTR_E_PARAM;
   if (!logits || !p || !coords2d || !coords3d_rel) return MTR_E_NULL;
   if (B < 0 || J <= 0 || D <= 0 || H <= 0 || W <= 0) return MTR_E_SHAPE;
   if (p->proc_side <= 0 || p->stride_test <= 0) return MTR_E_PARAM;
@@ -623,9 +797,9 @@ extern "C" int mtr_softargmax_decode(const void* logits, int dtype, int layout, 
   hipStream_t s = (hipStream_t)stream;
   if (layout == MTR_NHWC) {
     switch (dtype) {
-      case MTR_F32: return mtr::launch_decode_nhwc<float>(logits, B, J, D, H, W, hs, coords2d, coords3d_rel, s);
-      case MTR_F16: return mtr::launch_decode_nhwc<__half>(logits, B, J, D, H, W, hs, coords2d, coords3d_rel, s);
-      case MTR_BF16: return mtr::launch_decode_nhwc<__hip_bfloat16>(logits, B, J, D, H, W, hs, coords2d, coords3d_rel, s);
+      case MTR_F32: return mtr::launch_decode_nhwc<float>(logits, B, J, D, H, W, hs, coords2d, coords3d_rel, s, nhwc_staging);
+      case MTR_F16: return mtr::launch_decode_nhwc<__half>(logits, B, J, D, H, W, hs, coords2d, coords3d_rel, s, nhwc_staging);
+      case MTR_BF16: return mtr::launch_decode_nhwc<__hip_bfloat16>(logits, B, J, D, H, W, hs, coords2d, coords3d_rel, s, nhwc_staging);
       default: return MTR_E_DTYPE;
     }
   }

@@ -13,9 +13,11 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
-def softargmax_decode(logits, n_points, cfg, out=None):
+def softargmax_decode(logits, n_points, cfg, out=None, nhwc_staging=0):
     """logits [B, J*(1+D), H, W] (f32/f16/bf16, NCHW) -> (coords2d [B,J,2] px, coords3d_rel [B,J,3] mm).
-    MetrabsHeads.forward after the conv (metrabs_pytorch/models/metrabs.py:78-85)."""
+    MetrabsHeads.forward after the conv (metrabs_pytorch/models/metrabs.py:78-85).
+    nhwc_staging (channels_last logits; mtr_softargmax_decode_opts): 0 = the library's kernel choice, 1 = never the
+    LDS-staged kernel, 2 = whenever the crop fits; the same bits either way."""
     require_cuda(logits)
     lib = _lib.load()
     # torch channels_last logits (what a channels_last conv_final emits; the TF twin's
@@ -34,9 +36,10 @@ def softargmax_decode(logits, n_points, cfg, out=None):
     else:
         c2d, c3d = out
     hp = cfg.head_params()
-    check(lib.mtr_softargmax_decode(
+    check(lib.mtr_softargmax_decode_opts(
         _ptr(logits), dtype_code(logits.dtype), _lib.MTR_NHWC if nhwc else _lib.MTR_NCHW, B, J, D, H, W,
-        ctypes.byref(hp), _ptr(c2d), _ptr(c3d), current_stream_ptr(logits.device)), 'mtr_softargmax_decode')
+        ctypes.byref(hp), int(nhwc_staging), _ptr(c2d), _ptr(c3d), current_stream_ptr(logits.device)),
+        'mtr_softargmax_decode')
     return c2d, c3d
 
 

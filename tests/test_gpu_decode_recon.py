@@ -187,6 +187,50 @@ def test_decode_channels_last_large_batches_equal_the_small_batch_kernel(hip_lib
         assert float((big3 - small3).abs().max()) <= 5e-4 and float((big2 - small2).abs().max()) <= 1e-4, (B, J, D, H)
 
 
+@pytest.mark.parametrize('B,J,D,H,dtype,misalign', [
+    (2048, 17, 8, 8, torch.float32, 0), (2048, 17, 8, 8, torch.float16, 0), (2048, 17, 8, 8, torch.bfloat16, 0),
+    (1800, 17, 8, 8, torch.float32, 1), (1800, 17, 8, 8, torch.float16, 1), (1800, 17, 8, 8, torch.float16, 3),
+    (2048, 24, 8, 8, torch.float32, 0),    # 216 channels: lanes 32 apart on 8 banks (conflicts, not errors)
+    (6000, 5, 8, 12, torch.float32, 0),    # 12-wide rows
+    (8192, 4, 8, 16, torch.float32, 2),    # 16-wide rows, 36 channels: one wave, 28 idle lanes
+    (4096, 17, 8, 4, torch.float32, 0),    # 4-wide rows
+    (700, 100, 8, 4, torch.float16, 0),    # 900 channels = 15 waves, 28.8 KB
+    (3000, 7, 16, 8, torch.float32, 1)])   # 16 depth slices
+def test_decode_channels_last_staged_kernel_is_bit_equal(B, J, D, H, dtype, misalign, hip_lib):
+    """The LDS-staged NHWC kernel (round 6: a crop copied into LDS by 16-byte-per-lane global_load_lds, then the same
+    row walk out of LDS) against the kernel that walks global memory, on launches where both walk whole maps with
+    one lane per channel: the same operations in the same order -> torch.equal.  misalign: the logits start that many
+    elements past a 16-byte boundary (the copy starts at the granule below the crop)."""
+    from metrabs_amd import kernels, _lib
+    from metrabs_amd.config import MetrabsConfig
+    cfg = MetrabsConfig(depth=D, proc_side=H * 32)
+    N = J * (1 + D)
+    g = torch.Generator(device='cuda').manual_seed(B + J + H)
+    flat = torch.empty(B * H * H * N + 8, device='cuda', dtype=dtype)
+    x = flat[misalign:misalign + B * H * H * N].view(B, H, H, N)
+    x.copy_((torch.randn(B, H, H, N, generator=g, device='cuda') * 4.0).to(dtype))
+    x[3, :, :, 5] = -float('inf')
+    x[3, 0, 0, 5] = 1.0
+    x[4, 2, 3, :] = -float('inf')
+    x = x.permute(0, 3, 1, 2)
+    assert kernels._is_channels_last(x) and x.data_ptr() % 16 == (misalign * x.element_size()) % 16
+    w2, w3 = kernels.softargmax_decode(x, J, cfg, nhwc_staging=1)
+    s2, s3 = kernels.softargmax_decode(x, J, cfg, nhwc_staging=2)
+    assert torch.isfinite(s3).all() and torch.isfinite(s2).all()
+    assert torch.equal(s2, w2) and torch.equal(s3, w3)
+    d2, d3 = kernels.softargmax_decode(x, J, cfg)   # the library's own choice: one of the two
+    assert torch.equal(d2, w2) and torch.equal(d3, w3)
+    # ... and both are the NCHW kernel's answer within the usual bound
+    n2, n3 = kernels.softargmax_decode(x.contiguous(), J, cfg)
+    tol = 1e-3 if dtype == torch.float32 else 2e-3
+    assert float((s3 - n3).abs().max()) <= tol and float((s2 - n2).abs().max()) <= 4e-4
+    # small launches: the staged kernel on its own (the walking kernel merges position groups there: other sums)
+    k2, k3 = kernels.softargmax_decode(x[:5], J, cfg, nhwc_staging=2)
+    assert torch.equal(k2, s2[:5]) and torch.equal(k3, s3[:5])
+    lib = _lib.load()
+    assert lib.mtr_softargmax_decode_opts(None, 0, 1, 1, 17, 8, 8, 8, None, 3, None, None, None) < 0
+
+
 @pytest.mark.parametrize('name', list(cases.RECON_CASES))
 def test_reconstruct_vs_golden_and_oracle(name, hip_lib):
     """Identical coords -> absolute poses.  The reference solves with fp32 LAPACK lstsq (its own
