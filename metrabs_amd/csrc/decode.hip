@@ -53,7 +53,12 @@ __device__ __forceinline__ float vec_max(const float (&v)[VEC]) {
   return r;
 }
 
-template <typename T, int VEC, int LPJ, int AUX>
+// SPAN (round 6): a wave's 64 / LPJ joint groups are CONSECUTIVE (crop, joint) pairs of the whole batch instead of
+// joints of one crop -- at J = 17 the per-crop mapping left the last wave of every crop 1 / 8 (16-bit logits: eight
+// joints per wave, 17 = 8 + 8 + 1) or 1 / 4 (f32: 4 + 4 + 4 + 4 + 1) occupied: 71 % / 85 % of the lanes worked.  One
+// descriptor over the whole tensor (< 4 GiB; the host falls back otherwise), the crop in the per-lane offset; a
+// joint's arithmetic does not change: the same bits.
+template <typename T, int VEC, int LPJ, int AUX, bool SPAN>
 __global__ __launch_bounds__(256) void decode_nchw_kernel(
     const T* __restrict__ logits, int B, int J, int D, int H, int W, HeadScale hs, AxisInv ai,
     float* __restrict__ coords2d, float* __restrict__ coords3d_rel) {
@@ -65,21 +70,37 @@ __global__ __launch_bounds__(256) void decode_nchw_kernel(
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(
       (int)(blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave)));
-  const int groups_per_crop = (J + JPW - 1) / JPW;
-  const int b = wave / groups_per_crop;
-  if (b >= B) return;  // wave-uniform
-  const int j_raw = (wave % groups_per_crop) * JPW + lane / LPJ;
-  const bool joint_ok = j_raw < J;
-  // lanes past the last joint recompute joint J-1 (valid addresses, no exec masking) and skip
-  // the final store
-  const int j = joint_ok ? j_raw : J - 1;
-  const int li = lane % LPJ;
-
-  // one descriptor per wave over this crop's channels; per-lane part of the address in voff,
-  // the depth-slice part is a scalar offset
   const int crop_elems = J * (1 + D) * HW;
-  const buffer_rsrc_t rsrc =
-      make_rsrc(uniform_ptr(logits + (size_t)b * crop_elems), (unsigned)crop_elems * sizeof(T));
+  int b, j;
+  bool joint_ok;
+  buffer_rsrc_t rsrc;
+  int lane_base;  // element offset of the lane's crop inside the descriptor
+  if constexpr (SPAN) {
+    const long long total = (long long)B * J;
+    if ((long long)wave * JPW >= total) return;  // wave-uniform
+    const long long g_raw = (long long)wave * JPW + lane / LPJ;
+    joint_ok = g_raw < total;
+    // lanes past the last pair recompute it (valid addresses, no exec masking) and skip the final store
+    const int gj = (int)(joint_ok ? g_raw : total - 1);
+    b = gj / J;
+    j = gj - b * J;
+    rsrc = make_rsrc(uniform_ptr(logits), (unsigned)((size_t)B * crop_elems * sizeof(T)));
+    lane_base = b * crop_elems;
+  } else {
+    const int groups_per_crop = (J + JPW - 1) / JPW;
+    b = wave / groups_per_crop;
+    if (b >= B) return;  // wave-uniform
+    const int j_raw = (wave % groups_per_crop) * JPW + lane / LPJ;
+    joint_ok = j_raw < J;
+    // lanes past the last joint recompute joint J-1 (valid addresses, no exec masking) and skip
+    // the final store
+    j = joint_ok ? j_raw : J - 1;
+    // one descriptor per wave over this crop's channels; per-lane part of the address in voff,
+    // the depth-slice part is a scalar offset
+    rsrc = make_rsrc(uniform_ptr(logits + (size_t)b * crop_elems), (unsigned)crop_elems * sizeof(T));
+    lane_base = 0;
+  }
+  const int li = lane % LPJ;
   const int slice_bytes = J * HW * (int)sizeof(T);  // depth slice d sits d*J channels further
 
   // Running maxima are GROUP-wide (shared by the LPJ lanes of the joint), so every lane rescales
@@ -103,7 +124,7 @@ __global__ __launch_bounds__(256) void decode_nchw_kernel(
       fx[v] = (float)w;
       fy[v] = (float)h;
     }
-    const int voff = (j * HW + p0) * (int)sizeof(T);
+    const int voff = (int)((unsigned)(lane_base + j * HW + p0) * (unsigned)sizeof(T));
 
     // ---- the 2D heatmap load is issued together with the first round of depth slices
     float v2[VEC];
@@ -272,13 +293,21 @@ template <typename T, int VEC, int LPJ, int AUX>
 static int launch_decode_aux(const void* logits, int B, int J, int D, int H, int W,
                              const HeadScale& hs, float* c2d, float* c3d, hipStream_t stream) {
   constexpr int JPW = kWave / LPJ;
-  const long long waves = (long long)B * ((J + JPW - 1) / JPW);
+  // consecutive (crop, joint) pairs per wave when joints do not fill a crop's last wave and the tensor is one
+  // descriptor's worth (32-bit byte offsets)
+  const unsigned long long bytes = (unsigned long long)B * J * (1 + D) * H * W * sizeof(T);
+  const bool span = J % JPW != 0 && bytes < 0xffffffffull;
+  const long long waves = span ? ((long long)B * J + JPW - 1) / JPW : (long long)B * ((J + JPW - 1) / JPW);
   const int waves_per_block = 4;
   const long long blocks = (waves + waves_per_block - 1) / waves_per_block;
   if (blocks > 0x7fffffffLL) return MTR_E_SHAPE;
   MTR_CLEAR_STALE();
-  hipLaunchKernelGGL((decode_nchw_kernel<T, VEC, LPJ, AUX>), dim3((unsigned)blocks), dim3(256), 0,
-                     stream, (const T*)logits, B, J, D, H, W, hs, make_axis_inv(W, H, D), c2d, c3d);
+  if (span)
+    hipLaunchKernelGGL((decode_nchw_kernel<T, VEC, LPJ, AUX, true>), dim3((unsigned)blocks), dim3(256), 0,
+                       stream, (const T*)logits, B, J, D, H, W, hs, make_axis_inv(W, H, D), c2d, c3d);
+  else
+    hipLaunchKernelGGL((decode_nchw_kernel<T, VEC, LPJ, AUX, false>), dim3((unsigned)blocks), dim3(256), 0,
+                       stream, (const T*)logits, B, J, D, H, W, hs, make_axis_inv(W, H, D), c2d, c3d);
   MTR_CHECK_LAUNCH();
   return MTR_OK;
 }

@@ -43,6 +43,17 @@
                          // register, the plane and row offsets ride in the buffer instruction's scalar offset, and
                          // the byte window is one v_alignbyte.  64 crops, cache-resident frames: 25.6 -> 24.5 us.
 #endif
+#ifndef MTR_WARP_ASM
+#define MTR_WARP_ASM 0   // warp_rows_kernel, round 6 (a developer option, measured and left off): the six tap loads of a sample issued
+                         // from inline asm and awaited with a COUNTED s_waitcnt vmcnt tied to their registers.  The ISA of the
+                         // builtin-load pipeline waits vmcnt(0) in front of every other sample -- for the loads of the NEXT
+                         // sample and the previous pixel's stores too (the two alternative request paths meet in a join the
+                         // compiler's wait counting gives up on) -- so "one sample requested ahead" drains every second
+                         // sample.  With exact waits (vmcnt 6 / 9 / 9 / 3), same bits: 64 crops 28.2 -> 27.2 us planar, 25.0 ->
+                         // 25.2 interleaved levels; 320 TTA crops 154.9 -> 158.4; two or three samples ahead: the same
+                         // (profiles/r06u_warp_asm.jsonl).  Eight waves per SIMD already cover each other's waits: the
+                         // kernel is not latency-bound on its taps.
+#endif
 #ifndef MTR_WARP_ABLATE
 #define MTR_WARP_ABLATE 0   // developer-only timing ablations (tools/experiments/ablate_warp.py); in warp_rows_kernel:
                             // 1 = no tap loads, 2 = no LUT reads, 4 = no gamma pow, 8 = no stores, 16 = one gather pair for all channels.  Round 3, 64 crops,
@@ -661,6 +672,45 @@ __global__ __launch_bounds__(256) void warp_crops_kernel(
 // steady stream instead of one burst at its end, and
 // -- gfx9 counts loads and stores in the same in-order vmcnt -- the next taps are always OLDER than
 // the previous pixel's stores, so waiting for taps never waits for a store.
+// ---- counted waits for the row-walking sampler (MTR_WARP_ASM) ---------------------------------------------------
+using v4i_sgpr = __attribute__((ext_vector_type(4))) int;
+// the descriptor words of make_rsrc as four SGPRs an asm operand can name
+__device__ __forceinline__ v4i_sgpr make_rsrc_words(const void* wave_uniform_base, unsigned bytes) {
+  const unsigned long long v = (unsigned long long)wave_uniform_base;
+  v4i_sgpr r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(v >> 32) & 0xffffu));
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+// 8 bytes per lane through a buffer descriptor, asynchronous: the caller waits with tap_wait<N> before it reads r
+__device__ __forceinline__ unsigned long long tap_load_asm(v4i_sgpr rsrc, int voff, int soff) {
+  unsigned long long r;
+  asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=&v"(r) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  return r;
+}
+// Vector-memory operations the row walk issues between the LAST tap load of sample s and the point where sample s is
+// finished (the loads of the samples requested ahead, 6 each; the stores of the pixels completed meanwhile, 3 each):
+// a replay of the loop below.  gfx9 retires loads and stores through one in-order counter.
+constexpr int warp_ops_after(int s, int NS, int PD, int AA2) {
+  int ops = 0;
+  bool seen = false;
+  for (int q = 0; q < PD && q < NS; ++q) {  // the prologue's requests
+    if (seen) ops += 6;
+    if (q == s) seen = true;
+  }
+  for (int i = 0; i < NS; ++i) {
+    if (i + PD < NS) {
+      if (seen) ops += 6;
+      if (i + PD == s) seen = true;
+    }
+    if (i == s) return ops;
+    if ((i + 1) % AA2 == 0 && seen) ops += 3;  // (the pixel's three stores: always issued, see the store below)
+  }
+  return ops;
+}
+
 struct TapSet {
   unsigned long long raw[6];  // [channel][top, bottom]: the two x-taps of a row (f32 pair / byte window)
   float w00, w01, w10, w11;
@@ -752,8 +802,23 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
   // The sample pipeline, instantiated per kind of source: IL = interleaved uint8 level 0 (only in the
   // L0 == 2 kernel, whose levels 1 and 2 are f32 planes like everyone's: the split is made ONCE per
   // wave, below, so that each instance stays straight-line code).
-  auto run = [&](auto il_tag) {
+  auto run = [&](auto il_tag, auto asm_tag) {
   constexpr bool IL = decltype(il_tag)::value;
+  // ASMP: tap loads from inline asm + counted waits (MTR_WARP_ASM; the pitches are multiples of 4: one address register,
+  // the plane / row offsets in six scalars).  Straight-line code between a load and its wait: no branch may separate them
+  // (the compiler would copy the tied registers in front of the wait).
+  constexpr bool ASMP = decltype(asm_tag)::value;
+  v4i_sgpr rsrc_w = {0, 0, 0, 0};
+  int soffs[6] = {0, 0, 0, 0, 0, 0};
+  if constexpr (ASMP) {
+    rsrc_w = bytes0 ? make_rsrc_words(uniform_ptr((const uint8_t*)l0_any), (unsigned)u8_bytes)
+                    : make_rsrc_words(uniform_ptr(planes), (unsigned)(3 * plane_elems) * 4u);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      soffs[2 * c] = __builtin_amdgcn_readfirstlane(c * plane_bytes);
+      soffs[2 * c + 1] = __builtin_amdgcn_readfirstlane(c * plane_bytes + row_bytes);
+    }
+  }
   // sample s of this lane: row s / (AA*AA), sub-sample (sj, si) in the reference's loop order
   auto request = [&](int s) -> TapSet {
     const int r = s / (AA * AA), sj = (s / AA) % AA, si = s % AA;
@@ -823,6 +888,12 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
       return t;
     }
     t.off = ((__mul24(ys, W) + xs) << sh) + img_off;  // (full-rate 24-bit multiply: ys, W < 2^24)
+    if constexpr (ASMP) {
+      const int base = t.off & ~3;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) t.raw[k] = tap_load_asm(rsrc_w, base, soffs[k]);
+      return t;
+    }
     if (MTR_WARP_LEAN && same_shift) {
       // pitches that are multiples of 4: (off + c * plane + r * row) & ~3 = (off & ~3) + c * plane + r * row,
       // i.e. ONE vector address, the rest in the loads' scalar offset
@@ -878,7 +949,7 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
         const F2 tp = __builtin_bit_cast(F2, t.raw[2 * c]), bt = __builtin_bit_cast(F2, t.raw[2 * c + 1]);
         acc[c] += fmaf(bt.b, t.w11, fmaf(bt.a, t.w10, fmaf(tp.b, t.w01, tp.a * t.w00)));
       }
-    } else if (MTR_WARP_LEAN && same_shift) {
+    } else if (ASMP || (MTR_WARP_LEAN && same_shift)) {
       // the six byte windows of the sample share one alignment: bytes (off & 3), (off & 3) + 1 of each
       // 8-byte word = bytes 0, 1 of v_alignbyte(high dword, low dword, off & 3)
       const unsigned al = (unsigned)t.off & 3u;
@@ -922,6 +993,14 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     if (s + PD < NS) ring[(s + PD) % (PD + 1)] = request(s + PD);
+    if constexpr (ASMP) {
+      // the six loads of sample s have landed once at most [what was issued behind them] operations are outstanding
+      TapSet& t = ring[s % (PD + 1)];
+      asm volatile("s_waitcnt vmcnt(%6)"
+                   : "+v"(t.raw[0]), "+v"(t.raw[1]), "+v"(t.raw[2]), "+v"(t.raw[3]), "+v"(t.raw[4]), "+v"(t.raw[5])
+                   : "n"(warp_ops_after(s, NS, PD, AA * AA))
+                   : "memory");
+    }
     finish(ring[s % (PD + 1)], acc);
     if ((s + 1) % (AA * AA) == 0) {  // the pixel of row r is complete
       const int v = v_first + (s / (AA * AA)) * RI;
@@ -934,12 +1013,15 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
         acc[c] = 0.0f;
       }
       if ((MTR_WARP_ABLATE & 8) && px[0] != 12345.0f) continue;  // (timing ablation: no stores)
-      if (v < res) {
+      // (ASMP: the three stores are ALWAYS issued -- the wait counts above include them -- and a row below the crop
+      //  aims past the descriptor's range, where the hardware drops the store)
+      if (ASMP || v < res) {
         const int pix = v * res + x;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const OutT o = from_f32<OutT>(px[c]);
-          const int voff = (nhwc ? pix * 3 + c : pix) * (int)sizeof(OutT);
+          int voff = (nhwc ? pix * 3 + c : pix) * (int)sizeof(OutT);
+          if (ASMP && v >= res) voff = 0x7ffffff0;
           const int soff = nhwc ? 0 : c * chan_bytes;
           if constexpr (sizeof(OutT) == 4)
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), orsrc, voff, soff, 0);
@@ -950,11 +1032,18 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
     }
   }
   };  // run
+  constexpr bool kAsm = MTR_WARP_ASM && MTR_WARP_LEAN && !MTR_WARP_ABLATE;
+  auto run_planar = [&]() {  // (f32 levels, planar uint8 level 0: one request path)
+    if constexpr (kAsm) {
+      if (same_shift) { run(std::false_type{}, std::true_type{}); return; }
+    }
+    run(std::false_type{}, std::false_type{});
+  };
   if constexpr (HWC) {
-    if (bytes0) run(std::true_type{});
-    else run(std::false_type{});
+    if (bytes0) run(std::true_type{}, std::false_type{});
+    else run_planar();
   } else {
-    run(std::false_type{});
+    run_planar();
   }
   }  // items
 }

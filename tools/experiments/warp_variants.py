@@ -13,8 +13,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 OUT = os.path.join(ROOT, 'tools', 'experiments', '_build')
 # (round 5, profiles/r05v_*: ablations of the shipped kernel; the unaligned-load and late-LUT variants measured there
 #  were source edits that were not kept)
+if os.environ.get('MTR_WARP_SET') == 'asm':   # round 6: counted waits (MTR_WARP_ASM) x samples requested ahead
+    VARIANTS_R6 = {'builtin_waits_pd1': ['-DMTR_WARP_ASM=0'], 'asm_pd1': [], 'asm_pd2': ['-DMTR_WARP_PREFETCH=2'],
+                   'asm_pd3': ['-DMTR_WARP_PREFETCH=3'], 'builtin_waits_pd2': ['-DMTR_WARP_ASM=0', '-DMTR_WARP_PREFETCH=2']}
 VARIANTS = {'base': [], 'one_gather_pair': ['-DMTR_WARP_ABLATE=16'], 'no_taps': ['-DMTR_WARP_ABLATE=1'],
             'no_stores': ['-DMTR_WARP_ABLATE=8'], 'arithmetic_only': ['-DMTR_WARP_ABLATE=15']}
+
+
+if os.environ.get('MTR_WARP_SET') == 'asm':
+    VARIANTS = VARIANTS_R6
 
 
 def build():
@@ -94,7 +101,7 @@ if __name__ == '__main__':
     if sys.argv[1] == 'build':
         build()
     elif sys.argv[1] == 'run':
-        for m in VARIANTS:
+        for m in list(VARIANTS) * (2 if os.environ.get('MTR_WARP_SET') else 1):
             for layout in ('planar', 'interleaved'):
                 subprocess.run([sys.executable, __file__, 'one', m, layout])
     else:
