@@ -623,7 +623,7 @@ def source_footprint_bytes(wp, res, im_h, im_w):
 def decode_roofline(iters=20, nhwc=False, shape=(32768, 17, 8, 8)):
     """K2-K4 standalone on a batch beyond the 256 MiB Infinity Cache: J=17, 8x8, D=8, B=32768
     (1.28 GB of fp32 logits).  nhwc: the same logits in the TF twin's layout
-    ('b h w (d j)', metrabs_tf/models/metrabs.py:100-101; torch channels_last) through decode_nhwc_kernel."""
+    ('b h w (d j)', metrabs_tf/models/metrabs.py:100-101; torch channels_last) through the NHWC kernels of csrc/decode.hip."""
     from metrabs_amd import kernels
     from metrabs_amd.config import MetrabsConfig
     B, J, D, side = shape
@@ -638,7 +638,8 @@ def decode_roofline(iters=20, nhwc=False, shape=(32768, 17, 8, 8)):
     achieved = B * bytes_per_crop / t
     del logits
     torch.cuda.empty_cache()
-    return dict(kernel='decode_nhwc_kernel<float>' if nhwc else 'decode_nchw_kernel<float,4,16>', bound='hbm',
+    return dict(kernel='decode_nhwc_staged_kernel<float> (LDS ring fed by global_load_lds; >= 256 crops of <= 1,024 channels), else decode_nhwc_kernel<float>'
+                if nhwc else 'decode_nchw_kernel<float,4,16>', bound='hbm',
                 achieved=achieved / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s', frac=achieved / HBM_PEAK,
                 frac_of_measured_copy=achieved / HBM_COPY_MEASURED, avg_launch_us=t * 1e6,
                 crops=B, bytes_per_crop=bytes_per_crop, traffic=None)
