@@ -319,12 +319,18 @@ def head_auto_choice(C, J, D, H, W, channels_last=False, dtype=torch.float32):
         0.92 / 0.92 of the library pair's time, 16 bins 1.00 / 0.98, 24 bins 1.54 / 1.40, 32 bins 1.12 / 1.16,
         48 bins 1.14 / 1.15, 72 bins -- the metric string's shape -- 1.17 / 1.04, 80 bins 1.31 / 1.17: a
         joint's 1 + D rows no longer fit one 16-row tile and the multi-tile atoms quantise badly on 256 CUs).
-        16-bit features keep the fused kernel there (72 bins, f16: 45 vs 70 us at 64 crops)."""
+        16-bit features keep the fused kernel there (72 bins, f16: 45 vs 70 us at 64 crops),
+      * (round 6: the rule reads the LAYOUT) f32 channels_last features on maps of more than 64 positions: for them the
+        library path is a plain GEMM (`F.linear` on the [B H W, C] matrix the features already are -- 2 - 5 x faster
+        than the library's channels_last 1x1 convolution, which is what ran before) and is level with or ahead of the
+        fused kernel from 12x12 maps on (64 / 256 crops of 12x12: 47 / 135 vs 52 / 158 us, 16x16 76 / 242 vs 69 / 250,
+        20x20 104 / 401 vs 120 / 403; 8x8 with 8 / 16 bins stays fused: 23 / 64 vs 29 / 71, 34 / 121 vs 40 / 118;
+        profiles/r06x_layout_rule*.jsonl)."""
     if not head_fused_supported(C, J, D, H, W, channels_last, dtype):
         return False
     hw = H * W
     if dtype == torch.float32:
-        return hw < 576 and D <= 16
+        return (hw <= 64 if channels_last else hw < 576) and D <= 16
     return hw <= 256
 
 

@@ -343,6 +343,36 @@ def test_fused_equals_unfused_and_module(hip_lib):
     assert set(sd) == {'conv_final.weight', 'conv_final.bias'} and sd['conv_final.weight'].shape == (153, 128, 1, 1)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
+def test_library_path_on_channels_last_features_is_a_gemm(dtype, hip_lib):
+    """(round 6) channels_last features are the [B H W, C] matrix of a GEMM: the library path runs F.linear on that view
+    (NHWC logits, decoded in place) instead of the library's channels_last 1x1 convolution -- the same function: against
+    the NCHW library path and the fused kernel on the same features, whole head and its first points, 8 and 72 depth
+    bins; and the static rule reads the layout (f32 channels_last maps of 12x12 take the library pair)."""
+    from metrabs_amd import kernels
+    from metrabs_amd.config import MetrabsConfig
+    from metrabs_amd.models.metrabs import MetrabsHeads
+    torch.manual_seed(2)
+    for depth, side in ((8, 12), (72, 8)):
+        heads = MetrabsHeads(17, MetrabsConfig(depth=depth, proc_side=side * 32), in_channels=128, fused=False).cuda()
+        feat = (torch.randn(5, 128, side, side, device='cuda') * 0.5).to(dtype)
+        cl = feat.contiguous(memory_format=torch.channels_last)
+        with torch.inference_mode():
+            n2d, n3d = heads(feat)
+            c2d, c3d = heads(cl)
+            assert heads.last_path == 'library'
+            k2d, k3d = heads(cl, first_points=9)
+            heads.fused = True
+            f2d, f3d = heads(cl)
+            heads.fused = 'auto'
+            heads(cl)
+            assert heads.last_path == ('fused' if dtype != torch.float32 else 'library')
+        tol3, tol2 = (2e-3, 4e-4) if dtype == torch.float32 else (1.0, 0.2)   # (16-bit logits: as test_16bit_* above)
+        assert float((c3d - n3d).abs().max()) <= tol3 and float((c2d - n2d).abs().max()) <= tol2
+        assert float((c3d - f3d).abs().max()) <= tol3 and float((c2d - f2d).abs().max()) <= tol2
+        assert float((k3d - c3d[:, :9]).abs().max()) <= tol3 and float((k2d - c2d[:, :9]).abs().max()) <= tol2
+
+
 def test_auto_head_path_is_a_static_rule(hip_lib):
     """MetrabsHeads(fused='auto') (Metrabs' default): the path is a static function of (dtype, layout, C,
     H, W, J, D) -- kernels.head_auto_choice -- never of the batch size or of a clock: every batch size

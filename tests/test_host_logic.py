@@ -266,6 +266,10 @@ def test_head_plan_reads_the_batch_size_in_eights_and_the_auto_rule_not_at_all()
     assert kernels.head_auto_choice(1280, 17, 72, 8, 8, dtype=torch.float16)
     assert kernels.head_auto_choice(1280, 122, 8, 12, 12, dtype=torch.float16)
     assert not kernels.head_auto_choice(1280, 17, 8, 24, 24)
+    # (round 6) the layout is an input: f32 channels_last maps of more than 64 positions take the library GEMM (F.linear)
+    assert kernels.head_auto_choice(1280, 17, 8, 8, 8, True) and kernels.head_auto_choice(1280, 17, 8, 12, 12)
+    assert not kernels.head_auto_choice(1280, 17, 8, 12, 12, True) and not kernels.head_auto_choice(1280, 17, 72, 8, 8, True)
+    assert kernels.head_auto_choice(1280, 122, 8, 12, 12, True, torch.float16)
     assert not kernels.head_auto_choice(1280, 17, 8, 20, 20, dtype=torch.bfloat16)
     assert not kernels.head_auto_choice(1280, 17, 81, 8, 8)   # no fused kernel beyond 80 depth bins
 
