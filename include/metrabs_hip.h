@@ -86,9 +86,10 @@ int mtr_softargmax_decode(const void* logits, int dtype, int layout, int B, int 
                           int W, const mtr_head_params* p, float* coords2d, float* coords3d_rel,
                           mtr_stream_t stream);
 /* The same launch with the NHWC kernel choice made explicit (A/B measurements, the bit-identity tests):
- * nhwc_staging 0 = the library's rule, 1 = never, 2 = whenever the crop fits -- the kernel that copies a crop's logits
- * into LDS with 16-byte-per-lane global_load_lds and walks them there (launches of >= 256 crops of <= 52 KiB each by
- * the rule).  Same operations in the same order: the same bits.  Ignored for MTR_NCHW. */
+ * nhwc_staging 0 = the library's rule, 1 = never, 2 = whenever the shape allows, 3 = as 2 with two crops per workgroup
+ * where that fills the waves better (measured, never the rule's choice) -- the kernel that streams a crop's logits
+ * through a ring of LDS slots filled by 16-byte-per-lane global_load_lds and walks them there (by the rule: launches of
+ * >= 256 crops of <= 1,024 channels).  Same operations in the same order: the same bits.  Ignored for MTR_NCHW. */
 int mtr_softargmax_decode_opts(const void* logits, int dtype, int layout, int B, int J, int D, int H,
                                int W, const mtr_head_params* p, int nhwc_staging, float* coords2d,
                                float* coords3d_rel, mtr_stream_t stream);

@@ -123,6 +123,7 @@ __device__ __forceinline__ unsigned fastdiv(unsigned n, const FastDiv& f) {
 // two row-crossing steps of a 64-lane reduction go through __shfl_xor.
 constexpr int kDppXor1 = 0xB1;    // quad_perm [1,0,3,2]
 constexpr int kDppXor2 = 0x4E;    // quad_perm [2,3,0,1]
+constexpr int kDppQuadBcast1 = 0x55, kDppQuadBcast2 = 0xAA, kDppQuadBcast3 = 0xFF;  // quad_perm [k,k,k,k]: lane k of every quad
 constexpr int kDppRor4 = 0x124;   // row_ror:4
 constexpr int kDppRor8 = 0x128;   // row_ror:8
 constexpr int kDppHalfMirror = 0x141;  // row_half_mirror: lane i <-> 7 - i inside each 8 lanes

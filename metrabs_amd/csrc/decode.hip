@@ -514,7 +514,7 @@ __device__ __forceinline__ void nhwc_merge_and_store(float* row_m, double* row_s
     for (int d = 0; d < D; ++d) {  // slice order
       const int n = nj + d * nj + j;
       const double sd = row_s[n * 3];
-      S += sd; SX += row_s[n * 3 + 1]; SY += row_s[n * 3 + 2]; SZ += sd * (double)d;
+      S += sd; SX += row_s[n * 3 + 1]; SY += row_s[n * 3 + 2]; SZ = fma(sd, (double)d, SZ);
     }
     const double i3 = fast_rcp64(S);
     coords3d_rel[o * 3 + 0] = heatmap_to_mm_xy(axis_coord_rcp(SX, i3, ai.w), hs);
@@ -653,35 +653,102 @@ __device__ __forceinline__ void nhwc_wait_vmcnt_le(int n) {
   }
 }
 
-template <typename T, int U, int R>
+// The staged kernel's tail: the states are still in their lanes' registers (lane t = channel n of the workgroup's crop
+// cl).  The arithmetic of nhwc_merge_and_store with one position group -- levels through LDS, a depth slice shifted to its
+// joint's level, the slices of a joint summed in slice order from 0.0, the same reciprocal and scalings -- with the four
+// sums of a joint (S, SX, SY, SZ) in FOUR neighbouring lanes instead of one lane's four chains: the same operations per
+// accumulator in the same order, the same bits.
+template <int CPW>
+__device__ __forceinline__ void nhwc_staged_tail(char* smem_raw, int t, bool active, int cl, int n, float m, double s, double sx,
+                                                 double sy, int N, int J, int D, int b0, int B, const HeadScale& hs,
+                                                 const AxisInv& ai, float* __restrict__ coords2d,
+                                                 float* __restrict__ coords3d_rel) {
+  float* row_m = reinterpret_cast<float*>(smem_raw);                                 // [CPW][N]
+  double* row_s = reinterpret_cast<double*>(smem_raw + ((CPW * N * 4 + 15) & ~15));  // [CPW][N][3]
+  __syncthreads();  // every walk has left the ring: the states below overlay it
+  if (active) row_m[t] = m;
+  __syncthreads();
+  if (active) {
+    // (n / J without an integer division: exact for n < 2^16 -- N <= 1,024 here)
+    const int slice = (int)(((float)n + 0.5f) * __frcp_rn((float)J)), jj = n - slice * J;
+    if (slice > 0) {  // a depth slice: to the level of its joint's slices
+      const float* lv = row_m + cl * N + J + jj;
+      float M = -INFINITY;
+      for (int d = 0; d < D; ++d) M = fmaxf(M, lv[d * J]);
+      const int sh = m == -INFINITY ? 0 : (int)(m - M);
+      s = ldexp(s, sh); sx = ldexp(sx, sh); sy = ldexp(sy, sh);
+    }
+    row_s[t * 3 + 0] = s; row_s[t * 3 + 1] = sx; row_s[t * 3 + 2] = sy;
+  }
+  __syncthreads();
+  // lane 4 (c J + j) + q: quantity q of joint j of crop c
+  if (t < CPW * J * 4) {
+    const int q = t & 3, cj = t >> 2;
+    const int c = CPW == 1 ? 0 : (cj >= J ? 1 : 0), j = cj - c * J;
+    const double* rs = row_s + (size_t)c * N * 3;
+    double acc = 0.0;
+    const int col = q == 3 ? 0 : q;
+    for (int d = 0; d < D; ++d) {  // slice order
+      const double v = rs[(J + d * J + j) * 3 + col];
+      acc = q == 3 ? fma(v, (double)d, acc) : acc + v;
+    }
+    // quad lanes 1 .. 3 hand their sums to lane 0 (the 3D coordinates); lane 1 writes the 2D ones meanwhile
+    const double SX = dpp_move<kDppQuadBcast1>(acc), SY = dpp_move<kDppQuadBcast2>(acc), SZ = dpp_move<kDppQuadBcast3>(acc);
+    const size_t o = (size_t)(b0 + c) * J + j;
+    if (b0 + c < B) {
+      if (q == 0) {
+        const double i3 = fast_rcp64(acc);
+        coords3d_rel[o * 3 + 0] = heatmap_to_mm_xy(axis_coord_rcp(SX, i3, ai.w), hs);
+        coords3d_rel[o * 3 + 1] = heatmap_to_mm_xy(axis_coord_rcp(SY, i3, ai.h), hs);
+        coords3d_rel[o * 3 + 2] = heatmap_to_mm_z(axis_coord_rcp(SZ, i3, ai.d), hs);
+      } else if (q == 1) {
+        const double i2 = fast_rcp64(rs[j * 3]);
+        coords2d[o * 2 + 0] = heatmap_to_px(axis_coord_rcp(rs[j * 3 + 1], i2, ai.w), hs);
+        coords2d[o * 2 + 1] = heatmap_to_px(axis_coord_rcp(rs[j * 3 + 2], i2, ai.h), hs);
+      }
+    }
+  }
+}
+
+// CPW crops per workgroup (1 or 2): at 153 channels one crop is 64 + 64 + 25 lanes (80 % of three waves), two are 306 of
+// 320 (96 % of five) and share one tail.
+template <typename T, int U, int R, int CPW>
 __global__ __launch_bounds__(1024) void decode_nhwc_staged_kernel(const T* __restrict__ logits, int B, int J, int D,
                                                                   int H, int W, unsigned slot_bytes, HeadScale hs,
                                                                   AxisInv ai, float* __restrict__ coords2d,
                                                                   float* __restrict__ coords3d_rel) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int N = J * (1 + D), HW = H * W;
-  const int b = blockIdx.x;
+  const int b0 = blockIdx.x * CPW;
   const int n_batches = HW / U;
   const unsigned pitch = (unsigned)N * (unsigned)sizeof(T);  // bytes between positions
   const unsigned batch_bytes = (unsigned)U * pitch;
-  const char* crop = uniform_ptr(reinterpret_cast<const char*>(logits) + (size_t)b * HW * pitch);
-  const unsigned crop_lo = (unsigned)(reinterpret_cast<uintptr_t>(crop) & 15u);  // (wave-uniform)
+  const size_t crop_bytes = (size_t)HW * pitch;
+  const char* crop0 = uniform_ptr(reinterpret_cast<const char*>(logits) + (size_t)b0 * crop_bytes);
+  const unsigned lo0 = (unsigned)(reinterpret_cast<uintptr_t>(crop0) & 15u);  // (wave-uniform)
+  const unsigned lo1 = (unsigned)((reinterpret_cast<uintptr_t>(crop0) + crop_bytes) & 15u);
   const auto lds = (const __attribute__((address_space(3))) char*)smem_raw;
   const unsigned lds0 = (unsigned)(size_t)lds;
   const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63,
                  nw = blockDim.x >> 6;
-  // the copies of batch k: granules [start - shift, start + batch_bytes) -> slot k % R; returns this wave's count
+  // the copies of batch k: per crop the granules [start - shift, start + batch_bytes) -> slot k % R, part c; returns this
+  // wave's count
   auto issue = [&](int k) -> int {
-    const unsigned shift = (crop_lo + (unsigned)k * batch_bytes) & 15u;
-    const char* src = crop + (size_t)k * batch_bytes - shift;
-    const unsigned total = shift + batch_bytes;
-    const unsigned slot = lds0 + (unsigned)(k % R) * slot_bytes;
     int count = 0;
-    for (unsigned q = wave * 1024u; q < total; q += nw * 1024u) {  // (wave-uniform trip count)
-      const unsigned off = q + lane * 16u;
-      // (the last granule may reach <= 15 bytes past the batch: the same 16-byte granule, the same page)
-      if (off < total) nhwc_dma16(src, off, slot + q);
-      ++count;
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+      if (b0 + c >= B) break;  // (uniform: the last workgroup of an odd batch)
+      const unsigned shift = ((c ? lo1 : lo0) + (unsigned)k * batch_bytes) & 15u;
+      const char* src = crop0 + (size_t)c * crop_bytes + (size_t)k * batch_bytes - shift;
+      const unsigned total = shift + batch_bytes;
+      const unsigned slot = lds0 + ((unsigned)(k % R) * CPW + (unsigned)c) * slot_bytes;
+      // (the second crop's pieces start one wave further: the waves share the odd piece counts)
+      for (unsigned q = ((wave + nw - (unsigned)c) % nw) * 1024u; q < total; q += nw * 1024u) {  // (wave-uniform trip count)
+        const unsigned off = q + lane * 16u;
+        // (the last granule may reach <= 15 bytes past the batch: the same 16-byte granule, the same page)
+        if (off < total) nhwc_dma16(src, off, slot + q);
+        ++count;
+      }
     }
     return count;
   };
@@ -690,7 +757,10 @@ __global__ __launch_bounds__(1024) void decode_nhwc_staged_kernel(const T* __res
   for (int r = 0; r < R - 1; ++r) ahead[r] = r < n_batches ? issue(r) : 0;
 
   const int t = threadIdx.x;
-  const unsigned mine = (unsigned)t * (unsigned)sizeof(T);
+  const int cl = CPW == 1 ? 0 : (t >= N ? 1 : 0), n = t - cl * N;
+  const bool active = t < CPW * N && b0 + cl < B;
+  const unsigned mine = (unsigned)cl * slot_bytes + (unsigned)n * (unsigned)sizeof(T);
+  const unsigned my_lo = cl ? lo1 : lo0;
   NhwcRowWalk<T, U> st;
   for (int k = 0; k < n_batches; ++k) {
     int later = 0;
@@ -701,23 +771,16 @@ __global__ __launch_bounds__(1024) void decode_nhwc_staged_kernel(const T* __res
 #pragma unroll
     for (int r = 0; r + 1 < R - 1; ++r) ahead[r] = ahead[r + 1];
     ahead[R - 2] = k + R - 1 < n_batches ? issue(k + R - 1) : 0;
-    if (t < N) {
-      const unsigned shift = (crop_lo + (unsigned)k * batch_bytes) & 15u;
-      const auto from = lds + (unsigned)(k % R) * slot_bytes + shift + mine;
+    if (active) {
+      const unsigned shift = (my_lo + (unsigned)k * batch_bytes) & 15u;
+      const auto from = lds + (unsigned)(k % R) * CPW * slot_bytes + shift + mine;
       T raw[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) raw[u] = nhwc_lds_at<T>(from + (unsigned)u * pitch);
       st.batch(raw, W);
     }
   }
-  __syncthreads();  // every walk has left the ring: the states below overlay it
-  float* row_m = reinterpret_cast<float*>(smem_raw);                           // [N]
-  double* row_s = reinterpret_cast<double*>(smem_raw + ((N * 4 + 15) & ~15));  // [N][3]
-  if (t < N) {
-    row_m[t] = st.m;
-    row_s[t * 3 + 0] = st.s; row_s[t * 3 + 1] = st.sx; row_s[t * 3 + 2] = st.sy;
-  }
-  nhwc_merge_and_store(row_m, row_s, 1, N, J, 0, J, D, b, hs, ai, coords2d, coords3d_rel);
+  nhwc_staged_tail<CPW>(smem_raw, t, active, cl, n, st.m, st.s, st.sx, st.sy, N, J, D, b0, B, hs, ai, coords2d, coords3d_rel);
 }
 
 // The staged kernel's shapes: one lane per channel, the factored walk (W a multiple of 4), a ring of at most 48 KiB.
@@ -727,33 +790,46 @@ inline bool nhwc_staged_fits(long long N, int W, int U, int R, size_t elem) {
   return N <= 1024 && W % 4 == 0 && nhwc_slot_bytes(N, U, elem) * R <= 48 * 1024;
 }
 
-template <typename T, int R>
+// Two crops per workgroup (nhwc_staging = 3; measured, never the library's choice): where that fills the waves better
+// (153 channels: 306 lanes of 320 instead of 153 of 192), fits the ring and still leaves a workgroup per CU.  Same bits;
+// 32,768 crops of 8x8x153 218.9 -> 216.8 us f32, 166.0 -> 164.9 f16, but 4,096 crops 28.2 -> 29.5 and 8,192 crops of 216
+// f16 channels 52.9 -> 57.7 (profiles/r06y_nhwc_cpw.jsonl): five waves at one barrier per batch lose what the fuller
+// last wave and the shared tail buy.
+inline int nhwc_crops_per_wg(long long B, long long N, int U, int R, size_t elem) {
+  const long long waste1 = (N + 63) / 64 * 64 - N, waste2 = (2 * N + 63) / 64 * 64 - 2 * N;
+  return 2 * N <= 1024 && waste2 < 2 * waste1 && B >= 512 && nhwc_slot_bytes(N, U, elem) * R * 2 <= 48 * 1024 ? 2 : 1;
+}
+template <typename T, int R, int CPW>
 static void launch_decode_nhwc_staged(const void* logits, int B, int J, int D, int H, int W, int rb, const HeadScale& hs,
                                       float* c2d, float* c3d, hipStream_t stream) {
   const long long N = (long long)J * (1 + D);
-  auto kern = rb == 16 ? decode_nhwc_staged_kernel<T, 16, R> : rb == 12 ? decode_nhwc_staged_kernel<T, 12, R>
-              : rb == 8 ? decode_nhwc_staged_kernel<T, 8, R> : decode_nhwc_staged_kernel<T, 4, R>;
+  auto kern = rb == 16 ? decode_nhwc_staged_kernel<T, 16, R, CPW> : rb == 12 ? decode_nhwc_staged_kernel<T, 12, R, CPW>
+              : rb == 8 ? decode_nhwc_staged_kernel<T, 8, R, CPW> : decode_nhwc_staged_kernel<T, 4, R, CPW>;
   const size_t slot = nhwc_slot_bytes(N, rb, sizeof(T));
-  const size_t ring = slot * R;
-  const size_t tail = (size_t)((N * 4 + 15) & ~15LL) + (size_t)N * 24;
+  const size_t ring = slot * R * CPW;
+  const size_t tail = (size_t)((CPW * N * 4 + 15) & ~15LL) + (size_t)CPW * N * 24;
   const size_t lds = ring > tail ? ring : tail;
-  const int threads = (int)((N + 63) / 64 * 64);
-  hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(threads), lds, stream, (const T*)logits, B, J, D, H, W,
-                     (unsigned)slot, hs, make_axis_inv(W, H, D), c2d, c3d);
+  const int threads = (int)((CPW * N + 63) / 64 * 64);
+  hipLaunchKernelGGL(kern, dim3((unsigned)((B + CPW - 1) / CPW)), dim3(threads), lds, stream, (const T*)logits, B, J, D, H,
+                     W, (unsigned)slot, hs, make_axis_inv(W, H, D), c2d, c3d);
 }
 
 template <typename T>
 static int launch_decode_nhwc(const void* logits, int B, int J, int D, int H, int W, const HeadScale& hs,
                               float* c2d, float* c3d, hipStream_t stream, int staging = 0) {
   const long long N = (long long)J * (1 + D);
-  // staging: 0 = the library's rule (launches of >= 256 crops), 1 = never, 2 = whenever the shape allows
+  // staging: 0 = the library's rule (launches of >= 256 crops), 1 = never, 2 = whenever the shape allows, 3 = as 2 with
+  // two crops per workgroup where that fills the waves better
   {
     const int rb = (W == 12 || W == 16) ? W : (W % 8 == 0 ? 8 : 4);
     const int R = nhwc_ring_slots(B, N, sizeof(T));
-    if (staging != 1 && nhwc_staged_fits(N, W, rb, R, sizeof(T)) && (staging == 2 || B >= 256)) {
+    if (staging != 1 && nhwc_staged_fits(N, W, rb, R, sizeof(T)) && (staging >= 2 || B >= 256)) {
       MTR_CLEAR_STALE();
-      if (R == 4) launch_decode_nhwc_staged<T, 4>(logits, B, J, D, H, W, rb, hs, c2d, c3d, stream);
-      else launch_decode_nhwc_staged<T, 2>(logits, B, J, D, H, W, rb, hs, c2d, c3d, stream);
+      const int cpw = staging == 3 ? nhwc_crops_per_wg(B, N, rb, R, sizeof(T)) : 1;
+      if (R == 4 && cpw == 2) launch_decode_nhwc_staged<T, 4, 2>(logits, B, J, D, H, W, rb, hs, c2d, c3d, stream);
+      else if (R == 4) launch_decode_nhwc_staged<T, 4, 1>(logits, B, J, D, H, W, rb, hs, c2d, c3d, stream);
+      else if (cpw == 2) launch_decode_nhwc_staged<T, 2, 2>(logits, B, J, D, H, W, rb, hs, c2d, c3d, stream);
+      else launch_decode_nhwc_staged<T, 2, 1>(logits, B, J, D, H, W, rb, hs, c2d, c3d, stream);
       MTR_CHECK_LAUNCH();
       return MTR_OK;
     }
@@ -816,7 +892,7 @@ extern "C" int mtr_softargmax_decode(const void* logits, int dtype, int layout, 
 extern "C" int mtr_softargmax_decode_opts(const void* logits, int dtype, int layout, int B, int J, int D,
                                           int H, int W, const mtr_head_params* p, int nhwc_staging, float* coords2d,
                                           float* coords3d_rel, mtr_stream_t stream) {
-  if (nhwc_staging < 0 || nhwc_staging > 2) return MTR_E_PARAM;
+  if (nhwc_staging < 0 || nhwc_staging > 3) return MTR_E_PARAM;
   if (!logits || !p || !coords2d || !coords3d_rel) return MTR_E_NULL;
   if (B < 0 || J <= 0 || D <= 0 || H <= 0 || W <= 0) return MTR_E_SHAPE;
   if (p->proc_side <= 0 || p->stride_test <= 0) return MTR_E_PARAM;

@@ -17,7 +17,7 @@ def softargmax_decode(logits, n_points, cfg, out=None, nhwc_staging=0):
     """logits [B, J*(1+D), H, W] (f32/f16/bf16, NCHW) -> (coords2d [B,J,2] px, coords3d_rel [B,J,3] mm).
     MetrabsHeads.forward after the conv (metrabs_pytorch/models/metrabs.py:78-85).
     nhwc_staging (channels_last logits; mtr_softargmax_decode_opts): 0 = the library's kernel choice, 1 = never the
-    LDS-staged kernel, 2 = whenever the crop fits; the same bits either way."""
+    LDS-staged kernel, 2 = whenever the shape allows, 3 = as 2 with two crops per workgroup where that fills the waves; the same bits either way."""
     require_cuda(logits)
     lib = _lib.load()
     # torch channels_last logits (what a channels_last conv_final emits; the TF twin's

@@ -189,7 +189,7 @@ def test_decode_channels_last_large_batches_equal_the_small_batch_kernel(hip_lib
 
 @pytest.mark.parametrize('B,J,D,H,dtype,misalign', [
     (2048, 17, 8, 8, torch.float32, 0), (2048, 17, 8, 8, torch.float16, 0), (2048, 17, 8, 8, torch.bfloat16, 0),
-    (1800, 17, 8, 8, torch.float32, 1), (1800, 17, 8, 8, torch.float16, 1), (1800, 17, 8, 8, torch.float16, 3),
+    (1801, 17, 8, 8, torch.float32, 1), (1801, 17, 8, 8, torch.float16, 1), (1800, 17, 8, 8, torch.float16, 3),
     (2048, 24, 8, 8, torch.float32, 0),    # 216 channels: lanes 32 apart on 8 banks (conflicts, not errors)
     (6000, 5, 8, 12, torch.float32, 0),    # 12-wide rows
     (8192, 4, 8, 16, torch.float32, 2),    # 16-wide rows, 36 channels: one wave, 28 idle lanes
@@ -218,6 +218,8 @@ def test_decode_channels_last_staged_kernel_is_bit_equal(B, J, D, H, dtype, misa
     s2, s3 = kernels.softargmax_decode(x, J, cfg, nhwc_staging=2)
     assert torch.isfinite(s3).all() and torch.isfinite(s2).all()
     assert torch.equal(s2, w2) and torch.equal(s3, w3)
+    o2, o3 = kernels.softargmax_decode(x, J, cfg, nhwc_staging=3)   # two crops per workgroup where that fills the waves
+    assert torch.equal(o2, w2) and torch.equal(o3, w3)
     d2, d3 = kernels.softargmax_decode(x, J, cfg)   # the library's own choice: one of the two
     assert torch.equal(d2, w2) and torch.equal(d3, w3)
     # ... and both are the NCHW kernel's answer within the usual bound
@@ -228,7 +230,7 @@ def test_decode_channels_last_staged_kernel_is_bit_equal(B, J, D, H, dtype, misa
     k2, k3 = kernels.softargmax_decode(x[:5], J, cfg, nhwc_staging=2)
     assert torch.equal(k2, s2[:5]) and torch.equal(k3, s3[:5])
     lib = _lib.load()
-    assert lib.mtr_softargmax_decode_opts(None, 0, 1, 1, 17, 8, 8, 8, None, 3, None, None, None) < 0
+    assert lib.mtr_softargmax_decode_opts(None, 0, 1, 1, 17, 8, 8, 8, None, 4, None, None, None) < 0
 
 
 @pytest.mark.parametrize('name', list(cases.RECON_CASES))

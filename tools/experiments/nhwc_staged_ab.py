@@ -29,7 +29,7 @@ def main():
             cl = (torch.randn(B, side, side, J * (1 + D), device='cuda', generator=g) * 3).to(dt).permute(0, 3, 1, 2)
             nbytes = cl.numel() * cl.element_size() + B * J * 20
             for rnd in range(2):
-                for name, mode in (('walk_global', 1), ('staged_lds', 2), ('library_rule', 0)):
+                for name, mode in (('walk_global', 1), ('staged_lds', 2), ('staged_two_crops', 3), ('library_rule', 0)):
                     t = min(timeit(lambda: kernels.softargmax_decode(cl, J, cfg, nhwc_staging=mode)) for _ in range(3))
                     c2, c3 = kernels.softargmax_decode(cl, J, cfg, nhwc_staging=mode)
                     print(json.dumps(dict(lib=tag, variant=name, shape=[B, J, D, side, side], dtype=str(dt).split('.')[-1],
