@@ -414,11 +414,26 @@ struct NhwcRowWalk {
     // weight of the batch +0 again.  (One select per batch; it was a compare and two selects per logit.)
     const float nm = m == -INFINITY ? 0.0f : -m;
     double sb = 0.0, su = 0.0;
+    if constexpr (sizeof(T) == 2) {
+      // 16-bit logits (11 significant bits in): the batch's two sums in f32 -- at most 16 terms in (0, 1] -- promoted to
+      // f64 once per batch, as the NCHW kernel sums a position's depth slices: two f32 operations per logit instead of
+      // a conversion and two f64 ones (the walk is VALU-bound on 16-bit logits: same time per logit as f32 ones)
+      float sbf = 0.0f, suf = 0.0f;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const double e = (double)exp_shifted(v[u], nm);
-      sb += e;
-      su = fma(e, (double)u, su);
+      for (int u = 0; u < U; ++u) {
+        const float e = exp_shifted(v[u], nm);
+        sbf += e;
+        suf = fmaf(e, (float)u, suf);
+      }
+      sb = (double)sbf;
+      su = (double)suf;
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const double e = (double)exp_shifted(v[u], nm);
+        sb += e;
+        su = fma(e, (double)u, su);
+      }
     }
     s += sb;
     sx += fma((double)w0, sb, su);
