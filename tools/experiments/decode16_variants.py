@@ -11,8 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 OUT = os.path.join(ROOT, 'tools', 'experiments', '_build')
 SRCS = ['head_fused.hip', 'head_areg.hip', 'head_res.hip']
 VARIANTS = {'loop': ['-DMTR_DECODE_DC8=0'], 'dc8': ['-DMTR_DECODE_DC8=1']}
-if os.environ.get('MTR_DEC16_SET') == 'col32':   # round 6: f32 depth sums (different bits: a numerics change)
-    VARIANTS = {'dc8': ['-DMTR_DECODE_DC8=1'], 'col32': ['-DMTR_DECODE_COL32=1']}
+# (round 6: a third variant, f32 depth sums per position -- -DMTR_DECODE_COL32, a source edit that was not kept -- measured
+#  with this script: profiles/r06t_decode16_col32.jsonl)
 
 
 def build():
