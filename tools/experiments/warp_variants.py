@@ -22,6 +22,9 @@ VARIANTS = {'base': [], 'one_gather_pair': ['-DMTR_WARP_ABLATE=16'], 'no_taps': 
 
 if os.environ.get('MTR_WARP_SET') == 'asm':
     VARIANTS = VARIANTS_R6
+if os.environ.get('MTR_WARP_SET') == 'rows':   # round 6: fewer samples per wave (more, shorter waves)
+    VARIANTS = {'rows4': [], 'rows2': ['-DMTR_WARP_ROWS=2'], 'rows1': ['-DMTR_WARP_ROWS=1'], 'rows3': ['-DMTR_WARP_ROWS=3'],
+                'rows2_lx64': ['-DMTR_WARP_ROWS=2', '-DMTR_WARP_LX=64']}
 
 
 def build():
