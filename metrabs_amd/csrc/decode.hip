@@ -624,19 +624,22 @@ __global__ __launch_bounds__(1024) void decode_nhwc_kernel(const T* __restrict__
   nhwc_merge_and_store(row_m, row_s, G, N, nj, j0, J, D, b, hs, ai, coords2d, coords3d_rel);
 }
 
-// ---- NHWC, staged (round 6).  The walk above keeps U dword loads per lane in flight (a wave: U x 256 bytes that
-// straddle 128-byte lines -- a position's 153 channels are 612 bytes) and nothing while it sums: a CU's ~30 waves hold
-// ~30 KB in flight on average, about half of what the HBM latency asks for.  Here the logits of a crop reach LDS
-// through a RING of batch slots filled by global_load_lds_dwordx4 -- 16 bytes per lane, consecutive lanes consecutive
-// addresses (a crop is one contiguous run), no registers, R - 1 batches in flight per workgroup WHILE it sums -- and
-// the same walk (NhwcRowWalk: the same calls in the same order, the same bits) reads its channel out of LDS: lane n
-// reads dword p*N + n of a slot, consecutive lanes consecutive banks.  One workgroup per crop, one lane per channel,
-// one barrier per batch: [own copies of batch k landed] barrier [copies of batch k + R - 1 issued into the slot batch
-// k - 1 left] [batch k summed].  A batch's copy starts at the 16-byte granule that holds its first byte.
+// ---- NHWC, staged (round 6).  The walk above requests its logits as U dword loads per lane (a wave: U x 256 bytes that
+// straddle 128-byte lines -- a position's 153 channels are 612 bytes) and has nothing in flight while it sums.  Here the
+// logits of a crop reach LDS through a RING of batch slots filled by global_load_lds_dwordx4 -- 16 bytes per lane,
+// consecutive lanes consecutive addresses (a crop is one contiguous run), no registers, R - 1 batches in flight per
+// workgroup WHILE it sums -- and the same walk (NhwcRowWalk: the same calls in the same order, the same bits) reads its
+// channel out of LDS: lane n reads dword p*N + n of a slot, consecutive lanes consecutive banks.  One workgroup per
+// crop, one lane per channel, one barrier per batch: [own copies of batch k landed] barrier [copies of batch k + R - 1
+// issued into the slot batch k - 1 left] [batch k summed].  A batch's copy starts at the 16-byte granule that holds its
+// first byte.  What it buys (the walk itself is instruction-bound -- what moved the large f32
+// launches was the walk's own arithmetic): launches of a few rounds (1,024 crops 16.3 -> 9.4 us), 16-bit logits
+// (183 -> 165 us on 0.64 GB), 2 - 3 % on the 1.28 GB f32 shape.
 // Slots R of the ring, measured on one MI355X (profiles/r06r_nhwc_staged_ab*.jsonl, R = 2 / 3 / 4; 6 is slower
 // everywhere): f32 logits in launches that run for many rounds (32,768 crops of 8x8x153: 230 / 222 / 219 us) want
-// three batches in flight, everything else (16-bit logits: the walk is VALU-bound; launches of one or two rounds:
-// 1,024 crops 9.4 / 10.3 / 10.4 us) the shortest prologue and the most workgroups per CU.  The bits do not depend on R.
+// three batches in flight, everything else (16-bit logits; launches of one or two rounds: 1,024 crops 9.4 / 10.3 /
+// 10.4 us; one-wave workgroups) the shortest prologue and the most workgroups per CU -- nhwc_ring_slots.  The bits do
+// not depend on R.
 __device__ __forceinline__ void nhwc_dma16(const void* sbase, unsigned voff, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                :
