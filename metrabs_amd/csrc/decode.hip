@@ -732,15 +732,18 @@ __device__ __forceinline__ void nhwc_staged_tail(char* smem_raw, int t, bool act
 // 320 (96 % of five) and share one tail.
 template <typename T, int U, int R, int CPW>
 __global__ __launch_bounds__(1024) void decode_nhwc_staged_kernel(const T* __restrict__ logits, int B, int J, int D,
-                                                                  int H, int W, unsigned slot_bytes, HeadScale hs,
+                                                                  int H, int W, unsigned slot_bytes, int bps, HeadScale hs,
                                                                   AxisInv ai, float* __restrict__ coords2d,
                                                                   float* __restrict__ coords3d_rel) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int N = J * (1 + D), HW = H * W;
   const int b0 = blockIdx.x * CPW;
-  const int n_batches = HW / U;
+  // a ring slot holds `bps` batches of U positions (one copy, one wait, one barrier per slot; the walk still advances a
+  // batch -- a run of one map row -- at a time: the same calls in the same order whatever bps is)
+  const int n_batches = HW / (U * bps);   // slots to walk
   const unsigned pitch = (unsigned)N * (unsigned)sizeof(T);  // bytes between positions
-  const unsigned batch_bytes = (unsigned)U * pitch;
+  const unsigned walk_bytes = (unsigned)U * pitch;            // one batch of the walk
+  const unsigned batch_bytes = walk_bytes * (unsigned)bps;    // one slot
   const size_t crop_bytes = (size_t)HW * pitch;
   const char* crop0 = uniform_ptr(reinterpret_cast<const char*>(logits) + (size_t)b0 * crop_bytes);
   const unsigned lo0 = (unsigned)(reinterpret_cast<uintptr_t>(crop0) & 15u);  // (wave-uniform)
@@ -792,17 +795,28 @@ __global__ __launch_bounds__(1024) void decode_nhwc_staged_kernel(const T* __res
     if (active) {
       const unsigned shift = (my_lo + (unsigned)k * batch_bytes) & 15u;
       const auto from = lds + (unsigned)(k % R) * CPW * slot_bytes + shift + mine;
-      T raw[U];
+      for (int bb = 0; bb < bps; ++bb) {
+        T raw[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) raw[u] = nhwc_lds_at<T>(from + (unsigned)u * pitch);
-      st.batch(raw, W);
+        for (int u = 0; u < U; ++u) raw[u] = nhwc_lds_at<T>(from + (unsigned)bb * walk_bytes + (unsigned)u * pitch);
+        st.batch(raw, W);
+      }
     }
   }
   nhwc_staged_tail<CPW>(smem_raw, t, active, cl, n, st.m, st.s, st.sx, st.sy, N, J, D, b0, B, hs, ai, coords2d, coords3d_rel);
 }
 
 // The staged kernel's shapes: one lane per channel, the factored walk (W a multiple of 4), a ring of at most 48 KiB.
+#ifndef MTR_NHWC_BPS
+#define MTR_NHWC_BPS 2   // batches per ring slot for 16-BIT logits, where the map has an even number of them and the ring
+                         // still fits: half the barriers and copy bookkeeping, same bits -- 0.64 GB of f16 logits 156.0 ->
+                         // 151.1 us, 1,024 crops 8.6 -> 8.1; f32 logits want the smaller ring (32,768 crops 233 -> 251 us with
+                         // two, 8,192 x 36 channels 50.5 -> 58.7; profiles/r06zd_nhwc_bps.jsonl) and keep one
+#endif
 inline size_t nhwc_slot_bytes(long long N, int U, size_t elem) { return ((size_t)U * N * elem + 30 + 15) & ~(size_t)15; }
+inline int nhwc_batches_per_slot(long long N, int HW, int U, int R, int cpw, size_t elem) {
+  return MTR_NHWC_BPS == 2 && elem == 2 && (HW / U) % 2 == 0 && nhwc_slot_bytes(N, 2 * U, elem) * R * cpw <= 48 * 1024 ? 2 : 1;
+}
 inline int nhwc_ring_slots(long long B, long long N, size_t elem) { return elem == 4 && B >= 8192 && N >= 128 ? 4 : 2; }
 inline bool nhwc_staged_fits(long long N, int W, int U, int R, size_t elem) {
   return N <= 1024 && W % 4 == 0 && nhwc_slot_bytes(N, U, elem) * R <= 48 * 1024;
@@ -823,13 +837,14 @@ static void launch_decode_nhwc_staged(const void* logits, int B, int J, int D, i
   const long long N = (long long)J * (1 + D);
   auto kern = rb == 16 ? decode_nhwc_staged_kernel<T, 16, R, CPW> : rb == 12 ? decode_nhwc_staged_kernel<T, 12, R, CPW>
               : rb == 8 ? decode_nhwc_staged_kernel<T, 8, R, CPW> : decode_nhwc_staged_kernel<T, 4, R, CPW>;
-  const size_t slot = nhwc_slot_bytes(N, rb, sizeof(T));
+  const int bps = nhwc_batches_per_slot(N, H * W, rb, R, CPW, sizeof(T));
+  const size_t slot = nhwc_slot_bytes(N, rb * bps, sizeof(T));
   const size_t ring = slot * R * CPW;
   const size_t tail = (size_t)((CPW * N * 4 + 15) & ~15LL) + (size_t)CPW * N * 24;
   const size_t lds = ring > tail ? ring : tail;
   const int threads = (int)((CPW * N + 63) / 64 * 64);
   hipLaunchKernelGGL(kern, dim3((unsigned)((B + CPW - 1) / CPW)), dim3(threads), lds, stream, (const T*)logits, B, J, D, H,
-                     W, (unsigned)slot, hs, make_axis_inv(W, H, D), c2d, c3d);
+                     W, (unsigned)slot, bps, hs, make_axis_inv(W, H, D), c2d, c3d);
 }
 
 template <typename T>
