@@ -233,6 +233,37 @@ def test_decode_channels_last_staged_kernel_is_bit_equal(B, J, D, H, dtype, misa
     assert lib.mtr_softargmax_decode_opts(None, 0, 1, 1, 17, 8, 8, 8, None, 4, None, None, None) < 0
 
 
+@pytest.mark.parametrize('seed', range(12))
+def test_decode_channels_last_staged_kernel_random_shapes(seed, hip_lib):
+    """Random launches through the LDS-staged NHWC kernel (one and two crops per workgroup: torch.equal) against the NCHW
+    kernel on the same logits (<= 1e-3 mm / 4e-4 px: other sums) and the oracle on a sample: odd channel counts, 4 / 8 /
+    12 / 16 / 20 / 24-wide maps, 4 - 16 depth bins, odd batch sizes, the three dtypes."""
+    import random
+    from metrabs_amd import kernels
+    from metrabs_amd.config import MetrabsConfig
+    rng = random.Random(1000 + seed)
+    W = rng.choice([4, 8, 12, 16, 20, 24])
+    H = rng.choice([4, 8, 12]) if W > 12 else rng.choice([4, 8, 12, 16])
+    D = rng.choice([4, 8, 16])
+    J = rng.randint(1, 1024 // (1 + D) if W * (1 + D) * 4 * 16 < 40000 else 6)
+    B = rng.randint(256, 700)
+    dtype = rng.choice([torch.float32, torch.float32, torch.float16, torch.bfloat16])
+    cfg = MetrabsConfig(depth=D, proc_side=max(H, W) * 32)
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    x = (torch.randn(B, H, W, J * (1 + D), generator=g, device='cuda') * 3.0).to(dtype).permute(0, 3, 1, 2)
+    assert kernels._is_channels_last(x) or J * (1 + D) == 1 or H * W == 1
+    s2, s3 = kernels.softargmax_decode(x, J, cfg, nhwc_staging=2)
+    t2, t3 = kernels.softargmax_decode(x, J, cfg, nhwc_staging=3)
+    assert torch.equal(s2, t2) and torch.equal(s3, t3), (B, J, D, H, W, dtype)
+    n2, n3 = kernels.softargmax_decode(x.contiguous(), J, cfg)
+    tol = 1e-3 if dtype == torch.float32 else 3e-3
+    assert float((s3 - n3).abs().max()) <= tol and float((s2 - n2).abs().max()) <= 4e-4, (B, J, D, H, W, dtype)
+    if dtype == torch.float32:
+        with torch.inference_mode():
+            o2d, o3d = cpu_ref.heads_from_logits(x[:3].contiguous().cpu(), J, cpu_ref.HeadConfig(depth=D, proc_side=max(H, W) * 32))
+        assert float((s3[:3].cpu() - o3d).abs().max()) <= 1e-3 and float((s2[:3].cpu() - o2d).abs().max()) <= 2e-4
+
+
 @pytest.mark.parametrize('name', list(cases.RECON_CASES))
 def test_reconstruct_vs_golden_and_oracle(name, hip_lib):
     """Identical coords -> absolute poses.  The reference solves with fp32 LAPACK lstsq (its own
