@@ -167,8 +167,7 @@ class MetrabsHeads(torch.nn.Module):
         # 1x1 conv as a library GEMM (rocBLAS / MIOpen).  16-bit features (the autocast backbone's
         # output) meet f32 parameters here: run the conv as autocast would (multiperson_model.py:241)
         n_keep = self.n_points if n_keep is None else n_keep
-        needs_grad = torch.is_grad_enabled() and (inp.requires_grad or self.conv_final.weight.requires_grad)
-        if kernels._is_channels_last(inp) and not needs_grad:   # (the derived weight views below are detached)
+        if kernels._is_channels_last(inp):
             # channels_last features ARE the [B H W, C] matrix of a GEMM: F.linear on that view, NHWC logits (decoded in
             # place by the NHWC kernels) -- the library's channels_last 1x1 convolution is 2 - 5 x slower (round 6:
             # 64 crops of 8x8x1280 -> 1,241 channels 134 vs 315 us f32, 47 vs 192 us f16; profiles/r06x_layout_rule2.jsonl)
