@@ -43,6 +43,9 @@
                          // register, the plane and row offsets ride in the buffer instruction's scalar offset, and
                          // the byte window is one v_alignbyte.  64 crops, cache-resident frames: 25.6 -> 24.5 us.
 #endif
+#ifndef MTR_WARP_WAVES
+#define MTR_WARP_WAVES 4   // waves per workgroup of warp_rows_kernel (a workgroup = LX columns x WAVES * ROWS * 64 / LX rows)
+#endif
 #ifndef MTR_WARP_ASM
 #define MTR_WARP_ASM 0   // warp_rows_kernel, round 6 (a developer option, measured and left off): the six tap loads of a sample issued
                          // from inline asm and awaited with a COUNTED s_waitcnt vmcnt tied to their registers.  The ISA of the
@@ -726,21 +729,23 @@ struct TapSet {
 // a crop's 36 warp-row scalars, descriptors and level choice are set up once per run of its tiles instead of once
 // per 32 x 32 tile.  Same per-sample arithmetic, same bits.
 template <typename OutT, int AA, int ROWS, int L0, bool PERSIST = false>
-__global__ __launch_bounds__(256) void warp_rows_kernel(
+__global__ __launch_bounds__(64 * MTR_WARP_WAVES) void warp_rows_kernel(
     const void* __restrict__ l0_any, const float* __restrict__ l1, const float* __restrict__ l2,
     const float* __restrict__ lut_g, LevelDims dims, unsigned u8_bytes,
     const float* __restrict__ wp_all, int n_crops, int res, int nhwc, OutT* __restrict__ out) {
   constexpr bool L0U8 = L0 != 0, HWC = L0 == 2;
+  constexpr int NWV = MTR_WARP_WAVES;
   __shared__ float lut[L0U8 ? 256 : 1];
   if (L0U8) {
-    lut[threadIdx.x] = lut_g[threadIdx.x];
+#pragma unroll
+    for (int i = threadIdx.x; i < 256; i += 64 * NWV) lut[i] = lut_g[i];
     __syncthreads();
   }
   const float* __restrict__ l0 = (const float*)l0_any;
   // block = LX columns x 4*ROWS*RI rows (wave w owns the w-th band of ROWS*RI rows and walks it RI
   // rows at a time); all tiles of a crop on one XCD, as in warp_crops_kernel
   constexpr int LX = MTR_WARP_LX, RI = 64 / LX;  // a wave iteration covers LX columns x RI rows
-  const int row_tiles = (res + 4 * ROWS * RI - 1) / (4 * ROWS * RI);
+  const int row_tiles = (res + NWV * ROWS * RI - 1) / (NWV * ROWS * RI);
   const int x_tiles = (res + LX - 1) / LX;
   const int per_crop = row_tiles * x_tiles;
   const int id = blockIdx.x;
@@ -788,7 +793,7 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(
              : make_rsrc(uniform_ptr(planes), (unsigned)(3 * plane_elems) * 4u);
 
   const int x = tx * LX + (threadIdx.x & (LX - 1));
-  const int v_first = (ty * 4 + (threadIdx.x >> 6)) * ROWS * RI + ((threadIdx.x & 63) / LX);
+  const int v_first = (ty * NWV + (threadIdx.x >> 6)) * ROWS * RI + ((threadIdx.x & 63) / LX);
   if (x >= res || v_first >= res) continue;
 #if !MTR_WARP_LEAN
   const float fW = (float)W, fH = (float)H;
@@ -1066,17 +1071,17 @@ static int launch_warp(const void* l0, const float* l1, const float* l2, const f
   for (int l = 0; l < 3; ++l) degenerate |= dims.W[l] < 2 || dims.H[l] < 2;
   if constexpr (ROWS > 0 && AA <= 2) if (!degenerate) {
     constexpr int LX = MTR_WARP_LX, RI = 64 / LX;
-    const long long tiles = (long long)((res + LX - 1) / LX) * ((res + 4 * ROWS * RI - 1) / (4 * ROWS * RI));
+    const long long tiles = (long long)((res + LX - 1) / LX) * ((res + MTR_WARP_WAVES * ROWS * RI - 1) / (MTR_WARP_WAVES * ROWS * RI));
     const long long nblocks = (long long)((n_crops + 7) / 8) * 8 * tiles;
     if (nblocks > 0x7fffffffLL) return MTR_E_SHAPE;
     MTR_CLEAR_STALE();
     if constexpr (MTR_WARP_PERSIST > 0) {
       const long long want = 256LL * MTR_WARP_PERSIST;   // (a multiple of 8: whole slots per XCD)
       hipLaunchKernelGGL((warp_rows_kernel<OutT, AA, ROWS ? ROWS : 1, L0, true>), dim3((unsigned)(nblocks < want ? nblocks : want)),
-                         dim3(256), 0, stream, l0, l1, l2, lut, dims, u8_bytes, wp, n_crops, res, nhwc, (OutT*)out);
+                         dim3(64 * MTR_WARP_WAVES), 0, stream, l0, l1, l2, lut, dims, u8_bytes, wp, n_crops, res, nhwc, (OutT*)out);
     } else {
       hipLaunchKernelGGL((warp_rows_kernel<OutT, AA, ROWS ? ROWS : 1, L0>), dim3((unsigned)nblocks),
-                         dim3(256), 0, stream, l0, l1, l2, lut, dims, u8_bytes, wp, n_crops, res, nhwc,
+                         dim3(64 * MTR_WARP_WAVES), 0, stream, l0, l1, l2, lut, dims, u8_bytes, wp, n_crops, res, nhwc,
                          (OutT*)out);
     }
     MTR_CHECK_LAUNCH();

@@ -22,6 +22,9 @@ VARIANTS = {'base': [], 'one_gather_pair': ['-DMTR_WARP_ABLATE=16'], 'no_taps': 
 
 if os.environ.get('MTR_WARP_SET') == 'asm':
     VARIANTS = VARIANTS_R6
+if os.environ.get('MTR_WARP_SET') == 'waves':   # round 6: waves per workgroup
+    VARIANTS = {'waves4': [], 'waves1': ['-DMTR_WARP_WAVES=1'], 'waves2': ['-DMTR_WARP_WAVES=2'], 'waves8': ['-DMTR_WARP_WAVES=8'],
+                'waves1_rows8': ['-DMTR_WARP_WAVES=1', '-DMTR_WARP_ROWS=8'], 'waves2_rows8': ['-DMTR_WARP_WAVES=2', '-DMTR_WARP_ROWS=8']}
 if os.environ.get('MTR_WARP_SET') == 'rows':   # round 6: fewer samples per wave (more, shorter waves)
     VARIANTS = {'rows4': [], 'rows2': ['-DMTR_WARP_ROWS=2'], 'rows1': ['-DMTR_WARP_ROWS=1'], 'rows3': ['-DMTR_WARP_ROWS=3'],
                 'rows2_lx64': ['-DMTR_WARP_ROWS=2', '-DMTR_WARP_LX=64']}
