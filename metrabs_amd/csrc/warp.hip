@@ -43,6 +43,13 @@
                          // register, the plane and row offsets ride in the buffer instruction's scalar offset, and
                          // the byte window is one v_alignbyte.  64 crops, cache-resident frames: 25.6 -> 24.5 us.
 #endif
+#ifndef MTR_PYR_LUT_COPIES
+#define MTR_PYR_LUT_COPIES 16   // copies of the gamma table in build_pyramid_u8_wide_kernel's LDS (= KiB per workgroup).  32 (one per
+                                // bank: no conflict whatever the pixels) leaves five workgroups per CU; 16 (lanes l and l + 16 share a
+                                // copy: two-way when their values differ and have the same parity) leaves eight, the wave limit --
+                                // 8 x 1080p planar frames in rotation 22.7 -> 19.8 us (0.61 -> 0.70 of HBM), interleaved 21.3 -> 21.4;
+                                // 8 copies the same as 16; same bits (profiles/r06zf_pyramid_lut.jsonl)
+#endif
 #ifndef MTR_WARP_WAVES
 #define MTR_WARP_WAVES 4   // waves per workgroup of warp_rows_kernel (a workgroup = LX columns x WAVES * ROWS * 64 / LX rows)
 #endif
@@ -170,9 +177,10 @@ __global__ __launch_bounds__(256) void build_pyramid_kernel(
 // row), float4 stores to level 1 (1 KiB per wave and row), float2 stores to level 2.  (The 4x4
 // kernel reads 4 B and writes 8 B / 4 B per lane; a 16x4 strip per thread had 16-byte loads but
 // 32-byte-strided level-1 stores and was slower.)  Same values, same addition order.
-// The gamma LUT is replicated once per LDS bank ([value][32]): lanes l and l+32 of a ds_read_b32
-// are serviced separately and lane l always reads bank l & 31, so the lookups are conflict-free
-// whatever the pixel values (random pixels averaged ~3.5 ways on the shared 256-entry table).
+// The gamma LUT is replicated MTR_PYR_LUT_COPIES times ([value][copies]; lane l reads copy l & (copies - 1)): with 32
+// copies -- one per bank; lanes l and l+32 of a ds_read_b32 are serviced separately -- the lookups are conflict-free
+// whatever the pixel values (random pixels averaged ~3.5 ways on the shared 256-entry table); the shipped 16 trade a
+// two-way conflict on some lookups for eight workgroups per CU instead of five (see the macro).
 // HWC: interleaved frames [N,H,W,3]; `planes` is then the number of IMAGES and a thread owns the 8x8
 // tile of all three channels: 24 contiguous bytes per row (three 8-byte loads, lane-contiguous across
 // the wave as 1,536 B per row), the same level-1 / level-2 stores into each channel's plane.
@@ -180,16 +188,17 @@ template <bool HWC>
 __global__ __launch_bounds__(256) void build_pyramid_u8_wide_kernel(
     const uint8_t* __restrict__ src, int planes, int Hi, int Wi, float* __restrict__ l1,
     float* __restrict__ l2, float* __restrict__ lut_out, GammaLut lut_in, FastDiv by_tw, FastDiv by_th) {
-  __shared__ __attribute__((aligned(16))) float lut[256 * 32];
+  constexpr int COP = MTR_PYR_LUT_COPIES;  // copies of the table (32: one per bank)
+  __shared__ __attribute__((aligned(16))) float lut[256 * COP];
   {
     const float v = lut_in.v[threadIdx.x];
     if (lut_out != nullptr && blockIdx.x == 0) lut_out[threadIdx.x] = v;
     const float4 v4 = make_float4(v, v, v, v);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) reinterpret_cast<float4*>(lut + threadIdx.x * 32)[j] = v4;
+    for (int j = 0; j < COP / 4; ++j) reinterpret_cast<float4*>(lut + threadIdx.x * COP)[j] = v4;
     __syncthreads();
   }
-  const float* mylut = lut + (threadIdx.x & 31);
+  const float* mylut = lut + (threadIdx.x & (COP - 1));
   const int W1 = Wi / 2, W2 = Wi / 4, H1 = Hi / 2, H2 = Hi / 4;
   const int tw = Wi / 8, th = Hi / 8;  // tiles per row / tile rows
   const long long total = (long long)planes * th * tw;
@@ -230,7 +239,7 @@ __global__ __launch_bounds__(256) void build_pyramid_u8_wide_kernel(
 #pragma unroll
         for (int px = 0; px < 8; ++px) {
           const int k = px * NC + ch;  // byte of the row segment (compile-time after unrolling)
-          v[i][px] = mylut[((raw[2 * r + i][k >> 2] >> ((k & 3) * 8)) & 0xff) << 5];
+          v[i][px] = mylut[((raw[2 * r + i][k >> 2] >> ((k & 3) * 8)) & 0xff) * COP];
         }
 #pragma unroll
       for (int c = 0; c < 4; ++c)
@@ -1223,7 +1232,8 @@ static bool pyramid_wide_ok(const void* src, const void* l1, const void* l2, int
 static int pyramid_wide_grid(long long planes, int Hi, int Wi) {
   const long long tiles = planes * (Hi / 8) * (Wi / 8);
   long long grid = (tiles + 255) / 256;
-  if (grid > 256 * 5) grid = 256 * 5;  // persistent: 5 workgroups per CU (32 KiB LUT each)
+  constexpr int per_cu = 160 / MTR_PYR_LUT_COPIES > 8 ? 8 : 160 / MTR_PYR_LUT_COPIES;
+  if (grid > 256 * per_cu) grid = 256 * per_cu;  // persistent: as many workgroups per CU as their LUT copies leave room for (<= 8)
   return (int)grid;
 }
 

@@ -22,6 +22,8 @@ VARIANTS = {'base': [], 'one_gather_pair': ['-DMTR_WARP_ABLATE=16'], 'no_taps': 
 
 if os.environ.get('MTR_WARP_SET') == 'asm':
     VARIANTS = VARIANTS_R6
+if os.environ.get('MTR_WARP_SET') == 'pyr':   # round 6: the pyramid's LUT copies (LDS per workgroup -> workgroups per CU)
+    VARIANTS = {'lut32': [], 'lut16': ['-DMTR_PYR_LUT_COPIES=16'], 'lut8': ['-DMTR_PYR_LUT_COPIES=8']}
 if os.environ.get('MTR_WARP_SET') == 'waves':   # round 6: waves per workgroup
     VARIANTS = {'waves4': [], 'waves1': ['-DMTR_WARP_WAVES=1'], 'waves2': ['-DMTR_WARP_WAVES=2'], 'waves8': ['-DMTR_WARP_WAVES=8'],
                 'waves1_rows8': ['-DMTR_WARP_WAVES=1', '-DMTR_WARP_ROWS=8'], 'waves2_rows8': ['-DMTR_WARP_WAVES=2', '-DMTR_WARP_ROWS=8']}
@@ -65,6 +67,22 @@ def run_one(name, interleaved=False):
     pyrs = [kernels.build_pyramid(torch.randint(0, 256, (8, 3, 1080, 1920), dtype=torch.uint8, generator=g).cuda()
                                   .contiguous(memory_format=fmt)) for _ in range(4)]
     assert all(p.hwc == interleaved for p in pyrs)
+    if os.environ.get('MTR_WARP_SET') == 'pyr':   # the pyramid pass itself, frames in rotation (six sets: 300 MB of uint8)
+        import hashlib
+        from tools.microbench import timeit
+        frames = [torch.randint(0, 256, (8, 3, 1080, 1920), dtype=torch.uint8, generator=g).cuda().contiguous(memory_format=fmt)
+                  for _ in range(6)]
+        k = [0]
+
+        def step():
+            k[0] += 1
+            return kernels.build_pyramid(frames[k[0] % 6])
+        t = min(timeit(step, iters=30) for _ in range(3))
+        pyr = kernels.build_pyramid(frames[0])
+        lv = [x for x in (getattr(pyr, 'levels', None) or []) if x is not None and x.dtype == torch.float32]
+        h = hashlib.sha1(b''.join(x.cpu().numpy().tobytes() for x in lv[-2:])).hexdigest()[:12] if lv else ''
+        print(json.dumps({'variant': name, 'frames': 'interleaved' if interleaved else 'planar', 'kernel': 'build_pyramid', 'us': round(t * 1e6, 2), 'sha': h}), flush=True)
+        return
     for aug in (1, 5):
         n = 64
         tta = {k: v.cuda() for k, v in tta_parameters(aug).items()}
