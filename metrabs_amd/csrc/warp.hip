@@ -1232,7 +1232,11 @@ static bool pyramid_wide_ok(const void* src, const void* l1, const void* l2, int
 static int pyramid_wide_grid(long long planes, int Hi, int Wi) {
   const long long tiles = planes * (Hi / 8) * (Wi / 8);
   long long grid = (tiles + 255) / 256;
+#ifdef MTR_PYR_PER_CU
+  constexpr int per_cu = MTR_PYR_PER_CU;  // (developer builds)
+#else
   constexpr int per_cu = 160 / MTR_PYR_LUT_COPIES > 8 ? 8 : 160 / MTR_PYR_LUT_COPIES;
+#endif
   if (grid > 256 * per_cu) grid = 256 * per_cu;  // persistent: as many workgroups per CU as their LUT copies leave room for (<= 8)
   return (int)grid;
 }

@@ -23,7 +23,9 @@ VARIANTS = {'base': [], 'one_gather_pair': ['-DMTR_WARP_ABLATE=16'], 'no_taps': 
 if os.environ.get('MTR_WARP_SET') == 'asm':
     VARIANTS = VARIANTS_R6
 if os.environ.get('MTR_WARP_SET') == 'pyr':   # round 6: the pyramid's LUT copies (LDS per workgroup -> workgroups per CU)
-    VARIANTS = {'lut32': [], 'lut16': ['-DMTR_PYR_LUT_COPIES=16'], 'lut8': ['-DMTR_PYR_LUT_COPIES=8']}
+    VARIANTS = {'lut32': ['-DMTR_PYR_LUT_COPIES=32'], 'lut16': ['-DMTR_PYR_LUT_COPIES=16'], 'lut8': ['-DMTR_PYR_LUT_COPIES=8'],
+                'lut16_all_wgs': ['-DMTR_PYR_LUT_COPIES=16', '-DMTR_PYR_PER_CU=16'], 'lut8_all_wgs': ['-DMTR_PYR_LUT_COPIES=8', '-DMTR_PYR_PER_CU=16'],
+                'lut16_6': ['-DMTR_PYR_LUT_COPIES=16', '-DMTR_PYR_PER_CU=6']}
 if os.environ.get('MTR_WARP_SET') == 'waves':   # round 6: waves per workgroup
     VARIANTS = {'waves4': [], 'waves1': ['-DMTR_WARP_WAVES=1'], 'waves2': ['-DMTR_WARP_WAVES=2'], 'waves8': ['-DMTR_WARP_WAVES=8'],
                 'waves1_rows8': ['-DMTR_WARP_WAVES=1', '-DMTR_WARP_ROWS=8'], 'waves2_rows8': ['-DMTR_WARP_WAVES=2', '-DMTR_WARP_ROWS=8']}
